@@ -1,0 +1,157 @@
+/*
+ * mfbank.h -- C ABI of libmfbank.so: the MI355X (gfx950) Doppler matched-filter-bank hot path.
+ *
+ * This is the drop-in boundary for pyCuSDR's receive hot loop.  Every entry point replaces one
+ * device interaction of the reference's host driver; the citation after each prototype names the
+ * reference call sites it stands in for (paths relative to pyCuSDR/ in the reference tree,
+ *   DB  = demodulator/demodulator_base.py,  CU = demodulator/cuda_kernels.cu,
+ *   DEC = decoder.py, CUFFT = lib/cufft.py).
+ *
+ * Conventions
+ *   - plain C: opaque handle, raw pointers, sizes; no C++/torch types.
+ *   - complex64 is passed as interleaved float pairs (re, im), exactly numpy's layout.
+ *   - every function returns an int status (MFB_OK == 0); mfb_strerror() names it.  The Python
+ *     wrapper raises ValueError / TypeError / MemoryError / RuntimeError from these, mirroring
+ *     DB:188-190, DB:252-257, DB:306-308 and the cuFFT status table CUFFT:90-116.
+ *   - ownership: the caller owns every host array it passes in; the library owns all device
+ *     buffers and the pinned input buffer for the lifetime of the handle.
+ *   - threading: a handle is not thread-safe; one handle per process, like the reference's one
+ *     CUDA context per Demodulator_process (DB:177-181).
+ *   - synchronisation: calls that return values to the host synchronise the handle's stream at
+ *     the same points the reference blocks on memcpy_dtoh (DB:605, DB:730, DB:1000-1006); the
+ *     *_async calls only enqueue.
+ */
+#ifndef MFBANK_H
+#define MFBANK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFB_OK               0
+#define MFB_ERR_ARG          1   /* bad argument / shape      -> ValueError  (DB:188-190, 252-255) */
+#define MFB_ERR_DTYPE        2   /* wrong element type        -> TypeError   (DB:256-257)          */
+#define MFB_ERR_ALLOC        3   /* host/device allocation    -> MemoryError (CUFFT_ALLOC_FAILED)  */
+#define MFB_ERR_HIP          4   /* HIP runtime / launch      -> RuntimeError(CUFFT_EXEC_FAILED)   */
+#define MFB_ERR_STATE        5   /* filters/shifts/input unset-> RuntimeError(CUFFT_SETUP_FAILED)  */
+#define MFB_ERR_UNSUPPORTED  6   /* size outside built plans  -> ValueError  (CUFFT_INVALID_SIZE)  */
+
+typedef struct mfb_ctx mfb_ctx;
+
+/* Operation selector of find_centres (CU:73-76, DB:31-34). */
+#define MFB_CENTRES_ABS  0
+#define MFB_CENTRES_REAL 1
+#define MFB_CENTRES_IMAG 2
+
+const char *mfb_strerror(int status);
+/* Library/ABI version, bumped whenever a prototype changes. */
+int mfb_abi_version(void);
+
+/* Create a handle on HIP device `device` for blocks of N = 2^log2N samples, `num_dopplers`
+ * Doppler bins plus `doppler_offset` leading noise-reference bins (DB:150-159), M matched
+ * filters, findCentres window W (odd), and the two compile-time switches the reference bakes
+ * into its kernel header (SUM_ALL_MASKS, CODE_SEARCH_MASK_OFFSET; DB:398-418).
+ * Replaces: cuda.Device(...).make_context() DB:177-181, buffer allocation DB:433-476,479-514,
+ * FFT plan creation DB:275-338,501 and SourceModule JIT DB:214. */
+int mfb_create(mfb_ctx **out, int device, int log2N, int num_dopplers, int doppler_offset,
+               int M, int window_width, int sum_all_masks, int code_search_mask_offset);
+/* Replaces Demodulator.__del__ (DB:517-530): frees buffers, plans, stream. */
+int mfb_destroy(mfb_ctx *ctx);
+
+/* Run all device work of this handle on an existing HIP stream (hipStream_t passed as void*),
+ * e.g. torch's current stream so that RCCL collectives order naturally.  NULL restores the
+ * handle's own stream.  (The reference's analogue is cufftSetStream, CUFFT:365-375.) */
+int mfb_set_stream(mfb_ctx *ctx, void *hip_stream);
+/* Tuning knobs (0 keeps the current value): Doppler bins per launch of the two FFT passes (bounds
+ * the intermediate buffer; the reference's analogue is CUDA.batchSize, DB:301-313) and matched
+ * filters handled per workgroup in pass 1. */
+int mfb_set_tuning(mfb_ctx *ctx, int doppler_chunk, int masks_per_block);
+int mfb_get_tuning(mfb_ctx *ctx, int *doppler_chunk, int *masks_per_block);
+
+/* Upload the filter bank: host complex64 [M][N], row-major, already conj(fft(template, N)) as
+ * protocol.get_filter returns it.  Replaces __uploadMaskToGPU (DB:246-263).  `M`/`N` are what the
+ * caller believes the shape is; a mismatch with the handle returns MFB_ERR_ARG. */
+int mfb_set_filters(mfb_ctx *ctx, const float *masks_c64, int M, int N);
+/* Upload the Doppler shift table int32[count] (count must equal doppler_offset + num_dopplers);
+ * every entry must already be wrapped into [0, N).  Replaces memcpy_htod DB:221. */
+int mfb_set_shifts(mfb_ctx *ctx, const int32_t *shifts, int count);
+
+/* Page-locked host buffer of N complex64 owned by the handle; the caller fills it in place
+ * (overlap carry included).  Replaces pagelocked_empty(...DEVICEMAP) DB:456-457 /
+ * get_signalBufferHostPointer DB:1055-1060. */
+int mfb_input_buffer(mfb_ctx *ctx, float **host_c64);
+/* Copy the pinned buffer to the device and run the forward FFT (unnormalised, sign -1).
+ * Replaces uploadToGPU DB:548-558 (cufftExecC2C FORWARD). */
+int mfb_upload(mfb_ctx *ctx);
+/* Same, from an arbitrary host array of N complex64 (pageable is fine; staged through the pinned
+ * buffer). */
+int mfb_upload_from(mfb_ctx *ctx, const float *host_c64, int N);
+/* Same, from N complex64 already resident in device memory (no copy).  Used by bench.py so the
+ * timed region starts with inputs in HBM. */
+int mfb_upload_device(mfb_ctx *ctx, const void *dev_c64);
+
+/* Enqueue the Doppler search (shift-multiply, inverse FFT bank, |.|^2 row sums) for this handle's
+ * bins; leaves doppSum float32 [count][M] on the device.  Replaces setArrayToZeros +
+ * multInputVectorWithShiftedMasksDopp + batched cufftExecC2C INVERSE + blockAbsSumAtomic
+ * (DB:571-591; CU:853-857, 339-373, 421-480). */
+int mfb_search_async(mfb_ctx *ctx);
+/* Copy this handle's doppSum rows into rows [row_offset, row_offset+count) of a device array
+ * float32 [*][M] (e.g. the buffer that is then all-reduced across ranks).  Asynchronous. */
+int mfb_export_scores_async(mfb_ctx *ctx, void *dev_dst, int row_offset);
+/* Doppler pick on `dev_scores` float32 [offset+num][M] (NULL = the handle's own doppSum):
+ * top-2 weighted index and metric; synchronises and returns res = {idx, metric}.
+ * Replaces findDopplerEst + memcpy_dtoh (DB:601-605; CU:502-597). */
+int mfb_pick(mfb_ctx *ctx, const void *dev_scores, int num, int offset, float res[2]);
+/* mfb_search_async + mfb_pick on the handle's own bins: the device part of __findUHF
+ * (DB:567-605). */
+int mfb_find_carrier(mfb_ctx *ctx, float res[2]);
+/* Copy doppSum float32 [count][M] to the host (the reference reads it back only under
+ * STORE_BITS_IN_FILE, DB:593-599); synchronises. */
+int mfb_get_scores(mfb_ctx *ctx, float *host_scores);
+/* Read `count` complex64 spectrum bins starting at `start` (wrapping modulo N), for the host-side
+ * SNR estimate.  Replaces the zero-copy reads of GPU_bufSignalFreq_cpu_handle in computeSNR
+ * (DB:651-661); synchronises. */
+int mfb_get_spectrum(mfb_ctx *ctx, float *host_c64, int start, int count);
+
+/* Matched filters at one shift + symbol-rate/phase estimate.  Runs
+ *   multInputVectorWithShiftedMask (CU:174-185; DB:776-781), cufftExecC2C INVERSE batch M
+ *   (DB:785), sumXCorrBuffMasks (CU:191-205; DB:717-718), cufftExecR2C (DB:721),
+ *   findCodeRateAndPhase (CU:236-320; DB:725-726) over k in [k_offset, k_offset+k_len),
+ * then synchronises and returns res = {k*, arg P[k*], |P[k*]|^2} (DB:730). */
+int mfb_demodulate(mfb_ctx *ctx, int shift, int k_offset, int k_len, float res[3]);
+/* Symbol centres on the matched-filter outputs left by mfb_demodulate.  Replaces findCentres
+ * (CU:78-146) + the three memcpy_dtoh of cudaFindCentres (DB:996-1006).  Writes `count` =
+ * int(N/spSym) entries (must be <= capacity) of symbol index, centre sample and fp32 magnitude. */
+int mfb_find_centres(mfb_ctx *ctx, float spSym, float offset, int op, int count,
+                     int32_t *host_sym, int32_t *host_centre, float *host_mag);
+/* Copy the matched-filter outputs complex64 [M][N] to the host (debug/parity; the reference does
+ * this only under STORE_BITS_IN_FILE, DB:849-850). */
+int mfb_get_xcorr(mfb_ctx *ctx, float *host_c64);
+/* Copy the symbol-energy envelope float32 [N] (output of sumXCorrBuffMasks) to the host. */
+int mfb_get_envelope(mfb_ctx *ctx, float *host_f32);
+
+/* Batched sync/preamble correlation: for each of B bit streams (uint8 0/1, length L, row-major
+ * [B][L]) the full convolution with an integer template int8[T]:
+ *   score[b][i] = sum_t tmpl[t] * bits[b][i - t],   i in [0, L+T-1)
+ * exactly what np.convolve(bits, tmpl) returns at DEC:96 and DEC:112, as int32 [B][L+T-1].
+ * Host pointers in, host pointer out; runs on `device`. */
+int mfb_sync_correlate(int device, const uint8_t *bits, int B, int L,
+                       const int8_t *tmpl, int T, int32_t *scores);
+
+/* HIP-event stopwatch on the handle's stream (bench.py's live kernel timing). */
+int mfb_timer_start(mfb_ctx *ctx);
+int mfb_timer_stop(mfb_ctx *ctx, float *elapsed_ms);
+/* Per-kernel accounting: when enabled, every launch of the two FFT passes is bracketed by HIP
+ * events on the handle's stream; mfb_profile_read synchronises and returns launch counts and
+ * summed milliseconds for pass 1 and pass 2 of the Doppler search, then clears them. */
+int mfb_profile_enable(mfb_ctx *ctx, int on);
+int mfb_profile_read(mfb_ctx *ctx, int counts[2], float total_ms[2]);
+/* Block until all work enqueued on the handle's stream has finished. */
+int mfb_sync(mfb_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFBANK_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of libmfbank.so (the C ABI declared in include/mfbank.h).
+
+The product path has no CPU fallback: if the shared library is missing or cannot be loaded, every
+entry point raises ``MFBankLibraryError``.  Status codes are turned into Python exceptions the way
+the reference maps cuFFT statuses to exceptions (reference lib/cufft.py:90-116).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmfbank.so')
+
+MFB_OK, MFB_ERR_ARG, MFB_ERR_DTYPE, MFB_ERR_ALLOC, MFB_ERR_HIP, MFB_ERR_STATE, MFB_ERR_UNSUPPORTED = range(7)
+
+
+class MFBankLibraryError(ImportError):
+    """libmfbank.so is not built / not loadable; the HIP path is mandatory."""
+
+
+class MFBankError(RuntimeError):
+    """HIP runtime / state error reported by libmfbank (MFB_ERR_HIP, MFB_ERR_STATE)."""
+
+
+_EXC = {
+    MFB_ERR_ARG: ValueError,
+    MFB_ERR_DTYPE: TypeError,
+    MFB_ERR_ALLOC: MemoryError,
+    MFB_ERR_HIP: MFBankError,
+    MFB_ERR_STATE: MFBankError,
+    MFB_ERR_UNSUPPORTED: ValueError,
+}
+
+_vp, _i, _fp = C.c_void_p, C.c_int, C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes); exactly the prototypes of include/mfbank.h
+PROTOTYPES = {
+    'mfb_strerror': (C.c_char_p, [_i]),
+    'mfb_abi_version': (_i, []),
+    'mfb_create': (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i, _i]),
+    'mfb_destroy': (_i, [_vp]),
+    'mfb_set_stream': (_i, [_vp, _vp]),
+    'mfb_set_tuning': (_i, [_vp, _i, _i]),
+    'mfb_get_tuning': (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    'mfb_set_filters': (_i, [_vp, _vp, _i, _i]),
+    'mfb_set_shifts': (_i, [_vp, _vp, _i]),
+    'mfb_input_buffer': (_i, [_vp, C.POINTER(_fp)]),
+    'mfb_upload': (_i, [_vp]),
+    'mfb_upload_from': (_i, [_vp, _vp, _i]),
+    'mfb_upload_device': (_i, [_vp, _vp]),
+    'mfb_search_async': (_i, [_vp]),
+    'mfb_export_scores_async': (_i, [_vp, _vp, _i]),
+    'mfb_pick': (_i, [_vp, _vp, _i, _i, _fp]),
+    'mfb_find_carrier': (_i, [_vp, _fp]),
+    'mfb_get_scores': (_i, [_vp, _vp]),
+    'mfb_get_spectrum': (_i, [_vp, _vp, _i, _i]),
+    'mfb_demodulate': (_i, [_vp, _i, _i, _i, _fp]),
+    'mfb_find_centres': (_i, [_vp, C.c_float, C.c_float, _i, _i, _vp, _vp, _vp]),
+    'mfb_get_xcorr': (_i, [_vp, _vp]),
+    'mfb_get_envelope': (_i, [_vp, _vp]),
+    'mfb_sync_correlate': (_i, [_i, _vp, _i, _i, _vp, _i, _vp]),
+    'mfb_timer_start': (_i, [_vp]),
+    'mfb_timer_stop': (_i, [_vp, _fp]),
+    'mfb_profile_enable': (_i, [_vp, _i]),
+    'mfb_profile_read': (_i, [_vp, C.POINTER(_i), _fp]),
+    'mfb_sync': (_i, [_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmfbank.so once; raise MFBankLibraryError loudly if that is impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MFBankLibraryError(
+            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(hipcc --offload-arch=gfx950).  There is no CPU fallback for the matched-filter bank.')
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise MFBankLibraryError(f'cannot load {LIB_PATH}: {e}') from e
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise MFBankLibraryError(f'{LIB_PATH} does not export {name}') from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what=''):
+    if status == MFB_OK:
+        return
+    msg = load().mfb_strerror(status).decode()
+    raise _EXC.get(status, MFBankError)(f'libmfbank {what}: {msg} (status {status})')

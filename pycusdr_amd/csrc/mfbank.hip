@@ -1,0 +1,1000 @@
+// mfbank.hip -- hand-written gfx950 kernels + C ABI for the Doppler matched-filter bank.
+//
+// Data layout in HBM (N = N1*N2 samples per block, D Doppler bins, M matched filters):
+//   d_x     complex64 [N]        time-domain block (or caller's device pointer)
+//   d_X     complex64 [N]        spectrum, natural order
+//   d_masks complex64 [M][N]     filter bank as protocol.get_filter returns it (row-major)
+//   d_Z     complex64 [Dc*M][N1][N2]  intermediate of the two-pass inverse FFT for ONE chunk of
+//                                Dc Doppler bins: Z[row][n1][k2], already multiplied by the
+//                                inter-pass twiddle W_N^(k2*n1).  Never holds the whole D*M*N cube.
+//   d_part  float32 [D][M][PARTS] per-workgroup partial |.|^2 sums (fixed-order second reduction,
+//                                no float atomics -> bit-reproducible)
+//   d_sum   float32 [D][M]       doppSum, same meaning/layout as the reference's GPU_bufDoppSum
+//   d_xc    complex64 [M][N]     matched-filter outputs at the chosen shift (natural order)
+//
+// Two-pass inverse FFT of length N = N1*N2 with input index k = N2*k1 + k2 and output index
+// n = n1 + N1*n2:
+//   pass 1 (k_pass1): for 16 adjacent k2 ("tile"), all k1: load X[(k+shift) mod N]*mask[m][k] on the
+//           fly (128-byte coalesced segments), N1-point FFT over k1 in registers+LDS, multiply
+//           by W_N^(k2*n1), store Z[n1][k2] (128-byte segments).
+//   pass 2 (k_pass2): for every n1: N2-point FFT over k2 of the contiguous row Z[n1][:], then either
+//           reduce |y|^2 in registers -> wave -> workgroup (Doppler search; the time-domain rows
+//           are never written), or store y[n1 + N1*n2] (demodulation / forward FFT).
+//
+// Reference semantics reproduced (file:line in /root/reference/pyCuSDR):
+//   shift-multiply  demodulator/cuda_kernels.cu:339-373, 174-185
+//   |.|^2 / 2^18 row sums  cuda_kernels.cu:421-480      pick  cuda_kernels.cu:502-597
+//   envelope        cuda_kernels.cu:191-205             rate/phase  cuda_kernels.cu:236-320
+//   centres         cuda_kernels.cu:78-146
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/mfbank.h"
+#include "fft_core.hpp"
+
+#define KIND_BANK 0  // X shifted * mask, inverse
+#define KIND_FWDC 1  // complex input, forward (conjugate in)
+#define KIND_FWDR 2  // real input, forward
+#define MODE_REDUCE 0
+#define MODE_STORE 1
+
+#define TILE 16
+
+struct P1Args {
+    const cf *X;        // spectrum (BANK) or time-domain complex input (FWDC)
+    const float *Xr;    // real input (FWDR)
+    const cf *masks;    // [M][N]
+    cf *Z;              // [rows][N1][N2]
+    const int *shifts;  // device shift table
+    const cf *tw1;      // W_N1
+    const cf *twLo;     // W_N^x, x < 2^lo
+    const cf *twHi;     // W_N^(y*2^lo)
+    int N, N2, lo;
+    int M;        // masks in the bank
+    int mpb;      // masks per block
+    int j0;       // first Doppler index of this chunk (into shifts)
+    int fixed_shift;  // used when shifts == nullptr
+};
+
+struct P2Args {
+    const cf *Z;     // [rows][N1][N2]
+    const cf *tw2;   // W_N2
+    float *partials; // REDUCE: [..][PARTS]
+    cf *out;         // STORE: [rows][N]
+    int N, N1, N2;
+    int srb;         // sub-rows (n1 values) per block
+    int parts;       // N1 / srb
+    int part_row0;   // REDUCE: first (j*M+m) row of this chunk in the partials array
+    int conj_out;    // STORE: conjugate on store (forward transform)
+    float scale;     // REDUCE: 1/2^18
+};
+
+// ------------------------------------------------------------------------------------------------
+// pass 1: strided N1-point FFTs on a tile of 16 adjacent columns
+// ------------------------------------------------------------------------------------------------
+template <int L1, int KIND>
+__global__ void __launch_bounds__((L1 / 16) * TILE) k_pass1(P1Args a) {
+    constexpr int NT = L1 / 16;
+    constexpr int l1 = ilog2c(L1);
+    constexpr int NP = npass(l1);
+    constexpr int RL = radix_of(l1, NP - 1);  // radix of the last pass
+    constexpr int NBL = 16 / RL;
+    constexpr int PCL = L1 / RL;  // prefixCount of the last pass
+    extern __shared__ __attribute__((aligned(16))) cf lds[];
+
+    const int tid = threadIdx.x;
+    const int col = tid & (TILE - 1);
+    const int g = tid >> 4;
+    const int k2 = blockIdx.x * TILE + col;
+    const int jl = blockIdx.z;
+    const int N = a.N, N2 = a.N2;
+
+    // inter-pass twiddles W_N^(k2*n1) for the 16 outputs this thread will own; they depend on the
+    // thread only, not on mask or Doppler bin, so they are built once per workgroup.
+    cf twN[16];
+    sfor<0, NBL>([&](auto u) {
+        sfor<0, RL>([&](auto p) {
+            const int n1 = decltype(p)::value * PCL + g + NT * decltype(u)::value;
+            const unsigned t = (unsigned)k2 * (unsigned)n1;
+            twN[decltype(u)::value * RL + decltype(p)::value] = cmul(a.twHi[t >> a.lo], a.twLo[t & ((1u << a.lo) - 1u)]);
+        });
+    });
+
+    int shift = 0;
+    if constexpr (KIND == KIND_BANK) shift = a.shifts ? a.shifts[a.j0 + jl] : a.fixed_shift;
+
+    cf xv[16];
+    int e[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        e[i] = N2 * (g + NT * i) + k2;
+        if constexpr (KIND == KIND_BANK) xv[i] = a.X[(e[i] + shift) & (N - 1)];
+        else if constexpr (KIND == KIND_FWDC) xv[i] = cconj(a.X[e[i]]);
+        else xv[i] = make_float2(a.Xr[e[i]], 0.f);
+    }
+
+    const int m0 = (KIND == KIND_BANK) ? blockIdx.y * a.mpb : 0;
+    const int m1 = (KIND == KIND_BANK) ? min(m0 + a.mpb, a.M) : 1;
+    for (int m = m0; m < m1; ++m) {
+        cf v[16];
+        if constexpr (KIND == KIND_BANK) {
+            const cf *mk = a.masks + (size_t)m * N;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = cmul(xv[i], mk[e[i]]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = xv[i];
+        }
+        const size_t zrow = (KIND == KIND_BANK) ? ((size_t)jl * a.M + m) : 0;
+        cf *zb = a.Z + zrow * (size_t)N + k2;
+        auto store = [&](int n1, cf val, auto slot) { zb[(size_t)n1 * N2] = cmul(val, twN[decltype(slot)::value]); };
+        fft_passes<L1, TILE, 0>(v, lds, g, col, a.tw1, store);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 2: contiguous N2-point FFTs; RB rows side by side when N2/16 < 256 threads
+// ------------------------------------------------------------------------------------------------
+DEVI float wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+template <int L2, int MODE, int RB>
+__global__ void __launch_bounds__((L2 / 16) * RB) k_pass2(P2Args a) {
+    constexpr int NT = L2 / 16;
+    constexpr int NTHREADS = NT * RB;
+    extern __shared__ __attribute__((aligned(16))) cf lds[];
+    __shared__ float red[16];
+
+    const int tid = threadIdx.x;
+    const int g = tid % NT;
+    const int rb = tid / NT;
+    cf *mylds = lds + rb * padlen(L2);
+
+    const int row = blockIdx.y;  // (jl*M + m) for REDUCE, output row for STORE
+    const int sr0 = blockIdx.x * a.srb;
+    const cf *zrow = a.Z + (size_t)row * a.N;
+    float acc = 0.f;
+
+    // every thread runs the same number of iterations (the passes contain workgroup barriers);
+    // rows beyond the block's range are computed on zeros and discarded
+    for (int base = 0; base < a.srb; base += RB) {
+        const bool ok = (base + rb) < a.srb;
+        const int sr = sr0 + base + (ok ? rb : 0);
+        const cf *zr = zrow + (size_t)sr * L2;
+        cf v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = ok ? zr[g + NT * i] : make_float2(0.f, 0.f);
+        if constexpr (MODE == MODE_REDUCE) {
+            auto store = [&](int, cf val, auto) { acc += val.x * val.x + val.y * val.y; };
+            fft_passes<L2, 1, 0>(v, mylds, g, 0, a.tw2, store);
+        } else {
+            cf *ob = a.out + (size_t)row * a.N + sr;
+            const int N1 = a.N1;
+            const float sgn = a.conj_out ? -1.f : 1.f;
+            auto store = [&](int n2, cf val, auto) {
+                if (ok) ob[(size_t)n2 * N1] = make_float2(val.x, sgn * val.y);
+            };
+            fft_passes<L2, 1, 0>(v, mylds, g, 0, a.tw2, store);
+        }
+    }
+
+    if constexpr (MODE == MODE_REDUCE) {
+        // registers -> wavefront (64 lanes) -> workgroup, fixed order
+        acc = wave_sum(acc);
+        const int wid = tid >> 6;
+        if ((tid & 63) == 0) red[wid] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f;
+            for (int w = 0; w < NTHREADS / 64; ++w) s += red[w];
+            a.partials[(size_t)(a.part_row0 + row) * a.parts + blockIdx.x] = s * a.scale;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------------
+// doppSum[j][m] from the per-workgroup partials (fixed order).  SUM_ALL_MASKS: column 0 gets the
+// sum over masks, the other columns stay 0 (cuda_kernels.cu:453-464); else per mask (472-475).
+__global__ void k_finalize(const float *partials, float *dsum, int D, int M, int parts, int sum_all) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= D) return;
+    float tot = 0.f;
+    for (int m = 0; m < M; ++m) {
+        float s = 0.f;
+        const float *p = partials + ((size_t)j * M + m) * parts;
+        for (int q = 0; q < parts; ++q) s += p[q];
+        if (sum_all) {
+            tot += s;
+            dsum[j * M + m] = 0.f;
+        } else {
+            dsum[j * M + m] = s;
+        }
+    }
+    if (sum_all) dsum[j * M] = tot;
+}
+
+// findDopplerEst (cuda_kernels.cu:502-597).  One wavefront; lane x < M owns column x.
+// fp32 evaluation order is pinned with explicit intrinsics (see oracle/mfbank_oracle.py).
+__global__ void k_pick(const float *in, float *res, int num, int offset, int M, int sum_all) {
+    __shared__ float sIdx[64], sVal[64];
+    const int x = threadIdx.x;
+    float idxL = 0.f, valL = 0.f;
+    if (x < M) {
+        float maxVal[2] = {0.f, 0.f};
+        int maxIdx[2] = {0, 0};
+        int cur = 0;
+        for (int i = offset; i < num + offset; ++i) {
+            const float tmp = in[x + i * M];
+            if (tmp > maxVal[cur]) {
+                maxVal[cur] = tmp;
+                maxIdx[cur] = i;
+                cur = (maxVal[0] >= maxVal[1]) ? 1 : 0;
+            }
+        }
+        const float numr = __fmaf_rn((float)maxIdx[0], maxVal[0], __fmul_rn((float)maxIdx[1], maxVal[1]));
+        idxL = __fdiv_rn(numr, __fadd_rn(maxVal[0], maxVal[1]));
+        valL = __fdiv_rn(numr, (float)(maxIdx[0] + maxIdx[1]));
+        if (offset > 0) valL = __fdiv_rn(maxVal[(cur + 1) % 2], in[x]);
+    }
+    if (sum_all) {
+        if (x == 0) {
+            res[0] = idxL;
+            res[1] = 10.f * log10f(valL);
+        }
+        return;
+    }
+    int n = 1;
+    while (n < M) n <<= 1;
+    sIdx[x] = (x < M) ? idxL : 0.f;
+    sVal[x] = (x < M) ? valL : 0.f;
+    __syncthreads();
+    for (int step = n >> 1; step >= 1; step >>= 1) {
+        float a = 0.f, b = 0.f;
+        if (x < n) {
+            a = __fadd_rn(sIdx[x], sIdx[x ^ step]);
+            b = __fadd_rn(sVal[x], sVal[x ^ step]);
+        }
+        __syncthreads();
+        if (x < n) {
+            sIdx[x] = a;
+            sVal[x] = b;
+        }
+        __syncthreads();
+    }
+    if (x == 0) {
+        res[0] = __fdiv_rn(sIdx[0], (float)M);
+        res[1] = 10.f * log10f(__fdiv_rn(sVal[0], (float)M));
+    }
+}
+
+// |z|^2 the way nvcc contracts in.x*in.x+in.y*in.y (cuda_kernels.cu:1022-1026): fma(x,x,y*y)
+DEVI float abs2c(cf z) { return __fmaf_rn(z.x, z.x, __fmul_rn(z.y, z.y)); }
+
+// sumXCorrBuffMasks (cuda_kernels.cu:191-205)
+__global__ void k_envelope(const cf *xc, float *env, int N, int M, int off) {
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < N; x += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int m = off; m < M - off; ++m) s = __fadd_rn(s, abs2c(xc[(size_t)m * N + x]));
+        env[x] = s;
+    }
+}
+
+// findCodeRateAndPhase (cuda_kernels.cu:236-320): argmax |P[k]|^2 over [offset, offset+len);
+// ties resolve to the lowest k (deterministic).  out = {k, atan2(im,re), |P|^2}
+__global__ void k_code_rate(const cf *P, float *out, int offset, int len) {
+    __shared__ float sv[1024];
+    __shared__ int si[1024];
+    const int tid = threadIdx.x;
+    float best = -1.f;
+    int bi = 0x7fffffff;
+    for (int x = tid; x < len; x += blockDim.x) {
+        const float v = abs2c(P[x + offset]);
+        if (v > best) {
+            best = v;
+            bi = x + offset;
+        }
+    }
+    sv[tid] = best;
+    si[tid] = bi;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float ov = sv[tid + s];
+            const int oi = si[tid + s];
+            if (ov > sv[tid] || (ov == sv[tid] && oi < si[tid])) {
+                sv[tid] = ov;
+                si[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int k = (len > 0) ? si[0] : 0;
+        const cf z = P[k];
+        out[0] = (float)k;
+        out[1] = atan2f(z.y, z.x);
+        out[2] = sv[0];
+    }
+}
+
+// findCentres (cuda_kernels.cu:78-146); thread = symbol index.
+__global__ void k_centres(int *outSym, int *outIdx, float *mag, const cf *sig, float spSym, float offset,
+                          int lenSig, int M, int W, int op, int capacity) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= capacity) return;
+    const float half = (float)(W / 2);  // WINDOW_WIDTH/2 is an integer division (demodulator_base.py:407)
+    const float base = __fmaf_rn((float)x, spSym, -half);
+    int arrayIdx = (int)__fadd_rn(base, offset);
+    int maxArrayIdx = arrayIdx + W;
+    int offsetComp = (int)offset;
+    if (arrayIdx < 0) {
+        offsetComp -= arrayIdx;
+        arrayIdx = 0;
+    }
+    if (maxArrayIdx > lenSig) maxArrayIdx = lenSig;
+    maxArrayIdx -= arrayIdx;
+    int maxIdx = -1, maxCentreIdx = -1;
+    if (arrayIdx < lenSig) {
+        float maxVal = 0.f;
+        for (int m = 0; m < M; ++m) {
+            const cf *row = sig + (size_t)m * lenSig + arrayIdx;
+            for (int k = 0; k < maxArrayIdx; ++k) {
+                const cf z = row[k];
+                const float tmp = (op == 0) ? abs2c(z) : (op == 1 ? fabsf(z.x) : fabsf(z.y));
+                if (tmp > maxVal) {
+                    maxVal = tmp;
+                    maxIdx = m;
+                    maxCentreIdx = k;
+                }
+            }
+        }
+        outSym[x] = maxIdx;
+        outIdx[x] = (int)__fadd_rn(__fadd_rn(base, (float)maxCentreIdx), (float)offsetComp);
+        mag[x] = maxVal;
+    }
+}
+
+__global__ void k_fill_i32(int *p, int v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// batched sync-word correlation (decoder.py:96,112): full convolution, exact int32
+__global__ void k_sync_corr(const uint8_t *bits, const int8_t *tmpl, int32_t *out, int L, int T) {
+    extern __shared__ __attribute__((aligned(16))) int8_t sm[];
+    int8_t *st = sm;            // T taps
+    int8_t *sb = sm + T;        // blockDim.x + T - 1 bits
+    const int b = blockIdx.y;
+    const int i0 = blockIdx.x * blockDim.x;
+    const int outLen = L + T - 1;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) st[t] = tmpl[t];
+    const uint8_t *row = bits + (size_t)b * L;
+    for (int q = threadIdx.x; q < (int)blockDim.x + T - 1; q += blockDim.x) {
+        const int src = i0 - (T - 1) + q;
+        sb[q] = (src >= 0 && src < L) ? (int8_t)row[src] : (int8_t)0;
+    }
+    __syncthreads();
+    const int i = i0 + threadIdx.x;
+    if (i < outLen) {
+        int acc = 0;
+        // out[i] = sum_t tmpl[t]*bits[i-t];  bits[i-t] sits at sb[threadIdx.x + T-1 - t]
+        const int8_t *p = sb + threadIdx.x + T - 1;
+        for (int t = 0; t < T; ++t) acc += (int)st[t] * (int)p[-t];
+        out[(size_t)b * outLen + i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct mfb_ctx {
+    int device;
+    int log2N, N, N1, N2, l1, l2, lo;
+    int D, Doff, Dtot, M, W, sum_all, cs_off;
+    int chunk, mpb;
+    int parts, srb;
+    hipStream_t own_stream, stream;
+    cf *h_in;  // pinned
+    cf *d_x, *d_X, *d_masks, *d_Z, *d_xc, *d_P;
+    const cf *d_in;  // current time-domain input (d_x or caller's device pointer)
+    float *d_env;
+    int *d_shifts;
+    cf *d_tw1, *d_tw2, *d_twLo, *d_twHi;
+    float *d_part, *d_sum, *d_res, *d_cr;
+    int *d_sym, *d_cen;
+    float *d_mag;
+    int cap;  // capacity of the centres buffers
+    size_t z_rows;  // rows allocated in d_Z
+    bool have_filters, have_shifts, have_input, have_xc;
+    hipEvent_t t0, t1;
+    bool prof;
+    std::vector<hipEvent_t> ev[2];
+    std::vector<hipEvent_t> ev_pool;
+};
+
+#define HIPCHK(x)                                                                            \
+    do {                                                                                     \
+        hipError_t e_ = (x);                                                                 \
+        if (e_ != hipSuccess) {                                                              \
+            fprintf(stderr, "mfbank: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (e_ == hipErrorOutOfMemory) ? MFB_ERR_ALLOC : MFB_ERR_HIP;               \
+        }                                                                                    \
+    } while (0)
+
+extern "C" const char *mfb_strerror(int s) {
+    switch (s) {
+        case MFB_OK: return "ok";
+        case MFB_ERR_ARG: return "invalid argument or shape";
+        case MFB_ERR_DTYPE: return "invalid element type";
+        case MFB_ERR_ALLOC: return "allocation failed";
+        case MFB_ERR_HIP: return "HIP runtime error";
+        case MFB_ERR_STATE: return "filters, shifts or input not set";
+        case MFB_ERR_UNSUPPORTED: return "transform size not supported";
+        default: return "unknown status";
+    }
+}
+extern "C" int mfb_abi_version(void) { return 1; }
+
+static void make_twiddles(std::vector<cf> &v, int count, double denom, double stepmul) {
+    v.resize(count);
+    for (int i = 0; i < count; ++i) {
+        const double ang = 2.0 * M_PI * (double)i * stepmul / denom;
+        v[i] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+}
+
+static int upload_tw(cf **dst, const std::vector<cf> &v) {
+    HIPCHK(hipMalloc((void **)dst, v.size() * sizeof(cf)));
+    HIPCHK(hipMemcpy(*dst, v.data(), v.size() * sizeof(cf), hipMemcpyHostToDevice));
+    return MFB_OK;
+}
+
+static int alloc_Z(mfb_ctx *c) {
+    const size_t rows = (size_t)c->chunk * c->M;
+    const size_t need = rows > (size_t)c->M ? rows : (size_t)c->M;
+    if (c->d_Z && c->z_rows >= need) return MFB_OK;
+    if (c->d_Z) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipFree(c->d_Z));
+        c->d_Z = nullptr;
+    }
+    HIPCHK(hipMalloc((void **)&c->d_Z, need * c->N * sizeof(cf)));
+    c->z_rows = need;
+    return MFB_OK;
+}
+
+extern "C" int mfb_create(mfb_ctx **out, int device, int log2N, int num_dopplers, int doppler_offset, int M,
+                          int window_width, int sum_all_masks, int code_search_mask_offset) {
+    if (!out) return MFB_ERR_ARG;
+    *out = nullptr;
+    if (num_dopplers < 1 || doppler_offset < 0 || M < 1 || M > 64 || window_width < 1 || (window_width & 1) == 0 ||
+        code_search_mask_offset < 0 || 2 * code_search_mask_offset >= M)
+        return MFB_ERR_ARG;
+    if (log2N < 10 || log2N > 22) return MFB_ERR_UNSUPPORTED;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(device));
+
+    mfb_ctx *c = new mfb_ctx();
+    memset((void *)c, 0, offsetof(mfb_ctx, ev));
+    c->device = device;
+    c->log2N = log2N;
+    c->N = 1 << log2N;
+    c->l1 = log2N / 2 < 8 ? log2N / 2 : 8;
+    c->l2 = log2N - c->l1;
+    c->N1 = 1 << c->l1;
+    c->N2 = 1 << c->l2;
+    c->lo = (log2N + 1) / 2;
+    c->D = num_dopplers;
+    c->Doff = doppler_offset;
+    c->Dtot = num_dopplers + doppler_offset;
+    c->M = M;
+    c->W = window_width;
+    c->sum_all = sum_all_masks ? 1 : 0;
+    c->cs_off = code_search_mask_offset;
+    // chunk: keep the intermediate near 128 MiB so that it can stay in the 256 MiB Infinity Cache
+    {
+        const size_t row_bytes = (size_t)c->N * sizeof(cf) * M;
+        size_t ch = ((size_t)128 << 20) / row_bytes;
+        if (ch < 1) ch = 1;
+        if (ch > (size_t)c->Dtot) ch = c->Dtot;
+        c->chunk = (int)ch;
+    }
+    c->mpb = M < 4 ? M : 4;
+    // pass-2 work split: sub-rows per workgroup
+    {
+        const int NT = c->N2 / 16;
+        const int RB = NT >= 256 ? 1 : 256 / NT;
+        int srb = 16;
+        if (srb < RB) srb = RB;
+        if (srb > c->N1) srb = c->N1;
+        c->srb = srb;
+        c->parts = c->N1 / srb;
+    }
+
+    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIPCHK(hipEventCreate(&c->t0));
+    HIPCHK(hipEventCreate(&c->t1));
+    const size_t nb = (size_t)c->N * sizeof(cf);
+    HIPCHK(hipHostMalloc((void **)&c->h_in, nb, hipHostMallocDefault));
+    memset(c->h_in, 0, nb);
+    HIPCHK(hipMalloc((void **)&c->d_x, nb));
+    HIPCHK(hipMalloc((void **)&c->d_X, nb));
+    HIPCHK(hipMalloc((void **)&c->d_masks, nb * M));
+    HIPCHK(hipMalloc((void **)&c->d_xc, nb * M));
+    HIPCHK(hipMalloc((void **)&c->d_P, nb));
+    HIPCHK(hipMalloc((void **)&c->d_env, (size_t)c->N * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&c->d_shifts, (size_t)c->Dtot * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&c->d_part, (size_t)c->Dtot * M * c->parts * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&c->d_sum, (size_t)c->Dtot * M * sizeof(float)));
+    HIPCHK(hipMemset(c->d_sum, 0, (size_t)c->Dtot * M * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&c->d_res, 2 * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&c->d_cr, 3 * sizeof(float)));
+    c->cap = c->N / 2;  // symbols never shorter than 2 samples
+    HIPCHK(hipMalloc((void **)&c->d_sym, (size_t)c->cap * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&c->d_cen, (size_t)c->cap * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&c->d_mag, (size_t)c->cap * sizeof(float)));
+    int rc = alloc_Z(c);
+    if (rc) return rc;
+
+    std::vector<cf> t;
+    make_twiddles(t, c->N1, (double)c->N1, 1.0);
+    if ((rc = upload_tw(&c->d_tw1, t))) return rc;
+    make_twiddles(t, c->N2, (double)c->N2, 1.0);
+    if ((rc = upload_tw(&c->d_tw2, t))) return rc;
+    make_twiddles(t, 1 << c->lo, (double)c->N, 1.0);
+    if ((rc = upload_tw(&c->d_twLo, t))) return rc;
+    make_twiddles(t, c->N >> c->lo, (double)c->N, (double)(1 << c->lo));
+    if ((rc = upload_tw(&c->d_twHi, t))) return rc;
+    c->d_in = c->d_x;
+    *out = c;
+    return MFB_OK;
+}
+
+extern "C" int mfb_destroy(mfb_ctx *c) {
+    if (!c) return MFB_ERR_ARG;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    void *bufs[] = {c->d_x,  c->d_X,    c->d_masks, c->d_Z,   c->d_xc,  c->d_P,   c->d_env, c->d_shifts, c->d_tw1,
+                    c->d_tw2, c->d_twLo, c->d_twHi,  c->d_part, c->d_sum, c->d_res, c->d_cr,  c->d_sym,    c->d_cen, c->d_mag};
+    for (void *p : bufs)
+        if (p) hipFree(p);
+    if (c->h_in) hipHostFree(c->h_in);
+    for (auto &v : c->ev)
+        for (auto e : v) hipEventDestroy(e);
+    for (auto e : c->ev_pool) hipEventDestroy(e);
+    hipEventDestroy(c->t0);
+    hipEventDestroy(c->t1);
+    hipStreamDestroy(c->own_stream);
+    delete c;
+    return MFB_OK;
+}
+
+extern "C" int mfb_set_stream(mfb_ctx *c, void *s) {
+    if (!c) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return MFB_OK;
+}
+
+extern "C" int mfb_set_tuning(mfb_ctx *c, int chunk, int mpb) {
+    if (!c || chunk < 0 || mpb < 0) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (chunk > 0) c->chunk = chunk > c->Dtot ? c->Dtot : chunk;
+    if (c->chunk * c->M > 65535) c->chunk = 65535 / c->M;  // grid.y limit of pass 2
+    if (mpb > 0) c->mpb = mpb > c->M ? c->M : mpb;
+    return alloc_Z(c);
+}
+extern "C" int mfb_get_tuning(mfb_ctx *c, int *chunk, int *mpb) {
+    if (!c) return MFB_ERR_ARG;
+    if (chunk) *chunk = c->chunk;
+    if (mpb) *mpb = c->mpb;
+    return MFB_OK;
+}
+
+extern "C" int mfb_set_filters(mfb_ctx *c, const float *masks, int M, int N) {
+    if (!c || !masks) return MFB_ERR_ARG;
+    if (M != c->M || N != c->N) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->d_masks, masks, (size_t)M * N * sizeof(cf), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_filters = true;
+    return MFB_OK;
+}
+
+extern "C" int mfb_set_shifts(mfb_ctx *c, const int32_t *shifts, int count) {
+    if (!c || !shifts || count != c->Dtot) return MFB_ERR_ARG;
+    for (int i = 0; i < count; ++i)
+        if (shifts[i] < 0 || shifts[i] >= c->N) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->d_shifts, shifts, (size_t)count * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_shifts = true;
+    return MFB_OK;
+}
+
+extern "C" int mfb_input_buffer(mfb_ctx *c, float **p) {
+    if (!c || !p) return MFB_ERR_ARG;
+    *p = (float *)c->h_in;
+    return MFB_OK;
+}
+
+// ---- launch helpers ------------------------------------------------------------------------------
+static hipEvent_t get_event(mfb_ctx *c) {
+    if (!c->ev_pool.empty()) {
+        hipEvent_t e = c->ev_pool.back();
+        c->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+static void prof_mark(mfb_ctx *c, int which) {
+    if (!c->prof) return;
+    hipEvent_t e = get_event(c);
+    hipEventRecord(e, c->stream);
+    c->ev[which].push_back(e);
+}
+
+template <int L1, int KIND>
+static int launch_p1_t(mfb_ctx *c, const P1Args &a, dim3 grid) {
+    const size_t lds = (size_t)padlen(L1) * TILE * sizeof(cf);
+    hipLaunchKernelGGL((k_pass1<L1, KIND>), grid, dim3((L1 / 16) * TILE), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return MFB_OK;
+}
+template <int KIND>
+static int launch_p1(mfb_ctx *c, const P1Args &a, dim3 grid) {
+    switch (c->l1) {
+        case 5: return launch_p1_t<32, KIND>(c, a, grid);
+        case 6: return launch_p1_t<64, KIND>(c, a, grid);
+        case 7: return launch_p1_t<128, KIND>(c, a, grid);
+        case 8: return launch_p1_t<256, KIND>(c, a, grid);
+    }
+    return MFB_ERR_UNSUPPORTED;
+}
+
+template <int L2, int MODE>
+static int launch_p2_t(mfb_ctx *c, const P2Args &a, dim3 grid) {
+    constexpr int NT = L2 / 16;
+    constexpr int RB = NT >= 256 ? 1 : 256 / NT;
+    const size_t lds = (size_t)padlen(L2) * RB * sizeof(cf);
+    if (lds > 48 * 1024) {
+        static bool done = false;  // per instantiation
+        if (!done) {
+            HIPCHK(hipFuncSetAttribute((const void *)k_pass2<L2, MODE, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL((k_pass2<L2, MODE, RB>), grid, dim3(NT * RB), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return MFB_OK;
+}
+template <int MODE>
+static int launch_p2(mfb_ctx *c, const P2Args &a, dim3 grid) {
+    switch (c->l2) {
+        case 5: return launch_p2_t<32, MODE>(c, a, grid);
+        case 6: return launch_p2_t<64, MODE>(c, a, grid);
+        case 7: return launch_p2_t<128, MODE>(c, a, grid);
+        case 8: return launch_p2_t<256, MODE>(c, a, grid);
+        case 9: return launch_p2_t<512, MODE>(c, a, grid);
+        case 10: return launch_p2_t<1024, MODE>(c, a, grid);
+        case 11: return launch_p2_t<2048, MODE>(c, a, grid);
+        case 12: return launch_p2_t<4096, MODE>(c, a, grid);
+        case 13: return launch_p2_t<8192, MODE>(c, a, grid);
+        case 14: return launch_p2_t<16384, MODE>(c, a, grid);
+    }
+    return MFB_ERR_UNSUPPORTED;
+}
+
+static P1Args p1_base(mfb_ctx *c) {
+    P1Args a;
+    memset(&a, 0, sizeof(a));
+    a.masks = c->d_masks;
+    a.Z = c->d_Z;
+    a.tw1 = c->d_tw1;
+    a.twLo = c->d_twLo;
+    a.twHi = c->d_twHi;
+    a.N = c->N;
+    a.N2 = c->N2;
+    a.lo = c->lo;
+    a.M = c->M;
+    a.mpb = c->mpb;
+    return a;
+}
+static P2Args p2_base(mfb_ctx *c) {
+    P2Args a;
+    memset(&a, 0, sizeof(a));
+    a.Z = c->d_Z;
+    a.tw2 = c->d_tw2;
+    a.N = c->N;
+    a.N1 = c->N1;
+    a.N2 = c->N2;
+    a.srb = c->srb;
+    a.parts = c->parts;
+    a.scale = 1.0f / 262144.0f;
+    return a;
+}
+
+// forward FFT of one row: complex (src_c) or real (src_r) input -> dst natural order
+static int forward_fft(mfb_ctx *c, const cf *src_c, const float *src_r, cf *dst) {
+    P1Args a = p1_base(c);
+    a.X = src_c;
+    a.Xr = src_r;
+    dim3 g1(c->N2 / TILE, 1, 1);
+    int rc = src_c ? launch_p1<KIND_FWDC>(c, a, g1) : launch_p1<KIND_FWDR>(c, a, g1);
+    if (rc) return rc;
+    P2Args b = p2_base(c);
+    b.out = dst;
+    b.conj_out = 1;
+    dim3 g2(c->parts, 1, 1);
+    return launch_p2<MODE_STORE>(c, b, g2);
+}
+
+extern "C" int mfb_upload(mfb_ctx *c) {
+    if (!c) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->d_x, c->h_in, (size_t)c->N * sizeof(cf), hipMemcpyHostToDevice, c->stream));
+    c->d_in = c->d_x;
+    int rc = forward_fft(c, c->d_in, nullptr, c->d_X);
+    if (rc) return rc;
+    c->have_input = true;
+    c->have_xc = false;
+    return MFB_OK;
+}
+
+extern "C" int mfb_upload_from(mfb_ctx *c, const float *host, int N) {
+    if (!c || !host || N != c->N) return MFB_ERR_ARG;
+    if ((const void *)host != (const void *)c->h_in) {
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipStreamSynchronize(c->stream));  // pinned buffer may still be in flight
+        memcpy(c->h_in, host, (size_t)N * sizeof(cf));
+    }
+    return mfb_upload(c);
+}
+
+extern "C" int mfb_upload_device(mfb_ctx *c, const void *dev) {
+    if (!c || !dev) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    c->d_in = (const cf *)dev;
+    int rc = forward_fft(c, c->d_in, nullptr, c->d_X);
+    if (rc) return rc;
+    c->have_input = true;
+    c->have_xc = false;
+    return MFB_OK;
+}
+
+extern "C" int mfb_search_async(mfb_ctx *c) {
+    if (!c) return MFB_ERR_ARG;
+    if (!c->have_filters || !c->have_shifts || !c->have_input) return MFB_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    const int mgroups = (c->M + c->mpb - 1) / c->mpb;
+    for (int j0 = 0; j0 < c->Dtot; j0 += c->chunk) {
+        const int dc = (c->Dtot - j0) < c->chunk ? (c->Dtot - j0) : c->chunk;
+        P1Args a = p1_base(c);
+        a.X = c->d_X;
+        a.shifts = c->d_shifts;
+        a.j0 = j0;
+        prof_mark(c, 0);
+        int rc = launch_p1<KIND_BANK>(c, a, dim3(c->N2 / TILE, mgroups, dc));
+        prof_mark(c, 0);
+        if (rc) return rc;
+        P2Args b = p2_base(c);
+        b.partials = c->d_part;
+        b.part_row0 = j0 * c->M;
+        prof_mark(c, 1);
+        rc = launch_p2<MODE_REDUCE>(c, b, dim3(c->parts, dc * c->M, 1));
+        prof_mark(c, 1);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_finalize, dim3((c->Dtot + 63) / 64), dim3(64), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M,
+                       c->parts, c->sum_all);
+    HIPCHK(hipGetLastError());
+    return MFB_OK;
+}
+
+extern "C" int mfb_export_scores_async(mfb_ctx *c, void *dst, int row_offset) {
+    if (!c || !dst || row_offset < 0) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync((float *)dst + (size_t)row_offset * c->M, c->d_sum, (size_t)c->Dtot * c->M * sizeof(float),
+                          hipMemcpyDeviceToDevice, c->stream));
+    return MFB_OK;
+}
+
+extern "C" int mfb_pick(mfb_ctx *c, const void *scores, int num, int offset, float res[2]) {
+    if (!c || !res || num < 1 || offset < 0) return MFB_ERR_ARG;
+    if (!scores && (num != c->D || offset != c->Doff)) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    const float *in = scores ? (const float *)scores : c->d_sum;
+    hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, c->stream, in, c->d_res, num, offset, c->M, c->sum_all);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(res, c->d_res, 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MFB_OK;
+}
+
+extern "C" int mfb_find_carrier(mfb_ctx *c, float res[2]) {
+    int rc = mfb_search_async(c);
+    if (rc) return rc;
+    return mfb_pick(c, nullptr, c->D, c->Doff, res);
+}
+
+extern "C" int mfb_get_scores(mfb_ctx *c, float *host) {
+    if (!c || !host) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(host, c->d_sum, (size_t)c->Dtot * c->M * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MFB_OK;
+}
+
+extern "C" int mfb_get_spectrum(mfb_ctx *c, float *host, int start, int count) {
+    if (!c || !host || count < 0 || count > c->N) return MFB_ERR_ARG;
+    if (!c->have_input) return MFB_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    start = ((start % c->N) + c->N) % c->N;
+    const int first = (start + count <= c->N) ? count : c->N - start;
+    HIPCHK(hipMemcpyAsync(host, c->d_X + start, (size_t)first * sizeof(cf), hipMemcpyDeviceToHost, c->stream));
+    if (first < count)
+        HIPCHK(hipMemcpyAsync(host + 2 * (size_t)first, c->d_X, (size_t)(count - first) * sizeof(cf), hipMemcpyDeviceToHost,
+                              c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MFB_OK;
+}
+
+extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, float res[3]) {
+    if (!c || !res) return MFB_ERR_ARG;
+    if (!c->have_filters || !c->have_input) return MFB_ERR_STATE;
+    if (k_offset < 0 || k_len < 0 || k_offset + k_len > c->N) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    shift = ((shift % c->N) + c->N) % c->N;
+    // A9: matched filters at one shift -> xc[M][N] natural order
+    P1Args a = p1_base(c);
+    a.X = c->d_X;
+    a.shifts = nullptr;
+    a.fixed_shift = shift;
+    const int mgroups = (c->M + c->mpb - 1) / c->mpb;
+    int rc = launch_p1<KIND_BANK>(c, a, dim3(c->N2 / TILE, mgroups, 1));
+    if (rc) return rc;
+    P2Args b = p2_base(c);
+    b.out = c->d_xc;
+    b.conj_out = 0;
+    rc = launch_p2<MODE_STORE>(c, b, dim3(c->parts, c->M, 1));
+    if (rc) return rc;
+    // A10: envelope, spectrum of the envelope, windowed argmax
+    hipLaunchKernelGGL(k_envelope, dim3(1024), dim3(256), 0, c->stream, c->d_xc, c->d_env, c->N, c->M, c->cs_off);
+    HIPCHK(hipGetLastError());
+    rc = forward_fft(c, nullptr, c->d_env, c->d_P);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_code_rate, dim3(1), dim3(1024), 0, c->stream, c->d_P, c->d_cr, k_offset, k_len);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(res, c->d_cr, 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_xc = true;
+    return MFB_OK;
+}
+
+extern "C" int mfb_find_centres(mfb_ctx *c, float spSym, float offset, int op, int count, int32_t *sym, int32_t *cen,
+                                float *mag) {
+    if (!c || !sym || !cen || !mag) return MFB_ERR_ARG;
+    if (!c->have_xc) return MFB_ERR_STATE;
+    if (!(spSym >= 2.0f) || count < 0 || count > c->cap || op < 0 || op > 2) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    // same launch shape as the reference (ceil(N/spSym/256) blocks of 256, DB:996), bounded by capacity
+    int nthreads = (int)ceil((double)c->N / (double)spSym / 256.0) * 256;
+    if (nthreads > c->cap) nthreads = c->cap;
+    if (nthreads < count) nthreads = count;
+    const int nb = (nthreads + 255) / 256;
+    hipLaunchKernelGGL(k_fill_i32, dim3((c->cap + 255) / 256), dim3(256), 0, c->stream, c->d_sym, INT32_MIN, c->cap);
+    hipLaunchKernelGGL(k_fill_i32, dim3((c->cap + 255) / 256), dim3(256), 0, c->stream, c->d_cen, INT32_MIN, c->cap);
+    HIPCHK(hipMemsetAsync(c->d_mag, 0, (size_t)c->cap * sizeof(float), c->stream));
+    hipLaunchKernelGGL(k_centres, dim3(nb), dim3(256), 0, c->stream, c->d_sym, c->d_cen, c->d_mag, c->d_xc, spSym, offset, c->N,
+                       c->M, c->W, op, c->cap);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(sym, c->d_sym, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(cen, c->d_cen, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(mag, c->d_mag, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MFB_OK;
+}
+
+extern "C" int mfb_get_xcorr(mfb_ctx *c, float *host) {
+    if (!c || !host) return MFB_ERR_ARG;
+    if (!c->have_xc) return MFB_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(host, c->d_xc, (size_t)c->M * c->N * sizeof(cf), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MFB_OK;
+}
+
+extern "C" int mfb_get_envelope(mfb_ctx *c, float *host) {
+    if (!c || !host) return MFB_ERR_ARG;
+    if (!c->have_xc) return MFB_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(host, c->d_env, (size_t)c->N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MFB_OK;
+}
+
+extern "C" int mfb_sync_correlate(int device, const uint8_t *bits, int B, int L, const int8_t *tmpl, int T, int32_t *scores) {
+    if (!bits || !tmpl || !scores || B < 1 || L < 1 || T < 1 || T > 4096) return MFB_ERR_ARG;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(device));
+    const int outLen = L + T - 1;
+    uint8_t *d_bits = nullptr;
+    int8_t *d_t = nullptr;
+    int32_t *d_out = nullptr;
+    HIPCHK(hipMalloc((void **)&d_bits, (size_t)B * L));
+    HIPCHK(hipMalloc((void **)&d_t, (size_t)T));
+    HIPCHK(hipMalloc((void **)&d_out, (size_t)B * outLen * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(d_bits, bits, (size_t)B * L, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_t, tmpl, (size_t)T, hipMemcpyHostToDevice));
+    const int bs = 256;
+    const size_t lds = (size_t)T + bs + T - 1;
+    hipLaunchKernelGGL(k_sync_corr, dim3((outLen + bs - 1) / bs, B), dim3(bs), lds, 0, d_bits, d_t, d_out, L, T);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(scores, d_out, (size_t)B * outLen * sizeof(int32_t), hipMemcpyDeviceToHost));
+    hipFree(d_bits);
+    hipFree(d_t);
+    hipFree(d_out);
+    return MFB_OK;
+}
+
+extern "C" int mfb_timer_start(mfb_ctx *c) {
+    if (!c) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventRecord(c->t0, c->stream));
+    return MFB_OK;
+}
+extern "C" int mfb_timer_stop(mfb_ctx *c, float *ms) {
+    if (!c || !ms) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventRecord(c->t1, c->stream));
+    HIPCHK(hipEventSynchronize(c->t1));
+    HIPCHK(hipEventElapsedTime(ms, c->t0, c->t1));
+    return MFB_OK;
+}
+extern "C" int mfb_profile_enable(mfb_ctx *c, int on) {
+    if (!c) return MFB_ERR_ARG;
+    c->prof = on != 0;
+    return MFB_OK;
+}
+extern "C" int mfb_profile_read(mfb_ctx *c, int counts[2], float total_ms[2]) {
+    if (!c || !counts || !total_ms) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int w = 0; w < 2; ++w) {
+        counts[w] = (int)(c->ev[w].size() / 2);
+        double tot = 0.0;
+        for (size_t i = 0; i + 1 < c->ev[w].size(); i += 2) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[w][i], c->ev[w][i + 1]));
+            tot += ms;
+        }
+        total_ms[w] = (float)tot;
+        for (auto e : c->ev[w]) c->ev_pool.push_back(e);
+        c->ev[w].clear();
+    }
+    return MFB_OK;
+}
+extern "C" int mfb_sync(mfb_ctx *c) {
+    if (!c) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MFB_OK;
+}

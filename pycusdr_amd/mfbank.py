@@ -1,0 +1,184 @@
+"""MFBank -- Python handle over the libmfbank C ABI (one per process, like the reference's CUDA
+context per Demodulator_process, reference demodulator_base.py:177-181).
+
+Only numpy arrays and plain ints/floats cross this layer; all arithmetic of the hot path happens
+in the HIP kernels behind it.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class MFBank:
+    def __init__(self, log2N, num_dopplers, M, window_width=7, sum_all_masks=True,
+                 code_search_mask_offset=0, doppler_offset=0, device=0):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        self.N = 1 << int(log2N)
+        self.D = int(num_dopplers)
+        self.Doff = int(doppler_offset)
+        self.Dtot = self.D + self.Doff
+        self.M = int(M)
+        self.device = int(device)
+        _lib.check(self._lib.mfb_create(C.byref(self._h), self.device, int(log2N), self.D, self.Doff, self.M,
+                                        int(window_width), int(bool(sum_all_masks)), int(code_search_mask_offset)),
+                   'mfb_create')
+        buf = C.POINTER(C.c_float)()
+        _lib.check(self._lib.mfb_input_buffer(self._h, C.byref(buf)), 'mfb_input_buffer')
+        # writable complex64 view of the page-locked input buffer owned by the library
+        self.input = np.ctypeslib.as_array(buf, shape=(2 * self.N,)).view(np.complex64)
+
+    # -- lifetime --------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self.input = None
+            self._lib.mfb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration ---------------------------------------------------------------------------
+    def set_stream(self, hip_stream):
+        _lib.check(self._lib.mfb_set_stream(self._h, C.c_void_p(hip_stream or 0)), 'mfb_set_stream')
+
+    def set_tuning(self, doppler_chunk=0, masks_per_block=0):
+        _lib.check(self._lib.mfb_set_tuning(self._h, int(doppler_chunk), int(masks_per_block)), 'mfb_set_tuning')
+
+    def get_tuning(self):
+        a, b = C.c_int(), C.c_int()
+        _lib.check(self._lib.mfb_get_tuning(self._h, C.byref(a), C.byref(b)), 'mfb_get_tuning')
+        return a.value, b.value
+
+    def set_filters(self, masks):
+        masks = np.asarray(masks)
+        if masks.ndim != 2:
+            raise ValueError(f'filter bank must be 2-D (M, N), got shape {masks.shape}')
+        if masks.dtype != np.complex64:
+            raise TypeError(f'Datatype of masks {masks.dtype}, expected complex64')
+        masks = np.ascontiguousarray(masks)
+        _lib.check(self._lib.mfb_set_filters(self._h, _ptr(masks), masks.shape[0], masks.shape[1]), 'mfb_set_filters')
+
+    def set_shifts(self, shifts):
+        s = np.ascontiguousarray(np.asarray(shifts), dtype=np.int32)
+        _lib.check(self._lib.mfb_set_shifts(self._h, _ptr(s), s.size), 'mfb_set_shifts')
+
+    # -- data in ---------------------------------------------------------------------------------
+    def upload(self, samples=None):
+        """Forward-FFT the pinned input buffer (samples None or the buffer itself) or a host array."""
+        if samples is None or samples is self.input:
+            _lib.check(self._lib.mfb_upload(self._h), 'mfb_upload')
+            return
+        s = np.ascontiguousarray(samples, dtype=np.complex64)
+        _lib.check(self._lib.mfb_upload_from(self._h, _ptr(s), s.size), 'mfb_upload_from')
+
+    def upload_device(self, dev_ptr):
+        _lib.check(self._lib.mfb_upload_device(self._h, C.c_void_p(int(dev_ptr))), 'mfb_upload_device')
+
+    # -- Doppler search --------------------------------------------------------------------------
+    def search_async(self):
+        _lib.check(self._lib.mfb_search_async(self._h), 'mfb_search_async')
+
+    def export_scores_async(self, dev_ptr, row_offset):
+        _lib.check(self._lib.mfb_export_scores_async(self._h, C.c_void_p(int(dev_ptr)), int(row_offset)),
+                   'mfb_export_scores_async')
+
+    def pick(self, dev_scores=None, num=None, offset=None):
+        res = (C.c_float * 2)()
+        num = self.D if num is None else int(num)
+        offset = self.Doff if offset is None else int(offset)
+        _lib.check(self._lib.mfb_pick(self._h, C.c_void_p(int(dev_scores) if dev_scores else 0), num, offset, res), 'mfb_pick')
+        return np.float32(res[0]), np.float32(res[1])
+
+    def find_carrier(self):
+        res = (C.c_float * 2)()
+        _lib.check(self._lib.mfb_find_carrier(self._h, res), 'mfb_find_carrier')
+        return np.float32(res[0]), np.float32(res[1])
+
+    def get_scores(self):
+        out = np.empty((self.Dtot, self.M), dtype=np.float32)
+        _lib.check(self._lib.mfb_get_scores(self._h, _ptr(out)), 'mfb_get_scores')
+        return out
+
+    def get_spectrum(self, start=0, count=None):
+        count = self.N if count is None else int(count)
+        out = np.empty(count, dtype=np.complex64)
+        _lib.check(self._lib.mfb_get_spectrum(self._h, _ptr(out), int(start), count), 'mfb_get_spectrum')
+        return out
+
+    # -- demodulation ----------------------------------------------------------------------------
+    def demodulate(self, shift, k_offset, k_len):
+        res = (C.c_float * 3)()
+        _lib.check(self._lib.mfb_demodulate(self._h, int(shift), int(k_offset), int(k_len), res), 'mfb_demodulate')
+        return np.float32(res[0]), np.float32(res[1]), np.float32(res[2])
+
+    def find_centres(self, spSym, offset, op, count):
+        count = int(count)
+        sym = np.empty(count, dtype=np.int32)
+        cen = np.empty(count, dtype=np.int32)
+        mag = np.empty(count, dtype=np.float32)
+        _lib.check(self._lib.mfb_find_centres(self._h, C.c_float(spSym), C.c_float(offset), int(op), count,
+                                              _ptr(sym), _ptr(cen), _ptr(mag)), 'mfb_find_centres')
+        return sym, cen, mag
+
+    def get_xcorr(self):
+        out = np.empty((self.M, self.N), dtype=np.complex64)
+        _lib.check(self._lib.mfb_get_xcorr(self._h, _ptr(out)), 'mfb_get_xcorr')
+        return out
+
+    def get_envelope(self):
+        out = np.empty(self.N, dtype=np.float32)
+        _lib.check(self._lib.mfb_get_envelope(self._h, _ptr(out)), 'mfb_get_envelope')
+        return out
+
+    # -- timing ----------------------------------------------------------------------------------
+    def timer_start(self):
+        _lib.check(self._lib.mfb_timer_start(self._h), 'mfb_timer_start')
+
+    def timer_stop(self):
+        ms = C.c_float()
+        _lib.check(self._lib.mfb_timer_stop(self._h, C.byref(ms)), 'mfb_timer_stop')
+        return ms.value
+
+    def profile_enable(self, on=True):
+        _lib.check(self._lib.mfb_profile_enable(self._h, int(bool(on))), 'mfb_profile_enable')
+
+    def profile_read(self):
+        cnt = (C.c_int * 2)()
+        ms = (C.c_float * 2)()
+        _lib.check(self._lib.mfb_profile_read(self._h, cnt, ms), 'mfb_profile_read')
+        return (cnt[0], cnt[1]), (ms[0], ms[1])
+
+    def sync(self):
+        _lib.check(self._lib.mfb_sync(self._h), 'mfb_sync')
+
+
+def sync_correlate(bits, template, device=0):
+    """Batched full convolution of 0/1 bit streams with an integer template on the GPU
+    (reference decoder.py:96,112 does this with np.convolve).  ``bits`` uint8 [L] or [B, L];
+    returns int32 [L+T-1] or [B, L+T-1]."""
+    lib = _lib.load()
+    b = np.asarray(bits)
+    single = b.ndim == 1
+    b2 = np.ascontiguousarray(b.reshape(1, -1) if single else b)
+    if b2.dtype != np.uint8:
+        if not np.all((b2 == 0) | (b2 == 1)):
+            raise ValueError('sync_correlate expects a 0/1 bit stream')
+        b2 = b2.astype(np.uint8)
+    t = np.asarray(template)
+    ti = np.ascontiguousarray(t, dtype=np.int8)
+    if not np.array_equal(ti, t):
+        raise ValueError('template must hold small integers (int8)')
+    B, L = b2.shape
+    out = np.empty((B, L + ti.size - 1), dtype=np.int32)
+    _lib.check(lib.mfb_sync_correlate(int(device), _ptr(b2), B, L, _ptr(ti), ti.size, _ptr(out)), 'mfb_sync_correlate')
+    return out[0] if single else out

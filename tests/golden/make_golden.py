@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the *importable numpy parts* of the
+reference (pyCuSDR, mounted read-only at /root/reference in the authoring container).
+
+This script is test infrastructure.  It runs ONLY in the authoring container (the reference does
+not exist on the GPU box); its outputs (``*.npz`` next to this file) are committed and are what
+the tests read.  Nothing of the reference's source text is stored -- only inputs and outputs.
+
+What is captured (SURVEY.md section 8c, G1..G5 + host-logic KATs):
+  G1  filter banks            protocol.*.get_filter          (templates, small banks, digests)
+  G2  symbol LUTs             protocol.*.get_symbolLUT2
+  G3  decoder templates       protocol.*.get_mask / get_syncFlag (+ tolerances, counts)
+  G4  decoder KATs            decoder.Decoder.findFrames on seeded bit streams
+  G5  stimulus                examples/benchmark/create_signals.get_padded_packet
+  G7  host-logic KATs         Demodulator.checkSymbolOverlap / extractBitsNRZs (pure numpy
+                              methods, called unbound on a plain namespace object)
+
+Harness-side shims (the same ones SURVEY.md 8c lists): numpy aliases removed in numpy>=1.24
+(np.float, np.int), an empty ``crcmod`` module (packet CRC only; off the hot path) and, for G7
+only, empty ``pycuda`` / ``lib.cufft`` modules so that the module holding the two pure-numpy methods
+imports (both are glue to closed-source CUDA libraries that cannot exist here).
+No GPU code of the reference is executed (none can be: there is no CUDA here).
+
+Usage:  python tests/golden/make_golden.py      (writes tests/golden/*.npz)
+"""
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _install_shims():
+    sys.dont_write_bytecode = True
+    np.float = float  # noqa: removed aliases the reference still uses
+    np.int = int
+    crc = types.ModuleType('crcmod')
+    crc.mkCrcFun = lambda *a, **k: (lambda b: 0)
+    sys.modules['crcmod'] = crc
+    # pycuda is imported at module level by demodulator_base; only needed so the module object
+    # exists -- none of its functions are called by the pure-numpy methods we exercise.
+    pc = types.ModuleType('pycuda')
+    drv = types.ModuleType('pycuda.driver')
+    comp = types.ModuleType('pycuda.compiler')
+    comp.SourceModule = object
+    pc.driver = drv
+    pc.compiler = comp
+    sys.modules['pycuda'] = pc
+    sys.modules['pycuda.driver'] = drv
+    sys.modules['pycuda.compiler'] = comp
+    sys.path.insert(0, os.path.join(REF, 'pyCuSDR'))
+    sys.path.insert(0, os.path.join(REF, 'examples', 'benchmark'))
+    # lib/cufft.py raises OSError at import when libcufft is absent (lib/cufft.py:45-46); give the
+    # package an empty attribute of that name instead (G7 only; no FFT of the reference is run).
+    import lib as reflib
+    fake = types.ModuleType('lib.cufft')
+    sys.modules['lib.cufft'] = fake
+    reflib.cufft = fake
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def time_templates(bank, tlen):
+    """Recover the time-domain template each bank row was made from: row = conj(fft(t, N))."""
+    t = np.fft.ifft(np.conj(bank.astype(np.complex128)), axis=1)
+    return t[:, :tlen]
+
+
+def g1_g2_g3(out):
+    from protocol.benchmark.bench_GMSK import Bench_GMSK
+    from protocol.benchmark.bench_FSK import Bench_FSK
+    from protocol.benchmark.bench_GFSK import Bench_GFSK
+    from protocol.benchmark.bench_BPSK import Bench_BPSK
+    from protocol.CC11xx import CC11xx
+    from protocol.GFSK2_base import GFSK2
+    from protocol.benchmark.bench_base import Bench_base
+
+    bconf = {'Main': {'PacketLen': 10000, 'RandSeed': 123}}
+    cconf = {'Radios': {'Protocol': {
+        'rx_preamble': ['0xaa'] * 4, 'rx_sync_seq': ['0xd6', '0xba', '0xd6', '0xba'],
+        'tx_preamble': ['0xaa'], 'tx_num_preambles': 10,
+        'tx_sync_seq': ['0xd6', '0xba', '0xd6', '0xba']}}}
+
+    class _GFSK2(Bench_base, GFSK2):      # GFSK2.get_filter itself (CC11xx's alternative base)
+        def get_filter(self, *a):
+            return GFSK2.get_filter(self, *a)
+
+    cases = [
+        ('bench_GMSK', Bench_GMSK(conf=bconf), 16, 3),
+        ('bench_FSK', Bench_FSK(conf=bconf), 16, 3),
+        ('bench_GFSK', Bench_GFSK(conf=bconf), 16, 3),
+        ('bench_BPSK', Bench_BPSK(conf=bconf), 16, 5),
+        ('CC11xx_sps16', CC11xx(conf=cconf), 16, 3),
+        ('CC11xx_sps128', CC11xx(conf=cconf), 128, 3),
+        ('GFSK2_sps16', _GFSK2(conf=bconf), 16, 3),
+    ]
+    for name, p, sps, ms in cases:
+        nsmall = 1 << 10
+        M, bank = p.get_filter(nsmall, sps, ms)
+        out[f'g1/{name}/M'] = np.int64(M)
+        out[f'g1/{name}/sps'] = np.int64(sps)
+        out[f'g1/{name}/maskSize'] = np.int64(ms)
+        out[f'g1/{name}/bank_n1024'] = bank
+        # time-domain templates recovered at a size that holds them without aliasing
+        M2, bank2 = p.get_filter(1 << 12, sps, ms)
+        out[f'g1/{name}/templates'] = time_templates(bank2, ms * sps)
+        for lg in (16, 20):
+            if name not in ('bench_GMSK', 'CC11xx_sps128', 'bench_BPSK') and lg == 20:
+                continue
+            Mb, big = p.get_filter(1 << lg, sps, ms)
+            out[f'g1/{name}/n{lg}_head'] = big[:, :64].copy()
+            out[f'g1/{name}/n{lg}_tail'] = big[:, -64:].copy()
+            out[f'g1/{name}/n{lg}_stride'] = big[:, ::4099].copy()
+            out[f'g1/{name}/n{lg}_sha256'] = np.array(sha(big))
+            del big
+        if name == 'GFSK2_sps16':      # helper class: filter generator only, no LUT of its own
+            continue
+        lut = p.get_symbolLUT2(ms)
+        out[f'g2/{name}/bitLUT_is_none'] = np.bool_(lut[0] is None)
+        if lut[0] is not None:
+            out[f'g2/{name}/bitLUT'] = np.asarray(lut[0])
+        out[f'g2/{name}/symbolLUT'] = np.asarray(lut[1])
+        out[f'g2/{name}/sum_all_masks'] = np.bool_(getattr(p, 'SUM_ALL_MASKS_PYTHON', False))
+        if name in ('bench_GMSK', 'CC11xx_sps16'):
+            key = 'bench' if name == 'bench_GMSK' else 'CC11xx'
+            out[f'g3/{key}/mask'] = np.asarray(p.get_mask())
+            out[f'g3/{key}/syncFlag'] = np.asarray(p.get_syncFlag())
+            out[f'g3/{key}/numOnesHeader'] = np.float64(p.numOnesHeader)
+            out[f'g3/{key}/numOnesSyncSig'] = np.float64(p.numOnesSyncSig)
+            out[f'g3/{key}/headerTol'] = np.int64(p.headerTol)
+            out[f'g3/{key}/syncSigTol'] = np.int64(p.syncSigTol)
+            out[f'g3/{key}/numBitsOverlap'] = np.int64(p.numBitsOverlap)
+            out[f'g3/{key}/packetLen'] = np.int64(p.packetLen)
+    return cases
+
+
+def g4_decoder(out, cases):
+    """KATs for Decoder.findFrames: planted headers with k flipped bits, stream cut in 3 calls."""
+    import decoder as refdec
+    protos = {'bench': cases[0][1], 'CC11xx': cases[4][1]}
+    for key, p in protos.items():
+        tmpl = ((np.flipud(np.asarray(p.get_mask())) + 1) // 2).astype(np.int64)  # header bits
+        rs = np.random.RandomState(7 if key == 'bench' else 8)
+        plen = int(p.packetLen)
+        L = 3 * plen + 9000
+        stream = rs.randint(0, 2, L).astype(np.float64)
+        offsets = [700, 700 + plen + 3100, 700 + 2 * plen + 6000]
+        flips = [0, int(p.headerTol), int(p.headerTol) + 1]
+        payloads = []
+        for off, k in zip(offsets, flips):
+            pkt = rs.randint(0, 2, plen).astype(np.float64)
+            pkt[:len(tmpl)] = tmpl
+            if key == 'CC11xx':   # length byte (index 8), de-whitened with PN9[0]=0xff -> len 20
+                lb = 20 ^ 0xff
+                pkt[64:72] = [(lb >> (7 - i)) & 1 for i in range(8)]
+            fl = rs.choice(len(tmpl), size=k, replace=False)
+            pkt[fl] = 1 - pkt[fl]
+            stream[off:off + plen] = pkt
+            payloads.append(pkt)
+        cuts = [0, offsets[1] + 300, offsets[2] + plen - 40, L]   # 2nd & 3rd packet straddle calls
+        d = refdec.Decoder({}, p)
+        out[f'g4/{key}/stream'] = stream.astype(np.uint8)
+        out[f'g4/{key}/cuts'] = np.array(cuts)
+        out[f'g4/{key}/offsets'] = np.array(offsets)
+        out[f'g4/{key}/flips'] = np.array(flips)
+        for ci in range(3):
+            seg = stream[cuts[ci]:cuts[ci + 1]]
+            pk, bits, nsync = d.findFrames(seg, 0)
+            out[f'g4/{key}/call{ci}/numSyncSig'] = np.int64(nsync)
+            out[f'g4/{key}/call{ci}/npackets'] = np.int64(len(pk))
+            out[f'g4/{key}/call{ci}/overlapBuf_after'] = np.asarray(d.bitsOverlapBuf).astype(np.uint8)
+            for i, q in enumerate(pk):
+                if key == 'bench':
+                    out[f'g4/{key}/call{ci}/p{i}/start'] = np.int64(q.frameStartIdx)
+                    out[f'g4/{key}/call{ci}/p{i}/maskBitErrors'] = np.float64(q.maskBitErrors)
+                out[f'g4/{key}/call{ci}/p{i}/bits'] = np.asarray(q.bits).astype(np.uint8)
+
+
+def g5_stimulus(out):
+    import create_signals as cs
+    out['g5/payload_bits'] = cs.packetData().astype(np.uint8)
+    for mod in ('GMSK', 'FSK', 'GFSK', 'BPSK'):
+        sig, bits = cs.get_padded_packet(mod, 16, 153600)
+        sig = np.asarray(sig)
+        out[f'g5/{mod}/len'] = np.int64(len(sig))
+        out[f'g5/{mod}/dtype'] = np.array(str(sig.dtype))
+        out[f'g5/{mod}/head'] = sig[9990:10200].copy()
+        out[f'g5/{mod}/tail'] = sig[-10200:-9990].copy()
+        out[f'g5/{mod}/stride'] = sig[::397].copy()
+        out[f'g5/{mod}/sha256_c64'] = np.array(sha(sig.astype(np.complex64)))
+    # awgn semantics (legacy global RNG): seed, then one call
+    sig, _ = cs.get_padded_packet('GMSK', 16, 153600)
+    np.random.seed(1)
+    n = cs.awgn(sig[:4096], 10.0)
+    out['g5/awgn/in_head'] = sig[:4096].copy()
+    out['g5/awgn/out_seed1_snr10'] = n
+    # NRZ-S helper used by the BPSK stimulus
+    b = np.random.RandomState(3).randint(0, 2, 64)
+    out['g5/nrzs/in'] = b.astype(np.uint8)
+    out['g5/nrzs/out'] = cs.encodeNRZS(b)
+
+
+def g7_hostlogic(out, cases):
+    """Pure-numpy methods of the reference's Demodulator, called unbound on a namespace."""
+    import demodulator.demodulator_base as db
+    D = db.Demodulator
+    rs = np.random.RandomState(11)
+    N, sps = 1 << 12, 16.0
+
+    def mk_self(ov):
+        s = types.SimpleNamespace()
+        s.sigOverlapWin = ov // 2
+        s.Nfft = N
+        s.overlapOffset = 20
+        s.symbol_check_error_threshold = 1000
+        s.symbol_check_match_threshold = 10
+        s.poswinP = []
+        return s
+
+    # a continuous symbol stream observed through overlapping blocks, with a +/-1 slip injected
+    total = rs.randint(0, 2, 4000).astype(np.float64)
+    # 'short': overlap window (8 symbols) shorter than the 20-symbol comparison -> the reference's
+    # own try/except swallows a broadcast error and skips the alignment (DB:907-967)
+    scen = {'aligned': ([0, 0, 0, 0], 1 << 10), 'early': ([0, 0, 1, 0], 1 << 10),
+            'late': ([0, -1, 0, 0], 1 << 10), 'both': ([0, 1, -1, 0], 1 << 10),
+            'short': ([0, 0, 1, 0], 1 << 8)}
+    for name, (slips, ov) in scen.items():
+        s = mk_self(ov)
+        out[f'g7/overlap/{name}/ov'] = np.int64(ov)
+        step = (N - ov) / sps          # symbols advanced per block
+        for b, slip in enumerate(slips):
+            first = int(round(b * step)) + slip
+            nsym = int(N / sps)
+            centres = (np.arange(nsym) * sps + 5).astype(np.int32)
+            bits = total[first:first + nsym].copy()
+            trust = rs.randint(-128, 127, nsym).astype(np.int8)
+            cw, bw, tw, iw = D.checkSymbolOverlap(s, 0, centres, bits.astype(np.int32), bits, trust)
+            out[f'g7/overlap/{name}/b{b}/centres'] = centres
+            out[f'g7/overlap/{name}/b{b}/bits'] = bits
+            out[f'g7/overlap/{name}/b{b}/trust'] = trust
+            out[f'g7/overlap/{name}/b{b}/centresWin'] = np.asarray(cw)
+            out[f'g7/overlap/{name}/b{b}/bitsWin'] = np.asarray(bw)
+            out[f'g7/overlap/{name}/b{b}/trustWin'] = np.asarray(tw)
+    # NRZ-S extraction with the BPSK 3-D LUT
+    lut = np.asarray(cases[3][1].get_symbolLUT2(5)[1])
+    s = types.SimpleNamespace(symbolLUT=lut, bitLUT=None)
+    syms = rs.randint(0, 16, 500).astype(np.int32)
+    res, err = D.extractBitsNRZs(s, None, syms)
+    out['g7/nrzs/symbols'] = syms
+    out['g7/nrzs/bits'] = np.asarray(res)
+    out['g7/nrzs/symError'] = np.asarray(err, dtype=np.int64)
+
+
+def main():
+    if not os.path.isdir(REF):
+        raise SystemExit('reference not mounted; fixtures can only be regenerated in the authoring container')
+    _install_shims()
+    out = {}
+    cases = g1_g2_g3(out)
+    g4_decoder(out, cases)
+    g5_stimulus(out)
+    g7_hostlogic(out, cases)
+    flat = {k.replace('/', '__'): v for k, v in out.items()}
+    path = os.path.join(HERE, 'ref_goldens.npz')
+    np.savez_compressed(path, **flat)
+    print(f'wrote {path}: {len(flat)} arrays, {os.path.getsize(path)/1e6:.2f} MB')
+
+
+if __name__ == '__main__':
+    main()
