@@ -65,10 +65,12 @@ int mfb_destroy(mfb_ctx *ctx);
  * handle's own stream.  (The reference's analogue is cufftSetStream, CUFFT:365-375.) */
 int mfb_set_stream(mfb_ctx *ctx, void *hip_stream);
 /* Tuning knobs (0 keeps the current value): Doppler bins per launch of the two FFT passes (bounds
- * the intermediate buffer; the reference's analogue is CUDA.batchSize, DB:301-313) and matched
- * filters handled per workgroup in pass 1. */
-int mfb_set_tuning(mfb_ctx *ctx, int doppler_chunk, int masks_per_block);
-int mfb_get_tuning(mfb_ctx *ctx, int *doppler_chunk, int *masks_per_block);
+ * the intermediate buffer; the reference's analogue is CUDA.batchSize, DB:301-313), matched
+ * filters handled per workgroup in pass 1, FFT rows per workgroup in pass 2, and the number of
+ * workgroups that share the Doppler bins of one (tile, filter group) in pass 1.  None of them
+ * changes any result bit: all reductions are fixed-order. */
+int mfb_set_tuning(mfb_ctx *ctx, int doppler_chunk, int masks_per_block, int rows_per_block, int jsplit);
+int mfb_get_tuning(mfb_ctx *ctx, int *doppler_chunk, int *masks_per_block, int *rows_per_block, int *jsplit);
 
 /* Upload the filter bank: host complex64 [M][N], row-major, already conj(fft(template, N)) as
  * protocol.get_filter returns it.  Replaces __uploadMaskToGPU (DB:246-263).  `M`/`N` are what the

@@ -24,6 +24,27 @@ DEVI cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
 DEVI cf cmul(cf a, cf b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 DEVI cf cconj(cf a) { return make_float2(a.x, -a.y); }
 
+// ---- buffer (SRSRC) addressing: one VGPR byte offset + one SGPR offset per access, hardware range
+// check (out-of-range loads return 0, stores are dropped).  Keeps 64-bit per-access address
+// registers out of the unrolled 16-point load/store groups.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+DEVI __amdgpu_buffer_rsrc_t mk_rsrc(const void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), (short)0, (int)bytes, 0x00020000);
+}
+DEVI cf buf_load_cf(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+DEVI float buf_load_f(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+DEVI void buf_store_cf(__amdgpu_buffer_rsrc_t r, int voff, int soff, cf val) {
+    u32x2 v;
+    v.x = __float_as_uint(val.x);
+    v.y = __float_as_uint(val.y);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
+
 constexpr int ilog2c(int x) { return x <= 1 ? 0 : 1 + ilog2c(x >> 1); }
 // radix of pass s for a length-2^l transform: as many 16s as fit, then the remainder
 constexpr int radix_of(int l, int s) { return (s < l / 4) ? 16 : ((s == l / 4 && (l % 4)) ? (1 << (l % 4)) : 0); }
@@ -105,13 +126,44 @@ DEVI void bfly(cf (&v)[16]) {
 }
 
 // ---- pass chain ----------------------------------------------------------------------------
+// Twiddles.  Every pass but the last multiplies output p of butterfly (prefix, t') by
+// W_Lcur^(t'*p).  Only radix-16 passes are ever followed by another pass, so a thread needs 15
+// factors per twiddled pass, and they depend on the thread alone (not on the row / mask / Doppler
+// bin being transformed).  TwRegs keeps them in registers across the work loop of a kernel
+// (HOIST) -- or, for the very large transforms whose register budget is 128, reloads them from
+// the table each time.
+template <int L>
+struct TwRegs {
+    static constexpr int l = ilog2c(L);
+    static constexpr int NTW = npass(l) - 1;  // twiddled passes
+    cf r[NTW > 0 ? NTW : 1][16];
+};
+
+template <int L, int S = 0>
+DEVI void load_twiddles(TwRegs<L> &tw, const cf *__restrict__ table, const int g) {
+    constexpr int l = ilog2c(L);
+    if constexpr (S < npass(l) - 1) {
+        constexpr int Lcur = L >> (4 * S);
+        constexpr int Lnext = Lcur / 16;
+        constexpr int PC = L / Lcur;
+        const int t = g % Lnext;  // NB == 1 for radix-16 passes: beta == g
+        sfor<1, 16>([&](auto p) { tw.r[S][decltype(p)::value] = table[(t * decltype(p)::value) * PC]; });
+        load_twiddles<L, S + 1>(tw, table, g);
+    }
+}
+
 // v    : the thread's 16 points; on entry of pass 0 slot i holds element g + (L/16)*i
-// lds  : exchange buffer of padlen(L)*T elements; element (pos, col) at padi(pos)*T + col
+// lds  : exchange buffer: element (pos, col) at padi(pos)*T + col.  With PP (ping-pong) the buffer
+//        holds two halves of HALF elements used alternately (one barrier per exchange: a half is
+//        rewritten only after a later barrier that every reader of it has passed); without PP one
+//        half is used and every exchange takes two barriers.
+// ebuf : which half the next exchange uses (caller keeps it across calls)
 // g    : thread index inside the FFT group, 0 <= g < L/16 ;  col: column inside the tile
-// tw   : W_L^x = exp(+2*pi*i*x/L), x in [0, L)
-// store(n, value, slot): receives natural output index n; slot is a compile-time register slot id
-template <int L, int T, int S, class Store>
-DEVI void fft_passes(cf (&v)[16], cf *lds, const int g, const int col, const cf *__restrict__ tw, Store &store) {
+// store(n, value, slot, nu): natural output index n = nu + g; slot (register slot id) and nu are
+//        compile-time constants (std::integral_constant)
+template <int L, int T, int S, bool HOIST, bool PP, int HALF, class Store>
+DEVI void fft_passes(cf (&v)[16], cf *lds, int &ebuf, const int g, const int col, const TwRegs<L> &twr,
+                     const cf *__restrict__ table, Store &store) {
     constexpr int l = ilog2c(L);
     constexpr int NP = npass(l);
     constexpr int R = radix_of(l, S);
@@ -125,24 +177,34 @@ DEVI void fft_passes(cf (&v)[16], cf *lds, const int g, const int col, const cf 
 
     if constexpr (S == NP - 1) {
         sfor<0, NB>([&](auto u) {
-            const int beta = g + NT * decltype(u)::value;
             sfor<0, R>([&](auto p) {
                 constexpr int slot = decltype(u)::value * R + decltype(p)::value;
-                store(decltype(p)::value * PC + beta, v[decltype(u)::value * R + rev(R, decltype(p)::value)], std::integral_constant<int, slot>{});
+                // natural index n = nu + g with nu a compile-time constant (wave-uniform part)
+                constexpr int nu = decltype(p)::value * PC + NT * decltype(u)::value;
+                store(nu + g, v[decltype(u)::value * R + rev(R, decltype(p)::value)], std::integral_constant<int, slot>{},
+                      std::integral_constant<int, nu>{});
             });
         });
     } else {
-        sfor<0, NB>([&](auto u) {
-            const int beta = g + NT * decltype(u)::value;
-            const int prefix = beta / Lnext;
-            const int t = beta % Lnext;
+        static_assert(R == 16 && NB == 1, "only radix-16 passes are followed by another pass");
+        cf *buf = lds;
+        if constexpr (PP) {
+            buf = lds + (ebuf ? HALF : 0);
+            ebuf ^= 1;
+        }
+        {
+            const int prefix = g / Lnext;
+            const int t = g % Lnext;
             sfor<0, R>([&](auto p) {
                 constexpr int pp = decltype(p)::value;
-                cf val = v[decltype(u)::value * R + rev(R, pp)];
-                if constexpr (pp > 0) val = cmul(val, tw[(t * pp) * PC]);
-                lds[padi((pp * PC + prefix) * Lnext + t) * T + col] = val;
+                cf val = v[rev(R, pp)];
+                if constexpr (pp > 0) {
+                    if constexpr (HOIST) val = cmul(val, twr.r[S][pp]);
+                    else val = cmul(val, table[(t * pp) * PC]);
+                }
+                buf[padi((pp * PC + prefix) * Lnext + t) * T + col] = val;
             });
-        });
+        }
         __syncthreads();
         constexpr int R2 = radix_of(l, S + 1);
         constexpr int Lnn = Lnext / R2;
@@ -153,10 +215,10 @@ DEVI void fft_passes(cf (&v)[16], cf *lds, const int g, const int col, const cf 
             const int t = beta % Lnn;
             sfor<0, R2>([&](auto i) {
                 v[decltype(u)::value * R2 + decltype(i)::value] =
-                    lds[padi(prefix * Lnext + t + Lnn * decltype(i)::value) * T + col];
+                    buf[padi(prefix * Lnext + t + Lnn * decltype(i)::value) * T + col];
             });
         });
-        __syncthreads();
-        fft_passes<L, T, S + 1>(v, lds, g, col, tw, store);
+        if constexpr (!PP) __syncthreads();
+        fft_passes<L, T, S + 1, HOIST, PP, HALF>(v, lds, ebuf, g, col, twr, table, store);
     }
 }

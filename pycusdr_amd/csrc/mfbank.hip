@@ -58,6 +58,8 @@ struct P1Args {
     int M;        // masks in the bank
     int mpb;      // masks per block
     int j0;       // first Doppler index of this chunk (into shifts)
+    int dc;       // Doppler bins in this chunk
+    int ntiles, mgroups, jsplit;  // 1-D grid = ntiles * mgroups * jsplit workgroups
     int fixed_shift;  // used when shifts == nullptr
 };
 
@@ -76,10 +78,22 @@ struct P2Args {
 
 // ------------------------------------------------------------------------------------------------
 // pass 1: strided N1-point FFTs on a tile of 16 adjacent columns
+//   grid = (N2/16 tiles, mask groups, jsplit); a workgroup keeps its tile and mask group and walks
+//   over the Doppler bins jl = blockIdx.z, blockIdx.z + gridDim.z, ... of the chunk, so the
+//   per-thread twiddles (inner W_N1 and inter-pass W_N) are built once and stay in registers.
 // ------------------------------------------------------------------------------------------------
+template <int L1>
+struct P1Cfg {
+    static constexpr int NT = L1 / 16;
+    static constexpr int HALF = padlen(L1) * TILE;
+    static constexpr bool PP = true;  // 2 * 34 KiB at L1 = 256
+    static constexpr size_t lds_bytes = (size_t)HALF * (PP ? 2 : 1) * sizeof(cf);
+};
+
 template <int L1, int KIND>
 __global__ void __launch_bounds__((L1 / 16) * TILE) k_pass1(P1Args a) {
-    constexpr int NT = L1 / 16;
+    using Cfg = P1Cfg<L1>;
+    constexpr int NT = Cfg::NT;
     constexpr int l1 = ilog2c(L1);
     constexpr int NP = npass(l1);
     constexpr int RL = radix_of(l1, NP - 1);  // radix of the last pass
@@ -90,12 +104,34 @@ __global__ void __launch_bounds__((L1 / 16) * TILE) k_pass1(P1Args a) {
     const int tid = threadIdx.x;
     const int col = tid & (TILE - 1);
     const int g = tid >> 4;
-    const int k2 = blockIdx.x * TILE + col;
-    const int jl = blockIdx.z;
+    // XCD-aware decode of the 1-D grid.  Workgroups are dealt round-robin over the 8 XCDs
+    // (b % 8 names the XCD-sharing group), so inside one XCD consecutive workgroups are made to
+    // share a TILE and differ in the Doppler stream: the tile's filter rows (M x N1 x 128 B) are
+    // then served from that XCD's L2 for every Doppler bin instead of being re-fetched.
+    // Placement only affects speed, never results.
+    int tile, mg, zj;
+    {
+        const int b = blockIdx.x;
+        const int per_tile = a.mgroups * a.jsplit;
+        if ((a.ntiles & 7) == 0) {
+            const int x = b & 7, q = b >> 3;
+            tile = (q / per_tile) * 8 + x;
+            const int r = q % per_tile;
+            mg = r / a.jsplit;
+            zj = r % a.jsplit;
+        } else {
+            tile = b / per_tile;
+            const int r = b % per_tile;
+            mg = r / a.jsplit;
+            zj = r % a.jsplit;
+        }
+    }
+    const int k2 = tile * TILE + col;
     const int N = a.N, N2 = a.N2;
+    int ebuf = 0;
 
-    // inter-pass twiddles W_N^(k2*n1) for the 16 outputs this thread will own; they depend on the
-    // thread only, not on mask or Doppler bin, so they are built once per workgroup.
+    // inter-pass twiddles W_N^(k2*n1) for the 16 outputs this thread owns, and the inner twiddles:
+    // both depend on the thread only -> built once per workgroup, kept in registers.
     cf twN[16];
     sfor<0, NBL>([&](auto u) {
         sfor<0, RL>([&](auto p) {
@@ -104,36 +140,65 @@ __global__ void __launch_bounds__((L1 / 16) * TILE) k_pass1(P1Args a) {
             twN[decltype(u)::value * RL + decltype(p)::value] = cmul(a.twHi[t >> a.lo], a.twLo[t & ((1u << a.lo) - 1u)]);
         });
     });
+    TwRegs<L1> twr;
+    load_twiddles<L1>(twr, a.tw1, g);
 
-    int shift = 0;
-    if constexpr (KIND == KIND_BANK) shift = a.shifts ? a.shifts[a.j0 + jl] : a.fixed_shift;
+    const int ebase = N2 * g + k2;  // element index of slot i: ebase + i * (N2*NT)
+    const int estride = N2 * NT;
+    const unsigned rowbytes = (unsigned)N * sizeof(cf);
+    const int vo_in = ebase * (int)sizeof(cf);   // per-thread byte offset of input slot 0
+    const int vo_out = ebase * (int)sizeof(cf);  // output (n1 = g, k2) sits at the same offset in a Z row
+    const int so_in = estride * (int)sizeof(cf);
+    const int so_out = N2 * (int)sizeof(cf);     // per unit of n1
 
-    cf xv[16];
-    int e[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        e[i] = N2 * (g + NT * i) + k2;
-        if constexpr (KIND == KIND_BANK) xv[i] = a.X[(e[i] + shift) & (N - 1)];
-        else if constexpr (KIND == KIND_FWDC) xv[i] = cconj(a.X[e[i]]);
-        else xv[i] = make_float2(a.Xr[e[i]], 0.f);
-    }
+    // last pass emits n1 = p*PCL + g + NT*u  ->  scalar offset (p*PCL + NT*u) * N2 * 8
+    auto z_store = [&](__amdgpu_buffer_rsrc_t zr, cf val, auto slot, auto nu) {
+        buf_store_cf(zr, vo_out, decltype(nu)::value * so_out, cmul(val, twN[decltype(slot)::value]));
+    };
 
-    const int m0 = (KIND == KIND_BANK) ? blockIdx.y * a.mpb : 0;
-    const int m1 = (KIND == KIND_BANK) ? min(m0 + a.mpb, a.M) : 1;
-    for (int m = m0; m < m1; ++m) {
+    if constexpr (KIND != KIND_BANK) {
         cf v[16];
-        if constexpr (KIND == KIND_BANK) {
-            const cf *mk = a.masks + (size_t)m * N;
+        if constexpr (KIND == KIND_FWDC) {
+            const auto xr = mk_rsrc(a.X, rowbytes);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = cmul(xv[i], mk[e[i]]);
+            for (int i = 0; i < 16; ++i) v[i] = cconj(buf_load_cf(xr, vo_in, i * so_in));
         } else {
+            const auto xr = mk_rsrc(a.Xr, (unsigned)N * sizeof(float));
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = xv[i];
+            for (int i = 0; i < 16; ++i) v[i] = make_float2(buf_load_f(xr, vo_in / 2, i * (so_in / 2)), 0.f);
         }
-        const size_t zrow = (KIND == KIND_BANK) ? ((size_t)jl * a.M + m) : 0;
-        cf *zb = a.Z + zrow * (size_t)N + k2;
-        auto store = [&](int n1, cf val, auto slot) { zb[(size_t)n1 * N2] = cmul(val, twN[decltype(slot)::value]); };
-        fft_passes<L1, TILE, 0>(v, lds, g, col, a.tw1, store);
+        const auto zr = mk_rsrc(a.Z, rowbytes);
+        auto store = [&](int, cf val, auto slot, auto nu) { z_store(zr, val, slot, nu); };
+        fft_passes<L1, TILE, 0, true, Cfg::PP, Cfg::HALF>(v, lds, ebuf, g, col, twr, a.tw1, store);
+    } else {
+        const int m0 = mg * a.mpb;
+        const int m1 = min(m0 + a.mpb, a.M);
+        const auto xr = mk_rsrc(a.X, rowbytes);
+        cf mk[16];  // mask values of the NEXT transform (software prefetch)
+        {
+            const auto mr = mk_rsrc(a.masks + (size_t)m0 * N, rowbytes);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mk[i] = buf_load_cf(mr, vo_in, i * so_in);
+        }
+        for (int jl = zj; jl < a.dc; jl += a.jsplit) {
+            const int shift = a.shifts ? a.shifts[a.j0 + jl] : a.fixed_shift;
+            cf xv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                xv[i] = buf_load_cf(xr, ((ebase + i * estride + shift) & (N - 1)) * (int)sizeof(cf), 0);
+            for (int m = m0; m < m1; ++m) {
+                cf v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = cmul(xv[i], mk[i]);
+                const int mn = (m + 1 < m1) ? (m + 1) : m0;  // always valid: branch-free prefetch
+                const auto mr = mk_rsrc(a.masks + (size_t)mn * N, rowbytes);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mk[i] = buf_load_cf(mr, vo_in, i * so_in);
+                const auto zr = mk_rsrc(a.Z + ((size_t)jl * a.M + m) * (size_t)N, rowbytes);
+                auto store = [&](int, cf val, auto slot, auto nu) { z_store(zr, val, slot, nu); };
+                fft_passes<L1, TILE, 0, true, Cfg::PP, Cfg::HALF>(v, lds, ebuf, g, col, twr, a.tw1, store);
+            }
+        }
     }
 }
 
@@ -146,9 +211,21 @@ DEVI float wave_sum(float x) {
     return x;
 }
 
-template <int L2, int MODE, int RB>
-__global__ void __launch_bounds__((L2 / 16) * RB) k_pass2(P2Args a) {
-    constexpr int NT = L2 / 16;
+template <int L2>
+struct P2Cfg {
+    static constexpr int NT = L2 / 16;
+    static constexpr int RB = NT >= 256 ? 1 : 256 / NT;
+    static constexpr int HALF = padlen(L2) * RB;
+    static constexpr bool PP = (size_t)HALF * 2 * sizeof(cf) <= 72 * 1024;
+    static constexpr bool HOIST = L2 <= 8192;  // 16384-point rows run 1024 threads: 128-VGPR budget
+    static constexpr size_t lds_bytes = (size_t)HALF * (PP ? 2 : 1) * sizeof(cf);
+};
+
+template <int L2, int MODE>
+__global__ void __launch_bounds__((L2 / 16) * P2Cfg<L2>::RB) k_pass2(P2Args a) {
+    using Cfg = P2Cfg<L2>;
+    constexpr int NT = Cfg::NT;
+    constexpr int RB = Cfg::RB;
     constexpr int NTHREADS = NT * RB;
     extern __shared__ __attribute__((aligned(16))) cf lds[];
     __shared__ float red[16];
@@ -156,33 +233,61 @@ __global__ void __launch_bounds__((L2 / 16) * RB) k_pass2(P2Args a) {
     const int tid = threadIdx.x;
     const int g = tid % NT;
     const int rb = tid / NT;
-    cf *mylds = lds + rb * padlen(L2);
+    cf *mylds = lds + rb * padlen(L2);  // both ping-pong halves are laid out [half][rb][padlen]
+    int ebuf = 0;
 
     const int row = blockIdx.y;  // (jl*M + m) for REDUCE, output row for STORE
     const int sr0 = blockIdx.x * a.srb;
     const cf *zrow = a.Z + (size_t)row * a.N;
+    const unsigned fftbytes = (unsigned)L2 * sizeof(cf);
+    const int vo = g * (int)sizeof(cf);
+    constexpr int so = NT * (int)sizeof(cf);
     float acc = 0.f;
 
-    // every thread runs the same number of iterations (the passes contain workgroup barriers);
-    // rows beyond the block's range are computed on zeros and discarded
+    TwRegs<L2> twr;
+    if constexpr (Cfg::HOIST) load_twiddles<L2>(twr, a.tw2, g);
+
+    // Every thread runs the same number of iterations (the passes contain workgroup barriers).
+    // When RB does not divide the block's row range, the surplus row slots recompute the block's
+    // last row: their sums are weighted 0 and their stores rewrite identical values.
+    // For RB == 1 every row descriptor is wave-uniform (SGPRs); for RB > 1 (small transforms) rows
+    // differ inside a wave and the row offset goes into the per-thread byte offset instead.
+    cf nv[16];  // next row (software prefetch)
+    auto load_row = [&](int rsel) {
+        if constexpr (RB == 1) {
+            const auto zr = mk_rsrc(zrow + (size_t)(sr0 + rsel) * L2, fftbytes);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) nv[i] = buf_load_cf(zr, vo, i * so);
+        } else {
+            const auto zr = mk_rsrc(zrow + (size_t)sr0 * L2, (unsigned)a.srb * fftbytes);
+            const int vr = vo + rsel * (int)fftbytes;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) nv[i] = buf_load_cf(zr, vr, i * so);
+        }
+    };
+    load_row(min(rb, a.srb - 1));
     for (int base = 0; base < a.srb; base += RB) {
-        const bool ok = (base + rb) < a.srb;
-        const int sr = sr0 + base + (ok ? rb : 0);
-        const cf *zr = zrow + (size_t)sr * L2;
+        const int rsel = min(base + rb, a.srb - 1);
+        const float okf = (base + rb < a.srb) ? 1.f : 0.f;
         cf v[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = ok ? zr[g + NT * i] : make_float2(0.f, 0.f);
+        for (int i = 0; i < 16; ++i) v[i] = nv[i];
+        if (base + RB < a.srb) load_row(min(base + RB + rb, a.srb - 1));  // wave-uniform condition
         if constexpr (MODE == MODE_REDUCE) {
-            auto store = [&](int, cf val, auto) { acc += val.x * val.x + val.y * val.y; };
-            fft_passes<L2, 1, 0>(v, mylds, g, 0, a.tw2, store);
+            float racc = 0.f;
+            auto store = [&](int, cf val, auto, auto) { racc += val.x * val.x + val.y * val.y; };
+            fft_passes<L2, 1, 0, Cfg::HOIST, Cfg::PP, Cfg::HALF>(v, mylds, ebuf, g, 0, twr, a.tw2, store);
+            acc += (RB == 1) ? racc : racc * okf;
         } else {
-            cf *ob = a.out + (size_t)row * a.N + sr;
-            const int N1 = a.N1;
+            // y[n1 + N1*n2], n2 = nu + g: byte offset (sr + N1*g)*8 per thread + nu*N1*8 uniform
+            const auto orr = mk_rsrc(a.out + (size_t)row * a.N, (unsigned)a.N * sizeof(cf));
+            const int vout = (sr0 + rsel + a.N1 * g) * (int)sizeof(cf);
+            const int sout = a.N1 * (int)sizeof(cf);
             const float sgn = a.conj_out ? -1.f : 1.f;
-            auto store = [&](int n2, cf val, auto) {
-                if (ok) ob[(size_t)n2 * N1] = make_float2(val.x, sgn * val.y);
+            auto store = [&](int, cf val, auto, auto nu) {
+                buf_store_cf(orr, vout, decltype(nu)::value * sout, make_float2(val.x, sgn * val.y));
             };
-            fft_passes<L2, 1, 0>(v, mylds, g, 0, a.tw2, store);
+            fft_passes<L2, 1, 0, Cfg::HOIST, Cfg::PP, Cfg::HALF>(v, mylds, ebuf, g, 0, twr, a.tw2, store);
         }
     }
 
@@ -401,7 +506,7 @@ struct mfb_ctx {
     int device;
     int log2N, N, N1, N2, l1, l2, lo;
     int D, Doff, Dtot, M, W, sum_all, cs_off;
-    int chunk, mpb;
+    int chunk, mpb, jsplit;
     int parts, srb;
     hipStream_t own_stream, stream;
     cf *h_in;  // pinned
@@ -459,6 +564,19 @@ static int upload_tw(cf **dst, const std::vector<cf> &v) {
     return MFB_OK;
 }
 
+// pass-2 work split: sub-rows (n1 values) per workgroup; a power of two in [RB, N1]
+static void set_rows_per_block(mfb_ctx *c, int srb) {
+    const int NT = c->N2 / 16;
+    const int RB = NT >= 256 ? 1 : 256 / NT;
+    int p = 1;
+    while (p * 2 <= srb) p *= 2;
+    srb = p;
+    if (srb < RB) srb = RB;
+    if (srb > c->N1) srb = c->N1;
+    c->srb = srb;
+    c->parts = c->N1 / srb;
+}
+
 static int alloc_Z(mfb_ctx *c) {
     const size_t rows = (size_t)c->chunk * c->M;
     const size_t need = rows > (size_t)c->M ? rows : (size_t)c->M;
@@ -503,25 +621,21 @@ extern "C" int mfb_create(mfb_ctx **out, int device, int log2N, int num_dopplers
     c->W = window_width;
     c->sum_all = sum_all_masks ? 1 : 0;
     c->cs_off = code_search_mask_offset;
-    // chunk: keep the intermediate near 128 MiB so that it can stay in the 256 MiB Infinity Cache
+    // Doppler bins per launch: as many as a 16 GiB intermediate holds.  Measured on MI355X (C2:
+    // D=256, M=8, N=2^20): large chunks win -- long persistent loops amortise the per-workgroup
+    // twiddle setup and keep each XCD's L2 serving the filter tile to many Doppler streams; keeping
+    // the intermediate inside the 256 MiB Infinity Cache (chunk 1-2) was slower (under-filled grid).
     {
         const size_t row_bytes = (size_t)c->N * sizeof(cf) * M;
-        size_t ch = ((size_t)128 << 20) / row_bytes;
+        size_t ch = ((size_t)16 << 30) / row_bytes;
         if (ch < 1) ch = 1;
         if (ch > (size_t)c->Dtot) ch = c->Dtot;
+        if (ch * M > 65535) ch = 65535 / M;
         c->chunk = (int)ch;
     }
-    c->mpb = M < 4 ? M : 4;
-    // pass-2 work split: sub-rows per workgroup
-    {
-        const int NT = c->N2 / 16;
-        const int RB = NT >= 256 ? 1 : 256 / NT;
-        int srb = 16;
-        if (srb < RB) srb = RB;
-        if (srb > c->N1) srb = c->N1;
-        c->srb = srb;
-        c->parts = c->N1 / srb;
-    }
+    c->mpb = M < 8 ? M : 8;
+    c->jsplit = 32;
+    set_rows_per_block(c, 64);
 
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
@@ -537,7 +651,7 @@ extern "C" int mfb_create(mfb_ctx **out, int device, int log2N, int num_dopplers
     HIPCHK(hipMalloc((void **)&c->d_P, nb));
     HIPCHK(hipMalloc((void **)&c->d_env, (size_t)c->N * sizeof(float)));
     HIPCHK(hipMalloc((void **)&c->d_shifts, (size_t)c->Dtot * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&c->d_part, (size_t)c->Dtot * M * c->parts * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&c->d_part, (size_t)c->Dtot * M * c->N1 * sizeof(float)));
     HIPCHK(hipMalloc((void **)&c->d_sum, (size_t)c->Dtot * M * sizeof(float)));
     HIPCHK(hipMemset(c->d_sum, 0, (size_t)c->Dtot * M * sizeof(float)));
     HIPCHK(hipMalloc((void **)&c->d_res, 2 * sizeof(float)));
@@ -590,18 +704,23 @@ extern "C" int mfb_set_stream(mfb_ctx *c, void *s) {
     return MFB_OK;
 }
 
-extern "C" int mfb_set_tuning(mfb_ctx *c, int chunk, int mpb) {
-    if (!c || chunk < 0 || mpb < 0) return MFB_ERR_ARG;
+extern "C" int mfb_set_tuning(mfb_ctx *c, int chunk, int mpb, int rows_per_block, int jsplit) {
+    if (!c || chunk < 0 || mpb < 0 || rows_per_block < 0 || jsplit < 0) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (rows_per_block > 0) set_rows_per_block(c, rows_per_block);
+    if (jsplit > 0) c->jsplit = jsplit;
     if (chunk > 0) c->chunk = chunk > c->Dtot ? c->Dtot : chunk;
     if (c->chunk * c->M > 65535) c->chunk = 65535 / c->M;  // grid.y limit of pass 2
     if (mpb > 0) c->mpb = mpb > c->M ? c->M : mpb;
     return alloc_Z(c);
 }
-extern "C" int mfb_get_tuning(mfb_ctx *c, int *chunk, int *mpb) {
+extern "C" int mfb_get_tuning(mfb_ctx *c, int *chunk, int *mpb, int *rows_per_block, int *jsplit) {
     if (!c) return MFB_ERR_ARG;
     if (chunk) *chunk = c->chunk;
     if (mpb) *mpb = c->mpb;
+    if (rows_per_block) *rows_per_block = c->srb;
+    if (jsplit) *jsplit = c->jsplit;
     return MFB_OK;
 }
 
@@ -652,7 +771,14 @@ static void prof_mark(mfb_ctx *c, int which) {
 
 template <int L1, int KIND>
 static int launch_p1_t(mfb_ctx *c, const P1Args &a, dim3 grid) {
-    const size_t lds = (size_t)padlen(L1) * TILE * sizeof(cf);
+    const size_t lds = P1Cfg<L1>::lds_bytes;
+    if (lds > 48 * 1024) {
+        static bool done = false;  // per instantiation
+        if (!done) {
+            HIPCHK(hipFuncSetAttribute((const void *)k_pass1<L1, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            done = true;
+        }
+    }
     hipLaunchKernelGGL((k_pass1<L1, KIND>), grid, dim3((L1 / 16) * TILE), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return MFB_OK;
@@ -671,16 +797,16 @@ static int launch_p1(mfb_ctx *c, const P1Args &a, dim3 grid) {
 template <int L2, int MODE>
 static int launch_p2_t(mfb_ctx *c, const P2Args &a, dim3 grid) {
     constexpr int NT = L2 / 16;
-    constexpr int RB = NT >= 256 ? 1 : 256 / NT;
-    const size_t lds = (size_t)padlen(L2) * RB * sizeof(cf);
+    constexpr int RB = P2Cfg<L2>::RB;
+    const size_t lds = P2Cfg<L2>::lds_bytes;
     if (lds > 48 * 1024) {
         static bool done = false;  // per instantiation
         if (!done) {
-            HIPCHK(hipFuncSetAttribute((const void *)k_pass2<L2, MODE, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(hipFuncSetAttribute((const void *)k_pass2<L2, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             done = true;
         }
     }
-    hipLaunchKernelGGL((k_pass2<L2, MODE, RB>), grid, dim3(NT * RB), lds, c->stream, a);
+    hipLaunchKernelGGL((k_pass2<L2, MODE>), grid, dim3(NT * RB), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return MFB_OK;
 }
@@ -735,7 +861,10 @@ static int forward_fft(mfb_ctx *c, const cf *src_c, const float *src_r, cf *dst)
     P1Args a = p1_base(c);
     a.X = src_c;
     a.Xr = src_r;
-    dim3 g1(c->N2 / TILE, 1, 1);
+    a.ntiles = c->N2 / TILE;
+    a.mgroups = 1;
+    a.jsplit = 1;
+    dim3 g1(a.ntiles, 1, 1);
     int rc = src_c ? launch_p1<KIND_FWDC>(c, a, g1) : launch_p1<KIND_FWDR>(c, a, g1);
     if (rc) return rc;
     P2Args b = p2_base(c);
@@ -789,8 +918,13 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
         a.X = c->d_X;
         a.shifts = c->d_shifts;
         a.j0 = j0;
+        a.dc = dc;
+        const int js = c->jsplit < dc ? c->jsplit : dc;
+        a.ntiles = c->N2 / TILE;
+        a.mgroups = mgroups;
+        a.jsplit = js;
         prof_mark(c, 0);
-        int rc = launch_p1<KIND_BANK>(c, a, dim3(c->N2 / TILE, mgroups, dc));
+        int rc = launch_p1<KIND_BANK>(c, a, dim3(a.ntiles * mgroups * js, 1, 1));
         prof_mark(c, 0);
         if (rc) return rc;
         P2Args b = p2_base(c);
@@ -866,8 +1000,12 @@ extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, fl
     a.X = c->d_X;
     a.shifts = nullptr;
     a.fixed_shift = shift;
+    a.dc = 1;
     const int mgroups = (c->M + c->mpb - 1) / c->mpb;
-    int rc = launch_p1<KIND_BANK>(c, a, dim3(c->N2 / TILE, mgroups, 1));
+    a.ntiles = c->N2 / TILE;
+    a.mgroups = mgroups;
+    a.jsplit = 1;
+    int rc = launch_p1<KIND_BANK>(c, a, dim3(a.ntiles * mgroups, 1, 1));
     if (rc) return rc;
     P2Args b = p2_base(c);
     b.out = c->d_xc;

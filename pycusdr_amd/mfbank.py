@@ -51,13 +51,14 @@ class MFBank:
     def set_stream(self, hip_stream):
         _lib.check(self._lib.mfb_set_stream(self._h, C.c_void_p(hip_stream or 0)), 'mfb_set_stream')
 
-    def set_tuning(self, doppler_chunk=0, masks_per_block=0):
-        _lib.check(self._lib.mfb_set_tuning(self._h, int(doppler_chunk), int(masks_per_block)), 'mfb_set_tuning')
+    def set_tuning(self, doppler_chunk=0, masks_per_block=0, rows_per_block=0, jsplit=0):
+        _lib.check(self._lib.mfb_set_tuning(self._h, int(doppler_chunk), int(masks_per_block), int(rows_per_block),
+                                            int(jsplit)), 'mfb_set_tuning')
 
     def get_tuning(self):
-        a, b = C.c_int(), C.c_int()
-        _lib.check(self._lib.mfb_get_tuning(self._h, C.byref(a), C.byref(b)), 'mfb_get_tuning')
-        return a.value, b.value
+        a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _lib.check(self._lib.mfb_get_tuning(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), 'mfb_get_tuning')
+        return a.value, b.value, c.value, d.value
 
     def set_filters(self, masks):
         masks = np.asarray(masks)

@@ -1,0 +1,11 @@
+#!/bin/bash
+# usage: tools/pmc.sh <tag> <args to run1.py...>   (run on the GPU box)
+tag=$1; shift
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag/trace -- python3 tools/run1.py "$@" > gpurun_out/$tag.trace.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d gpurun_out/$tag/pmc1 -- python3 tools/run1.py "$@" > gpurun_out/$tag.pmc1.log 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM --output-format csv -d gpurun_out/$tag/pmc2 -- python3 tools/run1.py "$@" > gpurun_out/$tag.pmc2.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d gpurun_out/$tag/pmc3 -- python3 tools/run1.py "$@" > gpurun_out/$tag.pmc3.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/$tag/pmc4 -- python3 tools/run1.py "$@" > gpurun_out/$tag.pmc4.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/$tag/pmc5 -- python3 tools/run1.py "$@" > gpurun_out/$tag.pmc5.log 2>&1
+echo done
