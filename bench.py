@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py -- IQ Msamples/s through the Doppler matched-filter bank on MI355X.
+
+One "step" = one pass of the hot path over one N-sample block already resident in HBM:
+forward FFT -> shift-multiply -> D*M inverse FFTs -> |.|^2 row sums -> Doppler pick, including the
+8-byte result read-back the reference blocks on (A3..A7 of SURVEY.md section 8).
+
+  N=1 : config C2  (D=256 Doppler bins, M=8 GMSK matched filters, N=2^20, ov=2^10)
+  N>1 : config C4  (256 bins per GPU, D=256*G sharded by bin; every rank sees the same block;
+        one RCCL all-reduce of the [D, M] float32 scores per block, then the pick on every rank).
+        Weak scaling: per-GPU work is fixed.  `value` counts the samples every rank pushed through
+        its 256-bin bank, i.e. (N-ov) * G per step ("Msamples/s of 256-bin-bank work").
+
+Launch for N>1 (driver):  python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+                          --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12   # B/s, MI355X spec (MI355X_MICROARCH.md)
+
+
+def b_alg(D, M, N):
+    """Algorithmic bytes of one block through A3..A7."""
+    return 16.0 * D * M * N + 8.0 * N * (1 + M) + 16.0 * N + 4.0 * D
+
+
+def widen_range_rate(conf, radio, N, D):
+    """widen rangeRateMax until the D shifts are distinct after rounding."""
+    from pycusdr_amd.demodulator.demodulator_base import doppler_bin_table
+    rr = conf['Radios']['rangeRateMax']
+    while True:
+        _, _, shifts, _ = doppler_bin_table(conf['Radios']['Rx'][radio], rr, N)
+        if len(np.unique(shifts)) == len(shifts) or rr > 2.0e5:
+            return rr, shifts
+        rr *= 1.25
+
+
+def cpu_baseline(masks, shifts, x_block, N, ov, D, budget_bins=None):
+    """The oracle's Doppler search (numpy/scipy restatement, float32 arithmetic) timed on this
+    host's cores on a bounded sample of the same workload: the first `nb` of the D Doppler bins of
+    one block; the per-block figure is scaled by D/nb.  Reported baseline, not a target."""
+    import scipy.fft as sfft
+    from oracle import mfbank_oracle as orc
+    cores = os.cpu_count() or 1
+    X = orc.forward_fft(x_block)
+    Mw = masks.astype(np.complex64)
+
+    def run(nb):
+        t0 = time.perf_counter()
+        out = np.zeros(nb)
+        for j in range(nb):
+            prod = np.roll(X, -int(shifts[j]))[None, :] * Mw
+            y = sfft.ifft(prod, axis=-1, norm='forward', workers=cores)
+            out[j] = (y.real.astype(np.float64) ** 2 + y.imag.astype(np.float64) ** 2).sum() / orc.SCALE_2_18
+        return time.perf_counter() - t0, out
+    t1, _ = run(1)                       # warm-up + calibration
+    nb = budget_bins or int(max(2, min(D, round(12.0 / max(t1, 1e-3)))))
+    t, scores = run(nb)
+    t_block = t * D / nb
+    return {
+        'value': round((N - ov) / t_block / 1e6, 5), 'unit': 'Msamples/s', 'cores': cores, 'kind': 'port',
+        'sample': f'{nb} of {D} Doppler bins of one 2^{int(np.log2(N))}-sample block (M={masks.shape[0]}), '
+                  f'{t:.1f} s of scipy.fft complex64 work with workers={cores}; per-block time scaled by D/{nb}',
+    }, scores
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--log2n', type=int, default=20)
+    ap.add_argument('--bins', type=int, default=256, help='Doppler bins per GPU')
+    ap.add_argument('--protocol', default='bench_GMSK')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--tuning', default='', help='chunk,mpb,rows,jsplit (0 = default)')
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__
+    __graft_entry__.build()
+    from pycusdr_amd import config as cfg, signals as sg
+    from pycusdr_amd.mfbank import MFBank
+    from pycusdr_amd.protocol import loadProtocol
+    from pycusdr_amd.dist import DopplerShard, bin_slice
+
+    G = args.gpus
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if G > 1 or world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        G = dist.get_world_size()
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device('cuda', local_rank)
+
+    log2N, ov = args.log2n, 1 << 10
+    N = 1 << log2N
+    D_total = args.bins * G
+    M_size = 5 if args.protocol == 'bench_BPSK' else 3
+    conf = cfg.bench_config(args.protocol, blockSize=log2N, overlap=10, doppCarrierSteps=D_total, device=local_rank)
+    rr, shifts = widen_range_rate(conf, 'UHF-H', N, D_total)
+    conf['Radios']['rangeRateMax'] = rr
+    proto = loadProtocol(args.protocol)(conf=conf)
+    M, masks = proto.get_filter(N, 16, M_size)
+    lo, hi = bin_slice(D_total, rank, G)
+
+    bank = MFBank(log2N, hi - lo, M, window_width=7, sum_all_masks=True, device=local_rank)
+    bank.set_filters(masks)
+    bank.set_shifts(shifts[lo:hi])
+    if args.tuning:
+        bank.set_tuning(*[int(v) for v in args.tuning.split(',')])
+    shard = None
+    if G > 1:
+        shard = DopplerShard(rank=rank, world=G, device=dev)
+        shard.attach(bank, D_total, M)
+
+    # synthetic input S1: the reference's GMSK bench packet at +fs/4, tiled, AWGN 10 dB, resident in HBM
+    nblocks = 8
+    stream = sg.s1_stream(nblocks, N, ov, 'GMSK', 16, 153600, snr_db=10.0, seed=1)
+    host_blocks = np.stack([stream[b * (N - ov): b * (N - ov) + N] for b in range(nblocks)])
+    blocks = torch.from_numpy(host_blocks.view(np.float32).reshape(nblocks, 2 * N)).to(dev)
+    esz = blocks.element_size() * 2 * N
+
+    def step(i):
+        bank.upload_device(blocks.data_ptr() + (i % nblocks) * esz)
+        if shard is None:
+            return bank.find_carrier()
+        return shard.search_and_pick(bank, lo)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        res = step(i)
+    barrier()
+    bank.profile_enable(True)
+    bank.timer_start()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        res = step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ev_ms = bank.timer_stop()
+    counts, kms = bank.profile_read()
+    bank.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # live sanity: the pick must land on the +fs/4 carrier
+    frac_idx = float(res[0])
+    pick_shift = float(np.interp(frac_idx, np.arange(D_total), np.where(shifts > N // 2, shifts - N, shifts)))
+    spacing = float(np.median(np.diff(np.sort(shifts))))
+    carrier_ok = abs(pick_shift - N / 4) <= 1.5 * spacing
+
+    out = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = (N - ov) * G / (elapsed / args.steps) / 1e6
+        Dl = hi - lo
+        tun = bank.get_tuning()
+        # dominant kernel of the search and its own algorithmic bytes per launch
+        dom = 0 if kms[0] >= kms[1] else 1
+        names = ['k_pass1<256,BANK> (shift-multiply + column FFT + twiddle -> Z)',
+                 'k_pass2<4096,REDUCE> (row FFT + |.|^2 reduction)']
+        launches = max(counts[dom], 1)
+        bins_per_launch = Dl * args.steps / launches
+        if dom == 0:
+            k_bytes = 8.0 * bins_per_launch * M * N + 8.0 * N * (1 + M)   # Z write + spectrum + filter bank read once
+        else:
+            k_bytes = 8.0 * bins_per_launch * M * N + 4.0 * bins_per_launch * M  # Z read + partial sums
+        k_avg_s = kms[dom] / launches * 1e-3
+        achieved = k_bytes / k_avg_s
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(tfile):
+            try:
+                rec = json.load(open(tfile))
+                key = f'D{Dl}_M{M}_N{log2N}_chunk{tun[0]}'
+                traffic = rec.get(key, {}).get('pass1' if dom == 0 else 'pass2')
+            except Exception:
+                traffic = None
+        t_block_dev = ev_ms / args.steps * 1e-3
+        out = {
+            'metric': 'IQ Msamples/sec through Doppler matched-filter bank (256 bins, 2^20 chunk)',
+            'value': round(value, 3), 'unit': 'Msamples/s', 'n_gpus': G, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {
+                'workload': ('C2: single MI355X, D=256 Doppler bins, M=8 GMSK matched filters (bench_GMSK), '
+                             'N=2^20 complex64 chunk, ov=2^10' if G == 1 and log2N == 20 and args.bins == 256 else
+                             f'C4-style: D={D_total} Doppler bins sharded {Dl}/GPU over {G} GPUs, M={M}, N=2^{log2N}, '
+                             'RCCL all-reduce of the [D,M] scores per block'),
+                'D_total': D_total, 'D_per_gpu': Dl, 'M': M, 'log2N': log2N, 'overlap': ov,
+                'signal': 'S1: GMSK bench packet at +fs/4, tiled, AWGN 10 dB (RandomState(1)), resident in HBM',
+                'rangeRateMax_used': rr, 'tuning(chunk,mpb,rows,jsplit)': list(tun),
+                'units': 'samples through a 256-bin bank, summed over ranks',
+                'carrier_found': bool(carrier_ok),
+            },
+            'roofline': {
+                'bound': 'hbm', 'kernel': names[dom], 'achieved': round(achieved / 1e9, 2), 'peak': HBM_PEAK / 1e9,
+                'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK, 4), 'traffic': traffic,
+                'launches': launches, 'avg_launch_ms': round(k_avg_s * 1e3, 4), 'alg_bytes_per_launch': k_bytes,
+                'other_kernel_avg_ms': round(kms[1 - dom] / max(counts[1 - dom], 1), 4),
+                'pipeline': {'B_alg_per_block': b_alg(Dl, M, N), 'device_ms_per_block': round(t_block_dev * 1e3, 4),
+                             'achieved_GBps': round(b_alg(Dl, M, N) / t_block_dev / 1e9, 2),
+                             'frac': round(b_alg(Dl, M, N) / t_block_dev / HBM_PEAK, 4)},
+            },
+        }
+        if not args.no_cpu_baseline and G == 1:
+            cb, cscores = cpu_baseline(masks, shifts[lo:hi], host_blocks[(args.steps - 1) % nblocks], N, ov, Dl)
+            # the bounded CPU sample doubles as a full-size parity spot check of the last block
+            gscores = bank.get_scores()[:len(cscores), 0]
+            cb['max_rel_diff_vs_gpu'] = float(np.abs(gscores - cscores).max() / cscores.max())
+            out['cpu_baseline'] = cb
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    bank.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == '__main__':
+    main()

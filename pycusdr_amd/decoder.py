@@ -1,0 +1,140 @@
+"""Decoder: packet search in the demodulated bit stream by sync/preamble correlation.
+
+Same surface as the reference's ``decoder.Decoder`` (reference decoder.py:16-293):
+``Decoder(config, protocol)`` and ``findFrames(bits_raw, frameStartIdx) -> (packets, bits,
+numSyncSig)``.  The two correlations that the reference computes with ``np.convolve``
+(decoder.py:96,112) run on the GPU through ``mfb_sync_correlate`` (exact integers); the packet
+state machine around them is host logic, as in the reference.  ``correlator`` may be injected (tests
+pin the host logic on CPU-only machines with the oracle's correlator); the default is the HIP path
+and raises if libmfbank.so is unavailable.
+"""
+import logging
+
+import numpy as np
+
+from .protocol import PacketEndDetect
+
+log = logging.getLogger('pycusdr_amd.decoder')
+
+
+def _hip_correlator(bits, template):
+    from .mfbank import sync_correlate
+    return sync_correlate(bits, template)
+
+
+class Decoder:
+    maxPacketLenBits = int(2 ** 13)
+    minNumBitsBeforeProcessing = int(2 ** 10)
+
+    def __init__(self, config, protocol, correlator=None):
+        self.conf = config
+        self.protocol = protocol
+        self.correlate = correlator if correlator is not None else _hip_correlator
+        self.preprocessor = protocol.decoderPreprocessor
+        self.postprocessor = protocol.decoderPostprocessor
+        self.mask = protocol.get_mask()
+        self.syncSig = protocol.get_syncFlag()
+        self.numBitsOverlap = protocol.numBitsOverlap
+        self.bitsOverlapBuf = np.zeros(self.numBitsOverlap)
+        # cross-block packet state (FLAGS mode)
+        self.headerFrameStartIdx = None
+        self.packetBuffer = None
+        self.headerMaskBitErrors = None
+        self.packetEndDetectMode = protocol.packetEndDetectMode
+        self.packetEndLenDecoder = protocol.packetEndLenDecoder
+        self.packetSizes = protocol.packet_sizes
+        self.packetLen = protocol.packetLen
+        self.packetEndLenField = protocol.packetEndLenField
+        self.packetEndLenFieldNumBytes = protocol.packetEndLenFieldNumBytes
+        self.Packet = protocol.Packet
+
+    # ------------------------------------------------------------------------------------------
+    def correlate_streams(self, bits):
+        """Header and sync scores of one bit stream (the two np.convolve calls of the reference)."""
+        return self.correlate(bits, self.mask), self.correlate(bits, self.syncSig)
+
+    def findFrames(self, bits_raw, frameStartIdx, debugMode=False):
+        p = self.protocol
+        bits_less_raw = self.preprocessor(bits_raw)
+        rawBits_DS = np.concatenate((self.bitsOverlapBuf, bits_less_raw))
+        self.bitsOverlapBuf = rawBits_DS[-self.numBitsOverlap:]
+
+        score, syncSigs = self.correlate_streams(rawBits_DS)
+        idxCand = np.where(score >= p.numOnesHeader - p.headerTol)[0]
+        packetIdx = idxCand - len(self.mask) + 1          # the peak sits on the template's last bit
+        syncSigStartIdx = np.where(syncSigs >= p.numOnesSyncSig - p.syncSigTol)[0]
+        numSyncSig = len(syncSigStartIdx)
+
+        if self.packetEndDetectMode == PacketEndDetect.FLAGS:
+            packets = self._frames_by_flags(rawBits_DS, bits_less_raw, frameStartIdx, score, idxCand, packetIdx,
+                                            syncSigStartIdx)
+        elif self.packetEndDetectMode == PacketEndDetect.FIXED:
+            packets = self._frames_fixed(rawBits_DS, score, idxCand, packetIdx)
+        else:   # IN_DATA: the reference only calls protocol.packetDataProcessor() per header
+            packets = []
+            for _ in packetIdx:
+                self.protocol.packetDataProcessor()
+        return packets, bits_less_raw, numSyncSig
+
+    # ---- FIXED: packets of protocol.packetLen bits (reference decoder.py:245-280) ---------------
+    def _frames_fixed(self, stream, score, idxCand, packetIdx):
+        packets = []
+        for i, start in enumerate(packetIdx):
+            if len(stream) - start < self.packetLen:
+                # not all bits here yet: make sure the candidate survives in the overlap buffer
+                keep_from = max((0, start - 20))
+                if len(stream) - keep_from > self.numBitsOverlap:
+                    self.bitsOverlapBuf = stream[keep_from:]
+                break
+            bits = stream[start:start + self.packetLen]
+            if len(bits) > 0:
+                packets.append(self.Packet(bits, start, self.protocol.numOnesHeader - score[idxCand[i]]))
+            else:
+                log.error('length of bits = 0. len(stream) = %d, idx start %d', len(stream), start)
+        return packets
+
+    # ---- FLAGS: a packet runs from a header to the next sync flag (reference decoder.py:122-243) --
+    def _flag_end(self, syncSigStartIdx, after, strict_first):
+        """Index where a frame starting before ``after`` ends, or None."""
+        p = self.protocol
+        if len(syncSigStartIdx) == 0:
+            return None
+        k = np.argmax(syncSigStartIdx > after)
+        if strict_first and k == 0:
+            return None
+        if syncSigStartIdx[k] < p.numOnesSyncSig - p.syncSigTol:
+            return None
+        return np.min((syncSigStartIdx[k] + 16, syncSigStartIdx[-1]))
+
+    def _frames_by_flags(self, stream, new_bits, frameStartIdx, score, idxCand, packetIdx, syncSigStartIdx):
+        p = self.protocol
+        packets = []
+        if self.headerFrameStartIdx is not None:
+            end = self._flag_end(syncSigStartIdx, 0, strict_first=False)
+            if end is None:
+                room = self.maxPacketLenBits - len(self.packetBuffer)
+                if room > len(new_bits):
+                    self.packetBuffer = np.append(self.packetBuffer, new_bits)
+                else:
+                    # the reference's append result is discarded here (decoder.py:173)
+                    packets.append(self.Packet(self.packetBuffer, self.headerFrameStartIdx, self.headerMaskBitErrors))
+                    self.headerFrameStartIdx = None
+            else:
+                split = len(self.packetBuffer)
+                self.packetBuffer = np.append(self.packetBuffer, stream[self.numBitsOverlap:end])
+                packets.append(self.Packet(self.packetBuffer, self.headerFrameStartIdx, self.headerMaskBitErrors,
+                                           frameSplitIdx=split))
+                self.headerFrameStartIdx = None
+        if self.headerFrameStartIdx is None:
+            for i, start in enumerate(packetIdx):
+                end = self._flag_end(syncSigStartIdx, start + 120, strict_first=True)
+                errs = p.numOnesHeader - score[idxCand[i]]
+                if end is None:
+                    self.packetBuffer = stream[start:]
+                    self.headerFrameStartIdx = frameStartIdx + start - self.numBitsOverlap
+                    self.headerMaskBitErrors = errs
+                else:
+                    bits = stream[start:end]
+                    if len(bits) >= 128:
+                        packets.append(self.Packet(bits, start + frameStartIdx, errs))
+        return packets

@@ -1,0 +1,390 @@
+"""Host driver of the MI355X receive hot path: the ``Demodulator`` class.
+
+Same constructor, methods, return tuples and error behaviour as the reference's
+``demodulator.demodulator_base.Demodulator`` (reference demodulator_base.py:36-1060), so that the
+caller (``Demodulator_process.run``, reference demodulator_process.py:242-297) can switch to it
+unchanged.  Everything the reference did with PyCUDA kernels and cuFFT goes through the C ABI of
+libmfbank.so (hand-written HIP, include/mfbank.h); what the reference did in numpy on the host
+(Doppler table, index interpolation, SNR, bit LUTs, block-overlap alignment, clipped-peak tagging)
+stays numpy on the host.
+
+There is no CPU fallback: constructing a Demodulator without libmfbank.so / a GPU raises.
+"""
+import logging
+import time
+from enum import Enum
+
+import numpy as np
+
+from ..mfbank import MFBank
+
+log = logging.getLogger('pycusdr_amd.demodulator')
+
+SPEED_OF_LIGHT = 299792458.0  # scipy.constants.speed_of_light (reference DB:143)
+
+# defaults of the block-overlap symbol check (reference DB:19-26)
+SYMBOL_CHECK_OVERLAP_OFFSET = 20
+SYMBOL_CHECK_ERROR_THRESHOLD = 1000
+SYMBOL_CHECK_MATCH_NUM_ERRORS_ALLOWED = 10
+SYMBOL_MISMATCHVAL = 0
+
+TRUSTTYPE = np.int8  # reference __global__.py:25-26
+DATATYPE = np.int8
+
+
+class Operations(Enum):
+    CENTRES_ABS = 0
+    CENTRES_REAL = 1
+    CENTRES_IMAG = 2
+
+
+def doppler_bin_table(confRadio, rangeRateMax, Nfft):
+    """Doppler search grid (reference DB:130-165): normalised bin positions, Hz lookup, integer
+    spectrum shifts (negatives wrapped to the upper half) and the STX fixed shift."""
+    baud, spsym = confRadio['baud'], confRadio['samplesPerSym']
+    if_offset = confRadio['frequencyOffset_Hz']
+    carrier = confRadio['frequency_Hz'] - if_offset
+    centre = if_offset / baud / spsym
+    stx_idx = np.int32(centre * Nfft)
+    if stx_idx < 0:
+        stx_idx += Nfft
+    half_span = rangeRateMax * carrier / SPEED_OF_LIGHT / (baud * spsym)
+    grid = np.linspace(centre - half_span, centre + half_span, confRadio['doppCarrierSteps'])
+    noise_hz = confRadio.get('noise_measure_offset_Hz', False)
+    if noise_hz:
+        grid = np.concatenate((np.array([noise_hz / baud / spsym]), grid))
+    shifts = np.round(grid * Nfft).astype(np.int32)
+    shifts[shifts < 0] += Nfft
+    return grid, grid * spsym * baud, shifts, int(stx_idx)
+
+
+class Demodulator:
+    """One receive channel: Doppler search + symbol demodulation of N-sample blocks."""
+
+    def __init__(self, conf, protocol, radioName, shard=None):
+        self.protocol = protocol
+        self.radioName = radioName
+        self.confRadio = confRadio = conf['Radios']['Rx'][radioName]
+        self.confGPU = confGPU = conf['GPU'][confRadio['CUDA_settings']]
+        self.shard = shard
+
+        # block geometry
+        self.sigLen = 2 ** confGPU['blockSize']
+        self.sigOverlap = 2 ** confGPU['overlap']
+        self.sigOverlapWin = int(self.sigOverlap / 2)
+        self.Nfft = int(self.sigLen)
+        self.clippedPeakSpan = confGPU['clippedPeakSpan']
+        self.peakThresholdScale = confGPU['peakThresholdScale']
+        self.disablePeakThresholding = confRadio.get('disablePeakThresholding', False)
+        self.clippedPeakIPure = []
+        self.clippedPeakI = []
+
+        # block-overlap symbol check
+        self.overlapOffset = confGPU.get('symbol_check_overlap_offset', SYMBOL_CHECK_OVERLAP_OFFSET)
+        self.symbol_check_error_threshold = confGPU.get('symbol_check_error_threshold', SYMBOL_CHECK_ERROR_THRESHOLD)
+        self.symbol_check_match_threshold = self.overlapOffset - confGPU.get(
+            'symbol_check_match_num_errors_allowed', SYMBOL_CHECK_MATCH_NUM_ERRORS_ALLOWED)
+        self.poswinP = []
+
+        self.spsym = spsym = confRadio['samplesPerSym']
+        self.spsymMin = int(spsym / 2)
+        self.baudRate = confRadio['baud']
+        self.sampleRate = self.baudRate * spsym
+        self.voteWeight = confRadio.get('voteWeight', 1)
+
+        self.windowWidth = confGPU['bitWindowWidth']
+        self.windowWidthOffset = int(self.windowWidth / 2)
+        self.CODE_SEARCH_MASK_OFFSET = 0
+        self.SUM_ALL_MASKS_PYTHON = bool(getattr(protocol, 'SUM_ALL_MASKS_PYTHON', False))
+
+        # Doppler grid
+        self.num_dopplers = confRadio['doppCarrierSteps']
+        self.centreFreqOffset = confRadio['frequencyOffset_Hz']
+        self.doppIdxNorm, self.doppHzLUT, self.doppCyperSymNorm, self.doppOffsetIdx = doppler_bin_table(
+            confRadio, conf['Radios']['rangeRateMax'], self.Nfft)
+        self.doppIdxArrayLen = len(self.doppIdxNorm)
+        self.doppIdxArrayOffset = self.doppIdxArrayLen - self.num_dopplers
+        log.info('[%s]: Doppler scanning range %.0f to %.0f Hz', radioName, self.doppHzLUT[0], self.doppHzLUT[-1])
+
+        cuda_cfg = confGPU.get('CUDA', {})
+        self.numThreadsS = cuda_cfg.get('numThreadsS', 1024)
+        if self.Nfft / self.numThreadsS != np.round(self.Nfft / self.numThreadsS):
+            raise ValueError('[{}]: the size of the input signal has to be divisible by {}'.format(
+                radioName, self.numThreadsS))
+        device = cuda_cfg.get('device', 0)
+
+        # filters and LUTs from the protocol plugin
+        try:
+            self.num_masks, masks = protocol.get_filter(self.Nfft, spsym, confGPU['xcorrMaskSize'])
+        except Exception:
+            log.error('[%s]: Exception occured in protocol %s while preparing filters', radioName, protocol.name)
+            raise
+        self._check_masks(masks)
+        if self.num_masks > 32:
+            log.warning('[%s]: more than 32 masks is not supported by the reference', radioName)
+        try:
+            self.bitLUT, self.symbolLUT = protocol.get_symbolLUT2(confGPU['xcorrMaskSize'])
+        except Exception:
+            log.error('[%s]: Exception occured in protocol %s while preparing symbol lookup table', radioName, protocol.name)
+            raise
+        if self.symbolLUT is not None:
+            self.symbolLUT = np.asarray(self.symbolLUT)
+
+        # device side: this rank's slice of the Doppler bins (all of them without sharding)
+        if shard is not None:
+            if self.doppIdxArrayOffset:
+                raise ValueError('the noise-reference bin is not supported together with Doppler-bin sharding')
+            self._bin_lo, self._bin_hi = shard.bin_range(self.num_dopplers)
+        else:
+            self._bin_lo, self._bin_hi = 0, self.doppIdxArrayLen
+        nloc = self._bin_hi - self._bin_lo
+        self.bank = MFBank(confGPU['blockSize'], nloc - self.doppIdxArrayOffset, self.num_masks,
+                           window_width=self.windowWidth, sum_all_masks=self.SUM_ALL_MASKS_PYTHON,
+                           code_search_mask_offset=self.CODE_SEARCH_MASK_OFFSET,
+                           doppler_offset=self.doppIdxArrayOffset, device=device)
+        self.bank.set_filters(masks)
+        self.bank.set_shifts(self.doppCyperSymNorm[self._bin_lo:self._bin_hi])
+        if shard is not None:
+            shard.attach(self.bank, self.num_dopplers, self.num_masks)
+
+        # windowed argmax range of the symbol-rate estimate (reference DB:508-512)
+        self.symsTolLow = 0.9 * spsym
+        self.symsTolHigh = 1.1 * spsym
+        self.codeRateAndPhaseOffsetLow = int(self.Nfft / self.symsTolLow)
+        self.codeRateAndPhaseOffsetHigh = int(self.Nfft / self.symsTolHigh)
+        self.dopplerIdxlast = 0
+        log.info('[%s]: Initialization done', radioName)
+
+    # ------------------------------------------------------------------------------------------
+    def _check_masks(self, masks):
+        """Shape / dtype validation of the protocol's filter bank (reference DB:252-257)."""
+        if masks.shape != (self.num_masks, self.Nfft):
+            raise ValueError('Masks provided by protocol {} expected to be of dimensions {}, got dimensions {}'.format(
+                self.protocol.name, (self.num_masks, self.Nfft), masks.shape))
+        if not isinstance(masks[0, 0], np.complex64):
+            raise TypeError('Datatype of masks {}, expected {}'.format(type(masks[0, 0]), np.complex64))
+
+    def close(self):
+        bank = getattr(self, 'bank', None)
+        if bank is not None:
+            bank.close()
+            self.bank = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def get_signalBufferHostPointer(self):
+        """Writable page-locked complex64[N] the caller fills in place (reference DB:1055-1060)."""
+        return self.bank.input
+
+    # ---- input ---------------------------------------------------------------------------------
+    def uploadToGPU(self, samples):
+        """H2D copy + forward FFT (reference DB:548-558)."""
+        self.bank.upload(samples)
+
+    def thresholdInput(self, samples):
+        self._thresholdInput(samples)
+
+    def _thresholdInput(self, samples):
+        """Clip burst interference in place, twice, and remember where (reference DB:670-707)."""
+        mag = np.abs(samples)
+        thresh = self.peakThresholdScale * np.mean(mag)
+        hot = np.where(mag > thresh)[0]
+        samples[hot] = thresh * (samples[hot] / mag[hot])
+        mag[hot] = np.abs(samples[hot])
+        thresh = self.peakThresholdScale * np.mean(mag)
+        hot = np.where(mag > thresh)[0]
+        self.clippedPeakIPure = hot
+        samples[hot] = thresh * (samples[hot] / mag[hot])
+        if len(hot) > 0:
+            gaps = np.diff(hot)
+            real_gaps = np.where(gaps > 1)[0]
+            self.peakMinGap = 100
+            small = np.where(gaps[real_gaps] < self.peakMinGap)[0]
+            marks = np.zeros(self.Nfft, dtype=np.int8)
+            marks[hot] = 1
+            for gi in real_gaps[small]:
+                marks[hot[gi]:hot[gi] + gaps[gi]] = 1
+            self.clippedPeakI = np.where(marks == 1)[0]
+        else:
+            self.clippedPeakI = hot.copy()
+
+    def uploadAndFindUHF(self, samples):
+        self._thresholdInput(samples)
+        self.uploadToGPU(samples)
+        return self._findUHF(samples)
+
+    # ---- Doppler search ------------------------------------------------------------------------
+    def _device_search(self):
+        """Device part of the search: [index, metric] as float32."""
+        if self.shard is None:
+            return self.bank.find_carrier()
+        return self.shard.search_and_pick(self.bank, self._bin_lo)
+
+    def _findUHF(self, samples=None):
+        """Doppler estimate of the uploaded block (reference DB:567-632).  Returns
+        (freqOffset_Hz, metric, clippedPeakIdx, SNR_dB)."""
+        best = np.empty(2, dtype=np.float32)
+        best[0], best[1] = self._device_search()
+        try:
+            lowIdx = int(best[0])
+            highIdx = int(np.ceil(best[0]))
+            frac = float(best[0]) % 1
+            lowVal, highVal = self.doppHzLUT[lowIdx], self.doppHzLUT[highIdx]
+            bestDopplerScaled = lowVal + (highVal - lowVal) * frac
+            s_lo, s_hi = int(self.doppCyperSymNorm[lowIdx]), int(self.doppCyperSymNorm[highIdx])
+            self.dopplerIdxlast = np.int32(np.round(s_lo + (s_hi - s_lo) * frac))
+            SNR = self.computeSNR(lowIdx, highIdx, 5)
+            freqOffset = bestDopplerScaled - self.centreFreqOffset
+            # the reference names this 'sdev_Hz' (DB:623): metric scaled as if it were an index spread
+            sdev_Hz = float(best[1]) / self.Nfft * self.sampleRate
+        except ValueError as e:   # NaN index (all-zero block): skip the block (reference DB:625-630)
+            log.error('Error occurred during find_UHF -- skipping block. Message: %s', e)
+            self.dopplerIdxlast = 0
+            freqOffset = 0.
+            sdev_Hz = 0.
+            SNR = 0.
+        return freqOffset, sdev_Hz, self.clippedPeakIPure, SNR
+
+    def _spectrum_slice(self, a, b):
+        """``X[a:b]`` with numpy slice semantics, fetching only that window from the device."""
+        start, stop, _ = slice(a, b).indices(self.Nfft)
+        if stop <= start:
+            return np.empty(0, dtype=np.complex64)
+        return self.bank.get_spectrum(start, stop - start)
+
+    def computeSNR(self, doppMatchLow, doppMatchHigh, windowWidth):
+        """Signal band vs the band half a spectrum away (reference DB:635-667)."""
+        lo = int(self.doppCyperSymNorm[doppMatchLow])
+        hi = int(self.doppCyperSymNorm[doppMatchHigh])
+        nlo = (lo + int(self.Nfft // 2)) % self.Nfft
+        nhi = (hi + int(self.Nfft // 2)) % self.Nfft
+
+        def band(a, b):
+            if a > b:   # band wraps around 0 Hz
+                return np.mean(np.concatenate((np.abs(self._spectrum_slice(a - windowWidth, None)),
+                                               np.abs(self._spectrum_slice(None, b + windowWidth)))))
+            return np.mean(np.abs(self._spectrum_slice(a - windowWidth, b + windowWidth)))
+        with np.errstate(divide='ignore', invalid='ignore'):
+            return 20 * np.log10(band(lo, hi) / band(nlo, nhi) - 1)
+
+    # ---- demodulation ----------------------------------------------------------------------------
+    def findCodeRateAndPhaseGPU(self):
+        """Matched filters at ``dopplerIdxlast`` + symbol rate / phase (reference DB:711-752 together
+        with the shift-multiply and inverse FFT of DB:776-785, which the C ABI fuses into one call)."""
+        res = np.empty(3, dtype=np.float32)
+        res[0], res[1], res[2] = self.bank.demodulate(
+            int(self.dopplerIdxlast), self.codeRateAndPhaseOffsetHigh,
+            self.codeRateAndPhaseOffsetLow - self.codeRateAndPhaseOffsetHigh)
+        self._codeRateResult = res
+        k = float(res[0])              # host arithmetic is float64, as numpy<2 promoted it
+        if k == 0.0:
+            log.error('Code rate result 0 should not happen but happened -- fixing it to 10')
+            spSym = 10
+        else:
+            spSym = self.Nfft / k
+        codeOffset = -float(res[1]) / np.pi * spSym / 2
+        if codeOffset < 0:
+            codeOffset += spSym - 1
+        return spSym, codeOffset
+
+    def demodulateUHF(self):
+        return self._demodulate()
+
+    def demodulateSTX(self):
+        self.dopplerIdxlast = self.doppOffsetIdx
+        return self._demodulate()
+
+    def _demodulate(self):
+        """Symbols of the uploaded block at the found shift (reference DB:765-859).  Returns
+        (bits uint8[], centres uint8[] (mod 256), trust uint8[], spSym)."""
+        spSym, codeOffset = self.findCodeRateAndPhaseGPU()
+        idxSymbol, _, centres, _, _, trustSymbol = self.cudaFindCentres(spSym, codeOffset, Operations.CENTRES_ABS)
+        dataBits, symError_t = self.extractBits(centres, idxSymbol)
+        noError = len(symError_t)
+        centresWin, dataBitsWin, trustSymbolWin, _ = self.checkSymbolOverlap(noError, centres, idxSymbol, dataBits, trustSymbol)
+
+        # tag symbols next to clipped interference peaks (reference DB:830-837)
+        marks = np.zeros(self.Nfft, dtype=bool)
+        spSymc = int(np.ceil(spSym))
+        for cp in self.clippedPeakIPure:
+            marks[cp - 2 * spSymc:cp + 2 * spSymc + 1] = 1
+        trustSymbolWin[marks[centresWin]] = -2
+        return dataBitsWin.astype(np.uint8), centresWin.astype(np.uint8), trustSymbolWin.astype(np.uint8), spSym
+
+    def cudaFindCentres(self, spSym, codePhase, operation=Operations.CENTRES_ABS):
+        """Per-symbol argmax over filters and a W-sample window (reference DB:991-1009).
+
+        Quirk kept on purpose: the reference allocates and reads back the magnitude buffer as int8
+        although the kernel writes float32 (DB:472,1005-1006), so ``trust`` is the raw little-endian
+        bytes of the first S/4 magnitudes."""
+        if spSym < self.spsymMin:
+            spSym = self.spsymMin
+        count = int(self.Nfft / spSym)
+        symbols, centres, mag = self.bank.find_centres(np.float32(spSym), np.float32(codePhase), operation.value, count)
+        self.magnitudes = mag
+        trust = mag.view(TRUSTTYPE)[:count].copy()
+        return symbols, [], centres, 0, 0, trust
+
+    findCentres = cudaFindCentres
+
+    def extractBits(self, centres, symbols):
+        """Filter index -> bit (reference DB:1012-1023)."""
+        if self.bitLUT is None:
+            if self.symbolLUT is not None and len(self.symbolLUT.shape) == 3:
+                return self.extractBitsNRZs(centres, symbols)
+            raise NotImplementedError('protocol provides neither a bitLUT nor a 3-D NRZ-S symbolLUT '
+                                      '(the reference calls an undefined extractBitsOld here, DB:1017)')
+        return self.bitLUT[symbols], []
+
+    def extractBitsNRZs(self, centresCoherent, symbols):
+        """NRZ-S transition decode with the 3-D LUT symbolLUT[sym][0|1][successors]
+        (reference DB:1026-1051).  Returns (bits bool[S-1], indices of impossible transitions)."""
+        nxt = symbols[1:, None]
+        is_one = np.any(nxt == self.symbolLUT[symbols[:-1], 0, :], axis=1)
+        is_zero = np.any(nxt == self.symbolLUT[symbols[:-1], 1, :], axis=1)
+        bad = np.where((is_one + is_zero) == 0)[0].tolist()
+        is_one[bad] = int(SYMBOL_MISMATCHVAL)
+        return is_one, bad
+
+    def checkSymbolOverlap(self, noError, centres, idxSymbol, dataBits, trustSymbol):
+        """Keep the symbols whose centre lies in [ov/2, N-ov/2] and repair a +-1 symbol slip against
+        the previous block (reference DB:863-988).  Stateful: ``poswinP`` (symbols after this
+        block's window) and ``posSymEnd`` (last offset+1 kept symbols)."""
+        start = np.where(centres >= self.sigOverlapWin)[0][0]
+        end = np.where(centres > (self.Nfft - self.sigOverlapWin))[0][0]
+        win = dataBits[start:end]
+        pre = dataBits[:start]
+        o = self.overlapOffset
+        thr = self.symbol_check_match_threshold
+        try:
+            if noError > self.symbol_check_error_threshold:
+                pass
+            elif len(self.poswinP) > 0:
+                prev_post, prev_end = self.poswinP, self.posSymEnd
+                aligned = np.all(prev_post[:o] == win[:o]) or np.all(prev_end[-o:] == pre[-o:])
+                if not aligned:
+                    m_pre = (np.sum(prev_post[:o] == win[:o]),             # as is
+                             np.sum(prev_post[:o] == win[1:o + 1]),        # this block starts a symbol early
+                             np.sum(prev_post[1:o + 1] == win[0:o]))       # ... a symbol late
+                    m_pos = (np.sum(prev_end[-o:] == pre[-o:]),
+                             np.sum(prev_end[-o - 1:-1] == pre[-o:]),
+                             np.sum(prev_end[-o:] == pre[-o - 1:-1]))
+                    if thr < m_pre[1] and m_pre[1] == np.max(m_pre):
+                        if thr < m_pos[1] and m_pos[1] == np.max(m_pos):
+                            start += 1
+                            win = win[1:]
+                    elif thr < m_pre[2] and m_pre[2] == np.max(m_pre):
+                        if thr < m_pos[2] and m_pos[2] == np.max(m_pos):
+                            start -= 1
+                            win = np.r_[pre[-1], win]
+        except Exception as e:   # the reference logs and carries on (DB:965-967)
+            log.error('symbol overlap failed. reason: %s', e)
+
+        dataBitsWin = dataBits[start:end]
+        self.poswinP = dataBits[end:]
+        self.posSymEnd = dataBitsWin[-o - 1:]
+        return centres[start:end], dataBitsWin, trustSymbol[start:end], win

@@ -1,0 +1,73 @@
+"""OracleBank -- a CPU stand-in for pycusdr_amd.mfbank.MFBank built from oracle/ functions.
+
+TEST INFRASTRUCTURE ONLY.  Tests monkeypatch it into the Demodulator to (a) exercise the host logic
+end to end on machines without a GPU and (b) produce the oracle's answer for the same block on the
+GPU box, so that the HIP path can be compared stage by stage.  Nothing under pycusdr_amd/ imports
+this file.
+"""
+import numpy as np
+
+from oracle import mfbank_oracle as orc
+
+
+class OracleBank:
+    def __init__(self, log2N, num_dopplers, M, window_width=7, sum_all_masks=True,
+                 code_search_mask_offset=0, doppler_offset=0, device=0):
+        self.N = 1 << int(log2N)
+        self.D, self.Doff, self.M = int(num_dopplers), int(doppler_offset), int(M)
+        self.Dtot = self.D + self.Doff
+        self.W, self.sum_all, self.cs_off = int(window_width), bool(sum_all_masks), int(code_search_mask_offset)
+        self.input = np.zeros(self.N, dtype=np.complex64)
+        self.masks = self.shifts = self.X = self.xc = self.ds = None
+
+    def close(self):
+        pass
+
+    def set_stream(self, s):
+        pass
+
+    def set_filters(self, masks):
+        masks = np.asarray(masks)
+        if masks.dtype != np.complex64:
+            raise TypeError('complex64 expected')
+        if masks.shape != (self.M, self.N):
+            raise ValueError('shape')
+        self.masks = masks
+
+    def set_shifts(self, shifts):
+        s = np.asarray(shifts, dtype=np.int32)
+        if s.size != self.Dtot or s.min() < 0 or s.max() >= self.N:
+            raise ValueError('shifts')
+        self.shifts = s
+
+    def upload(self, samples=None):
+        x = self.input if samples is None else np.asarray(samples, dtype=np.complex64)
+        self.X = orc.forward_fft(x)
+
+    def find_carrier(self):
+        self.ds = orc.doppler_scores(self.X, self.masks, self.shifts, self.sum_all).astype(np.float32)
+        return orc.find_doppler_est(self.ds, self.D, self.Doff, self.sum_all)
+
+    def get_scores(self):
+        return self.ds
+
+    def get_spectrum(self, start=0, count=None):
+        count = self.N if count is None else count
+        idx = (start + np.arange(count)) % self.N
+        return self.X[idx]
+
+    def demodulate(self, shift, k_offset, k_len):
+        self.xc = orc.demod_xcorr(self.X, self.masks, shift).astype(np.complex64)
+        self.env = orc.envelope(self.xc, self.cs_off)
+        k, arg, val = orc.code_rate_and_phase(self.env, k_offset, k_len)
+        return np.float32(k), np.float32(arg), np.float32(val)
+
+    def find_centres(self, spSym, offset, op, count):
+        sym, cen, mag = orc.find_centres(self.xc, spSym, offset, self.W, op)
+        return sym[:count], cen[:count], mag[:count]
+
+    def get_xcorr(self):
+        return self.xc
+
+    def get_envelope(self):
+        return self.env.astype(np.float32)
