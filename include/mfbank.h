@@ -67,8 +67,10 @@ int mfb_set_stream(mfb_ctx *ctx, void *hip_stream);
 /* Tuning knobs (0 keeps the current value): Doppler bins per launch of the two FFT passes (bounds
  * the intermediate buffer; the reference's analogue is CUDA.batchSize, DB:301-313), matched
  * filters handled per workgroup in pass 1, FFT rows per workgroup in pass 2, and the number of
- * workgroups that share the Doppler bins of one (tile, filter group) in pass 1.  None of them
- * changes any result bit: all reductions are fixed-order. */
+ * workgroups that share the Doppler bins of one (tile, filter group) in pass 1.  All reductions are
+ * fixed-order (no float atomics), so results are bit-reproducible run to run; doppler_chunk,
+ * masks_per_block and jsplit never change a result bit, rows_per_block regroups the fp32 partial
+ * sums (results then agree to rounding, ~1e-7). */
 int mfb_set_tuning(mfb_ctx *ctx, int doppler_chunk, int masks_per_block, int rows_per_block, int jsplit);
 int mfb_get_tuning(mfb_ctx *ctx, int *doppler_chunk, int *masks_per_block, int *rows_per_block, int *jsplit);
 

@@ -21,7 +21,7 @@
 //           reduce |y|^2 in registers -> wave -> workgroup (Doppler search; the time-domain rows
 //           are never written), or store y[n1 + N1*n2] (demodulation / forward FFT).
 //
-// Reference semantics reproduced (file:line in /root/reference/pyCuSDR):
+// Reference semantics reproduced (file:line in the reference tree, pyCuSDR/):
 //   shift-multiply  demodulator/cuda_kernels.cu:339-373, 174-185
 //   |.|^2 / 2^18 row sums  cuda_kernels.cu:421-480      pick  cuda_kernels.cu:502-597
 //   envelope        cuda_kernels.cu:191-205             rate/phase  cuda_kernels.cu:236-320

@@ -1,0 +1,76 @@
+"""The C-ABI shared library loads and exports every symbol include/mfbank.h declares (no compute
+calls: there is no GPU in the authoring container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib_path():
+    import __graft_entry__
+    return __graft_entry__.build()
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, 'include', 'mfbank.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(mfb_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_header_declares_the_expected_surface():
+    names = _declared_functions()
+    for must in ('mfb_create', 'mfb_destroy', 'mfb_set_filters', 'mfb_set_shifts', 'mfb_input_buffer', 'mfb_upload',
+                 'mfb_find_carrier', 'mfb_demodulate', 'mfb_find_centres', 'mfb_sync_correlate', 'mfb_get_scores'):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    lib = ctypes.CDLL(lib_path)
+    for name in _declared_functions():
+        assert hasattr(lib, name), f'{name} declared in include/mfbank.h but not exported'
+
+
+def test_python_binding_covers_the_header(lib_path):
+    from pycusdr_amd import _lib
+    assert sorted(_lib.PROTOTYPES) == _declared_functions()
+    lib = _lib.load()
+    assert lib.mfb_abi_version() >= 1
+    assert lib.mfb_strerror(0) == b'ok' and b'argument' in lib.mfb_strerror(1)
+
+
+def test_status_codes_map_to_python_exceptions(lib_path):
+    from pycusdr_amd import _lib
+    _lib.load()
+    with pytest.raises(ValueError):
+        _lib.check(_lib.MFB_ERR_ARG, 'x')
+    with pytest.raises(TypeError):
+        _lib.check(_lib.MFB_ERR_DTYPE, 'x')
+    with pytest.raises(MemoryError):
+        _lib.check(_lib.MFB_ERR_ALLOC, 'x')
+    with pytest.raises(RuntimeError):
+        _lib.check(_lib.MFB_ERR_HIP, 'x')
+    with pytest.raises(ValueError):
+        _lib.check(_lib.MFB_ERR_UNSUPPORTED, 'x')
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from pycusdr_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_lib.MFBankLibraryError):
+        _lib.load()
+
+
+def test_product_path_never_imports_the_oracle():
+    """pycusdr_amd/ must not reference oracle/ (the oracle is the checker, never the product)."""
+    pkg = os.path.join(ROOT, 'pycusdr_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.hpp', '.h')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+                assert '/root/reference' not in src, f

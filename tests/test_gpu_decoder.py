@@ -1,0 +1,48 @@
+"""Decoder through its default (HIP) sync correlator against the reference KATs (fixtures G4)."""
+import numpy as np
+import pytest
+
+from oracle import mfbank_oracle as orc
+from pycusdr_amd import config as cfg
+from pycusdr_amd.decoder import Decoder, _hip_correlator
+from pycusdr_amd.mfbank import sync_correlate
+from pycusdr_amd.protocol import loadProtocol
+
+from test_decoder_host import CASES, run_kat
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('key,pname,conf', CASES)
+def test_findframes_kats_on_hip_correlator(goldens, key, pname, conf):
+    run_kat(goldens, key, pname, conf, None)       # None -> default HIP path
+
+
+def test_batched_streams_s_1024():
+    """1024 synthetic bit streams, header planted every 4000 bits."""
+    p = loadProtocol('bench_GMSK')(conf=cfg.bench_config())
+    mask = p.get_mask()
+    hdr = ((np.flipud(mask) + 1) // 2).astype(np.uint8)
+    rs = np.random.RandomState(2)
+    B, L = 1024, 16384
+    bits = rs.randint(0, 2, (B, L)).astype(np.uint8)
+    for s in range(0, L - 128, 4000):
+        bits[:, s:s + 128] = hdr
+    out = sync_correlate(bits, mask)
+    assert out.shape == (B, L + 127) and out.dtype == np.int32
+    for b in (0, 511, 1023):
+        assert np.array_equal(out[b], orc.sync_correlate(bits[b], mask))
+    hits = np.where(out[7] >= p.numOnesHeader)[0] - 127
+    assert set(range(0, L - 128, 4000)).issubset(set(hits.tolist()))
+
+
+def test_edge_cases_and_errors():
+    assert np.array_equal(sync_correlate(np.array([1], np.uint8), np.array([1, -1, 1])), [1, -1, 1])
+    with pytest.raises(ValueError):
+        sync_correlate(np.array([0, 2, 1]), np.array([1, -1]))          # not a bit stream
+    with pytest.raises(ValueError):
+        sync_correlate(np.zeros(0, np.uint8), np.array([1, -1]))        # empty input
+    with pytest.raises(ValueError):
+        sync_correlate(np.array([0, 1], np.uint8), np.array([0.5, 1]))  # non-integer template
+    f = _hip_correlator(np.array([1., 0., 1., 1.]), np.array([1., -1.]))
+    assert np.array_equal(f, np.convolve([1, 0, 1, 1], [1, -1]))

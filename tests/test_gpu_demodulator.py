@@ -1,0 +1,128 @@
+"""End-to-end parity on the GPU: the Demodulator over libmfbank.so against the same host driver
+over the CPU oracle bank, on the reference's own bench packets (stimulus pinned by fixture G5)."""
+import numpy as np
+import pytest
+
+from oracle import mfbank_oracle as orc
+from pycusdr_amd import config as cfg, signals as sg
+from pycusdr_amd.decoder import Decoder
+from pycusdr_amd.demodulator import UHF
+from pycusdr_amd.protocol import loadProtocol
+import pycusdr_amd.demodulator.demodulator_base as dbm
+
+from oracle_bank import OracleBank
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(pname, bs, D, monkeypatch):
+    conf = cfg.bench_config(pname, blockSize=bs, doppCarrierSteps=D)
+    p = loadProtocol(pname)(conf=conf)
+    gpu = UHF.Demodulator(conf, p, 'UHF-H')
+    with monkeypatch.context() as m:
+        m.setattr(dbm, 'MFBank', OracleBank)
+        cpu = UHF.Demodulator(conf, loadProtocol(pname)(conf=conf), 'UHF-H')
+    assert type(gpu.bank).__name__ == 'MFBank' and type(cpu.bank).__name__ == 'OracleBank'
+    return conf, p, gpu, cpu
+
+
+# 60 dB stands for "noiseless": with exactly-zero padding the matched-filter outputs there are pure FFT
+# round-off and the per-symbol argmax is arbitrary in both implementations; a whisper of noise makes
+# every decision well defined without disturbing the packet.
+@pytest.mark.parametrize('mod,pname,snr', [('GMSK', 'bench_GMSK', 60.0), ('GMSK', 'bench_GMSK', 10.0),
+                                           ('FSK', 'bench_FSK', 60.0), ('GFSK', 'bench_GFSK', 12.0),
+                                           ('BPSK', 'bench_BPSK', 60.0)])
+def test_stream_bits_identical_to_oracle_and_packet_error_free(monkeypatch, mod, pname, snr):
+    bs, ov, D = 15, 1 << 10, 32
+    N = 1 << bs
+    conf, p, gpu, cpu = _pair(pname, bs, D, monkeypatch)
+    sig, payload = sg.get_padded_packet(mod, 16, 153600)
+    sig = np.concatenate((sig, np.zeros(N)))
+    if snr is not None:
+        sig = sg.awgn(sig, snr, rng=np.random.RandomState(1))
+    sig = sig.astype(np.complex64)
+    nblocks = (len(sig) - ov) // (N - ov)
+    dec = Decoder({}, p)                       # HIP sync correlator
+    packets = []
+    for dm in (gpu, cpu):                      # tap the un-truncated centres of the kept symbols
+        def tapped(*a, _orig=dm.checkSymbolOverlap, _dm=dm, **k):
+            out = _orig(*a, **k)
+            _dm._centresWin = np.asarray(out[0])
+            return out
+        dm.checkSymbolOverlap = tapped
+    rg, rc = gpu.get_signalBufferHostPointer(), cpu.get_signalBufferHostPointer()
+    rg[:ov] = rc[:ov] = sig[:ov]
+    for b in range(nblocks):
+        rg[ov:] = rc[ov:] = sig[ov + b * (N - ov): ov + (b + 1) * (N - ov)]
+        og = gpu.uploadAndFindCarrier(rg)
+        oc = cpu.uploadAndFindCarrier(rc)
+        sg_, sc_ = gpu.bank.get_scores(), cpu.bank.get_scores()
+        if sc_.max() > 0:
+            assert np.abs(sg_ - sc_).max() / sc_.max() < 1e-5          # correlation magnitudes, 1e-5
+        assert int(gpu.dopplerIdxlast) == int(cpu.dopplerIdxlast)
+        assert abs(og[0] - oc[0]) <= 1e-3 * max(1.0, abs(oc[0])) + 0.05  # Hz
+        if np.isfinite(oc[3]) and oc[3] != 0:
+            assert abs(og[3] - oc[3]) < 1e-2                              # SNR dB
+        bg, cg, tg, spg = gpu.demodulate()
+        bc, cc, tc, spc = cpu.demodulate()
+        assert spg == spc                                                 # same FFT bin -> same float
+        if snr <= 20:
+            # noise floor far above fp32 round-off: decisions agree except at numerical ties between
+            # two candidates (fp32 device vs fp64 oracle FFTs; at most 1 symbol in 1000).  Exact
+            # equality on identical matched-filter outputs is asserted in tests/test_gpu_kernels.py.
+            assert len(bg) == len(bc)
+            assert np.count_nonzero(bg != bc) <= max(1, len(bg) // 1000), f'block {b}: symbol decisions differ'
+            # peak sample index: equal except where two neighbouring |xc|^2 samples tie to within
+            # fp32-vs-fp64 round-off (the kernel itself is bit-exact against the oracle on its own
+            # matched-filter outputs: tests/test_gpu_kernels.py)
+            dcen = gpu._centresWin - cpu._centresWin
+            assert np.abs(dcen).max() <= 3 and np.count_nonzero(dcen) <= 0.02 * len(dcen)
+        else:
+            # quiet padding: the matched-filter outputs there are fp32 FFT round-off of the strong
+            # packet, so the argmax is arbitrary in BOTH implementations; decisions must agree on
+            # every symbol that carries signal (|x|^2 around its centre above 1/4 of the carrier)
+            pw = np.convolve(np.abs(rg) ** 2, np.ones(16) / 16, mode='same')
+
+            def strong(bits, demod):
+                c = demod._centresWin            # full int32 centres of the kept symbols
+                keep = pw[c] > 0.25
+                return c[keep], bits[keep]
+            (cgs, bgs), (ccs, bcs) = strong(bg, gpu), strong(bc, cpu)
+            assert np.array_equal(bgs, bcs), f'block {b}: decisions on signal-bearing symbols differ'
+            # the sample index of the peak may move by one where two neighbouring samples of the
+            # noiseless matched-filter peak are equal to within round-off
+            assert np.abs(cgs - ccs).max() <= 3
+            assert np.count_nonzero(cgs != ccs) <= 0.02 * len(cgs)
+        pk, _, _ = dec.findFrames(bg, 0)
+        packets.extend(pk)
+        rg[:ov] = rg[-ov:]
+        rc[:ov] = rc[-ov:]
+    assert len(packets) == 1
+    assert packets[0].checkPacketData() == 0
+    gpu.close()
+
+
+def test_known_carrier_bin_and_symbol_rate(monkeypatch):
+    bs, D = 16, 64
+    N = 1 << bs
+    conf, p, gpu, _ = _pair('bench_GMSK', bs, D, monkeypatch)
+    sig = sg.s1_stream(2, N, 1 << 10, 'GMSK', snr_db=10.0, seed=1)
+    raw = gpu.get_signalBufferHostPointer()
+    raw[:] = sig[:N]
+    fo, metric, clipped, snr = gpu.uploadAndFindCarrier(raw)
+    assert int(gpu.dopplerIdxlast) == N // 4          # carrier at fs/4 (create_signals.py:181-182)
+    assert abs(fo) < 100.0 and len(clipped) == 0
+    bits, cen, trust, spSym = gpu.demodulate()
+    assert abs(spSym - 16.0) < 0.5
+    # trust bytes are the raw bytes of the leading fp32 magnitudes (reference quirk Q3)
+    assert trust.dtype == np.uint8
+    gpu.close()
+
+
+def test_all_zero_block_is_skipped(monkeypatch):
+    conf, p, gpu, _ = _pair('bench_GMSK', 12, 8, monkeypatch)
+    raw = gpu.get_signalBufferHostPointer()
+    raw[:] = 0
+    assert gpu.uploadAndFindCarrier(raw) == (0., 0., [], 0.)
+    assert gpu.dopplerIdxlast == 0
+    gpu.close()

@@ -1,0 +1,212 @@
+"""Full-size configurations (BASELINE.json C2/C3/C5) through size-independent properties, and the
+C-ABI's error behaviour."""
+import numpy as np
+import pytest
+
+from oracle import mfbank_oracle as orc
+from pycusdr_amd import config as cfg, signals as sg
+from pycusdr_amd.mfbank import MFBank
+from pycusdr_amd.protocol import loadProtocol
+
+pytestmark = pytest.mark.gpu
+
+
+def _rc(rs, *s):
+    return (rs.standard_normal(s) + 1j * rs.standard_normal(s)).astype(np.complex64)
+
+
+@pytest.fixture(scope='module')
+def c2():
+    """C2: D=256, M=8 GMSK filters, N=2^20, bench geometry, S1 signal."""
+    log2N, D = 20, 256
+    N = 1 << log2N
+    conf = cfg.bench_config('bench_GMSK', blockSize=log2N, doppCarrierSteps=D)
+    from pycusdr_amd.demodulator.demodulator_base import doppler_bin_table
+    _, _, shifts, _ = doppler_bin_table(conf['Radios']['Rx']['UHF-H'], 7500, N)
+    M, masks = loadProtocol('bench_GMSK')(conf=conf).get_filter(N, 16, 3)
+    x = sg.s1_stream(1, N, 1 << 10, 'GMSK', snr_db=10.0, seed=1)[:N]
+    bank = MFBank(log2N, D, M)
+    bank.set_filters(masks)
+    bank.set_shifts(shifts)
+    bank.upload(x)
+    yield dict(bank=bank, masks=masks, shifts=shifts, x=x, N=N, D=D, M=M)
+    bank.close()
+
+
+def test_c2_parseval_checksum_and_carrier(c2):
+    bank = c2['bank']
+    idx, metric = bank.find_carrier()
+    ds = bank.get_scores()
+    X = bank.get_spectrum()
+    ref = orc.doppler_scores_parseval(X, c2['masks'], c2['shifts'])      # IFFT-free identity
+    assert np.abs(ds[:, 0] - ref).max() / ref.max() < 1e-5
+    assert np.all(ds[:, 1:] == 0)
+    Xref = np.fft.fft(c2['x'].astype(np.complex128))
+    assert np.abs(X - Xref).max() / np.abs(Xref).max() < 2e-6
+    oidx, ometric = orc.find_doppler_est(ds, c2['D'], 0, True)
+    assert idx == oidx
+    pick = orc.interpolate_doppler(idx, c2['shifts'], np.zeros(c2['D']))
+    spacing = np.median(np.diff(c2['shifts']))
+    assert abs(pick['dopplerIdxlast'] - c2['N'] // 4) <= spacing       # carrier at +fs/4
+
+
+def test_c2_rows_against_oracle_sample(c2):
+    """A bounded sample (6 bins) of the full-size bank against the oracle's real IFFTs."""
+    bank = c2['bank']
+    bank.find_carrier()
+    ds = bank.get_scores()[:, 0]
+    X = bank.get_spectrum()
+    sel = [0, 1, 127, 128, 200, 255]
+    ref = orc.doppler_scores(X, c2['masks'], c2['shifts'][sel], True)[:, 0]
+    assert np.abs(ds[sel] - ref).max() / ref.max() < 1e-5
+
+
+def test_c2_tuning_invariance_and_repeatability(c2):
+    bank = c2['bank']
+    base_t = bank.get_tuning()
+    bank.find_carrier()
+    a = bank.get_scores().copy()
+    bank.find_carrier()
+    assert np.array_equal(a, bank.get_scores())                          # bit-reproducible
+    # chunking, filters per workgroup and the Doppler split never change a bit ...
+    for tun in ((32, 4, 0, 8), (7, 3, 0, 5), (256, 8, 0, 256), (1, 1, 0, 1)):
+        bank.set_tuning(*tun)
+        bank.find_carrier()
+        assert np.array_equal(a, bank.get_scores()), tun
+    # ... rows per workgroup regroups the fp32 partial sums: equal to rounding only
+    for rows in (1, 16, 256):
+        bank.set_tuning(0, 0, rows, 0)
+        bank.find_carrier()
+        b = bank.get_scores()
+        assert np.abs(a - b).max() / a.max() < 1e-6, rows
+    bank.set_tuning(*base_t)
+
+
+def test_c2_linearity(c2):
+    """score(a*x) = |a|^2 score(x): exact for a power of two."""
+    bank = c2['bank']
+    bank.upload(c2['x'])
+    bank.find_carrier()
+    a = bank.get_scores()[:, 0].copy()
+    bank.upload((c2['x'] * np.complex64(4)).astype(np.complex64))
+    bank.find_carrier()
+    assert np.array_equal(bank.get_scores()[:, 0], a * 16)
+    bank.upload(c2['x'])
+
+
+def test_c2_demod_stage_fullsize(c2):
+    bank = c2['bank']
+    N = c2['N']
+    k_off, k_len = orc.code_rate_window(N, 16)
+    k, arg, val = bank.demodulate(N // 4, k_off, k_len)
+    assert int(k) == N // 16                                            # 16 samples per symbol
+    env = bank.get_envelope()
+    xc = bank.get_xcorr()
+    assert np.abs(env - orc.envelope(xc)).max() / env.max() < 1e-6
+    ok, oarg, oval = orc.code_rate_and_phase(env, k_off, k_len)
+    assert ok == int(k) and abs(float(arg) - oarg) < 1e-3
+    spSym, codeOffset = orc.code_rate_host(k, arg, N)
+    S = int(N / spSym)
+    sym, cen, mag = bank.find_centres(np.float32(spSym), np.float32(codeOffset), 0, S)
+    osym, ocen, omag = orc.find_centres(xc, spSym, codeOffset, 7, 0)
+    assert np.array_equal(sym, osym) and np.array_equal(cen, ocen)
+    assert np.array_equal(mag.view(np.uint32), omag.view(np.uint32))
+    # one matched-filter row against numpy
+    X = bank.get_spectrum()
+    ref0 = np.fft.ifft(np.roll(X.astype(np.complex128), -(N // 4)) * c2['masks'][3]) * N
+    assert np.abs(xc[3] - ref0).max() / np.abs(ref0).max() < 5e-6
+
+
+def test_c3_1024_bins_parseval():
+    """C3: D=1024 at N=2^20 (HBM stress): Parseval identity on all bins."""
+    log2N, D, M = 20, 1024, 8
+    N = 1 << log2N
+    rs = np.random.RandomState(3)
+    masks = _rc(rs, M, N)
+    shifts = np.sort(rs.choice(N, D, replace=False)).astype(np.int32)
+    bank = MFBank(log2N, D, M)
+    try:
+        bank.set_filters(masks)
+        bank.set_shifts(shifts)
+        bank.upload(_rc(rs, N))
+        bank.find_carrier()
+        ds = bank.get_scores()[:, 0]
+        ref = orc.doppler_scores_parseval(bank.get_spectrum(), masks, shifts)
+    finally:
+        bank.close()
+    assert np.abs(ds - ref).max() / ref.max() < 1e-5
+
+
+def test_c5_bpsk_bank_32_filters_per_mask_mode():
+    """C5-style second instance: 32 BPSK filters (maskSize 5); per-mask sums (SUM_ALL_MASKS off)."""
+    log2N, D = 16, 16
+    N = 1 << log2N
+    conf = cfg.bench_config('bench_BPSK', blockSize=log2N, doppCarrierSteps=D)
+    M, masks = loadProtocol('bench_BPSK')(conf=conf).get_filter(N, 16, 5)
+    assert M == 32
+    from pycusdr_amd.demodulator.demodulator_base import doppler_bin_table
+    _, _, shifts, _ = doppler_bin_table(conf['Radios']['Rx']['UHF-H'], 7500, N)
+    x = sg.get_padded_packet('BPSK')[0][20000:20000 + N].astype(np.complex64)
+    for sum_all in (True, False):
+        bank = MFBank(log2N, D, M, sum_all_masks=sum_all)
+        try:
+            bank.set_filters(masks)
+            bank.set_shifts(shifts)
+            bank.upload(x)
+            idx, metric = bank.find_carrier()
+            ds = bank.get_scores()
+            ref = orc.doppler_scores(bank.get_spectrum(), masks, shifts, sum_all)
+        finally:
+            bank.close()
+        assert np.abs(ds - ref).max() / ref.max() < 1e-5
+        oidx, _ = orc.find_doppler_est(ds, D, 0, sum_all)
+        assert idx == oidx
+        if not sum_all:     # a filter and its bit-complement are exact negatives: identical energy
+            assert np.array_equal(ds[:, :16], ds[:, :15:-1])
+
+
+def test_error_behaviour():
+    with pytest.raises(ValueError):
+        MFBank(9, 4, 2)                          # N below the built plans
+    with pytest.raises(ValueError):
+        MFBank(23, 4, 2)
+    with pytest.raises(ValueError):
+        MFBank(12, 0, 2)                         # no Doppler bins
+    with pytest.raises(ValueError):
+        MFBank(12, 4, 2, window_width=6)         # window must be odd
+    with pytest.raises(ValueError):
+        MFBank(12, 4, 2, device=99)
+    bank = MFBank(12, 4, 2)
+    try:
+        with pytest.raises(RuntimeError):
+            bank.find_carrier()                  # nothing configured yet
+        with pytest.raises(ValueError):
+            bank.set_filters(np.zeros((2, 2048), np.complex64))
+        with pytest.raises(ValueError):
+            bank.set_filters(np.zeros((3, 4096), np.complex64))
+        with pytest.raises(TypeError):
+            bank.set_filters(np.zeros((2, 4096), np.complex128))
+        with pytest.raises(ValueError):
+            bank.set_shifts([0, 1, 2])           # wrong count
+        with pytest.raises(ValueError):
+            bank.set_shifts([0, 1, 2, 4096])     # not wrapped into [0, N)
+        with pytest.raises(ValueError):
+            bank.upload(np.zeros(100, np.complex64))
+        bank.set_filters(np.zeros((2, 4096), np.complex64))
+        bank.set_shifts([0, 1, 2, 3])
+        with pytest.raises(RuntimeError):
+            bank.find_carrier()                  # no input uploaded
+        bank.upload(np.zeros(4096, np.complex64))
+        idx, metric = bank.find_carrier()
+        assert np.isnan(idx)                     # all-zero block: NaN index, caller skips the block
+        with pytest.raises(RuntimeError):
+            bank.find_centres(16.0, 0.0, 0, 10)  # before demodulate
+        bank.demodulate(0, 200, 100)
+        with pytest.raises(ValueError):
+            bank.find_centres(1.0, 0.0, 0, 10)   # spSym below 2
+        with pytest.raises(ValueError):
+            bank.demodulate(0, 4000, 200)        # window outside the spectrum
+        # ragged pinned-buffer use: the input buffer is writable and N long
+        assert bank.input.shape == (4096,) and bank.input.flags.writeable
+    finally:
+        bank.close()
