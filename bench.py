@@ -84,6 +84,7 @@ def main():
     ap.add_argument('--protocol', default='bench_GMSK')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--tuning', default='', help='chunk,mpb,rows,jsplit (0 = default)')
+    ap.add_argument('--force-dist', action='store_true', help='run the sharded/RCCL path even with one rank (rehearsal)')
     args = ap.parse_args()
 
     import torch
@@ -98,8 +99,11 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if G > 1 or world > 1:
+    if G > 1 or world > 1 or args.force_dist:
         import torch.distributed as dist
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
@@ -127,7 +131,7 @@ def main():
     if args.tuning:
         bank.set_tuning(*[int(v) for v in args.tuning.split(',')])
     shard = None
-    if G > 1:
+    if G > 1 or args.force_dist:
         shard = DopplerShard(rank=rank, world=G, device=dev)
         shard.attach(bank, D_total, M)
 
