@@ -16,13 +16,50 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
-typedef float2 cf;
+// Complex values are 2-wide float vectors so that complex arithmetic maps onto the packed-fp32
+// VALU ops of gfx950 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32).  Measured on MI355X
+// (tools/ubench/valu.hip): one SIMD issues a wave64 fp32 VALU op every ~4.6 cycles, scalar OR packed,
+// so a packed op does twice the work per issue slot; the FFT passes are VALU-issue-bound, which
+// makes packing worth ~1.8x.  The swizzled forms (multiply by i, complex multiply) use the VOP3P
+// op_sel / neg modifiers through inline asm: op_sel[i] / op_sel_hi[i] pick the half of source i
+// that feeds the low / high result lane (defaults 0 / 1), neg_lo / neg_hi negate it.
+typedef float cf __attribute__((ext_vector_type(2)));
 #define DEVI __device__ __forceinline__
 
-DEVI cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
-DEVI cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
-DEVI cf cmul(cf a, cf b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-DEVI cf cconj(cf a) { return make_float2(a.x, -a.y); }
+DEVI cf mkc(float x, float y) { return (cf){x, y}; }
+DEVI cf cadd(cf a, cf b) { return a + b; }
+DEVI cf csub(cf a, cf b) { return a - b; }
+DEVI cf cconj(cf a) { return (cf){a.x, -a.y}; }
+// a + i*b = (a.x - b.y, a.y + b.x)
+DEVI cf add_i(cf a, cf b) {
+    cf d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// a - i*b = (a.x + b.y, a.y - b.x)
+DEVI cf sub_i(cf a, cf b) {
+    cf d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// complex product: (a.x*w.x - a.y*w.y, a.x*w.y + a.y*w.x) in two packed ops
+DEVI cf cmul(cf a, cf w) {
+    cf p, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "v"(w), "v"(p));
+    return d;
+}
+// (x.x - x.y, x.x + x.y)  and  (-x.x - x.y, x.x - x.y)
+DEVI cf rot45_sum(cf x) {
+    cf d;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,1]" : "=v"(d) : "v"(x));
+    return d;
+}
+DEVI cf rot135_sum(cf x) {
+    cf d;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[1,1] neg_hi:[0,1]" : "=v"(d) : "v"(x));
+    return d;
+}
 
 // ---- buffer (SRSRC) addressing: one VGPR byte offset + one SGPR offset per access, hardware range
 // check (out-of-range loads return 0, stores are dropped).  Keeps 64-bit per-access address
@@ -33,7 +70,7 @@ DEVI __amdgpu_buffer_rsrc_t mk_rsrc(const void *p, unsigned bytes) {
 }
 DEVI cf buf_load_cf(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+    return mkc(__uint_as_float(v.x), __uint_as_float(v.y));
 }
 DEVI float buf_load_f(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
@@ -66,25 +103,38 @@ DEVI void sfor(F &&f) {
 // ---- in-register butterflies (inverse sign) ---------------------------------------------------
 DEVI void b2(cf &a, cf &b) {
     cf t = a;
-    a = cadd(t, b);
-    b = csub(t, b);
+    a = t + b;
+    b = t - b;
+}
+// (a, i*b) -> (a + i*b, a - i*b): radix-2 whose second input still has to be multiplied by i
+DEVI void b2_bi(cf &a, cf &b) {
+    cf t = a, u = b;
+    a = add_i(t, u);
+    b = sub_i(t, u);
 }
 DEVI void b4(cf &a0, cf &a1, cf &a2, cf &a3) {
-    cf t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = csub(a1, a3);
-    a0 = cadd(t0, t2);
-    a2 = csub(t0, t2);
-    a1 = make_float2(t1.x - t3.y, t1.y + t3.x);  // t1 + i*t3
-    a3 = make_float2(t1.x + t3.y, t1.y - t3.x);  // t1 - i*t3
+    cf t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = a1 - a3;
+    a0 = t0 + t2;
+    a2 = t0 - t2;
+    a1 = add_i(t1, t3);  // t1 + i*t3
+    a3 = sub_i(t1, t3);  // t1 - i*t3
+}
+// radix-4 whose third input (a2) still has to be multiplied by i
+DEVI void b4_a2i(cf &a0, cf &a1, cf &a2, cf &a3) {
+    cf t0 = add_i(a0, a2), t1 = sub_i(a0, a2), t2 = a1 + a3, t3 = a1 - a3;
+    a0 = t0 + t2;
+    a2 = t0 - t2;
+    a1 = add_i(t1, t3);
+    a3 = sub_i(t1, t3);
 }
 #define MFB_H 0.70710678118654752440f
 #define MFB_C 0.92387953251128675613f
 #define MFB_S 0.38268343236508977173f
-DEVI cf mul_w8_1(cf x) { return make_float2(MFB_H * (x.x - x.y), MFB_H * (x.x + x.y)); }   // e^{+i pi/4}
-DEVI cf mul_i(cf x) { return make_float2(-x.y, x.x); }                                      // e^{+i pi/2}
-DEVI cf mul_w8_3(cf x) { return make_float2(-MFB_H * (x.x + x.y), MFB_H * (x.x - x.y)); }  // e^{+i 3pi/4}
-DEVI cf mul_w16_1(cf x) { return cmul(x, make_float2(MFB_C, MFB_S)); }
-DEVI cf mul_w16_3(cf x) { return cmul(x, make_float2(MFB_S, MFB_C)); }
-DEVI cf mul_w16_9(cf x) { return cmul(x, make_float2(-MFB_C, -MFB_S)); }
+DEVI cf mul_w8_1(cf x) { return rot45_sum(x) * MFB_H; }   // e^{+i pi/4}
+DEVI cf mul_w8_3(cf x) { return rot135_sum(x) * MFB_H; }  // e^{+i 3pi/4}
+DEVI cf mul_w16_1(cf x) { return cmul(x, mkc(MFB_C, MFB_S)); }
+DEVI cf mul_w16_3(cf x) { return cmul(x, mkc(MFB_S, MFB_C)); }
+DEVI cf mul_w16_9(cf x) { return cmul(x, mkc(-MFB_C, -MFB_S)); }
 
 template <int R, int O>
 DEVI void bfly(cf (&v)[16]) {
@@ -96,11 +146,10 @@ DEVI void bfly(cf (&v)[16]) {
         b4(v[O + 0], v[O + 2], v[O + 4], v[O + 6]);
         b4(v[O + 1], v[O + 3], v[O + 5], v[O + 7]);
         v[O + 3] = mul_w8_1(v[O + 3]);
-        v[O + 5] = mul_i(v[O + 5]);
         v[O + 7] = mul_w8_3(v[O + 7]);
         b2(v[O + 0], v[O + 1]);
         b2(v[O + 2], v[O + 3]);
-        b2(v[O + 4], v[O + 5]);
+        b2_bi(v[O + 4], v[O + 5]);  // v[O+5] carries W8^2 = i, folded into the butterfly
         b2(v[O + 6], v[O + 7]);
     } else {
         static_assert(R == 16 && O == 0, "radix");
@@ -113,14 +162,14 @@ DEVI void bfly(cf (&v)[16]) {
         v[9] = mul_w8_1(v[9]);     // t=1,p1=2 -> W16^2
         v[13] = mul_w16_3(v[13]);  // t=1,p1=3
         v[6] = mul_w8_1(v[6]);     // t=2,p1=1 -> W16^2
-        v[10] = mul_i(v[10]);      // t=2,p1=2 -> W16^4
+        //  v[10]: t=2,p1=2 -> W16^4 = i, folded into the second-stage butterfly below
         v[14] = mul_w8_3(v[14]);   // t=2,p1=3 -> W16^6
         v[7] = mul_w16_3(v[7]);    // t=3,p1=1
         v[11] = mul_w8_3(v[11]);   // t=3,p1=2 -> W16^6
         v[15] = mul_w16_9(v[15]);  // t=3,p1=3 -> W16^9
         b4(v[0], v[1], v[2], v[3]);
         b4(v[4], v[5], v[6], v[7]);
-        b4(v[8], v[9], v[10], v[11]);
+        b4_a2i(v[8], v[9], v[10], v[11]);
         b4(v[12], v[13], v[14], v[15]);
     }
 }

@@ -165,7 +165,7 @@ __global__ void __launch_bounds__((L1 / 16) * TILE) k_pass1(P1Args a) {
         } else {
             const auto xr = mk_rsrc(a.Xr, (unsigned)N * sizeof(float));
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = make_float2(buf_load_f(xr, vo_in / 2, i * (so_in / 2)), 0.f);
+            for (int i = 0; i < 16; ++i) v[i] = mkc(buf_load_f(xr, vo_in / 2, i * (so_in / 2)), 0.f);
         }
         const auto zr = mk_rsrc(a.Z, rowbytes);
         auto store = [&](int, cf val, auto slot, auto nu) { z_store(zr, val, slot, nu); };
@@ -274,10 +274,11 @@ __global__ void __launch_bounds__((L2 / 16) * P2Cfg<L2>::RB) k_pass2(P2Args a) {
         for (int i = 0; i < 16; ++i) v[i] = nv[i];
         if (base + RB < a.srb) load_row(min(base + RB + rb, a.srb - 1));  // wave-uniform condition
         if constexpr (MODE == MODE_REDUCE) {
-            float racc = 0.f;
-            auto store = [&](int, cf val, auto, auto) { racc += val.x * val.x + val.y * val.y; };
+            cf racc = mkc(0.f, 0.f);   // (sum re^2, sum im^2): one packed FMA per point
+            auto store = [&](int, cf val, auto, auto) { racc = __builtin_elementwise_fma(val, val, racc); };
             fft_passes<L2, 1, 0, Cfg::HOIST, Cfg::PP, Cfg::HALF>(v, mylds, ebuf, g, 0, twr, a.tw2, store);
-            acc += (RB == 1) ? racc : racc * okf;
+            const float rs = racc.x + racc.y;
+            acc += (RB == 1) ? rs : rs * okf;
         } else {
             // y[n1 + N1*n2], n2 = nu + g: byte offset (sr + N1*g)*8 per thread + nu*N1*8 uniform
             const auto orr = mk_rsrc(a.out + (size_t)row * a.N, (unsigned)a.N * sizeof(cf));
@@ -285,7 +286,7 @@ __global__ void __launch_bounds__((L2 / 16) * P2Cfg<L2>::RB) k_pass2(P2Args a) {
             const int sout = a.N1 * (int)sizeof(cf);
             const float sgn = a.conj_out ? -1.f : 1.f;
             auto store = [&](int, cf val, auto, auto nu) {
-                buf_store_cf(orr, vout, decltype(nu)::value * sout, make_float2(val.x, sgn * val.y));
+                buf_store_cf(orr, vout, decltype(nu)::value * sout, mkc(val.x, sgn * val.y));
             };
             fft_passes<L2, 1, 0, Cfg::HOIST, Cfg::PP, Cfg::HALF>(v, mylds, ebuf, g, 0, twr, a.tw2, store);
         }
@@ -554,7 +555,7 @@ static void make_twiddles(std::vector<cf> &v, int count, double denom, double st
     v.resize(count);
     for (int i = 0; i < count; ++i) {
         const double ang = 2.0 * M_PI * (double)i * stepmul / denom;
-        v[i] = make_float2((float)cos(ang), (float)sin(ang));
+        v[i] = (cf){(float)cos(ang), (float)sin(ang)};
     }
 }
 
