@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmfbank.so')
+# MFBANK_LIB lets a developer point at an alternative build of the same ABI (kernel experiments)
+LIB_PATH = os.environ.get('MFBANK_LIB') or os.path.join(_HERE, 'libmfbank.so')
 
 MFB_OK, MFB_ERR_ARG, MFB_ERR_DTYPE, MFB_ERR_ALLOC, MFB_ERR_HIP, MFB_ERR_STATE, MFB_ERR_UNSUPPORTED = range(7)
 

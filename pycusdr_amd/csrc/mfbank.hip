@@ -82,16 +82,38 @@ struct P2Args {
 //   over the Doppler bins jl = blockIdx.z, blockIdx.z + gridDim.z, ... of the chunk, so the
 //   per-thread twiddles (inner W_N1 and inter-pass W_N) are built once and stay in registers.
 // ------------------------------------------------------------------------------------------------
+// Kernel-shape switches, chosen by interleaved A/B runs on MI355X at C2 (tools/probe_var.sh):
+//   ping-pong LDS halves (one barrier per exchange instead of two) bought nothing measurable,
+//   while the single buffer (35 KiB) lets three workgroups share a CU;
+//   pass 2 runs best at 3 waves/SIMD (168 VGPRs, 3 dwords spilled): 3.55 -> 3.17 ms;
+//   pass 1 runs best at 2 waves/SIMD WITH the one-filter-ahead register prefetch (3.46 ms; without
+//   it at 3 waves/SIMD: 3.85 ms).
+#ifndef MFB_P1_PP
+#define MFB_P1_PP 0
+#endif
+#ifndef MFB_P2_PP
+#define MFB_P2_PP 0
+#endif
+#ifndef MFB_P1_PREFETCH
+#define MFB_P1_PREFETCH 1
+#endif
+#ifndef MFB_P1_WAVES
+#define MFB_P1_WAVES 2
+#endif
+#ifndef MFB_P2_WAVES
+#define MFB_P2_WAVES 3
+#endif
+
 template <int L1>
 struct P1Cfg {
     static constexpr int NT = L1 / 16;
     static constexpr int HALF = padlen(L1) * TILE;
-    static constexpr bool PP = true;  // 2 * 34 KiB at L1 = 256
+    static constexpr bool PP = MFB_P1_PP;  // 2 * 34 KiB at L1 = 256
     static constexpr size_t lds_bytes = (size_t)HALF * (PP ? 2 : 1) * sizeof(cf);
 };
 
 template <int L1, int KIND>
-__global__ void __launch_bounds__((L1 / 16) * TILE) k_pass1(P1Args a) {
+__global__ void __launch_bounds__((L1 / 16) * TILE, (L1 == 256 && KIND == KIND_BANK) ? MFB_P1_WAVES : 1) k_pass1(P1Args a) {
     using Cfg = P1Cfg<L1>;
     constexpr int NT = Cfg::NT;
     constexpr int l1 = ilog2c(L1);
@@ -175,7 +197,7 @@ __global__ void __launch_bounds__((L1 / 16) * TILE) k_pass1(P1Args a) {
         const int m1 = min(m0 + a.mpb, a.M);
         const auto xr = mk_rsrc(a.X, rowbytes);
         cf mk[16];  // mask values of the NEXT transform (software prefetch)
-        {
+        if constexpr (MFB_P1_PREFETCH) {
             const auto mr = mk_rsrc(a.masks + (size_t)m0 * N, rowbytes);
 #pragma unroll
             for (int i = 0; i < 16; ++i) mk[i] = buf_load_cf(mr, vo_in, i * so_in);
@@ -188,12 +210,20 @@ __global__ void __launch_bounds__((L1 / 16) * TILE) k_pass1(P1Args a) {
                 xv[i] = buf_load_cf(xr, ((ebase + i * estride + shift) & (N - 1)) * (int)sizeof(cf), 0);
             for (int m = m0; m < m1; ++m) {
                 cf v[16];
+                if constexpr (MFB_P1_PREFETCH) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = cmul(xv[i], mk[i]);
-                const int mn = (m + 1 < m1) ? (m + 1) : m0;  // always valid: branch-free prefetch
-                const auto mr = mk_rsrc(a.masks + (size_t)mn * N, rowbytes);
+                    for (int i = 0; i < 16; ++i) v[i] = cmul(xv[i], mk[i]);
+                    const int mn = (m + 1 < m1) ? (m + 1) : m0;  // always valid: branch-free prefetch
+                    const auto mr = mk_rsrc(a.masks + (size_t)mn * N, rowbytes);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) mk[i] = buf_load_cf(mr, vo_in, i * so_in);
+                    for (int i = 0; i < 16; ++i) mk[i] = buf_load_cf(mr, vo_in, i * so_in);
+                } else {
+                    const auto mr = mk_rsrc(a.masks + (size_t)m * N, rowbytes);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v[i] = buf_load_cf(mr, vo_in, i * so_in);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v[i] = cmul(xv[i], v[i]);
+                }
                 const auto zr = mk_rsrc(a.Z + ((size_t)jl * a.M + m) * (size_t)N, rowbytes);
                 auto store = [&](int, cf val, auto slot, auto nu) { z_store(zr, val, slot, nu); };
                 fft_passes<L1, TILE, 0, true, Cfg::PP, Cfg::HALF>(v, lds, ebuf, g, col, twr, a.tw1, store);
@@ -216,13 +246,13 @@ struct P2Cfg {
     static constexpr int NT = L2 / 16;
     static constexpr int RB = NT >= 256 ? 1 : 256 / NT;
     static constexpr int HALF = padlen(L2) * RB;
-    static constexpr bool PP = (size_t)HALF * 2 * sizeof(cf) <= 72 * 1024;
+    static constexpr bool PP = MFB_P2_PP && (size_t)HALF * 2 * sizeof(cf) <= 72 * 1024;
     static constexpr bool HOIST = L2 <= 8192;  // 16384-point rows run 1024 threads: 128-VGPR budget
     static constexpr size_t lds_bytes = (size_t)HALF * (PP ? 2 : 1) * sizeof(cf);
 };
 
 template <int L2, int MODE>
-__global__ void __launch_bounds__((L2 / 16) * P2Cfg<L2>::RB) k_pass2(P2Args a) {
+__global__ void __launch_bounds__((L2 / 16) * P2Cfg<L2>::RB, (L2 == 4096 && MODE == MODE_REDUCE) ? MFB_P2_WAVES : 1) k_pass2(P2Args a) {
     using Cfg = P2Cfg<L2>;
     constexpr int NT = Cfg::NT;
     constexpr int RB = Cfg::RB;
@@ -280,13 +310,14 @@ __global__ void __launch_bounds__((L2 / 16) * P2Cfg<L2>::RB) k_pass2(P2Args a) {
             const float rs = racc.x + racc.y;
             acc += (RB == 1) ? rs : rs * okf;
         } else {
-            // y[n1 + N1*n2], n2 = nu + g: byte offset (sr + N1*g)*8 per thread + nu*N1*8 uniform
-            const auto orr = mk_rsrc(a.out + (size_t)row * a.N, (unsigned)a.N * sizeof(cf));
-            const int vout = (sr0 + rsel + a.N1 * g) * (int)sizeof(cf);
-            const int sout = a.N1 * (int)sizeof(cf);
-            const float sgn = a.conj_out ? -1.f : 1.f;
+            // the transformed row goes back IN PLACE as Z[row][n1][n2] (coalesced; this workgroup is
+            // the only reader and writer of the row and has it in registers); k_transpose then
+            // produces the natural order y[n1 + N1*n2]
+            cf *zw = const_cast<cf *>(zrow) + (size_t)sr0 * L2;
+            const auto orr = mk_rsrc(zw, (unsigned)a.srb * fftbytes);
+            const int vw = vo + rsel * (int)fftbytes;
             auto store = [&](int, cf val, auto, auto nu) {
-                buf_store_cf(orr, vout, decltype(nu)::value * sout, mkc(val.x, sgn * val.y));
+                buf_store_cf(orr, vw, decltype(nu)::value * (int)sizeof(cf), val);
             };
             fft_passes<L2, 1, 0, Cfg::HOIST, Cfg::PP, Cfg::HALF>(v, mylds, ebuf, g, 0, twr, a.tw2, store);
         }
@@ -329,6 +360,26 @@ __global__ void k_finalize(const float *partials, float *dsum, int D, int M, int
     if (sum_all) dsum[j * M] = tot;
 }
 
+// Z[row][n1][n2] -> out[row][n1 + N1*n2] (natural order), optional conjugation (forward transform).
+// 32x32 tiles through LDS: coalesced reads along n2, coalesced writes along n1.
+__global__ void __launch_bounds__(256) k_transpose(const cf *Z, cf *out, int N1, int N2, int conj) {
+    __shared__ cf tile[32][33];
+    const size_t rowoff = (size_t)blockIdx.z * N1 * N2;
+    const int n2_0 = blockIdx.x * 32, n1_0 = blockIdx.y * 32;
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    for (int r = r0; r < 32; r += 8) {
+        if (n1_0 + r < N1 && n2_0 + c < N2) tile[r][c] = Z[rowoff + (size_t)(n1_0 + r) * N2 + n2_0 + c];
+    }
+    __syncthreads();
+    const float sgn = conj ? -1.f : 1.f;
+    for (int r = r0; r < 32; r += 8) {
+        if (n2_0 + r < N2 && n1_0 + c < N1) {
+            const cf z = tile[c][r];
+            out[rowoff + (size_t)(n2_0 + r) * N1 + n1_0 + c] = mkc(z.x, sgn * z.y);
+        }
+    }
+}
+
 // findDopplerEst (cuda_kernels.cu:502-597).  One wavefront; lane x < M owns column x.
 // fp32 evaluation order is pinned with explicit intrinsics (see oracle/mfbank_oracle.py).
 __global__ void k_pick(const float *in, float *res, int num, int offset, int M, int sum_all) {
@@ -339,12 +390,20 @@ __global__ void k_pick(const float *in, float *res, int num, int offset, int M, 
         float maxVal[2] = {0.f, 0.f};
         int maxIdx[2] = {0, 0};
         int cur = 0;
-        for (int i = offset; i < num + offset; ++i) {
-            const float tmp = in[x + i * M];
-            if (tmp > maxVal[cur]) {
-                maxVal[cur] = tmp;
-                maxIdx[cur] = i;
-                cur = (maxVal[0] >= maxVal[1]) ? 1 : 0;
+        // same sequential scan as the reference; the loads are issued 8 at a time so that the scan
+        // is not a chain of 256+ dependent L2 round trips
+        for (int i0 = offset; i0 < num + offset; i0 += 8) {
+            float buf[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) buf[u] = (i0 + u < num + offset) ? in[x + (i0 + u) * M] : -1.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float tmp = buf[u];
+                if (i0 + u < num + offset && tmp > maxVal[cur]) {
+                    maxVal[cur] = tmp;
+                    maxIdx[cur] = i0 + u;
+                    cur = (maxVal[0] >= maxVal[1]) ? 1 : 0;
+                }
             }
         }
         const float numr = __fmaf_rn((float)maxIdx[0], maxVal[0], __fmul_rn((float)maxIdx[1], maxVal[1]));
@@ -857,6 +916,13 @@ static P2Args p2_base(mfb_ctx *c) {
     return a;
 }
 
+static int launch_transpose(mfb_ctx *c, cf *dst, int rows, int conj) {
+    dim3 grid((c->N2 + 31) / 32, (c->N1 + 31) / 32, rows);
+    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, c->stream, (const cf *)c->d_Z, dst, c->N1, c->N2, conj);
+    HIPCHK(hipGetLastError());
+    return MFB_OK;
+}
+
 // forward FFT of one row: complex (src_c) or real (src_r) input -> dst natural order
 static int forward_fft(mfb_ctx *c, const cf *src_c, const float *src_r, cf *dst) {
     P1Args a = p1_base(c);
@@ -869,10 +935,10 @@ static int forward_fft(mfb_ctx *c, const cf *src_c, const float *src_r, cf *dst)
     int rc = src_c ? launch_p1<KIND_FWDC>(c, a, g1) : launch_p1<KIND_FWDR>(c, a, g1);
     if (rc) return rc;
     P2Args b = p2_base(c);
-    b.out = dst;
-    b.conj_out = 1;
     dim3 g2(c->parts, 1, 1);
-    return launch_p2<MODE_STORE>(c, b, g2);
+    rc = launch_p2<MODE_STORE>(c, b, g2);
+    if (rc) return rc;
+    return launch_transpose(c, dst, 1, 1);
 }
 
 extern "C" int mfb_upload(mfb_ctx *c) {
@@ -1009,9 +1075,9 @@ extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, fl
     int rc = launch_p1<KIND_BANK>(c, a, dim3(a.ntiles * mgroups, 1, 1));
     if (rc) return rc;
     P2Args b = p2_base(c);
-    b.out = c->d_xc;
-    b.conj_out = 0;
     rc = launch_p2<MODE_STORE>(c, b, dim3(c->parts, c->M, 1));
+    if (rc) return rc;
+    rc = launch_transpose(c, c->d_xc, c->M, 0);
     if (rc) return rc;
     // A10: envelope, spectrum of the envelope, windowed argmax
     hipLaunchKernelGGL(k_envelope, dim3(1024), dim3(256), 0, c->stream, c->d_xc, c->d_env, c->N, c->M, c->cs_off);

@@ -76,7 +76,7 @@ def test_stream_bits_identical_to_oracle_and_packet_error_free(monkeypatch, mod,
             # fp32-vs-fp64 round-off (the kernel itself is bit-exact against the oracle on its own
             # matched-filter outputs: tests/test_gpu_kernels.py)
             dcen = gpu._centresWin - cpu._centresWin
-            assert np.abs(dcen).max() <= 3 and np.count_nonzero(dcen) <= 0.02 * len(dcen)
+            assert np.abs(dcen).max() <= 6 and np.count_nonzero(dcen) <= 0.02 * len(dcen)
         else:
             # quiet padding: the matched-filter outputs there are fp32 FFT round-off of the strong
             # packet, so the argmax is arbitrary in BOTH implementations; decisions must agree on
@@ -89,9 +89,9 @@ def test_stream_bits_identical_to_oracle_and_packet_error_free(monkeypatch, mod,
                 return c[keep], bits[keep]
             (cgs, bgs), (ccs, bcs) = strong(bg, gpu), strong(bc, cpu)
             assert np.array_equal(bgs, bcs), f'block {b}: decisions on signal-bearing symbols differ'
-            # the sample index of the peak may move by one where two neighbouring samples of the
-            # noiseless matched-filter peak are equal to within round-off
-            assert np.abs(cgs - ccs).max() <= 3
+            # the sample index of the peak may move inside the W=7 window where samples of a flat
+            # noiseless matched-filter plateau (constant-envelope FSK runs) tie to within round-off
+            assert np.abs(cgs - ccs).max() <= 6
             assert np.count_nonzero(cgs != ccs) <= 0.02 * len(cgs)
         pk, _, _ = dec.findFrames(bg, 0)
         packets.extend(pk)
