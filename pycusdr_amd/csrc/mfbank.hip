@@ -94,6 +94,9 @@ struct P2Args {
 #ifndef MFB_P2_PP
 #define MFB_P2_PP 0
 #endif
+#ifndef MFB_P1_TILEMAP
+#define MFB_P1_TILEMAP 0
+#endif
 #ifndef MFB_P1_PREFETCH
 #define MFB_P1_PREFETCH 1
 #endif
@@ -137,7 +140,11 @@ __global__ void __launch_bounds__((L1 / 16) * TILE, (L1 == 256 && KIND == KIND_B
         const int per_tile = a.mgroups * a.jsplit;
         if ((a.ntiles & 7) == 0) {
             const int x = b & 7, q = b >> 3;
+#if MFB_P1_TILEMAP
+            tile = x * (a.ntiles >> 3) + (q / per_tile);   // each XCD owns a contiguous range of tiles
+#else
             tile = (q / per_tile) * 8 + x;
+#endif
             const int r = q % per_tile;
             mg = r / a.jsplit;
             zj = r % a.jsplit;
@@ -382,30 +389,34 @@ __global__ void __launch_bounds__(256) k_transpose(const cf *Z, cf *out, int N1,
 
 // findDopplerEst (cuda_kernels.cu:502-597).  One wavefront; lane x < M owns column x.
 // fp32 evaluation order is pinned with explicit intrinsics (see oracle/mfbank_oracle.py).
-__global__ void k_pick(const float *in, float *res, int num, int offset, int M, int sum_all) {
+__global__ void __launch_bounds__(256) k_pick(const float *in, float *res, int num, int offset, int M, int sum_all) {
     __shared__ float sIdx[64], sVal[64];
+    __shared__ float stage[8192];   // chunk of rows x M scores, staged with all 256 threads
     const int x = threadIdx.x;
     float idxL = 0.f, valL = 0.f;
-    if (x < M) {
-        float maxVal[2] = {0.f, 0.f};
-        int maxIdx[2] = {0, 0};
-        int cur = 0;
-        // same sequential scan as the reference; the loads are issued 8 at a time so that the scan
-        // is not a chain of 256+ dependent L2 round trips
-        for (int i0 = offset; i0 < num + offset; i0 += 8) {
-            float buf[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) buf[u] = (i0 + u < num + offset) ? in[x + (i0 + u) * M] : -1.f;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float tmp = buf[u];
-                if (i0 + u < num + offset && tmp > maxVal[cur]) {
+    float maxVal[2] = {0.f, 0.f};
+    int maxIdx[2] = {0, 0};
+    int cur = 0;
+    const int rows_per_chunk = 8192 / M;
+    for (int r0 = offset; r0 < num + offset; r0 += rows_per_chunk) {
+        const int nr = min(rows_per_chunk, num + offset - r0);
+        __syncthreads();
+        for (int q = x; q < nr * M; q += 256) stage[q] = in[(size_t)r0 * M + q];
+        __syncthreads();
+        if (x < M) {
+            // the reference's sequential scan (strict '>', slot of the smaller value is replaced)
+#pragma unroll 8
+            for (int r = 0; r < nr; ++r) {
+                const float tmp = stage[r * M + x];
+                if (tmp > maxVal[cur]) {
                     maxVal[cur] = tmp;
-                    maxIdx[cur] = i0 + u;
+                    maxIdx[cur] = r0 + r;
                     cur = (maxVal[0] >= maxVal[1]) ? 1 : 0;
                 }
             }
         }
+    }
+    if (x < M) {
         const float numr = __fmaf_rn((float)maxIdx[0], maxVal[0], __fmul_rn((float)maxIdx[1], maxVal[1]));
         idxL = __fdiv_rn(numr, __fadd_rn(maxVal[0], maxVal[1]));
         valL = __fdiv_rn(numr, (float)(maxIdx[0] + maxIdx[1]));
@@ -420,8 +431,10 @@ __global__ void k_pick(const float *in, float *res, int num, int offset, int M, 
     }
     int n = 1;
     while (n < M) n <<= 1;
-    sIdx[x] = (x < M) ? idxL : 0.f;
-    sVal[x] = (x < M) ? valL : 0.f;
+    if (x < 64) {
+        sIdx[x] = (x < M) ? idxL : 0.f;
+        sVal[x] = (x < M) ? valL : 0.f;
+    }
     __syncthreads();
     for (int step = n >> 1; step >= 1; step >>= 1) {
         float a = 0.f, b = 0.f;
@@ -902,6 +915,17 @@ static P1Args p1_base(mfb_ctx *c) {
     a.mpb = c->mpb;
     return a;
 }
+// rows per workgroup for the STORE transforms (1 or M rows only): small, so the launch fills the chip
+static void p2_store_split(mfb_ctx *c, P2Args &b, int rows) {
+    const int NT = c->N2 / 16;
+    const int RB = NT >= 256 ? 1 : 256 / NT;
+    int srb = rows >= 4 ? 2 : 1;
+    if (srb < RB) srb = RB;
+    if (srb > c->N1) srb = c->N1;
+    b.srb = srb;
+    b.parts = c->N1 / srb;
+}
+
 static P2Args p2_base(mfb_ctx *c) {
     P2Args a;
     memset(&a, 0, sizeof(a));
@@ -935,7 +959,8 @@ static int forward_fft(mfb_ctx *c, const cf *src_c, const float *src_r, cf *dst)
     int rc = src_c ? launch_p1<KIND_FWDC>(c, a, g1) : launch_p1<KIND_FWDR>(c, a, g1);
     if (rc) return rc;
     P2Args b = p2_base(c);
-    dim3 g2(c->parts, 1, 1);
+    p2_store_split(c, b, 1);
+    dim3 g2(b.parts, 1, 1);
     rc = launch_p2<MODE_STORE>(c, b, g2);
     if (rc) return rc;
     return launch_transpose(c, dst, 1, 1);
@@ -1021,7 +1046,7 @@ extern "C" int mfb_pick(mfb_ctx *c, const void *scores, int num, int offset, flo
     if (!scores && (num != c->D || offset != c->Doff)) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     const float *in = scores ? (const float *)scores : c->d_sum;
-    hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, c->stream, in, c->d_res, num, offset, c->M, c->sum_all);
+    hipLaunchKernelGGL(k_pick, dim3(1), dim3(256), 0, c->stream, in, c->d_res, num, offset, c->M, c->sum_all);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(res, c->d_res, 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1075,7 +1100,8 @@ extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, fl
     int rc = launch_p1<KIND_BANK>(c, a, dim3(a.ntiles * mgroups, 1, 1));
     if (rc) return rc;
     P2Args b = p2_base(c);
-    rc = launch_p2<MODE_STORE>(c, b, dim3(c->parts, c->M, 1));
+    p2_store_split(c, b, c->M);
+    rc = launch_p2<MODE_STORE>(c, b, dim3(b.parts, c->M, 1));
     if (rc) return rc;
     rc = launch_transpose(c, c->d_xc, c->M, 0);
     if (rc) return rc;
