@@ -1,0 +1,109 @@
+"""The per-block streaming loop around the hot path -- the caller of the Demodulator.
+
+Mirrors the body of the reference's ``Demodulator_process.run`` (reference
+demodulator_process.py:242-338): overlap carry in the page-locked input buffer, ``uploadAndFindCarrier``
+then ``demodulate``, the result dict that goes to the decoder (same keys, DP:259-276), moving-average
+timing and the rate line in ksamples/s (DP:186-190, 324-333).  The reference moves blocks over ZeroMQ
+between OS processes; transport is out of scope here, so blocks come from any iterable and results
+are handed to a callback (or returned) instead of ``zmq.send_pyobj``.
+"""
+import logging
+import time
+
+import numpy as np
+
+from . import demodulator as demod_backends
+
+log = logging.getLogger('pycusdr_amd.demodulator_process')
+
+
+def radioBackendVoteGroupIDX(radioBackend):
+    """Back-end name -> (module, vote group), as the reference maps it (DP:25-36)."""
+    if radioBackend == 'UHF':
+        return demod_backends.UHF, 0
+    if radioBackend in ('STX', 'SBAND'):
+        return demod_backends.STX, 1
+    raise TypeError(f'Invalid radio mode {radioBackend}')
+
+
+class DemodulatorRunner:
+    """One receive channel, in-process.  ``feed(new_samples)`` takes exactly
+    ``blockSize - overlap`` new complex64 samples and returns the result dict of that block."""
+
+    def __init__(self, conf, protocol, radio, shard=None):
+        self.conf, self.protocol, self.radioName = conf, protocol, radio
+        self.confRadio = confRadio = conf['Radios']['Rx'][radio]
+        confGPU = conf['GPU'][confRadio['CUDA_settings']]
+        self.overlap = 2 ** confGPU['overlap']
+        self.blockSize = 2 ** confGPU['blockSize']
+        self.samplesPerSlice = self.blockSize - self.overlap
+        self.baudRate = confRadio['baud']
+        self.spSym = confRadio['samplesPerSym']
+        self.Fs = self.baudRate * self.spSym
+        worker_radio_name = confRadio.get('name', radio)
+        self.workerId = conf['Main']['workerId'] + '-' + worker_radio_name
+        self.radioBackend = confRadio['radioBackend']
+        if 'voteGroup' in confRadio:
+            self.demodulator = radioBackendVoteGroupIDX(self.radioBackend)[0]
+            self.voteGroup = radioBackendVoteGroupIDX(confRadio['voteGroup'])[1]
+        else:
+            self.demodulator, self.voteGroup = radioBackendVoteGroupIDX(self.radioBackend)
+        self.decoderProtocol = confRadio.get('Protocol', 'None')
+        self.frequencyOffset_Hz = confRadio['frequencyOffset_Hz']
+        self.timeMA = 0.0
+        self.iterCount = 0
+        self.count = 0
+        self.demod = self.demodulator.Demodulator(conf, protocol, radio, shard=shard)
+        self.raw = self.demod.get_signalBufferHostPointer()
+        self.raw[:] = 0
+
+    def close(self):
+        self.demod.close()
+
+    def computeMATime(self, t):
+        self.iterCount += 1
+        self.timeMA = self.timeMA + (t - self.timeMA) / self.iterCount
+        return self.timeMA
+
+    def feed(self, new_samples):
+        if len(new_samples) != self.samplesPerSlice:
+            raise ValueError(f'expected {self.samplesPerSlice} new samples per block, got {len(new_samples)}')
+        raw = self.raw
+        raw[self.overlap:] = new_samples
+        stamp = time.time()
+        data = {'workerId': self.workerId, 'count': self.count, 'timestamp': stamp, 'voteGroup': self.voteGroup,
+                'baudRate': self.baudRate, 'sample_rate': self.Fs, 'protocol': self.decoderProtocol}
+        data['doppler'], data['doppler_std'], _, data['SNR'] = self.demod.uploadAndFindCarrier(raw)
+        data['data'], centres, data['trust'], data['spSymEst'] = self.demod.demodulate()
+        data['baudrate_est'] = self.Fs / data['spSymEst']
+        # range rate implied by the measured frequency offset (reference computeTxFreqOffset, DP:359-379)
+        fc = self.confRadio['frequency_Hz']
+        data['rangerate'] = -data['doppler'] / fc * 299792458.0
+        spent = time.time() - stamp
+        self.computeMATime(spent)
+        data['time_ms'] = spent * 1e3
+        data['rate_ksps'] = self.samplesPerSlice / spent / 1000
+        data['rate_ksps_avg'] = self.samplesPerSlice / self.timeMA / 1000
+        raw[:self.overlap] = raw[-self.overlap:]      # overlap carry for the next block
+        self.count += 1
+        return data
+
+    def run(self, sample_source, sink=None, decoder=None):
+        """Drive the loop over an iterable of new-sample slices.  With a ``decoder`` every block's
+        bits go through ``findFrames`` and the packets are collected."""
+        results, packets = [], []
+        for chunk in sample_source:
+            d = self.feed(np.asarray(chunk, dtype=np.complex64))
+            if decoder is not None:
+                pk, _, nsync = decoder.findFrames(d['data'], 0)
+                d['numSyncSig'] = nsync
+                packets.extend(pk)
+            if sink is not None:
+                sink(d)
+            else:
+                results.append(d)
+            if d['count'] % 50 == 0:
+                log.info('[%s]: freq offset % 6.0f Hz, SNR % 2.1f dB, est spsym % 3.2f, time % 3.2f ms (avg % 3.2f ms), '
+                         'rate %5.0f ksamples/s (avg %5.0f)', self.radioName, d['doppler'], d['SNR'], d['spSymEst'],
+                         d['time_ms'], self.timeMA * 1e3, d['rate_ksps'], d['rate_ksps_avg'])
+        return results, packets

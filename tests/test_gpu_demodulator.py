@@ -126,3 +126,27 @@ def test_all_zero_block_is_skipped(monkeypatch):
     assert gpu.uploadAndFindCarrier(raw) == (0., 0., [], 0.)
     assert gpu.dopplerIdxlast == 0
     gpu.close()
+
+
+def test_streaming_runner_result_dict_and_ber(monkeypatch):
+    """The caller's loop (next-scope row N1): overlap carry, result dict keys, decoder hand-off."""
+    from pycusdr_amd.demodulator_process import DemodulatorRunner
+    bs, ov = 15, 1 << 10
+    N = 1 << bs
+    conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=32)
+    p = loadProtocol('bench_GMSK')(conf=conf)
+    run = DemodulatorRunner(conf, p, 'UHF-H')
+    sig = sg.awgn(np.concatenate((sg.get_padded_packet('GMSK')[0], np.zeros(N))), 12.0, rng=np.random.RandomState(4))
+    sig = sig.astype(np.complex64)
+    step = N - ov
+    chunks = [sig[i * step:(i + 1) * step] for i in range(len(sig) // step)]
+    results, packets = run.run(chunks, decoder=Decoder({}, p))
+    assert len(results) == len(chunks) and [r['count'] for r in results] == list(range(len(chunks)))
+    for key in ('workerId', 'timestamp', 'voteGroup', 'doppler', 'doppler_std', 'data', 'trust', 'spSymEst', 'SNR',
+                'baudRate', 'sample_rate', 'protocol', 'rangerate', 'baudrate_est'):
+        assert key in results[0]
+    assert results[0]['workerId'] == 'bench_GMSK-UHF-H' and results[0]['data'].dtype == np.uint8
+    assert len(packets) == 1 and packets[0].checkPacketData() == 0
+    with pytest.raises(ValueError):
+        run.feed(np.zeros(10, np.complex64))
+    run.close()
