@@ -182,7 +182,7 @@ __global__ void __launch_bounds__((L1 / 16) * TILE, (L1 == 256 && KIND == KIND_B
 
     // last pass emits n1 = p*PCL + g + NT*u  ->  scalar offset (p*PCL + NT*u) * N2 * 8
     auto z_store = [&](__amdgpu_buffer_rsrc_t zr, cf val, auto slot, auto nu) {
-        buf_store_cf(zr, vo_out, decltype(nu)::value * so_out, cmul(val, twN[decltype(slot)::value]));
+        buf_store_cf<MFB_AUX_ZSTORE>(zr, vo_out, decltype(nu)::value * so_out, cmul(val, twN[decltype(slot)::value]));
     };
 
     if constexpr (KIND != KIND_BANK) {
@@ -294,12 +294,12 @@ __global__ void __launch_bounds__((L2 / 16) * P2Cfg<L2>::RB, (L2 == 4096 && MODE
         if constexpr (RB == 1) {
             const auto zr = mk_rsrc(zrow + (size_t)(sr0 + rsel) * L2, fftbytes);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) nv[i] = buf_load_cf(zr, vo, i * so);
+            for (int i = 0; i < 16; ++i) nv[i] = buf_load_cf<MFB_AUX_ZLOAD>(zr, vo, i * so);
         } else {
             const auto zr = mk_rsrc(zrow + (size_t)sr0 * L2, (unsigned)a.srb * fftbytes);
             const int vr = vo + rsel * (int)fftbytes;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) nv[i] = buf_load_cf(zr, vr, i * so);
+            for (int i = 0; i < 16; ++i) nv[i] = buf_load_cf<MFB_AUX_ZLOAD>(zr, vr, i * so);
         }
     };
     load_row(min(rb, a.srb - 1));
@@ -694,13 +694,15 @@ extern "C" int mfb_create(mfb_ctx **out, int device, int log2N, int num_dopplers
     c->W = window_width;
     c->sum_all = sum_all_masks ? 1 : 0;
     c->cs_off = code_search_mask_offset;
-    // Doppler bins per launch: as many as a 16 GiB intermediate holds.  Measured on MI355X (C2:
-    // D=256, M=8, N=2^20): large chunks win -- long persistent loops amortise the per-workgroup
-    // twiddle setup and keep each XCD's L2 serving the filter tile to many Doppler streams; keeping
-    // the intermediate inside the 256 MiB Infinity Cache (chunk 1-2) was slower (under-filled grid).
+    // Doppler bins per launch: as many as an 8 GiB intermediate holds.  Measured on MI355X (C2:
+    // D=256, M=8, N=2^20): long persistent loops amortise the per-workgroup twiddle setup and keep
+    // each XCD's L2 serving the filter tile to many Doppler streams, so big chunks win (chunk 16:
+    // 9.8 ms, 64: 6.65 ms, 128: 6.55 ms per block) -- but a 16 GiB intermediate (chunk 256) costs
+    // 0.4 ms more than two 8 GiB launches.  Keeping the intermediate inside the 256 MiB Infinity
+    // Cache (chunk 1-2) does not pay: the cache streams no faster than HBM (tools/ubench/mall.hip).
     {
         const size_t row_bytes = (size_t)c->N * sizeof(cf) * M;
-        size_t ch = ((size_t)16 << 30) / row_bytes;
+        size_t ch = ((size_t)8 << 30) / row_bytes;
         if (ch < 1) ch = 1;
         if (ch > (size_t)c->Dtot) ch = c->Dtot;
         if (ch * M > 65535) ch = 65535 / M;
