@@ -67,12 +67,10 @@ struct P2Args {
     const cf *Z;     // [rows][N1][N2]
     const cf *tw2;   // W_N2
     float *partials; // REDUCE: [..][PARTS]
-    cf *out;         // STORE: [rows][N]
     int N, N1, N2;
     int srb;         // sub-rows (n1 values) per block
     int parts;       // N1 / srb
     int part_row0;   // REDUCE: first (j*M+m) row of this chunk in the partials array
-    int conj_out;    // STORE: conjugate on store (forward transform)
     float scale;     // REDUCE: 1/2^18
 };
 

@@ -210,3 +210,32 @@ def test_error_behaviour():
         assert bank.input.shape == (4096,) and bank.input.flags.writeable
     finally:
         bank.close()
+
+
+@pytest.mark.parametrize('log2N', [19, 21, 22])
+def test_largest_supported_blocks(log2N):
+    """Maximum sizes: N = 2^21 runs 8192-point rows (512 threads), N = 2^22 runs 16384-point rows
+    (1024 threads, twiddles re-read instead of hoisted).  Real inverse FFTs of the oracle, D=3, M=2."""
+    N = 1 << log2N
+    rs = np.random.RandomState(log2N)
+    D, M = 3, 2
+    x, masks = _rc(rs, N), _rc(rs, M, N)
+    shifts = np.array([0, N // 3, N - 1], dtype=np.int32)
+    bank = MFBank(log2N, D, M, sum_all_masks=False)
+    try:
+        bank.set_filters(masks)
+        bank.set_shifts(shifts)
+        bank.upload(x)
+        X = bank.get_spectrum()
+        bank.find_carrier()
+        ds = bank.get_scores()
+        k, arg, val = bank.demodulate(int(shifts[1]), 100, 1000)
+        xc0 = bank.get_xcorr()[1]
+    finally:
+        bank.close()
+    Xref = np.fft.fft(x.astype(np.complex128))
+    assert np.abs(X - Xref).max() / np.abs(Xref).max() < 3e-6
+    ref = orc.doppler_scores(X, masks, shifts, False)
+    assert np.abs(ds - ref).max() / ref.max() < 1e-5
+    yref = np.fft.ifft(np.roll(X.astype(np.complex128), -int(shifts[1])) * masks[1]) * N
+    assert np.abs(xc0 - yref).max() / np.abs(yref).max() < 5e-6
