@@ -171,6 +171,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # secondary figure: find_carrier + demodulate (A3..A11 device part), outside the timed steps
+    full_ms = None
+    if shard is None:
+        from oracle import mfbank_oracle as orc          # window helper only (host arithmetic)
+        k_off, k_len = orc.code_rate_window(N, 16)
+        reps = 5
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for i in range(reps):
+            r = step(i)
+            k, arg, _ = bank.demodulate(N // 4, k_off, k_len)
+            spS, cOff = orc.code_rate_host(k, arg, N)
+            bank.find_centres(np.float32(spS), np.float32(cOff), 0, int(N / spS))
+        torch.cuda.synchronize(dev)
+        full_ms = (time.perf_counter() - t1) / reps * 1e3
+
     # live sanity: the pick must land on the +fs/4 carrier
     frac_idx = float(res[0])
     pick_shift = float(np.interp(frac_idx, np.arange(D_total), np.where(shifts > N // 2, shifts - N, shifts)))
@@ -220,6 +236,7 @@ def main():
                 'rangeRateMax_used': rr, 'tuning(chunk,mpb,rows,jsplit)': list(tun),
                 'units': 'samples through a 256-bin bank, summed over ranks',
                 'carrier_found': bool(carrier_ok),
+                'find_carrier_plus_demodulate_ms': None if full_ms is None else round(full_ms, 4),
             },
             'roofline': {
                 'bound': 'hbm', 'kernel': names[dom], 'achieved': round(achieved / 1e9, 2), 'peak': HBM_PEAK / 1e9,

@@ -1160,29 +1160,45 @@ extern "C" int mfb_get_envelope(mfb_ctx *c, float *host) {
     return MFB_OK;
 }
 
+// grow-only device workspace of the (handle-less) sync correlator, one per device
+struct SyncWs {
+    uint8_t *bits = nullptr;
+    int8_t *tmpl = nullptr;
+    int32_t *out = nullptr;
+    size_t cap_bits = 0, cap_tmpl = 0, cap_out = 0;
+};
+static SyncWs g_sync_ws[16];
+
+template <class T>
+static int ws_reserve(T **p, size_t *cap, size_t need) {
+    if (*cap >= need) return MFB_OK;
+    if (*p) HIPCHK(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    HIPCHK(hipMalloc((void **)p, need));
+    *cap = need;
+    return MFB_OK;
+}
+
 extern "C" int mfb_sync_correlate(int device, const uint8_t *bits, int B, int L, const int8_t *tmpl, int T, int32_t *scores) {
     if (!bits || !tmpl || !scores || B < 1 || L < 1 || T < 1 || T > 4096) return MFB_ERR_ARG;
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
-    if (device < 0 || device >= ndev) return MFB_ERR_ARG;
+    if (device < 0 || device >= ndev || device >= 16) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(device));
     const int outLen = L + T - 1;
-    uint8_t *d_bits = nullptr;
-    int8_t *d_t = nullptr;
-    int32_t *d_out = nullptr;
-    HIPCHK(hipMalloc((void **)&d_bits, (size_t)B * L));
-    HIPCHK(hipMalloc((void **)&d_t, (size_t)T));
-    HIPCHK(hipMalloc((void **)&d_out, (size_t)B * outLen * sizeof(int32_t)));
-    HIPCHK(hipMemcpy(d_bits, bits, (size_t)B * L, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_t, tmpl, (size_t)T, hipMemcpyHostToDevice));
+    SyncWs &w = g_sync_ws[device];
+    int rc;
+    if ((rc = ws_reserve(&w.bits, &w.cap_bits, (size_t)B * L))) return rc;
+    if ((rc = ws_reserve(&w.tmpl, &w.cap_tmpl, (size_t)T))) return rc;
+    if ((rc = ws_reserve(&w.out, &w.cap_out, (size_t)B * outLen * sizeof(int32_t)))) return rc;
+    HIPCHK(hipMemcpy(w.bits, bits, (size_t)B * L, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(w.tmpl, tmpl, (size_t)T, hipMemcpyHostToDevice));
     const int bs = 256;
     const size_t lds = (size_t)T + bs + T - 1;
-    hipLaunchKernelGGL(k_sync_corr, dim3((outLen + bs - 1) / bs, B), dim3(bs), lds, 0, d_bits, d_t, d_out, L, T);
+    hipLaunchKernelGGL(k_sync_corr, dim3((outLen + bs - 1) / bs, B), dim3(bs), lds, 0, w.bits, w.tmpl, w.out, L, T);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(scores, d_out, (size_t)B * outLen * sizeof(int32_t), hipMemcpyDeviceToHost));
-    hipFree(d_bits);
-    hipFree(d_t);
-    hipFree(d_out);
+    HIPCHK(hipMemcpy(scores, w.out, (size_t)B * outLen * sizeof(int32_t), hipMemcpyDeviceToHost));
     return MFB_OK;
 }
 
