@@ -174,15 +174,19 @@ def main():
     # secondary figure: find_carrier + demodulate (A3..A11 device part), outside the timed steps
     full_ms = None
     if shard is None:
-        from oracle import mfbank_oracle as orc          # window helper only (host arithmetic)
-        k_off, k_len = orc.code_rate_window(N, 16)
+        # host arithmetic of the demodulation stage, as Demodulator.findCodeRateAndPhaseGPU does it
+        k_off = int(N / (1.1 * 16))
+        k_len = int(N / (0.9 * 16)) - k_off
         reps = 5
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         for i in range(reps):
             r = step(i)
             k, arg, _ = bank.demodulate(N // 4, k_off, k_len)
-            spS, cOff = orc.code_rate_host(k, arg, N)
+            spS = N / float(k) if float(k) else 10.0
+            cOff = -float(arg) / np.pi * spS / 2
+            if cOff < 0:
+                cOff += spS - 1
             bank.find_centres(np.float32(spS), np.float32(cOff), 0, int(N / spS))
         torch.cuda.synchronize(dev)
         full_ms = (time.perf_counter() - t1) / reps * 1e3
