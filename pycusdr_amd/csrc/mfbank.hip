@@ -752,19 +752,19 @@ extern "C" int mfb_create(mfb_ctx **out, int device, int log2N, int num_dopplers
 
 extern "C" int mfb_destroy(mfb_ctx *c) {
     if (!c) return MFB_ERR_ARG;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_x,  c->d_X,    c->d_masks, c->d_Z,   c->d_xc,  c->d_P,   c->d_env, c->d_shifts, c->d_tw1,
                     c->d_tw2, c->d_twLo, c->d_twHi,  c->d_part, c->d_sum, c->d_res, c->d_cr,  c->d_sym,    c->d_cen, c->d_mag};
     for (void *p : bufs)
-        if (p) hipFree(p);
-    if (c->h_in) hipHostFree(c->h_in);
+        if (p) (void)hipFree(p);
+    if (c->h_in) (void)hipHostFree(c->h_in);
     for (auto &v : c->ev)
-        for (auto e : v) hipEventDestroy(e);
-    for (auto e : c->ev_pool) hipEventDestroy(e);
-    hipEventDestroy(c->t0);
-    hipEventDestroy(c->t1);
-    hipStreamDestroy(c->own_stream);
+        for (auto e : v) (void)hipEventDestroy(e);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(c->t0);
+    (void)hipEventDestroy(c->t1);
+    (void)hipStreamDestroy(c->own_stream);
     delete c;
     return MFB_OK;
 }
@@ -832,13 +832,13 @@ static hipEvent_t get_event(mfb_ctx *c) {
         return e;
     }
     hipEvent_t e;
-    hipEventCreate(&e);
+    (void)hipEventCreate(&e);
     return e;
 }
 static void prof_mark(mfb_ctx *c, int which) {
     if (!c->prof) return;
     hipEvent_t e = get_event(c);
-    hipEventRecord(e, c->stream);
+    (void)hipEventRecord(e, c->stream);
     c->ev[which].push_back(e);
 }
 
