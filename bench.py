@@ -84,6 +84,9 @@ def main():
     ap.add_argument('--protocol', default='bench_GMSK')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--tuning', default='', help='chunk,mpb,rows,jsplit (0 = default)')
+    ap.add_argument('--shard', choices=['bins', 'blocks'], default='bins',
+                    help='N>1: bins = C4, Doppler bins sharded 256/GPU + RCCL all-reduce per block (default); '
+                         'blocks = every GPU runs the full 256-bin bank on different time blocks, no collective')
     ap.add_argument('--force-dist', action='store_true', help='run the sharded/RCCL path even with one rank (rehearsal)')
     args = ap.parse_args()
 
@@ -116,14 +119,15 @@ def main():
 
     log2N, ov = args.log2n, 1 << 10
     N = 1 << log2N
-    D_total = args.bins * G
+    by_blocks = args.shard == 'blocks'
+    D_total = args.bins if by_blocks else args.bins * G
     M_size = 5 if args.protocol == 'bench_BPSK' else 3
     conf = cfg.bench_config(args.protocol, blockSize=log2N, overlap=10, doppCarrierSteps=D_total, device=local_rank)
     rr, shifts = widen_range_rate(conf, 'UHF-H', N, D_total)
     conf['Radios']['rangeRateMax'] = rr
     proto = loadProtocol(args.protocol)(conf=conf)
     M, masks = proto.get_filter(N, 16, M_size)
-    lo, hi = bin_slice(D_total, rank, G)
+    lo, hi = (0, D_total) if by_blocks else bin_slice(D_total, rank, G)
 
     bank = MFBank(log2N, hi - lo, M, window_width=7, sum_all_masks=True, device=local_rank)
     bank.set_filters(masks)
@@ -131,7 +135,7 @@ def main():
     if args.tuning:
         bank.set_tuning(*[int(v) for v in args.tuning.split(',')])
     shard = None
-    if G > 1 or args.force_dist:
+    if (G > 1 or args.force_dist) and not by_blocks:
         shard = DopplerShard(rank=rank, world=G, device=dev)
         shard.attach(bank, D_total, M)
 
@@ -143,7 +147,7 @@ def main():
     esz = blocks.element_size() * 2 * N
 
     def step(i):
-        bank.upload_device(blocks.data_ptr() + (i % nblocks) * esz)
+        bank.upload_device(blocks.data_ptr() + ((i * (G if by_blocks else 1) + (rank if by_blocks else 0)) % nblocks) * esz)
         if shard is None:
             return bank.find_carrier()
         return shard.search_and_pick(bank, lo)
@@ -233,6 +237,8 @@ def main():
             'config': {
                 'workload': ('C2: single MI355X, D=256 Doppler bins, M=8 GMSK matched filters (bench_GMSK), '
                              'N=2^20 complex64 chunk, ov=2^10' if G == 1 and log2N == 20 and args.bins == 256 else
+                             (f'block round-robin: every one of {G} GPUs runs the full D={D_total} bank on different time '
+                              f'blocks, M={M}, N=2^{log2N}, no data-path collective') if by_blocks else
                              f'C4-style: D={D_total} Doppler bins sharded {Dl}/GPU over {G} GPUs, M={M}, N=2^{log2N}, '
                              'RCCL all-reduce of the [D,M] scores per block'),
                 'D_total': D_total, 'D_per_gpu': Dl, 'M': M, 'log2N': log2N, 'overlap': ov,
