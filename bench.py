@@ -140,7 +140,7 @@ def main():
         shard.attach(bank, D_total, M)
 
     # synthetic input S1: the reference's GMSK bench packet at +fs/4, tiled, AWGN 10 dB, resident in HBM
-    nblocks = 8
+    nblocks = 16
     stream = sg.s1_stream(nblocks, N, ov, 'GMSK', 16, 153600, snr_db=10.0, seed=1)
     host_blocks = np.stack([stream[b * (N - ov): b * (N - ov) + N] for b in range(nblocks)])
     blocks = torch.from_numpy(host_blocks.view(np.float32).reshape(nblocks, 2 * N)).to(dev)
@@ -157,6 +157,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    step(0)            # initialisation: first launches load the code objects and touch the 8 GiB workspace
     for i in range(args.warmup):
         res = step(i)
     barrier()
