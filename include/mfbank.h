@@ -144,6 +144,15 @@ int mfb_get_envelope(mfb_ctx *ctx, float *host_f32);
 int mfb_sync_correlate(int device, const uint8_t *bits, int B, int L,
                        const int8_t *tmpl, int T, int32_t *scores);
 
+/* Thresholded form of the same correlation: for every stream the positions i (ascending) with
+ * score[b][i] >= threshold and their scores -- exactly np.where(np.convolve(bits, tmpl) >= threshold)
+ * as used at DEC:101 and DEC:113 -- without moving the full score arrays to the host.
+ * counts[b] receives the TOTAL number of hits of stream b; the first min(counts[b], max_hits) of them
+ * are stored in hit_idx[b][..] / hit_score[b][..] (row stride max_hits).  A caller that sees
+ * counts[b] > max_hits repeats the call with a larger max_hits (or uses mfb_sync_correlate). */
+int mfb_sync_find(int device, const uint8_t *bits, int B, int L, const int8_t *tmpl, int T,
+                  int threshold, int max_hits, int32_t *hit_idx, int32_t *hit_score, int32_t *counts);
+
 /* HIP-event stopwatch on the handle's stream (bench.py's live kernel timing). */
 int mfb_timer_start(mfb_ctx *ctx);
 int mfb_timer_stop(mfb_ctx *ctx, float *elapsed_ms);

@@ -60,6 +60,7 @@ PROTOTYPES = {
     'mfb_get_xcorr': (_i, [_vp, _vp]),
     'mfb_get_envelope': (_i, [_vp, _vp]),
     'mfb_sync_correlate': (_i, [_i, _vp, _i, _i, _vp, _i, _vp]),
+    'mfb_sync_find': (_i, [_i, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'mfb_timer_start': (_i, [_vp]),
     'mfb_timer_stop': (_i, [_vp, _fp]),
     'mfb_profile_enable': (_i, [_vp, _i]),

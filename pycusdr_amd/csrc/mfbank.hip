@@ -570,6 +570,82 @@ __global__ void k_sync_corr(const uint8_t *bits, const int8_t *tmpl, int32_t *ou
     }
 }
 
+// Thresholded form of the sync correlation: what decoder.py:101,113 does with np.where on the full
+// score array.  Three tiny kernels keep the hits of every stream in ascending position order
+// without atomics: (1) hits per 1024-position segment, (2) exclusive scan over the segments of a
+// stream, (3) recompute and write (position, score) at segment offset + rank inside the segment.
+#define SYNC_SEG 1024
+template <bool WRITE>
+__global__ void __launch_bounds__(256) k_sync_find(const uint8_t *bits, const int8_t *tmpl, int L, int T, int thr,
+                                                   int nseg, int *segcnt, const int *segoff, int max_hits,
+                                                   int32_t *hit_idx, int32_t *hit_score) {
+    extern __shared__ __attribute__((aligned(16))) int8_t sm[];
+    __shared__ int wsum[4];
+    int8_t *st = sm;      // T taps
+    int8_t *sb = sm + T;  // SYNC_SEG + T - 1 bits
+    const int b = blockIdx.y, seg = blockIdx.x;
+    const int i0 = seg * SYNC_SEG;
+    const int outLen = L + T - 1;
+    for (int t = threadIdx.x; t < T; t += 256) st[t] = tmpl[t];
+    const uint8_t *row = bits + (size_t)b * L;
+    for (int q = threadIdx.x; q < SYNC_SEG + T - 1; q += 256) {
+        const int src = i0 - (T - 1) + q;
+        sb[q] = (src >= 0 && src < L) ? (int8_t)row[src] : (int8_t)0;
+    }
+    __syncthreads();
+    int sc[4];
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {      // thread owns 4 consecutive positions -> order = (thread, u)
+        const int li = threadIdx.x * 4 + u;
+        int acc = 0;
+        const int8_t *p = sb + li + T - 1;
+        for (int t = 0; t < T; ++t) acc += (int)st[t] * (int)p[-t];
+        sc[u] = acc;
+        cnt += (i0 + li < outLen && acc >= thr) ? 1 : 0;
+    }
+    // exclusive scan of cnt over the 256 threads: wave prefix (64 lanes) + 4 wave totals
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if ((threadIdx.x & 63) >= o) incl += v;
+    }
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) wsum[wid] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < wid; ++w) wbase += wsum[w];
+    if constexpr (!WRITE) {
+        if (threadIdx.x == 255) segcnt[(size_t)b * nseg + seg] = wbase + incl;
+    } else {
+        int pos = segoff[(size_t)b * nseg + seg] + wbase + incl - cnt;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int li = threadIdx.x * 4 + u;
+            if (i0 + li < outLen && sc[u] >= thr) {
+                if (pos < max_hits) {
+                    hit_idx[(size_t)b * max_hits + pos] = i0 + li;
+                    hit_score[(size_t)b * max_hits + pos] = sc[u];
+                }
+                ++pos;
+            }
+        }
+    }
+}
+
+// one thread per stream: exclusive scan of the segment counts, total per stream
+__global__ void k_sync_scan(const int *segcnt, int *segoff, int *counts, int B, int nseg) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int run = 0;
+    for (int s = 0; s < nseg; ++s) {
+        segoff[(size_t)b * nseg + s] = run;
+        run += segcnt[(size_t)b * nseg + s];
+    }
+    counts[b] = run;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1165,7 +1241,9 @@ struct SyncWs {
     uint8_t *bits = nullptr;
     int8_t *tmpl = nullptr;
     int32_t *out = nullptr;
-    size_t cap_bits = 0, cap_tmpl = 0, cap_out = 0;
+    int *seg = nullptr;     // segcnt | segoff | counts
+    int32_t *hits = nullptr;  // hit_idx | hit_score
+    size_t cap_bits = 0, cap_tmpl = 0, cap_out = 0, cap_seg = 0, cap_hits = 0;
 };
 static SyncWs g_sync_ws[16];
 
@@ -1199,6 +1277,39 @@ extern "C" int mfb_sync_correlate(int device, const uint8_t *bits, int B, int L,
     hipLaunchKernelGGL(k_sync_corr, dim3((outLen + bs - 1) / bs, B), dim3(bs), lds, 0, w.bits, w.tmpl, w.out, L, T);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(scores, w.out, (size_t)B * outLen * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return MFB_OK;
+}
+
+extern "C" int mfb_sync_find(int device, const uint8_t *bits, int B, int L, const int8_t *tmpl, int T, int threshold,
+                             int max_hits, int32_t *hit_idx, int32_t *hit_score, int32_t *counts) {
+    if (!bits || !tmpl || !hit_idx || !hit_score || !counts || B < 1 || L < 1 || T < 1 || T > 4096 || max_hits < 1)
+        return MFB_ERR_ARG;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev || device >= 16) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(device));
+    const int outLen = L + T - 1;
+    const int nseg = (outLen + SYNC_SEG - 1) / SYNC_SEG;
+    SyncWs &w = g_sync_ws[device];
+    int rc;
+    if ((rc = ws_reserve(&w.bits, &w.cap_bits, (size_t)B * L))) return rc;
+    if ((rc = ws_reserve(&w.tmpl, &w.cap_tmpl, (size_t)T))) return rc;
+    if ((rc = ws_reserve(&w.seg, &w.cap_seg, ((size_t)2 * B * nseg + B) * sizeof(int)))) return rc;
+    if ((rc = ws_reserve(&w.hits, &w.cap_hits, (size_t)2 * B * max_hits * sizeof(int32_t)))) return rc;
+    int *segcnt = w.seg, *segoff = w.seg + (size_t)B * nseg, *d_counts = w.seg + (size_t)2 * B * nseg;
+    int32_t *d_idx = w.hits, *d_sc = w.hits + (size_t)B * max_hits;
+    HIPCHK(hipMemcpy(w.bits, bits, (size_t)B * L, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(w.tmpl, tmpl, (size_t)T, hipMemcpyHostToDevice));
+    const size_t lds = (size_t)T + SYNC_SEG + T - 1;
+    hipLaunchKernelGGL((k_sync_find<false>), dim3(nseg, B), dim3(256), lds, 0, w.bits, w.tmpl, L, T, threshold, nseg, segcnt,
+                       (const int *)nullptr, max_hits, (int32_t *)nullptr, (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_sync_scan, dim3((B + 63) / 64), dim3(64), 0, 0, (const int *)segcnt, segoff, d_counts, B, nseg);
+    hipLaunchKernelGGL((k_sync_find<true>), dim3(nseg, B), dim3(256), lds, 0, w.bits, w.tmpl, L, T, threshold, nseg, segcnt,
+                       (const int *)segoff, max_hits, d_idx, d_sc);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(counts, d_counts, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hit_idx, d_idx, (size_t)B * max_hits * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hit_score, d_sc, (size_t)B * max_hits * sizeof(int32_t), hipMemcpyDeviceToHost));
     return MFB_OK;
 }
 

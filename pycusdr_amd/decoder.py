@@ -22,6 +22,11 @@ def _hip_correlator(bits, template):
     return sync_correlate(bits, template)
 
 
+def _hip_finder(bits, template, threshold):
+    from .mfbank import sync_find
+    return sync_find(bits, template, threshold)
+
+
 class Decoder:
     maxPacketLenBits = int(2 ** 13)
     minNumBitsBeforeProcessing = int(2 ** 10)
@@ -29,7 +34,10 @@ class Decoder:
     def __init__(self, config, protocol, correlator=None):
         self.conf = config
         self.protocol = protocol
+        # default: thresholded correlation on the GPU (positions + scores only come back); an injected
+        # correlator returns the full np.convolve-style score array and is thresholded on the host
         self.correlate = correlator if correlator is not None else _hip_correlator
+        self._finder = _hip_finder if correlator is None else None
         self.preprocessor = protocol.decoderPreprocessor
         self.postprocessor = protocol.decoderPostprocessor
         self.mask = protocol.get_mask()
@@ -49,9 +57,14 @@ class Decoder:
         self.Packet = protocol.Packet
 
     # ------------------------------------------------------------------------------------------
-    def correlate_streams(self, bits):
-        """Header and sync scores of one bit stream (the two np.convolve calls of the reference)."""
-        return self.correlate(bits, self.mask), self.correlate(bits, self.syncSig)
+    def hits(self, bits, template, threshold):
+        """(positions, scores there) where the correlation with ``template`` reaches ``threshold`` --
+        np.where(np.convolve(bits, template) >= threshold) of the reference (decoder.py:96-113)."""
+        if self._finder is not None:
+            return self._finder(bits, template, threshold)
+        score = self.correlate(bits, template)
+        idx = np.where(score >= threshold)[0]
+        return idx, score[idx]
 
     def findFrames(self, bits_raw, frameStartIdx, debugMode=False):
         p = self.protocol
@@ -59,17 +72,15 @@ class Decoder:
         rawBits_DS = np.concatenate((self.bitsOverlapBuf, bits_less_raw))
         self.bitsOverlapBuf = rawBits_DS[-self.numBitsOverlap:]
 
-        score, syncSigs = self.correlate_streams(rawBits_DS)
-        idxCand = np.where(score >= p.numOnesHeader - p.headerTol)[0]
+        idxCand, candScore = self.hits(rawBits_DS, self.mask, p.numOnesHeader - p.headerTol)
         packetIdx = idxCand - len(self.mask) + 1          # the peak sits on the template's last bit
-        syncSigStartIdx = np.where(syncSigs >= p.numOnesSyncSig - p.syncSigTol)[0]
+        syncSigStartIdx, _ = self.hits(rawBits_DS, self.syncSig, p.numOnesSyncSig - p.syncSigTol)
         numSyncSig = len(syncSigStartIdx)
 
         if self.packetEndDetectMode == PacketEndDetect.FLAGS:
-            packets = self._frames_by_flags(rawBits_DS, bits_less_raw, frameStartIdx, score, idxCand, packetIdx,
-                                            syncSigStartIdx)
+            packets = self._frames_by_flags(rawBits_DS, bits_less_raw, frameStartIdx, candScore, packetIdx, syncSigStartIdx)
         elif self.packetEndDetectMode == PacketEndDetect.FIXED:
-            packets = self._frames_fixed(rawBits_DS, score, idxCand, packetIdx)
+            packets = self._frames_fixed(rawBits_DS, candScore, packetIdx)
         else:   # IN_DATA: the reference only calls protocol.packetDataProcessor() per header
             packets = []
             for _ in packetIdx:
@@ -77,7 +88,7 @@ class Decoder:
         return packets, bits_less_raw, numSyncSig
 
     # ---- FIXED: packets of protocol.packetLen bits (reference decoder.py:245-280) ---------------
-    def _frames_fixed(self, stream, score, idxCand, packetIdx):
+    def _frames_fixed(self, stream, candScore, packetIdx):
         packets = []
         for i, start in enumerate(packetIdx):
             if len(stream) - start < self.packetLen:
@@ -88,7 +99,7 @@ class Decoder:
                 break
             bits = stream[start:start + self.packetLen]
             if len(bits) > 0:
-                packets.append(self.Packet(bits, start, self.protocol.numOnesHeader - score[idxCand[i]]))
+                packets.append(self.Packet(bits, start, self.protocol.numOnesHeader - candScore[i]))
             else:
                 log.error('length of bits = 0. len(stream) = %d, idx start %d', len(stream), start)
         return packets
@@ -106,7 +117,7 @@ class Decoder:
             return None
         return np.min((syncSigStartIdx[k] + 16, syncSigStartIdx[-1]))
 
-    def _frames_by_flags(self, stream, new_bits, frameStartIdx, score, idxCand, packetIdx, syncSigStartIdx):
+    def _frames_by_flags(self, stream, new_bits, frameStartIdx, candScore, packetIdx, syncSigStartIdx):
         p = self.protocol
         packets = []
         if self.headerFrameStartIdx is not None:
@@ -128,7 +139,7 @@ class Decoder:
         if self.headerFrameStartIdx is None:
             for i, start in enumerate(packetIdx):
                 end = self._flag_end(syncSigStartIdx, start + 120, strict_first=True)
-                errs = p.numOnesHeader - score[idxCand[i]]
+                errs = p.numOnesHeader - candScore[i]
                 if end is None:
                     self.packetBuffer = stream[start:]
                     self.headerFrameStartIdx = frameStartIdx + start - self.numBitsOverlap

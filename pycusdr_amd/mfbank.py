@@ -163,6 +163,42 @@ class MFBank:
         _lib.check(self._lib.mfb_sync(self._h), 'mfb_sync')
 
 
+def _as_bits_and_template(bits, template):
+    b = np.asarray(bits)
+    single = b.ndim == 1
+    b2 = np.ascontiguousarray(b.reshape(1, -1) if single else b)
+    if b2.dtype != np.uint8:
+        if not np.all((b2 == 0) | (b2 == 1)):
+            raise ValueError('expected a 0/1 bit stream')
+        b2 = b2.astype(np.uint8)
+    t = np.asarray(template)
+    ti = np.ascontiguousarray(t, dtype=np.int8)
+    if not np.array_equal(ti, t):
+        raise ValueError('template must hold small integers (int8)')
+    return single, b2, ti
+
+
+def sync_find(bits, template, threshold, max_hits=1024, device=0):
+    """Positions where the sync/preamble correlation reaches ``threshold`` and the scores there:
+    ``np.where(np.convolve(bits, template) >= threshold)`` per stream, computed and thresholded on the
+    GPU.  Returns (idx int32[], score int32[]) for a 1-D input, a list of such pairs for [B, L]."""
+    lib = _lib.load()
+    single, b2, ti = _as_bits_and_template(bits, template)
+    B, L = b2.shape
+    thr = int(np.ceil(threshold))
+    while True:
+        idx = np.empty((B, max_hits), dtype=np.int32)
+        sc = np.empty((B, max_hits), dtype=np.int32)
+        cnt = np.empty(B, dtype=np.int32)
+        _lib.check(lib.mfb_sync_find(int(device), _ptr(b2), B, L, _ptr(ti), ti.size, thr, int(max_hits),
+                                     _ptr(idx), _ptr(sc), _ptr(cnt)), 'mfb_sync_find')
+        if cnt.max() <= max_hits:
+            break
+        max_hits = int(cnt.max())
+    out = [(idx[b, :cnt[b]].copy(), sc[b, :cnt[b]].copy()) for b in range(B)]
+    return out[0] if single else out
+
+
 def sync_correlate(bits, template, device=0):
     """Batched full convolution of 0/1 bit streams with an integer template on the GPU
     (reference decoder.py:96,112 does this with np.convolve).  ``bits`` uint8 [L] or [B, L];

@@ -46,3 +46,19 @@ def test_edge_cases_and_errors():
         sync_correlate(np.array([0, 1], np.uint8), np.array([0.5, 1]))  # non-integer template
     f = _hip_correlator(np.array([1., 0., 1., 1.]), np.array([1., -1.]))
     assert np.array_equal(f, np.convolve([1, 0, 1, 1], [1, -1]))
+
+
+def test_sync_find_equals_where_of_convolve():
+    from pycusdr_amd.mfbank import sync_find
+    rs = np.random.RandomState(12)
+    for B, L, T, thr in ((1, 70000, 64, 20), (5, 3000, 128, 24), (3, 900, 16, 4), (2, 5000, 32, -40)):
+        bits = rs.randint(0, 2, (B, L)).astype(np.uint8)
+        tmpl = (rs.randint(0, 2, T) * 2 - 1).astype(np.int8)
+        got = sync_find(bits, tmpl, thr, max_hits=8)        # small max_hits forces the regrow path
+        for b in range(B):
+            ref = orc.sync_correlate(bits[b], tmpl)
+            idx = np.where(ref >= thr)[0]
+            assert np.array_equal(got[b][0], idx) and np.array_equal(got[b][1], ref[idx])
+    i1, s1 = sync_find(bits[0], tmpl, 3.5)                   # 1-D input, fractional threshold
+    ref = orc.sync_correlate(bits[0], tmpl)
+    assert np.array_equal(i1, np.where(ref >= 3.5)[0]) and np.array_equal(s1, ref[ref >= 3.5])

@@ -2,7 +2,7 @@
 import sys, time
 import numpy as np
 sys.path.insert(0, '.')
-from pycusdr_amd.mfbank import sync_correlate
+from pycusdr_amd.mfbank import sync_correlate, sync_find
 rs = np.random.RandomState(2)
 B, L, T = 1024, 65536 + 2048, 64
 bits = rs.randint(0, 2, (B, L)).astype(np.uint8)
@@ -12,3 +12,11 @@ t = time.perf_counter(); out = sync_correlate(bits, tmpl); dt = time.perf_counte
 t = time.perf_counter(); ref = [np.convolve(bits[b].astype(np.int64), tmpl.astype(np.int64)) for b in range(8)]; dc = (time.perf_counter() - t) / 8
 assert all(np.array_equal(out[b], ref[b]) for b in range(8))
 print(f'GPU (host in/out, int32 scores): {dt*1e3:.1f} ms for {B} streams -> {B/dt:.0f} streams/s; np.convolve: {dc*1e3:.2f} ms/stream -> {1/dc:.0f} streams/s/core')
+
+thr = 36 - 5   # CC11xx: 36 ones in the 64-tap preamble+sync template, tolerance 5
+sync_find(bits[:2], tmpl, thr)
+t = time.perf_counter(); hits = sync_find(bits, tmpl, thr); dt2 = time.perf_counter() - t
+for b in range(8):
+    idx = np.where(ref[b] >= thr)[0]
+    assert np.array_equal(hits[b][0], idx) and np.array_equal(hits[b][1], ref[b][idx])
+print(f'GPU thresholded (positions+scores only): {dt2*1e3:.1f} ms for {B} streams -> {B/dt2:.0f} streams/s')
