@@ -65,8 +65,18 @@ DEVI cf rot135_sum(cf x) {
 // check (out-of-range loads return 0, stores are dropped).  Keeps 64-bit per-access address
 // registers out of the unrolled 16-point load/store groups.
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// Every descriptor in this library is wave-uniform by construction (per-lane parts go into the
+// byte offset).  The compiler cannot always prove it -- anything derived from threadIdx, even
+// threadIdx.x / 256 in a 256-thread workgroup, is divergent to it -- and would then wrap EACH buffer
+// access in a "waterfall" loop (readfirstlane x4, compare, saveexec, access, loop).  Passing base and
+// size through readfirstlane once per descriptor makes the uniformity explicit.
 DEVI __amdgpu_buffer_rsrc_t mk_rsrc(const void *p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), (short)0, (int)bytes, 0x00020000);
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const unsigned nb = __builtin_amdgcn_readfirstlane(bytes);
+    void *q = (void *)(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, (short)0, (int)nb, 0x00020000);
 }
 // Cache policy of the intermediate Z (written once by pass 1, read once by pass 2, 16 GiB apart):
 // aux = 2 is the non-temporal hint ("nt").  Measured A/B at C2: nt on both the Z stores and the Z
