@@ -83,6 +83,7 @@ def main():
     ap.add_argument('--bins', type=int, default=256, help='Doppler bins per GPU')
     ap.add_argument('--protocol', default='bench_GMSK')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-demod-leg', action='store_true', help='skip the untimed find_carrier+demodulate figure (profiling runs)')
     ap.add_argument('--tuning', default='', help='chunk,mpb,rows,jsplit (0 = default)')
     ap.add_argument('--shard', choices=['bins', 'blocks'], default='bins',
                     help='N>1: bins = C4, Doppler bins sharded 256/GPU + RCCL all-reduce per block (default); '
@@ -178,7 +179,7 @@ def main():
 
     # secondary figure: find_carrier + demodulate (A3..A11 device part), outside the timed steps
     full_ms = None
-    if shard is None:
+    if shard is None and not args.no_demod_leg:
         # host arithmetic of the demodulation stage, as Demodulator.findCodeRateAndPhaseGPU does it
         k_off = int(N / (1.1 * 16))
         k_len = int(N / (0.9 * 16)) - k_off
