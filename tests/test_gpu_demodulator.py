@@ -150,3 +150,59 @@ def test_streaming_runner_result_dict_and_ber(monkeypatch):
     with pytest.raises(ValueError):
         run.feed(np.zeros(10, np.complex64))
     run.close()
+
+
+def test_stx_backend_and_peak_clipping(monkeypatch):
+    """STX back end (next-scope row N3): input peak clipping on the host, fixed shift, no Doppler
+    search; clipped positions tag the trust of nearby symbols with -2 (= 254 as uint8)."""
+    from pycusdr_amd.demodulator import STX
+    bs = 14
+    N = 1 << bs
+    conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=4)
+    conf['GPU']['UHF']['peakThresholdScale'] = 4.5
+    p = loadProtocol('bench_GMSK')(conf=conf)
+    gpu = STX.Demodulator(conf, p, 'UHF-H')
+    with monkeypatch.context() as m:
+        m.setattr(dbm, 'MFBank', OracleBank)
+        cpu = STX.Demodulator(conf, loadProtocol('bench_GMSK')(conf=conf), 'UHF-H')
+    x = sg.awgn(sg.get_padded_packet('GMSK')[0][30000:30000 + N], 15.0, rng=np.random.RandomState(3)).astype(np.complex64)
+    x[5000] *= 60           # an interference spike inside the packet
+    rg, rc = gpu.get_signalBufferHostPointer(), cpu.get_signalBufferHostPointer()
+    rg[:] = x
+    rc[:] = x
+    og, oc = gpu.uploadAndFindCarrier(rg), cpu.uploadAndFindCarrier(rc)
+    assert og[:2] == (0, 0) and list(og[2]) == list(oc[2]) == [5000]
+    assert abs(rg[5000]) < 10 and np.array_equal(rg, rc)            # clipped in place, identically
+    bg, cg, tg, sg_ = gpu.demodulate()
+    bc, cc, tc, sc_ = cpu.demodulate()
+    assert int(gpu.dopplerIdxlast) == N // 4 and sg_ == sc_
+    assert np.count_nonzero(bg != bc) <= 1
+    # trust bytes are raw bytes of fp32 magnitudes (quirk Q3), so a stray 254 can occur anywhere; the
+    # tag itself is the run of >= 4 consecutive symbols around the clipped sample, same place in both
+    def tagged_run(t):
+        both = (t == 254).astype(int)
+        runs = np.flatnonzero(np.convolve(both, np.ones(4, int), 'valid') == 4)
+        return runs[0] if len(runs) else -1
+    assert tagged_run(tg) >= 0 and tagged_run(tg) == tagged_run(tc)
+    gpu.close()
+
+
+def test_noise_reference_bin_through_the_demodulator(monkeypatch):
+    """noise_measure_offset_Hz prepends a noise bin (reference DB:150-159): the pick skips it and the
+    metric becomes the peak-to-noise-bin ratio."""
+    bs = 14
+    N = 1 << bs
+    conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=16)
+    conf['Radios']['Rx']['UHF-H']['noise_measure_offset_Hz'] = -38400
+    p = loadProtocol('bench_GMSK')(conf=conf)
+    gpu = UHF.Demodulator(conf, p, 'UHF-H')
+    assert gpu.doppIdxArrayLen == 17 and gpu.doppIdxArrayOffset == 1
+    with monkeypatch.context() as m:
+        m.setattr(dbm, 'MFBank', OracleBank)
+        cpu = UHF.Demodulator(conf, loadProtocol('bench_GMSK')(conf=conf), 'UHF-H')
+    x = sg.awgn(sg.get_padded_packet('GMSK')[0][30000:30000 + N], 10.0, rng=np.random.RandomState(5)).astype(np.complex64)
+    og, oc = gpu.uploadAndFindCarrier(x), cpu.uploadAndFindCarrier(x)
+    assert int(gpu.dopplerIdxlast) == int(cpu.dopplerIdxlast)
+    assert abs(og[1] - oc[1]) <= 1e-4 * abs(oc[1]) + 1e-6 and og[1] > 0          # peak / noise-bin metric
+    assert abs(og[0] - oc[0]) < 0.5
+    gpu.close()
