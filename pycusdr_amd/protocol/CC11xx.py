@@ -21,9 +21,47 @@ def _bytes_to_bits(byte_list):
     return np.unpackbits(np.asarray(byte_list, dtype=np.uint8)).astype(np.float64)
 
 
+def pn9_bytes(n):
+    """PN9 whitening bytes of the CC11xx (x^9 + x^5 + 1, all-ones start, one byte per 8 clocks):
+    0xFF 0xE1 0x1D 0x9A ...  Same sequence as the reference's lib/shift_registers.PN9 (:76-91);
+    pinned by fixture G8."""
+    reg = [1] * 9
+    out = np.empty(n, dtype=np.int64)
+    for i in range(n):
+        out[i] = sum(reg[k] << k for k in range(8))
+        for _ in range(8):
+            reg = reg[1:] + [reg[0] ^ reg[5]]
+    return out
+
+
 def pn9_first_byte():
     """First whitening byte of the PN9 sequence (all-ones start): 0xFF."""
     return 0xFF
+
+
+def crc16_cc11xx(data):
+    """CRC-16 of the CC11xx: polynomial 0x8005, initial value 0xFFFF, MSB first, no final XOR
+    (what the reference builds with crcmod.mkCrcFun(0x18005, rev=False, initCrc=0xFFFF, xorOut=0),
+    CC11xx.py:255; catalogue name CRC-16/CMS, check value 0xAEE7 for b"123456789")."""
+    crc = 0xFFFF
+    for byte in bytes(bytearray(int(b) & 0xFF for b in data)):
+        crc ^= byte << 8
+        for _ in range(8):
+            crc = ((crc << 1) ^ 0x8005) & 0xFFFF if crc & 0x8000 else (crc << 1) & 0xFFFF
+    return crc
+
+
+def frame_bits(payload, preamble=(0xAA,) * 4, sync=(0xD6, 0xBA, 0xD6, 0xBA), whiten=True):
+    """Bits of one CC11xx frame as the reference's TX framer builds it (modulator/encoders/CC11xx.py
+    :64-118): preamble | sync | whiten([len = n+2 | payload | CRC low byte | CRC high byte]), MSB first.
+    Test stimulus for the receive path; the transmit chain itself is out of scope."""
+    payload = np.asarray(payload, dtype=np.uint8)
+    body = np.r_[len(payload) + 2, payload].astype(np.uint8)
+    crc = crc16_cc11xx(body)
+    body = np.r_[body, crc & 0xFF, crc >> 8].astype(np.uint8)
+    if whiten:
+        body = np.bitwise_xor(body, pn9_bytes(len(body)).astype(np.uint8))
+    return np.unpackbits(np.r_[np.asarray(preamble, np.uint8), np.asarray(sync, np.uint8), body])
 
 
 class CC11xx(FSK2):
@@ -100,3 +138,22 @@ class PacketCC11xx(Packet):
         # (DEFAULT_NUM_PREAMBLE = 4 flag bytes): flags + sync + len + CRC
         overhead = DEFAULT_NUM_PREAMBLE + self.maskLen + self.pLen + self.CRClen
         super().__init__(protocol, bits[:int(self.packetLen + overhead) * 8], frameStartIdx, maskBitErrors, frameSplitIdx)
+        self._pre = DEFAULT_NUM_PREAMBLE + self.maskLen + self.pLen      # bytes before the length-counted part
+
+    def getBinaryData(self):
+        """(bytes after the length byte, de-whitened; CRC error flag; the same bytes).
+
+        Same return shape as the reference (CC11xx.py:274-300): ``packetLen`` bytes follow the length
+        byte, the last two of them are the CRC (low byte first).  The reference compares its CRC with the
+        two bytes *behind* the frame and runs it over the CRC bytes too, so its flag is always set; here
+        the CRC is checked where the TX framer puts it (over [len | payload])."""
+        n = int(self.packetLen)
+        body = np.asarray(self.bits[self._pre * 8:(self._pre + n) * 8]).astype(np.int64)
+        data = np.dot(body.reshape(-1, 8), 2 ** np.arange(7, -1, -1)).astype(np.uint8)
+        if self.protocol.deWhiten:
+            data = np.bitwise_xor(data, pn9_bytes(len(data) + 1)[1:].astype(np.uint8))
+        if len(data) < 2 or len(data) < n:
+            return data, True, data
+        crc_rx = int(data[-2]) | (int(data[-1]) << 8)
+        crc_ok = crc16_cc11xx(np.r_[n, data[:-2]]) == crc_rx
+        return data, (not crc_ok), data

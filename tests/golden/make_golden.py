@@ -14,6 +14,7 @@ What is captured (SURVEY.md section 8c, G1..G5 + host-logic KATs):
   G5  stimulus                examples/benchmark/create_signals.get_padded_packet
   G7  host-logic KATs         Demodulator.checkSymbolOverlap / extractBitsNRZs (pure numpy
                               methods, called unbound on a plain namespace object)
+  G8  PN9 whitening bytes     lib.shift_registers.PN9 (CC11xx framing, next-scope row N2)
 
 Harness-side shims (the same ones SURVEY.md 8c lists): numpy aliases removed in numpy>=1.24
 (np.float, np.int), an empty ``crcmod`` module (packet CRC only; off the hot path) and, for G7
@@ -257,6 +258,12 @@ def g7_hostlogic(out, cases):
     out['g7/nrzs/symError'] = np.asarray(err, dtype=np.int64)
 
 
+def g8_pn9(out):
+    """PN9 whitening bytes of the CC11xx framing (lib/shift_registers.PN9, pure numpy)."""
+    from lib.shift_registers import PN9
+    out['g8/pn9_300'] = np.asarray(PN9()).astype(np.int64)
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit('reference not mounted; fixtures can only be regenerated in the authoring container')
@@ -266,6 +273,7 @@ def main():
     g4_decoder(out, cases)
     g5_stimulus(out)
     g7_hostlogic(out, cases)
+    g8_pn9(out)
     flat = {k.replace('/', '__'): v for k, v in out.items()}
     path = os.path.join(HERE, 'ref_goldens.npz')
     np.savez_compressed(path, **flat)

@@ -206,3 +206,24 @@ def test_noise_reference_bin_through_the_demodulator(monkeypatch):
     assert abs(og[1] - oc[1]) <= 1e-4 * abs(oc[1]) + 1e-6 and og[1] > 0          # peak / noise-bin metric
     assert abs(og[0] - oc[0]) < 0.5
     gpu.close()
+
+
+def test_cc11xx_frame_received_and_crc_ok():
+    """The same CC11xx end-to-end check as the CPU suite, on the HIP path, at the C5 geometry's
+    samples per symbol (128) and a longer block."""
+    from pycusdr_amd.demodulator_process import DemodulatorRunner
+    from test_demod_hostlogic import _cc11xx_stimulus
+    bs, sps = 17, 128
+    conf = cfg.cc11xx_config(blockSize=bs, doppCarrierSteps=64, samplesPerSym=sps)
+    p = loadProtocol('CC11xx')(conf=conf)
+    run = DemodulatorRunner(conf, p, 'UHF-H')
+    payload = np.arange(1, 41, dtype=np.uint8)
+    sig = _cc11xx_stimulus(bs, sps, payload)
+    step = (1 << bs) - (1 << 10)
+    chunks = [sig[i * step:(i + 1) * step] for i in range(4)]      # 2136 bits must follow the header
+    res, packets = run.run(chunks, decoder=Decoder({}, p))
+    assert abs(res[0]['doppler']) < 600 and abs(res[0]['spSymEst'] - 128) < 1
+    assert len(packets) == 1
+    data, crc_err, _ = packets[0].getBinaryData()
+    assert packets[0].packetLen == 42 and not crc_err and np.array_equal(data[:-2], payload)
+    run.close()

@@ -109,3 +109,21 @@ def test_awgn_and_nrzs(goldens):
     assert np.array_equal(decodeNRZS(enc)[1:], goldens['g5/nrzs/in'][1:])
     with pytest.raises(TypeError):
         sg.get_padded_packet('QAM')
+
+
+def test_cc11xx_pn9_crc_and_framing(goldens):
+    from pycusdr_amd.protocol.CC11xx import pn9_bytes, crc16_cc11xx, frame_bits
+    assert np.array_equal(pn9_bytes(300), goldens['g8/pn9_300'])
+    assert crc16_cc11xx(b'123456789') == 0xAEE7           # CRC-16/CMS catalogue check value
+    payload = np.arange(1, 21, dtype=np.uint8)
+    bits = frame_bits(payload)
+    assert len(bits) == (4 + 4 + 1 + 20 + 2) * 8
+    assert np.array_equal(np.packbits(bits[:64]), [0xAA] * 4 + [0xD6, 0xBA, 0xD6, 0xBA])
+    assert np.packbits(bits[64:72])[0] == (22 ^ 0xFF)     # whitened length byte
+    p = loadProtocol('CC11xx')(conf=CCONF)
+    pk = p.Packet(np.r_[bits, np.zeros(64, np.uint8)].astype(np.float64), 0, 0)
+    data, err, _ = pk.getBinaryData()
+    assert pk.packetLen == 22 and not err and np.array_equal(data[:-2], payload)
+    bad = bits.copy()
+    bad[100] ^= 1
+    assert p.Packet(np.r_[bad, np.zeros(64, np.uint8)].astype(np.float64), 0, 0).getBinaryData()[1]
