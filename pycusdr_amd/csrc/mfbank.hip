@@ -55,7 +55,8 @@ struct P1Args {
     const cf *twLo;     // W_N^x, x < 2^lo
     const cf *twHi;     // W_N^(y*2^lo)
     int N, N2, lo;
-    int M;        // masks in the bank
+    int M;        // filter rows this launch transforms per Doppler bin (all M, or the unique ones)
+    const int *rows;  // bank row of each of them (nullptr: identity)
     int mpb;      // masks per block
     int j0;       // first Doppler index of this chunk (into shifts)
     int dc;       // Doppler bins in this chunk
@@ -203,7 +204,8 @@ __global__ void __launch_bounds__((L1 / 16) * TILE, (L1 == 256 && KIND == KIND_B
         const auto xr = mk_rsrc(a.X, rowbytes);
         cf mk[16];  // mask values of the NEXT transform (software prefetch)
         if constexpr (MFB_P1_PREFETCH) {
-            const auto mr = mk_rsrc(a.masks + (size_t)m0 * N, rowbytes);
+            const int r0 = a.rows ? a.rows[m0] : m0;
+            const auto mr = mk_rsrc(a.masks + (size_t)r0 * N, rowbytes);
 #pragma unroll
             for (int i = 0; i < 16; ++i) mk[i] = buf_load_cf(mr, vo_in, i * so_in);
         }
@@ -219,11 +221,13 @@ __global__ void __launch_bounds__((L1 / 16) * TILE, (L1 == 256 && KIND == KIND_B
 #pragma unroll
                     for (int i = 0; i < 16; ++i) v[i] = cmul(xv[i], mk[i]);
                     const int mn = (m + 1 < m1) ? (m + 1) : m0;  // always valid: branch-free prefetch
-                    const auto mr = mk_rsrc(a.masks + (size_t)mn * N, rowbytes);
+                    const int rn = a.rows ? a.rows[mn] : mn;
+                    const auto mr = mk_rsrc(a.masks + (size_t)rn * N, rowbytes);
 #pragma unroll
                     for (int i = 0; i < 16; ++i) mk[i] = buf_load_cf(mr, vo_in, i * so_in);
                 } else {
-                    const auto mr = mk_rsrc(a.masks + (size_t)m * N, rowbytes);
+                    const int rm = a.rows ? a.rows[m] : m;
+                    const auto mr = mk_rsrc(a.masks + (size_t)rm * N, rowbytes);
 #pragma unroll
                     for (int i = 0; i < 16; ++i) v[i] = buf_load_cf(mr, vo_in, i * so_in);
 #pragma unroll
@@ -347,13 +351,15 @@ __global__ void __launch_bounds__((L2 / 16) * P2Cfg<L2>::RB, (L2 == 4096 && MODE
 // ------------------------------------------------------------------------------------------------
 // doppSum[j][m] from the per-workgroup partials (fixed order).  SUM_ALL_MASKS: column 0 gets the
 // sum over masks, the other columns stay 0 (cuda_kernels.cu:453-464); else per mask (472-475).
-__global__ void k_finalize(const float *partials, float *dsum, int D, int M, int parts, int sum_all) {
+// The partials hold MU <= M rows per bin (filters that are exact copies or exact negatives of an
+// earlier filter are transformed once: |.|^2 is identical bit for bit); rep[m] names filter m's row.
+__global__ void k_finalize(const float *partials, float *dsum, int D, int M, int MU, const int *rep, int parts, int sum_all) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= D) return;
     float tot = 0.f;
     for (int m = 0; m < M; ++m) {
         float s = 0.f;
-        const float *p = partials + ((size_t)j * M + m) * parts;
+        const float *p = partials + ((size_t)j * MU + rep[m]) * parts;
         for (int q = 0; q < parts; ++q) s += p[q];
         if (sum_all) {
             tot += s;
@@ -654,6 +660,9 @@ struct mfb_ctx {
     int log2N, N, N1, N2, l1, l2, lo;
     int D, Doff, Dtot, M, W, sum_all, cs_off;
     int chunk, mpb, jsplit;
+    int MU;               // unique filter rows (up to sign)
+    bool chunk_auto;      // chunk still at its default (recomputed when the bank turns out to have duplicates)
+    int *d_uniq, *d_rep;  // [MU] bank row of each unique filter; [M] unique index of each filter
     int parts, srb;
     hipStream_t own_stream, stream;
     cf *h_in;  // pinned
@@ -724,8 +733,17 @@ static void set_rows_per_block(mfb_ctx *c, int srb) {
     c->parts = c->N1 / srb;
 }
 
+static int default_chunk(const mfb_ctx *c) {
+    const size_t row_bytes = (size_t)c->N * sizeof(cf) * c->MU;
+    size_t ch = ((size_t)8 << 30) / row_bytes;
+    if (ch < 1) ch = 1;
+    if (ch > (size_t)c->Dtot) ch = c->Dtot;
+    if (ch * c->MU > 65535) ch = 65535 / c->MU;
+    return (int)ch;
+}
+
 static int alloc_Z(mfb_ctx *c) {
-    const size_t rows = (size_t)c->chunk * c->M;
+    const size_t rows = (size_t)c->chunk * c->MU;   // the search stores only the unique filter rows
     const size_t need = rows > (size_t)c->M ? rows : (size_t)c->M;
     if (c->d_Z && c->z_rows >= need) return MFB_OK;
     if (c->d_Z) {
@@ -774,14 +792,9 @@ extern "C" int mfb_create(mfb_ctx **out, int device, int log2N, int num_dopplers
     // 9.8 ms, 64: 6.65 ms, 128: 6.55 ms per block) -- but a 16 GiB intermediate (chunk 256) costs
     // 0.4 ms more than two 8 GiB launches.  Keeping the intermediate inside the 256 MiB Infinity
     // Cache (chunk 1-2) does not pay: the cache streams no faster than HBM (tools/ubench/mall.hip).
-    {
-        const size_t row_bytes = (size_t)c->N * sizeof(cf) * M;
-        size_t ch = ((size_t)8 << 30) / row_bytes;
-        if (ch < 1) ch = 1;
-        if (ch > (size_t)c->Dtot) ch = c->Dtot;
-        if (ch * M > 65535) ch = 65535 / M;
-        c->chunk = (int)ch;
-    }
+    c->MU = M;
+    c->chunk_auto = true;
+    c->chunk = default_chunk(c);
     c->mpb = M < 8 ? M : 8;
     c->jsplit = 32;
     set_rows_per_block(c, 64);
@@ -804,6 +817,8 @@ extern "C" int mfb_create(mfb_ctx **out, int device, int log2N, int num_dopplers
     HIPCHK(hipMalloc((void **)&c->d_sum, (size_t)c->Dtot * M * sizeof(float)));
     HIPCHK(hipMemset(c->d_sum, 0, (size_t)c->Dtot * M * sizeof(float)));
     HIPCHK(hipMalloc((void **)&c->d_res, 2 * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&c->d_uniq, (size_t)M * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&c->d_rep, (size_t)M * sizeof(int)));
     HIPCHK(hipMalloc((void **)&c->d_cr, 3 * sizeof(float)));
     c->cap = c->N / 2;  // symbols never shorter than 2 samples
     HIPCHK(hipMalloc((void **)&c->d_sym, (size_t)c->cap * sizeof(int)));
@@ -830,7 +845,7 @@ extern "C" int mfb_destroy(mfb_ctx *c) {
     if (!c) return MFB_ERR_ARG;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    void *bufs[] = {c->d_x,  c->d_X,    c->d_masks, c->d_Z,   c->d_xc,  c->d_P,   c->d_env, c->d_shifts, c->d_tw1,
+    void *bufs[] = {c->d_uniq, c->d_rep, c->d_x,  c->d_X,    c->d_masks, c->d_Z,   c->d_xc,  c->d_P,   c->d_env, c->d_shifts, c->d_tw1,
                     c->d_tw2, c->d_twLo, c->d_twHi,  c->d_part, c->d_sum, c->d_res, c->d_cr,  c->d_sym,    c->d_cen, c->d_mag};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -859,8 +874,11 @@ extern "C" int mfb_set_tuning(mfb_ctx *c, int chunk, int mpb, int rows_per_block
     HIPCHK(hipStreamSynchronize(c->stream));
     if (rows_per_block > 0) set_rows_per_block(c, rows_per_block);
     if (jsplit > 0) c->jsplit = jsplit;
-    if (chunk > 0) c->chunk = chunk > c->Dtot ? c->Dtot : chunk;
-    if (c->chunk * c->M > 65535) c->chunk = 65535 / c->M;  // grid.y limit of pass 2
+    if (chunk > 0) {
+        c->chunk = chunk > c->Dtot ? c->Dtot : chunk;
+        c->chunk_auto = false;
+    }
+    if (c->chunk * c->MU > 65535) c->chunk = 65535 / c->MU;  // grid.y limit of pass 2
     if (mpb > 0) c->mpb = mpb > c->M ? c->M : mpb;
     return alloc_Z(c);
 }
@@ -878,7 +896,35 @@ extern "C" int mfb_set_filters(mfb_ctx *c, const float *masks, int M, int N) {
     if (M != c->M || N != c->N) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c->d_masks, masks, (size_t)M * N * sizeof(cf), hipMemcpyHostToDevice, c->stream));
+    // Filters that are exact copies or exact negatives of an earlier one (the BPSK bank: pattern p
+    // and its complement) give bit-identical |.|^2; the Doppler search transforms each such class once.
+    std::vector<int> uniq, rep(M);
+    for (int m = 0; m < M; ++m) {
+        const float *rm = masks + (size_t)m * 2 * N;
+        int found = -1;
+        for (size_t u = 0; u < uniq.size() && found < 0; ++u) {
+            const float *ru = masks + (size_t)uniq[u] * 2 * N;
+            bool same = true, neg = true;
+            for (size_t i = 0; i < (size_t)2 * N && (same || neg); ++i) {
+                same = same && (rm[i] == ru[i]);
+                neg = neg && (rm[i] == -ru[i]);
+            }
+            if (same || neg) found = (int)u;
+        }
+        if (found < 0) {
+            found = (int)uniq.size();
+            uniq.push_back(m);
+        }
+        rep[m] = found;
+    }
+    c->MU = (int)uniq.size();
+    HIPCHK(hipMemcpyAsync(c->d_uniq, uniq.data(), uniq.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_rep, rep.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->chunk_auto) c->chunk = default_chunk(c);
+    if (c->chunk * c->MU > 65535) c->chunk = 65535 / c->MU;
+    int rcz = alloc_Z(c);
+    if (rcz) return rcz;
     c->have_filters = true;
     return MFB_OK;
 }
@@ -1079,7 +1125,9 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
     if (!c) return MFB_ERR_ARG;
     if (!c->have_filters || !c->have_shifts || !c->have_input) return MFB_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
-    const int mgroups = (c->M + c->mpb - 1) / c->mpb;
+    const int MU = c->MU;
+    const int mpb = c->mpb < MU ? c->mpb : MU;
+    const int mgroups = (MU + mpb - 1) / mpb;
     for (int j0 = 0; j0 < c->Dtot; j0 += c->chunk) {
         const int dc = (c->Dtot - j0) < c->chunk ? (c->Dtot - j0) : c->chunk;
         P1Args a = p1_base(c);
@@ -1087,6 +1135,9 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
         a.shifts = c->d_shifts;
         a.j0 = j0;
         a.dc = dc;
+        a.M = MU;
+        a.mpb = mpb;
+        a.rows = (MU < c->M) ? c->d_uniq : nullptr;
         const int js = c->jsplit < dc ? c->jsplit : dc;
         a.ntiles = c->N2 / TILE;
         a.mgroups = mgroups;
@@ -1097,14 +1148,14 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
         if (rc) return rc;
         P2Args b = p2_base(c);
         b.partials = c->d_part;
-        b.part_row0 = j0 * c->M;
+        b.part_row0 = j0 * MU;
         prof_mark(c, 1);
-        rc = launch_p2<MODE_REDUCE>(c, b, dim3(c->parts, dc * c->M, 1));
+        rc = launch_p2<MODE_REDUCE>(c, b, dim3(c->parts, dc * MU, 1));
         prof_mark(c, 1);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_finalize, dim3((c->Dtot + 63) / 64), dim3(64), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M,
-                       c->parts, c->sum_all);
+    hipLaunchKernelGGL(k_finalize, dim3((c->Dtot + 63) / 64), dim3(64), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, MU,
+                       (const int *)c->d_rep, c->parts, c->sum_all);
     HIPCHK(hipGetLastError());
     return MFB_OK;
 }
