@@ -140,3 +140,34 @@ def test_sync_correlate_exact(B, L, T):
     out = sync_correlate(bits, tmpl)
     for b in range(B):
         assert np.array_equal(out[b], orc.sync_correlate(bits[b], tmpl))
+
+
+@pytest.mark.parametrize('sum_all', [True, False])
+def test_duplicate_and_negated_filters_are_transformed_once_but_reported_for_all(sum_all):
+    """Bank rows [A, B, -A, A, C]: the search transforms 3 unique rows; doppSum must still be what the
+    oracle gets from all 5 (bit-identical energies for the copies)."""
+    from pycusdr_amd.mfbank import MFBank
+    rs = np.random.RandomState(77)
+    log2N, D = 13, 9
+    N = 1 << log2N
+    A, B, Cc = _rand_c64(rs, N), _rand_c64(rs, N), _rand_c64(rs, N)
+    masks = np.stack([A, B, -A, A, Cc]).astype(np.complex64)
+    shifts = rs.randint(0, N, D).astype(np.int32)
+    bank = MFBank(log2N, D, 5, sum_all_masks=sum_all)
+    try:
+        bank.set_filters(masks)
+        bank.set_shifts(shifts)
+        bank.upload(_rand_c64(rs, N))
+        idx, metric = bank.find_carrier()
+        ds = bank.get_scores()
+        X = bank.get_spectrum()
+        k, arg, val = bank.demodulate(int(shifts[0]), 100, 200)     # demodulation keeps all 5 rows
+        xc = bank.get_xcorr()
+    finally:
+        bank.close()
+    ref = orc.doppler_scores(X, masks, shifts, sum_all)
+    assert np.abs(ds - ref).max() / ref.max() < 1e-5
+    if not sum_all:
+        assert np.array_equal(ds[:, 0], ds[:, 2]) and np.array_equal(ds[:, 0], ds[:, 3])
+    assert idx == orc.find_doppler_est(ds, D, 0, sum_all)[0]
+    assert np.array_equal(xc[2], -xc[0]) and np.array_equal(xc[3], xc[0])
