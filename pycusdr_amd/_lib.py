@@ -71,6 +71,25 @@ PROTOTYPES = {
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64/libhsa-runtime64 and
+    loads them by full path; libmfbank.so asks for libamdhip64.so.7 by name.  If libmfbank came
+    first it would pull in /opt/rocm's copy, and a later `import torch` would bring a SECOND runtime
+    into the process, which then finds no GPU ("No HIP GPUs are available").  Loading torch's copy
+    (without importing torch) before libmfbank makes both use the same one, in either order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    for d in (spec.submodule_search_locations if spec and spec.submodule_search_locations else []):
+        path = os.path.join(d, 'lib', 'libamdhip64.so')
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+            return path
+    return None
+
+
 def load():
     """Load libmfbank.so once; raise MFBankLibraryError loudly if that is impossible."""
     global _lib
@@ -81,6 +100,7 @@ def load():
             f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
             '(hipcc --offload-arch=gfx950).  There is no CPU fallback for the matched-filter bank.')
     try:
+        _preload_hip_runtime()
         lib = C.CDLL(LIB_PATH)
     except OSError as e:
         raise MFBankLibraryError(f'cannot load {LIB_PATH}: {e}') from e

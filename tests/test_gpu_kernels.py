@@ -171,3 +171,62 @@ def test_duplicate_and_negated_filters_are_transformed_once_but_reported_for_all
         assert np.array_equal(ds[:, 0], ds[:, 2]) and np.array_equal(ds[:, 0], ds[:, 3])
     assert idx == orc.find_doppler_est(ds, D, 0, sum_all)[0]
     assert np.array_equal(xc[2], -xc[0]) and np.array_equal(xc[3], xc[0])
+
+
+def test_find_centres_randomised_parameters_bit_exact():
+    """Symbol-centre search over random symbol rates, phases, window widths and operations: symbol
+    index, centre and fp32 magnitude must equal the oracle's bit for bit (same matched-filter outputs)."""
+    from pycusdr_amd.mfbank import MFBank
+    rs = np.random.RandomState(2024)
+    log2N = 13
+    N = 1 << log2N
+    for W in (3, 7, 9):
+        M = int(rs.choice([2, 5, 8]))
+        bank = MFBank(log2N, 2, M, window_width=W)
+        try:
+            bank.set_filters(_rand_c64(rs, M, N))
+            bank.set_shifts([0, 1])
+            x = _rand_c64(rs, N)
+            x[3000:3300] = 0                       # a dead stretch: symbols with no maximum (-1)
+            bank.upload(x)
+            bank.demodulate(int(rs.randint(0, N)), 10, 50)
+            xc = bank.get_xcorr()
+            for _ in range(6):
+                spSym = float(rs.uniform(4.0, 40.0))
+                offset = float(rs.uniform(0.0, spSym))
+                op = int(rs.randint(0, 3))
+                S = int(N / spSym)
+                sym, cen, mag = bank.find_centres(np.float32(spSym), np.float32(offset), op, S)
+                osym, ocen, omag = orc.find_centres(xc, spSym, offset, W, op)
+                assert np.array_equal(sym, osym), (W, M, spSym, offset, op)
+                assert np.array_equal(cen, ocen)
+                assert np.array_equal(mag.view(np.uint32), omag.view(np.uint32))
+        finally:
+            bank.close()
+
+
+def test_pick_randomised_tables_exact():
+    """Doppler pick on externally supplied score tables (the multi-GPU path hands the all-reduced table
+    to mfb_pick): index bit-exact, metric to 1 ulp-ish, for random D, M, noise-bin offsets, both modes,
+    including ties and all-equal tables."""
+    import torch
+    from pycusdr_amd.mfbank import MFBank
+    rs = np.random.RandomState(99)
+    for M, sum_all in ((1, True), (4, True), (8, False), (32, False), (3, False)):
+        bank = MFBank(10, 4, M, sum_all_masks=sum_all)
+        try:
+            for trial in range(6):
+                D = int(rs.randint(2, 700))
+                off = int(rs.randint(0, 2))
+                tab = rs.rand(D + off, M).astype(np.float32) + 0.01
+                if trial == 4:
+                    tab[:] = 1.0                                   # every bin ties
+                if trial == 5:
+                    tab[off + D // 2] = tab[off + D // 3]          # two equal maxima candidates
+                t = torch.from_numpy(tab).cuda()
+                idx, metric = bank.pick(t.data_ptr(), num=D, offset=off)
+                oidx, ometric = orc.find_doppler_est(tab, D, off, sum_all)
+                assert idx == oidx, (M, sum_all, D, off, trial)
+                assert abs(float(metric) - float(ometric)) <= 3e-6 * abs(float(ometric)) + 1e-6
+        finally:
+            bank.close()
