@@ -174,3 +174,27 @@ def test_cc11xx_frame_received_and_crc_ok_on_oracle_backend(oracle_backend):
     assert len(packets) == 1
     data, crc_err, _ = packets[0].getBinaryData()
     assert packets[0].packetLen == 12 and not crc_err and np.array_equal(data[:-2], payload)
+
+
+def test_streaming_runner_on_oracle_backend(oracle_backend):
+    """The caller's loop (N1) on the CPU: overlap carry, result-dict keys, rate bookkeeping."""
+    from pycusdr_amd.demodulator_process import DemodulatorRunner, radioBackendVoteGroupIDX
+    bs, ov = 14, 1 << 10
+    N = 1 << bs
+    conf = cfg.bench_config('bench_FSK', blockSize=bs, doppCarrierSteps=8)
+    p = loadProtocol('bench_FSK')(conf=conf)
+    run = DemodulatorRunner(conf, p, 'UHF-H')
+    sig = sg.get_padded_packet('FSK')[0][9000:9000 + 3 * N].astype(np.complex64)
+    step = N - ov
+    chunks = [sig[i * step:(i + 1) * step] for i in range(3)]
+    seen = []
+    run.run(chunks, sink=seen.append)
+    assert [d['count'] for d in seen] == [0, 1, 2] and run.iterCount == 3 and run.timeMA > 0
+    # the overlap carry: the head of the pinned buffer holds the tail of the previous block
+    assert np.array_equal(run.raw[:ov], np.asarray(chunks[2][-ov:]))
+    d = seen[1]
+    assert d['voteGroup'] == 0 and d['protocol'] == 'UHF' and d['sample_rate'] == 153600 and abs(d['spSymEst'] - 16) < 0.1
+    assert abs(d['doppler']) < 50 and d['rate_ksps'] > 0
+    assert radioBackendVoteGroupIDX('STX')[1] == 1
+    with pytest.raises(TypeError):
+        radioBackendVoteGroupIDX('LBAND')
