@@ -1,17 +1,28 @@
-"""Protocol plugin loader -- same names as the reference's protocol/loadProtocol.py:3-20."""
+"""Protocol plugin registry.
+
+``loadProtocol(name)`` returns the plugin class for the names the reference's loader knows
+(reference protocol/loadProtocol.py:3-20) and raises ImportError for anything else.  Plugins are
+imported lazily so that a receiver only pays for the protocol it runs.
+"""
+import importlib
+
+# name -> (module relative to this package, class name)
+_REGISTRY = {
+    'CC11xx': ('.CC11xx', 'CC11xx'),
+    'bench_GMSK': ('.benchmark.bench_GMSK', 'Bench_GMSK'),
+    'bench_BPSK': ('.benchmark.bench_BPSK', 'Bench_BPSK'),
+    'bench_FSK': ('.benchmark.bench_FSK', 'Bench_FSK'),
+    'bench_GFSK': ('.benchmark.bench_GFSK', 'Bench_GFSK'),
+}
+
+
+def known_protocols():
+    return sorted(_REGISTRY)
 
 
 def loadProtocol(protocolName):
-    if protocolName == 'CC11xx':
-        from .CC11xx import CC11xx as cls
-    elif protocolName == 'bench_GMSK':
-        from .benchmark.bench_GMSK import Bench_GMSK as cls
-    elif protocolName == 'bench_BPSK':
-        from .benchmark.bench_BPSK import Bench_BPSK as cls
-    elif protocolName == 'bench_FSK':
-        from .benchmark.bench_FSK import Bench_FSK as cls
-    elif protocolName == 'bench_GFSK':
-        from .benchmark.bench_GFSK import Bench_GFSK as cls
-    else:
-        raise ImportError('Protocol %s does not exist' % (protocolName,))
-    return cls
+    try:
+        module, cls = _REGISTRY[protocolName]
+    except KeyError:
+        raise ImportError('Protocol %s does not exist' % (protocolName,)) from None
+    return getattr(importlib.import_module(module, __package__), cls)
