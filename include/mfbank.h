@@ -74,6 +74,11 @@ int mfb_set_stream(mfb_ctx *ctx, void *hip_stream);
 int mfb_set_tuning(mfb_ctx *ctx, int doppler_chunk, int masks_per_block, int rows_per_block, int jsplit);
 int mfb_get_tuning(mfb_ctx *ctx, int *doppler_chunk, int *masks_per_block, int *rows_per_block, int *jsplit);
 
+/* Geometry the handle settled on: the two FFT factors N = N1 * N2 and, after mfb_set_filters, the number
+ * of filter rows the Doppler search actually transforms (filters that are exact copies or exact
+ * negatives of an earlier one are transformed once).  Any pointer may be NULL. */
+int mfb_get_info(mfb_ctx *ctx, int *N1, int *N2, int *unique_filters);
+
 /* Upload the filter bank: host complex64 [M][N], row-major, already conj(fft(template, N)) as
  * protocol.get_filter returns it.  Replaces __uploadMaskToGPU (DB:246-263).  `M`/`N` are what the
  * caller believes the shape is; a mismatch with the handle returns MFB_ERR_ARG. */

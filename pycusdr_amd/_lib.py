@@ -43,6 +43,7 @@ PROTOTYPES = {
     'mfb_set_stream': (_i, [_vp, _vp]),
     'mfb_set_tuning': (_i, [_vp, _i, _i, _i, _i]),
     'mfb_get_tuning': (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    'mfb_get_info': (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     'mfb_set_filters': (_i, [_vp, _vp, _i, _i]),
     'mfb_set_shifts': (_i, [_vp, _vp, _i]),
     'mfb_input_buffer': (_i, [_vp, C.POINTER(_fp)]),

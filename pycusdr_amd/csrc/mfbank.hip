@@ -891,6 +891,14 @@ extern "C" int mfb_get_tuning(mfb_ctx *c, int *chunk, int *mpb, int *rows_per_bl
     return MFB_OK;
 }
 
+extern "C" int mfb_get_info(mfb_ctx *c, int *N1, int *N2, int *unique_filters) {
+    if (!c) return MFB_ERR_ARG;
+    if (N1) *N1 = c->N1;
+    if (N2) *N2 = c->N2;
+    if (unique_filters) *unique_filters = c->MU;
+    return MFB_OK;
+}
+
 extern "C" int mfb_set_filters(mfb_ctx *c, const float *masks, int M, int N) {
     if (!c || !masks) return MFB_ERR_ARG;
     if (M != c->M || N != c->N) return MFB_ERR_ARG;

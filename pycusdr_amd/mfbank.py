@@ -60,6 +60,12 @@ class MFBank:
         _lib.check(self._lib.mfb_get_tuning(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), 'mfb_get_tuning')
         return a.value, b.value, c.value, d.value
 
+    def get_info(self):
+        """(N1, N2, unique filter rows transformed by the search)."""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(self._lib.mfb_get_info(self._h, C.byref(a), C.byref(b), C.byref(c)), 'mfb_get_info')
+        return a.value, b.value, c.value
+
     def set_filters(self, masks):
         masks = np.asarray(masks)
         if masks.ndim != 2:
