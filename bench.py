@@ -146,6 +146,7 @@ def main():
     host_blocks = np.stack([stream[b * (N - ov): b * (N - ov) + N] for b in range(nblocks)])
     blocks = torch.from_numpy(host_blocks.view(np.float32).reshape(nblocks, 2 * N)).to(dev)
     esz = blocks.element_size() * 2 * N
+    torch.cuda.synchronize(dev)        # the blocks are resident before any other stream reads them
 
     def step(i):
         bank.upload_device(blocks.data_ptr() + ((i * (G if by_blocks else 1) + (rank if by_blocks else 0)) % nblocks) * esz)
