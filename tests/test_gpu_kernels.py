@@ -29,7 +29,8 @@ def test_forward_fft_matches_numpy(log2N):
 
 
 @pytest.mark.parametrize('log2N,D,M,sum_all', [(10, 5, 2, True), (12, 8, 4, True), (13, 3, 8, False),
-                                                (15, 8, 8, True), (16, 32, 8, True), (17, 4, 3, False)])
+                                                (15, 8, 8, True), (16, 32, 8, True), (17, 4, 3, False),
+                                                (12, 4, 64, False), (12, 3, 33, True)])
 def test_doppler_scores_match_oracle(log2N, D, M, sum_all):
     from pycusdr_amd.mfbank import MFBank
     rs = np.random.RandomState(100 + log2N)
