@@ -34,6 +34,11 @@ def b_alg(D, M, N):
     return 16.0 * D * M * N + 8.0 * N * (1 + M) + 16.0 * N + 4.0 * D
 
 
+def b_ref(D, M, N):
+    """Traffic of the reference's unfused four-stage formulation, for context."""
+    return 32.0 * D * M * N + 8.0 * N * (3 + M) + 4.0 * D * (1 + M)
+
+
 def widen_range_rate(conf, radio, N, D):
     """widen rangeRateMax until the D shifts are distinct after rounding."""
     from pycusdr_amd.demodulator.demodulator_base import doppler_bin_table
@@ -257,7 +262,7 @@ def main():
                 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK, 4), 'traffic': traffic,
                 'launches': launches, 'avg_launch_ms': round(k_avg_s * 1e3, 4), 'alg_bytes_per_launch': k_bytes,
                 'other_kernel_avg_ms': round(kms[1 - dom] / max(counts[1 - dom], 1), 4),
-                'pipeline': {'B_alg_per_block': b_alg(Dl, Mu, N), 'device_ms_per_block': round(t_block_dev * 1e3, 4),
+                'pipeline': {'B_alg_per_block': b_alg(Dl, Mu, N), 'B_ref_unfused_per_block': b_ref(Dl, M, N), 'device_ms_per_block': round(t_block_dev * 1e3, 4),
                              'achieved_GBps': round(b_alg(Dl, Mu, N) / t_block_dev / 1e9, 2),
                              'frac': round(b_alg(Dl, Mu, N) / t_block_dev / HBM_PEAK, 4)},
             },
