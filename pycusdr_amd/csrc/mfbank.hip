@@ -4,10 +4,10 @@
 //   d_x     complex64 [N]        time-domain block (or caller's device pointer)
 //   d_X     complex64 [N]        spectrum, natural order
 //   d_masks complex64 [M][N]     filter bank as protocol.get_filter returns it (row-major)
-//   d_Z     complex64 [Dc*M][N1][N2]  intermediate of the two-pass inverse FFT for ONE chunk of
-//                                Dc Doppler bins: Z[row][n1][k2], already multiplied by the
-//                                inter-pass twiddle W_N^(k2*n1).  Never holds the whole D*M*N cube.
-//   d_part  float32 [D][M][PARTS] per-workgroup partial |.|^2 sums (fixed-order second reduction,
+//   d_Z     complex64 [Dc*MU][N1][N2] intermediate of the two-pass inverse FFT for ONE chunk of
+//                                Dc Doppler bins x MU unique filters: Z[row][n1][k2], already multiplied
+//                                by the inter-pass twiddle W_N^(k2*n1).  Never holds the D*M*N cube.
+//   d_part  float32 [D][MU][PARTS] per-workgroup partial |.|^2 sums (fixed-order second reduction,
 //                                no float atomics -> bit-reproducible)
 //   d_sum   float32 [D][M]       doppSum, same meaning/layout as the reference's GPU_bufDoppSum
 //   d_xc    complex64 [M][N]     matched-filter outputs at the chosen shift (natural order)
@@ -19,7 +19,8 @@
 //           by W_N^(k2*n1), store Z[n1][k2] (128-byte segments).
 //   pass 2 (k_pass2): for every n1: N2-point FFT over k2 of the contiguous row Z[n1][:], then either
 //           reduce |y|^2 in registers -> wave -> workgroup (Doppler search; the time-domain rows
-//           are never written), or store y[n1 + N1*n2] (demodulation / forward FFT).
+//           are never written), or write the row back in place and let k_transpose produce
+//           y[n1 + N1*n2] (demodulation / forward FFT).
 //
 // Reference semantics reproduced (file:line in the reference tree, pyCuSDR/):
 //   shift-multiply  demodulator/cuda_kernels.cu:339-373, 174-185
@@ -110,7 +111,7 @@ template <int L1>
 struct P1Cfg {
     static constexpr int NT = L1 / 16;
     static constexpr int HALF = padlen(L1) * TILE;
-    static constexpr bool PP = MFB_P1_PP;  // 2 * 34 KiB at L1 = 256
+    static constexpr bool PP = MFB_P1_PP;  // exchange buffer: 34 KiB at L1 = 256 (x2 with ping-pong)
     static constexpr size_t lds_bytes = (size_t)HALF * (PP ? 2 : 1) * sizeof(cf);
 };
 
