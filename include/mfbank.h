@@ -47,7 +47,7 @@ typedef struct mfb_ctx mfb_ctx;
 
 const char *mfb_strerror(int status);
 /* Library/ABI version, bumped whenever a prototype changes. */
-int mfb_abi_version(void);
+int mfb_abi_version(void);   /* 2: search paths, mfb_xcorr */
 
 /* Create a handle on HIP device `device` for blocks of N = 2^log2N samples, `num_dopplers`
  * Doppler bins plus `doppler_offset` leading noise-reference bins (DB:150-159), M matched
@@ -73,6 +73,31 @@ int mfb_set_stream(mfb_ctx *ctx, void *hip_stream);
  * sums (results then agree to rounding, ~1e-7). */
 int mfb_set_tuning(mfb_ctx *ctx, int doppler_chunk, int masks_per_block, int rows_per_block, int jsplit);
 int mfb_get_tuning(mfb_ctx *ctx, int *doppler_chunk, int *masks_per_block, int *rows_per_block, int *jsplit);
+
+/* Search path.  The Doppler search and the matched filtering at the chosen shift have two
+ * implementations with identical results (within fp32 rounding, ~1e-7):
+ *   MFB_PATH_SEGMENT  single-pass overlap-save: mfb_set_filters measures the impulse-response support
+ *                     T of the bank (every shipped protocol: 48...640 taps); for T <= L/2 the block is cut
+ *                     into L-point segments (L = 2^log2L, 256...4096), each mixed to the Doppler shift in
+ *                     time, transformed, multiplied by the L-point filter spectra, transformed back and
+ *                     reduced -- in registers and LDS, with no length-N intermediate in HBM.
+ *   MFB_PATH_TWOPASS  length-N two-pass transforms through an HBM intermediate (any filter).
+ * MFB_PATH_AUTO (default) takes the segment path whenever the bank allows it.  log2L = 0 chooses L by
+ * a cost model; wg_per_cu / filters_per_pass = 0 keep the defaults.  Requesting MFB_PATH_SEGMENT for a bank
+ * without short support returns MFB_ERR_UNSUPPORTED and leaves the previous setting in force.
+ * (The reference's knobs of this kind are CUDA.batchSize / CUDA.streams, DB:171-178, 301-338.) */
+#define MFB_PATH_AUTO    0
+#define MFB_PATH_TWOPASS 1
+#define MFB_PATH_SEGMENT 2
+int mfb_set_search_path(mfb_ctx *ctx, int path, int log2L, int wg_per_cu, int filters_per_pass);
+/* What is in force: path (TWOPASS or SEGMENT), log2L, taps T of the bank (N if it has no short
+ * support), valid outputs per segment and number of segments (0 on the two-pass path).  Any pointer
+ * may be NULL. */
+int mfb_get_search_path(mfb_ctx *ctx, int *path, int *log2L, int *taps, int *valid_per_segment, int *segments);
+/* Host-only helper (no device work): common circular support window [start, start+len) of the impulse
+ * responses ifft(H_m) of a filter bank complex64 [M][N]; len == N when some filter has no short support.
+ * This is the analysis mfb_set_filters runs; exported so it can be checked without a GPU. */
+int mfb_analyze_filters(const float *masks_c64, int M, int N, int *support_start, int *support_len);
 
 /* Geometry the handle settled on: the two FFT factors N = N1 * N2 and, after mfb_set_filters, the number
  * of filter rows the Doppler search actually transforms (filters that are exact copies or exact
@@ -158,12 +183,21 @@ int mfb_sync_correlate(int device, const uint8_t *bits, int B, int L,
 int mfb_sync_find(int device, const uint8_t *bits, int B, int L, const int8_t *tmpl, int T,
                   int threshold, int max_hits, int32_t *hit_idx, int32_t *hit_score, int32_t *counts);
 
+/* Bit-stream alignment cross-correlation of the soft combiner:
+ *   out = ifft( fft(a, N) * conj(fft(b, N)) ),  N = the handle's block length,
+ * a, b real float32 sequences truncated / zero-padded to N as np.fft.fft(a, N) does; out complex64 [N].
+ * Replaces customXCorr (lib/customXCorr.py:5-18; call site softCombiner.py:701-706).  Uses the handle's
+ * spectrum / filter / output buffers as scratch: give it a handle of its own (M = 1); filters and input
+ * of the handle are invalidated. */
+int mfb_xcorr(mfb_ctx *ctx, const float *a, int Na, const float *b, int Nb, float *out_c64);
+
 /* HIP-event stopwatch on the handle's stream (bench.py's live kernel timing). */
 int mfb_timer_start(mfb_ctx *ctx);
 int mfb_timer_stop(mfb_ctx *ctx, float *elapsed_ms);
-/* Per-kernel accounting: when enabled, every launch of the two FFT passes is bracketed by HIP
+/* Per-kernel accounting: when enabled, every launch of the search kernels is bracketed by HIP
  * events on the handle's stream; mfb_profile_read synchronises and returns launch counts and
- * summed milliseconds for pass 1 and pass 2 of the Doppler search, then clears them. */
+ * summed milliseconds, then clears them: slot 0 = pass 1 (two-pass) or the segment kernel,
+ * slot 1 = pass 2 (two-pass; stays 0 on the segment path). */
 int mfb_profile_enable(mfb_ctx *ctx, int on);
 int mfb_profile_read(mfb_ctx *ctx, int counts[2], float total_ms[2]);
 /* Block until all work enqueued on the handle's stream has finished. */

@@ -44,6 +44,9 @@ PROTOTYPES = {
     'mfb_set_tuning': (_i, [_vp, _i, _i, _i, _i]),
     'mfb_get_tuning': (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     'mfb_get_info': (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    'mfb_set_search_path': (_i, [_vp, _i, _i, _i, _i]),
+    'mfb_get_search_path': (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    'mfb_analyze_filters': (_i, [_vp, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     'mfb_set_filters': (_i, [_vp, _vp, _i, _i]),
     'mfb_set_shifts': (_i, [_vp, _vp, _i]),
     'mfb_input_buffer': (_i, [_vp, C.POINTER(_fp)]),
@@ -62,6 +65,7 @@ PROTOTYPES = {
     'mfb_get_envelope': (_i, [_vp, _vp]),
     'mfb_sync_correlate': (_i, [_i, _vp, _i, _i, _vp, _i, _vp]),
     'mfb_sync_find': (_i, [_i, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    'mfb_xcorr': (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     'mfb_timer_start': (_i, [_vp]),
     'mfb_timer_stop': (_i, [_vp, _fp]),
     'mfb_profile_enable': (_i, [_vp, _i]),

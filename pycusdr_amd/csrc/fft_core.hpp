@@ -49,6 +49,14 @@ DEVI cf cmul(cf a, cf w) {
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "v"(w), "v"(p));
     return d;
 }
+// conj(a) * w = (a.x*w.x + a.y*w.y, a.x*w.y - a.y*w.x): the forward transform of the segment search is
+// run as conj(IFFT(conj(u))), and both conjugations fold into the multiplies next to it
+DEVI cf cmul_cj(cf a, cf w) {
+    cf p, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "=v"(d) : "v"(a), "v"(w), "v"(p));
+    return d;
+}
 // (x.x - x.y, x.x + x.y)  and  (-x.x - x.y, x.x - x.y)
 DEVI cf rot45_sum(cf x) {
     cf d;
@@ -223,6 +231,21 @@ DEVI void load_twiddles(TwRegs<L> &tw, const cf *__restrict__ table, const int g
     }
 }
 
+// Exchange synchronisation.  SYNC 0: the FFT group spans several wavefronts -> workgroup barrier.
+// SYNC 1: the whole group (L/16 threads) lives inside ONE wavefront (L <= 1024): LDS operations of a
+// wave execute in issue order, so a store followed by a load needs no s_barrier at all -- only the
+// compiler must not reorder them.  Waves then run fully independently of each other.
+template <int SYNC>
+DEVI void xsync() {
+    if constexpr (SYNC == 0) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // v    : the thread's 16 points; on entry of pass 0 slot i holds element g + (L/16)*i
 // lds  : exchange buffer: element (pos, col) at padi(pos)*T + col.  With PP (ping-pong) the buffer
 //        holds two halves of HALF elements used alternately (one barrier per exchange: a half is
@@ -232,7 +255,7 @@ DEVI void load_twiddles(TwRegs<L> &tw, const cf *__restrict__ table, const int g
 // g    : thread index inside the FFT group, 0 <= g < L/16 ;  col: column inside the tile
 // store(n, value, slot, nu): natural output index n = nu + g; slot (register slot id) and nu are
 //        compile-time constants (std::integral_constant)
-template <int L, int T, int S, bool HOIST, bool PP, int HALF, class Store>
+template <int L, int T, int S, bool HOIST, bool PP, int HALF, int SYNC = 0, class Store>
 DEVI void fft_passes(cf (&v)[16], cf *lds, int &ebuf, const int g, const int col, const TwRegs<L> &twr,
                      const cf *__restrict__ table, Store &store) {
     constexpr int l = ilog2c(L);
@@ -276,7 +299,7 @@ DEVI void fft_passes(cf (&v)[16], cf *lds, int &ebuf, const int g, const int col
                 buf[padi((pp * PC + prefix) * Lnext + t) * T + col] = val;
             });
         }
-        __syncthreads();
+        xsync<SYNC>();
         constexpr int R2 = radix_of(l, S + 1);
         constexpr int Lnn = Lnext / R2;
         constexpr int NB2 = 16 / R2;
@@ -289,7 +312,7 @@ DEVI void fft_passes(cf (&v)[16], cf *lds, int &ebuf, const int g, const int col
                     buf[padi(prefix * Lnext + t + Lnn * decltype(i)::value) * T + col];
             });
         });
-        if constexpr (!PP) __syncthreads();
-        fft_passes<L, T, S + 1, HOIST, PP, HALF>(v, lds, ebuf, g, col, twr, table, store);
+        if constexpr (!PP) xsync<SYNC>();
+        fft_passes<L, T, S + 1, HOIST, PP, HALF, SYNC>(v, lds, ebuf, g, col, twr, table, store);
     }
 }

@@ -1,0 +1,201 @@
+// filter_taps.hpp -- host-side (double precision, init-time only) analysis of the filter bank.
+//
+// The boundary hands the bank over as spectra H_m[k] = conj(fft(template_m, N)) (complex64 [M][N],
+// reference demodulator_base.py:196,246-263).  Every shipped protocol builds them from templates of
+// maskSize * samplesPerSym = 48 ... 640 samples (reference protocol/FSK2_base.py:17-46,
+// benchmark/bench_GMSK.py:40-61, bench_BPSK.py:47-73), so the impulse response h_m = ifft(H_m) is
+// non-zero on a short circular window only.  That is what makes the single-pass overlap-save search
+// possible: X[(k+s) mod N] * H_m[k] (reference cuda_kernels.cu:339-373) is the spectrum of the
+// circular convolution of x[n] e^{-2 pi i s n / N} with h_m, and a T-tap convolution can be evaluated
+// on short segments without ever writing a length-N intermediate.
+//
+// This file recovers the window and the taps from the spectra: a plain radix-2 double-precision FFT
+// (run once per filter row, rows in parallel on host threads), a significance scan, and the L-point
+// segment spectra the device kernel multiplies with.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <complex>
+#include <thread>
+#include <vector>
+
+namespace taps {
+
+typedef std::complex<double> cd;
+
+// in-place radix-2 FFT of length n = 2^k; sign = -1 forward, +1 inverse; unnormalised
+struct Fft {
+    int n = 0;
+    std::vector<cd> w;          // w[j] = e^{+2 pi i j / n}, j < n/2
+    std::vector<uint32_t> rev;
+    explicit Fft(int n_) : n(n_), w(n_ / 2 > 0 ? n_ / 2 : 1), rev(n_) {
+        for (int j = 0; j < n / 2; ++j) {
+            const double a = 2.0 * M_PI * (double)j / (double)n;
+            w[j] = cd(cos(a), sin(a));
+        }
+        int lg = 0;
+        while ((1 << lg) < n) ++lg;
+        rev[0] = 0;
+        for (int i = 1; i < n; ++i) rev[i] = (rev[i >> 1] >> 1) | ((uint32_t)(i & 1) << (lg - 1));
+    }
+    void run(cd *a, int sign) const {
+        for (int i = 0; i < n; ++i)
+            if ((uint32_t)i < rev[i]) std::swap(a[i], a[rev[i]]);
+        for (int len = 2; len <= n; len <<= 1) {
+            const int half = len >> 1, step = n / len;
+            for (int i = 0; i < n; i += len) {
+                for (int j = 0; j < half; ++j) {
+                    cd tw = w[(size_t)j * step];
+                    if (sign < 0) tw = std::conj(tw);
+                    const cd u = a[i + j], v = a[i + j + half] * tw;
+                    a[i + j] = u + v;
+                    a[i + j + half] = u - v;
+                }
+            }
+        }
+    }
+};
+
+struct RowTaps {
+    int start = 0;            // first sample of the row's own window (circular)
+    std::vector<cd> c;        // h[(start + r) mod N], r < c.size(); empty for an all-zero row
+};
+
+struct Bank {
+    int N = 0, M = 0;
+    int start = 0;            // common window [start, start + T) mod N
+    int T = 0;                // N when some row has no short support
+    std::vector<RowTaps> rows;
+};
+
+// A sample belongs to the support of row m when |h_m[n]|^2 > REL * E_m / N (E_m = sum |h_m|^2).  The
+// complex64 rounding of H_m puts ~1.2e-15 * E_m / N of noise energy on every sample; 1e-13 is 80x
+// that (never crossed by the noise) while everything left outside sums to < 1e-13 * E_m, i.e. < 3.2e-7
+// of the output amplitude in the worst case and ~3e-8 (the rounding noise itself) in practice.
+static constexpr double REL = 1e-13;
+static constexpr int ROW_TAPS_MAX = 16384;
+
+// largest circular gap between marked samples -> complement window.  Returns false if nothing is marked.
+static inline bool window_of(const std::vector<uint8_t> &mark, int N, int *start, int *len) {
+    int first = -1, prev = -1, best_gap = -1, best_next = 0;
+    for (int n = 0; n < N; ++n) {
+        if (!mark[n]) continue;
+        if (first < 0) first = n;
+        if (prev >= 0 && n - prev > best_gap) {
+            best_gap = n - prev;
+            best_next = n;
+        }
+        prev = n;
+    }
+    if (first < 0) return false;
+    const int wrap_gap = first + N - prev;     // from the last marked sample round to the first
+    if (wrap_gap > best_gap) {
+        best_gap = wrap_gap;
+        best_next = first;
+    }
+    *start = best_next;
+    *len = N - best_gap + 1;
+    return true;
+}
+
+static inline void analyse_row(const Fft &plan, const float *H, int N, RowTaps *out, std::vector<cd> &buf,
+                               std::vector<uint8_t> &mark) {
+    buf.resize(N);
+    for (int k = 0; k < N; ++k) buf[k] = cd((double)H[2 * k], (double)H[2 * k + 1]);
+    plan.run(buf.data(), +1);
+    const double inv = 1.0 / (double)N;
+    double E = 0.0;
+    for (int n = 0; n < N; ++n) {
+        buf[n] *= inv;
+        E += std::norm(buf[n]);
+    }
+    mark.assign(N, 0);
+    const double thr = REL * E / (double)N;
+    for (int n = 0; n < N; ++n) mark[n] = std::norm(buf[n]) > thr ? 1 : 0;
+    int st = 0, len = 0;
+    out->c.clear();
+    out->start = 0;
+    if (!window_of(mark, N, &st, &len)) return;       // all-zero row
+    out->start = st;
+    if (len > ROW_TAPS_MAX) {                         // no short support: only the length matters
+        out->c.resize((size_t)len);                   // (values unused; the caller falls back)
+        return;
+    }
+    out->c.resize((size_t)len);
+    for (int r = 0; r < len; ++r) out->c[r] = buf[(st + r) & (N - 1)];
+}
+
+// masks: complex64 [M][N] interleaved; N a power of two
+static inline void analyse(const float *masks, int M, int N, Bank *bank) {
+    bank->N = N;
+    bank->M = M;
+    bank->rows.assign(M, RowTaps());
+    const Fft plan(N);
+    unsigned hw = std::thread::hardware_concurrency();
+    int nthr = (int)std::min<unsigned>(hw ? hw : 1, 16);
+    if (nthr > M) nthr = M;
+    if (nthr < 1) nthr = 1;
+    auto work = [&](int t) {
+        std::vector<cd> buf;
+        std::vector<uint8_t> mark;
+        for (int m = t; m < M; m += nthr) analyse_row(plan, masks + (size_t)m * 2 * N, N, &bank->rows[m], buf, mark);
+    };
+    if (nthr == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthr; ++t) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    // common window: union of the rows' windows
+    std::vector<uint8_t> cover(N, 0);
+    bool any = false, too_long = false;
+    for (const auto &r : bank->rows) {
+        if (r.c.empty()) continue;
+        any = true;
+        if ((int)r.c.size() > ROW_TAPS_MAX) too_long = true;
+        for (size_t i = 0; i < r.c.size(); ++i) cover[(r.start + (int)i) & (N - 1)] = 1;
+    }
+    if (!any) {
+        bank->start = 0;
+        bank->T = 1;
+        return;
+    }
+    int st = 0, len = 0;
+    window_of(cover, N, &st, &len);
+    bank->start = st;
+    bank->T = too_long ? N : len;
+}
+
+// tap r of row m in the COMMON window: h_m[(start + r) mod N]; zero outside the row's own window
+static inline cd tap(const Bank &b, int m, int r) {
+    const RowTaps &row = b.rows[m];
+    if (row.c.empty()) return cd(0.0, 0.0);
+    const int n = (b.start + r) & (b.N - 1);
+    const int off = (n - row.start) & (b.N - 1);
+    return off < (int)row.c.size() ? row.c[off] : cd(0.0, 0.0);
+}
+
+// L-point segment spectra, complex64 [M][L]:  G_m = (N/L) * FFT_L(c'_m), c'_m[(r - (T-1)) mod L] = tap r.
+// With this rotation the valid outputs of a segment that starts at sample b0 are i = 0 .. L-T and
+// output i is y[(b0 + i + start + T - 1) mod N] of the length-N formulation.
+static inline void segment_spectra(const Bank &b, int L, std::vector<float> *out) {
+    const Fft plan(L);
+    out->assign((size_t)b.M * 2 * L, 0.f);
+    std::vector<cd> buf(L);
+    const double scale = (double)b.N / (double)L;
+    for (int m = 0; m < b.M; ++m) {
+        std::fill(buf.begin(), buf.end(), cd(0.0, 0.0));
+        for (int r = 0; r < b.T; ++r) buf[(r - (b.T - 1)) & (L - 1)] = tap(b, m, r);
+        plan.run(buf.data(), -1);
+        float *o = out->data() + (size_t)m * 2 * L;
+        for (int k = 0; k < L; ++k) {
+            o[2 * k] = (float)(buf[k].real() * scale);
+            o[2 * k + 1] = (float)(buf[k].imag() * scale);
+        }
+    }
+}
+
+}  // namespace taps

@@ -22,6 +22,10 @@
 //           are never written), or write the row back in place and let k_transpose produce
 //           y[n1 + N1*n2] (demodulation / forward FFT).
 //
+// Short filters (every shipped protocol) take the single-pass overlap-save path instead (seg_kernels.hpp):
+// no intermediate at all; the two-pass path below stays as the fallback for filters without a short
+// impulse response and for blocks too small to segment, and serves the plain forward transforms.
+//
 // Reference semantics reproduced (file:line in the reference tree, pyCuSDR/):
 //   shift-multiply  demodulator/cuda_kernels.cu:339-373, 174-185
 //   |.|^2 / 2^18 row sums  cuda_kernels.cu:421-480      pick  cuda_kernels.cu:502-597
@@ -33,10 +37,13 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <vector>
 
 #include "../../include/mfbank.h"
 #include "fft_core.hpp"
+#include "filter_taps.hpp"
+#include "seg_kernels.hpp"
 
 #define KIND_BANK 0  // X shifted * mask, inverse
 #define KIND_FWDC 1  // complex input, forward (conjugate in)
@@ -680,6 +687,15 @@ struct mfb_ctx {
     bool have_filters, have_shifts, have_input, have_xc;
     hipEvent_t t0, t1;
     bool prof;
+    // single-pass overlap-save path (seg_kernels.hpp)
+    int path_req, segl_req;   // requested: MFB_PATH_*, log2 L (0 = automatic)
+    int path, segl;           // resolved
+    int T, win_start, V, Q;   // taps, window start, valid outputs per segment, segments
+    int seg_wpc, seg_mpb;     // workgroups per CU, filters per team pass (0 = automatic)
+    cf *d_G, *d_twL;
+    int twL_len;
+    size_t part_cap;          // floats allocated in d_part
+    taps::Bank *bank;         // host copy of the taps (kept so that L can be changed)
     std::vector<hipEvent_t> ev[2];
     std::vector<hipEvent_t> ev_pool;
 };
@@ -705,7 +721,7 @@ extern "C" const char *mfb_strerror(int s) {
         default: return "unknown status";
     }
 }
-extern "C" int mfb_abi_version(void) { return 1; }
+extern "C" int mfb_abi_version(void) { return 2; }
 
 static void make_twiddles(std::vector<cf> &v, int count, double denom, double stepmul) {
     v.resize(count);
@@ -743,17 +759,133 @@ static int default_chunk(const mfb_ctx *c) {
     return (int)ch;
 }
 
-static int alloc_Z(mfb_ctx *c) {
+// Intermediate of the two-pass transforms.  The segment path needs one row only (the plain forward
+// transforms of A3 / A10 still run two-pass); the two-pass search needs chunk * MU rows.
+static size_t z_rows_needed(const mfb_ctx *c) {
+    if (!c->have_filters || c->path == MFB_PATH_SEGMENT) return 1;
     const size_t rows = (size_t)c->chunk * c->MU;   // the search stores only the unique filter rows
-    const size_t need = rows > (size_t)c->M ? rows : (size_t)c->M;
+    return rows > (size_t)c->M ? rows : (size_t)c->M;
+}
+static int alloc_Z(mfb_ctx *c) {
+    const size_t need = z_rows_needed(c);
     if (c->d_Z && c->z_rows >= need) return MFB_OK;
     if (c->d_Z) {
         HIPCHK(hipStreamSynchronize(c->stream));
         HIPCHK(hipFree(c->d_Z));
         c->d_Z = nullptr;
+        c->z_rows = 0;
     }
     HIPCHK(hipMalloc((void **)&c->d_Z, need * c->N * sizeof(cf)));
     c->z_rows = need;
+    return MFB_OK;
+}
+
+static int reserve_partials(mfb_ctx *c, size_t floats) {
+    if (c->part_cap >= floats) return MFB_OK;
+    if (c->d_part) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipFree(c->d_part));
+        c->d_part = nullptr;
+        c->part_cap = 0;
+    }
+    HIPCHK(hipMalloc((void **)&c->d_part, floats * sizeof(float)));
+    c->part_cap = floats;
+    return MFB_OK;
+}
+
+// ---- per-device kernel attributes ------------------------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): it is set for every
+// instantiation that can need more than 48 KiB whenever a handle is created, on that handle's device.
+template <int L1>
+static int attr_p1() {
+    if (P1Cfg<L1>::lds_bytes > 48 * 1024) {
+        const int b = (int)P1Cfg<L1>::lds_bytes;
+        HIPCHK(hipFuncSetAttribute((const void *)k_pass1<L1, KIND_BANK>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
+        HIPCHK(hipFuncSetAttribute((const void *)k_pass1<L1, KIND_FWDC>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
+        HIPCHK(hipFuncSetAttribute((const void *)k_pass1<L1, KIND_FWDR>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
+    }
+    return MFB_OK;
+}
+template <int L2>
+static int attr_p2() {
+    if (P2Cfg<L2>::lds_bytes > 48 * 1024) {
+        const int b = (int)P2Cfg<L2>::lds_bytes;
+        HIPCHK(hipFuncSetAttribute((const void *)k_pass2<L2, MODE_REDUCE>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
+        HIPCHK(hipFuncSetAttribute((const void *)k_pass2<L2, MODE_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
+    }
+    return MFB_OK;
+}
+template <int L>
+static int attr_seg() {
+    const int b = (int)SegCfg<L>::lds_bytes(SEG_MPB_MAX);
+    HIPCHK(hipFuncSetAttribute((const void *)k_seg<L, SEG_REDUCE>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
+    HIPCHK(hipFuncSetAttribute((const void *)k_seg<L, SEG_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
+    return MFB_OK;
+}
+static int set_kernel_attributes(const mfb_ctx *c) {
+    int rc = MFB_OK;
+    switch (c->l1) {
+        case 5: rc = attr_p1<32>(); break;
+        case 6: rc = attr_p1<64>(); break;
+        case 7: rc = attr_p1<128>(); break;
+        case 8: rc = attr_p1<256>(); break;
+    }
+    if (rc) return rc;
+    switch (c->l2) {
+        case 13: rc = attr_p2<8192>(); break;
+        case 14: rc = attr_p2<16384>(); break;
+        default: break;   // <= 4096 points: 35 KiB
+    }
+    if (rc) return rc;
+    if ((rc = attr_seg<256>())) return rc;
+    if ((rc = attr_seg<512>())) return rc;
+    if ((rc = attr_seg<1024>())) return rc;
+    if ((rc = attr_seg<2048>())) return rc;
+    return attr_seg<4096>();
+}
+
+static int create_impl(mfb_ctx *c) {
+    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIPCHK(hipEventCreate(&c->t0));
+    HIPCHK(hipEventCreate(&c->t1));
+    int rc = set_kernel_attributes(c);
+    if (rc) return rc;
+    const int M = c->M;
+    const size_t nb = (size_t)c->N * sizeof(cf);
+    HIPCHK(hipHostMalloc((void **)&c->h_in, nb, hipHostMallocDefault));
+    memset(c->h_in, 0, nb);
+    HIPCHK(hipMalloc((void **)&c->d_x, nb));
+    HIPCHK(hipMalloc((void **)&c->d_X, nb));
+    HIPCHK(hipMalloc((void **)&c->d_masks, nb * M));
+    HIPCHK(hipMalloc((void **)&c->d_xc, nb * M));
+    HIPCHK(hipMalloc((void **)&c->d_P, nb));
+    HIPCHK(hipMalloc((void **)&c->d_env, (size_t)c->N * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&c->d_shifts, (size_t)c->Dtot * sizeof(int)));
+    if ((rc = reserve_partials(c, (size_t)c->Dtot * M * c->N1))) return rc;
+    HIPCHK(hipMalloc((void **)&c->d_sum, (size_t)c->Dtot * M * sizeof(float)));
+    HIPCHK(hipMemset(c->d_sum, 0, (size_t)c->Dtot * M * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&c->d_res, 2 * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&c->d_uniq, (size_t)M * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&c->d_rep, (size_t)M * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&c->d_cr, 3 * sizeof(float)));
+    c->cap = c->N / 2;  // symbols never shorter than 2 samples
+    HIPCHK(hipMalloc((void **)&c->d_sym, (size_t)c->cap * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&c->d_cen, (size_t)c->cap * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&c->d_mag, (size_t)c->cap * sizeof(float)));
+    // one row for the plain forward transforms; the search's share is sized when the filters arrive
+    if ((rc = alloc_Z(c))) return rc;
+
+    std::vector<cf> t;
+    make_twiddles(t, c->N1, (double)c->N1, 1.0);
+    if ((rc = upload_tw(&c->d_tw1, t))) return rc;
+    make_twiddles(t, c->N2, (double)c->N2, 1.0);
+    if ((rc = upload_tw(&c->d_tw2, t))) return rc;
+    make_twiddles(t, 1 << c->lo, (double)c->N, 1.0);
+    if ((rc = upload_tw(&c->d_twLo, t))) return rc;
+    make_twiddles(t, c->N >> c->lo, (double)c->N, (double)(1 << c->lo));
+    if ((rc = upload_tw(&c->d_twHi, t))) return rc;
+    c->d_in = c->d_x;
     return MFB_OK;
 }
 
@@ -771,7 +903,7 @@ extern "C" int mfb_create(mfb_ctx **out, int device, int log2N, int num_dopplers
     HIPCHK(hipSetDevice(device));
 
     mfb_ctx *c = new mfb_ctx();
-    memset((void *)c, 0, offsetof(mfb_ctx, ev));
+    memset((void *)c, 0, offsetof(mfb_ctx, ev));  // everything before the vectors
     c->device = device;
     c->log2N = log2N;
     c->N = 1 << log2N;
@@ -787,10 +919,10 @@ extern "C" int mfb_create(mfb_ctx **out, int device, int log2N, int num_dopplers
     c->W = window_width;
     c->sum_all = sum_all_masks ? 1 : 0;
     c->cs_off = code_search_mask_offset;
-    // Doppler bins per launch: as many as an 8 GiB intermediate holds.  Measured on MI355X (C2:
-    // D=256, M=8, N=2^20): long persistent loops amortise the per-workgroup twiddle setup and keep
-    // each XCD's L2 serving the filter tile to many Doppler streams, so big chunks win (chunk 16:
-    // 9.8 ms, 64: 6.65 ms, 128: 6.55 ms per block) -- but a 16 GiB intermediate (chunk 256) costs
+    // Two-pass search, Doppler bins per launch: as many as an 8 GiB intermediate holds.  Measured on
+    // MI355X (C2: D=256, M=8, N=2^20): long persistent loops amortise the per-workgroup twiddle setup
+    // and keep each XCD's L2 serving the filter tile to many Doppler streams, so big chunks win (chunk
+    // 16: 9.8 ms, 64: 6.65 ms, 128: 6.55 ms per block) -- but a 16 GiB intermediate (chunk 256) costs
     // 0.4 ms more than two 8 GiB launches.  Keeping the intermediate inside the 256 MiB Infinity
     // Cache (chunk 1-2) does not pay: the cache streams no faster than HBM (tools/ubench/mall.hip).
     c->MU = M;
@@ -799,45 +931,16 @@ extern "C" int mfb_create(mfb_ctx **out, int device, int log2N, int num_dopplers
     c->mpb = M < 8 ? M : 8;
     c->jsplit = 32;
     set_rows_per_block(c, 64);
+    c->path_req = MFB_PATH_AUTO;
+    c->path = MFB_PATH_TWOPASS;
 
-    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    c->stream = c->own_stream;
-    HIPCHK(hipEventCreate(&c->t0));
-    HIPCHK(hipEventCreate(&c->t1));
-    const size_t nb = (size_t)c->N * sizeof(cf);
-    HIPCHK(hipHostMalloc((void **)&c->h_in, nb, hipHostMallocDefault));
-    memset(c->h_in, 0, nb);
-    HIPCHK(hipMalloc((void **)&c->d_x, nb));
-    HIPCHK(hipMalloc((void **)&c->d_X, nb));
-    HIPCHK(hipMalloc((void **)&c->d_masks, nb * M));
-    HIPCHK(hipMalloc((void **)&c->d_xc, nb * M));
-    HIPCHK(hipMalloc((void **)&c->d_P, nb));
-    HIPCHK(hipMalloc((void **)&c->d_env, (size_t)c->N * sizeof(float)));
-    HIPCHK(hipMalloc((void **)&c->d_shifts, (size_t)c->Dtot * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&c->d_part, (size_t)c->Dtot * M * c->N1 * sizeof(float)));
-    HIPCHK(hipMalloc((void **)&c->d_sum, (size_t)c->Dtot * M * sizeof(float)));
-    HIPCHK(hipMemset(c->d_sum, 0, (size_t)c->Dtot * M * sizeof(float)));
-    HIPCHK(hipMalloc((void **)&c->d_res, 2 * sizeof(float)));
-    HIPCHK(hipMalloc((void **)&c->d_uniq, (size_t)M * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&c->d_rep, (size_t)M * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&c->d_cr, 3 * sizeof(float)));
-    c->cap = c->N / 2;  // symbols never shorter than 2 samples
-    HIPCHK(hipMalloc((void **)&c->d_sym, (size_t)c->cap * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&c->d_cen, (size_t)c->cap * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&c->d_mag, (size_t)c->cap * sizeof(float)));
-    int rc = alloc_Z(c);
-    if (rc) return rc;
-
-    std::vector<cf> t;
-    make_twiddles(t, c->N1, (double)c->N1, 1.0);
-    if ((rc = upload_tw(&c->d_tw1, t))) return rc;
-    make_twiddles(t, c->N2, (double)c->N2, 1.0);
-    if ((rc = upload_tw(&c->d_tw2, t))) return rc;
-    make_twiddles(t, 1 << c->lo, (double)c->N, 1.0);
-    if ((rc = upload_tw(&c->d_twLo, t))) return rc;
-    make_twiddles(t, c->N >> c->lo, (double)c->N, (double)(1 << c->lo));
-    if ((rc = upload_tw(&c->d_twHi, t))) return rc;
-    c->d_in = c->d_x;
+    // any failure below frees what was allocated so far (mfb_destroy tolerates partial handles):
+    // the counterpart of the reference's context teardown, demodulator_base.py:517-530
+    const int rc = create_impl(c);
+    if (rc) {
+        (void)mfb_destroy(c);
+        return rc;
+    }
     *out = c;
     return MFB_OK;
 }
@@ -845,18 +948,20 @@ extern "C" int mfb_create(mfb_ctx **out, int device, int log2N, int num_dopplers
 extern "C" int mfb_destroy(mfb_ctx *c) {
     if (!c) return MFB_ERR_ARG;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_uniq, c->d_rep, c->d_x,  c->d_X,    c->d_masks, c->d_Z,   c->d_xc,  c->d_P,   c->d_env, c->d_shifts, c->d_tw1,
-                    c->d_tw2, c->d_twLo, c->d_twHi,  c->d_part, c->d_sum, c->d_res, c->d_cr,  c->d_sym,    c->d_cen, c->d_mag};
+                    c->d_tw2, c->d_twLo, c->d_twHi,  c->d_part, c->d_sum, c->d_res, c->d_cr,  c->d_sym,    c->d_cen, c->d_mag,
+                    c->d_G, c->d_twL};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (c->h_in) (void)hipHostFree(c->h_in);
     for (auto &v : c->ev)
         for (auto e : v) (void)hipEventDestroy(e);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    (void)hipEventDestroy(c->t0);
-    (void)hipEventDestroy(c->t1);
-    (void)hipStreamDestroy(c->own_stream);
+    if (c->t0) (void)hipEventDestroy(c->t0);
+    if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c->bank;
     delete c;
     return MFB_OK;
 }
@@ -881,6 +986,7 @@ extern "C" int mfb_set_tuning(mfb_ctx *c, int chunk, int mpb, int rows_per_block
     }
     if (c->chunk * c->MU > 65535) c->chunk = 65535 / c->MU;  // grid.y limit of pass 2
     if (mpb > 0) c->mpb = mpb > c->M ? c->M : mpb;
+    if (!c->have_filters) return MFB_OK;   // the intermediate is sized when the filters arrive
     return alloc_Z(c);
 }
 extern "C" int mfb_get_tuning(mfb_ctx *c, int *chunk, int *mpb, int *rows_per_block, int *jsplit) {
@@ -897,6 +1003,130 @@ extern "C" int mfb_get_info(mfb_ctx *c, int *N1, int *N2, int *unique_filters) {
     if (N1) *N1 = c->N1;
     if (N2) *N2 = c->N2;
     if (unique_filters) *unique_filters = c->MU;
+    return MFB_OK;
+}
+
+// ---- search path ---------------------------------------------------------------------------------
+// Cost of one valid output sample per filter, in packed-fp32 VALU instructions per thread-point: the
+// instruction count of an L-point transform (radix-16 passes + remainder + twiddles, counted from the
+// ISA) plus the pointwise work, divided by the segment efficiency V / L.
+static double seg_cost(int l, int T) {
+    static const double ops[13] = {0, 0, 0, 0, 0, 0, 0, 0, 194, 240, 256, 280, 322};
+    const int L = 1 << l;
+    const int V = L - T + 1;
+    if (V < 1) return 1e30;
+    return (ops[l] + 55.0) * (double)L / (double)V;
+}
+
+static int choose_segl(const mfb_ctx *c, int T) {
+    int best = 0;
+    double bc = 1e30;
+    for (int l = 8; l <= 12; ++l) {
+        const int L = 1 << l;
+        if (2 * T > L || 4 * L > c->N) continue;    // at least half of every segment valid, >= 4 segments
+        const double cost = seg_cost(l, T);
+        if (cost < bc) {
+            bc = cost;
+            best = l;
+        }
+    }
+    return best;
+}
+
+// settle path and segment length from the request and the analysed bank; (re)build G and W_L
+static int resolve_path(mfb_ctx *c) {
+    if (!c->have_filters || !c->bank) return MFB_OK;
+    const int T = c->bank->T;
+    int l = 0;
+    if (c->path_req != MFB_PATH_TWOPASS) {
+        if (c->segl_req) {
+            const int L = 1 << c->segl_req;
+            if (c->segl_req >= 8 && c->segl_req <= 12 && T <= L && 2 * L <= c->N) l = c->segl_req;
+        } else {
+            l = choose_segl(c, T);
+        }
+    }
+    if (c->path_req == MFB_PATH_SEGMENT && !l) return MFB_ERR_UNSUPPORTED;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (!l) {
+        c->path = MFB_PATH_TWOPASS;
+        c->segl = 0;
+    } else {
+        const int L = 1 << l;
+        if (c->segl != l || !c->d_G) {
+            std::vector<float> G;
+            taps::segment_spectra(*c->bank, L, &G);
+            if (c->d_G) HIPCHK(hipFree(c->d_G));
+            c->d_G = nullptr;
+            HIPCHK(hipMalloc((void **)&c->d_G, G.size() * sizeof(float)));
+            HIPCHK(hipMemcpy(c->d_G, G.data(), G.size() * sizeof(float), hipMemcpyHostToDevice));
+            if (c->twL_len != L) {
+                if (c->d_twL) HIPCHK(hipFree(c->d_twL));
+                c->d_twL = nullptr;
+                c->twL_len = 0;
+                std::vector<cf> t;
+                make_twiddles(t, L, (double)L, 1.0);
+                int rc = upload_tw(&c->d_twL, t);
+                if (rc) return rc;
+                c->twL_len = L;
+            }
+        }
+        c->path = MFB_PATH_SEGMENT;
+        c->segl = l;
+        c->T = T;
+        c->win_start = c->bank->start;
+        c->V = L - T + 1;
+        c->Q = (c->N + c->V - 1) / c->V;
+    }
+    if (c->path == MFB_PATH_TWOPASS) {
+        if (c->chunk_auto) c->chunk = default_chunk(c);
+        if (c->chunk * c->MU > 65535) c->chunk = 65535 / c->MU;
+        int rc = reserve_partials(c, (size_t)c->Dtot * c->M * c->N1);
+        if (rc) return rc;
+    } else if (c->d_Z && c->z_rows > 1) {   // give the big intermediate back
+        HIPCHK(hipFree(c->d_Z));
+        c->d_Z = nullptr;
+        c->z_rows = 0;
+    }
+    return alloc_Z(c);
+}
+
+extern "C" int mfb_set_search_path(mfb_ctx *c, int path, int log2L, int wg_per_cu, int filters_per_pass) {
+    if (!c || path < 0 || path > MFB_PATH_SEGMENT || log2L < 0 || wg_per_cu < 0 || wg_per_cu > 8 || filters_per_pass < 0 ||
+        filters_per_pass > SEG_MPB_MAX)
+        return MFB_ERR_ARG;
+    if (log2L && (log2L < 8 || log2L > 12)) return MFB_ERR_UNSUPPORTED;
+    HIPCHK(hipSetDevice(c->device));
+    const int old_path = c->path_req, old_l = c->segl_req;
+    c->path_req = path;
+    c->segl_req = log2L;
+    c->seg_wpc = wg_per_cu;
+    c->seg_mpb = filters_per_pass;
+    const int rc = resolve_path(c);
+    if (rc) {           // keep the previous, working configuration
+        c->path_req = old_path;
+        c->segl_req = old_l;
+        (void)resolve_path(c);
+    }
+    return rc;
+}
+
+extern "C" int mfb_get_search_path(mfb_ctx *c, int *path, int *log2L, int *taps_out, int *valid_per_segment, int *segments) {
+    if (!c) return MFB_ERR_ARG;
+    if (path) *path = c->path;
+    if (log2L) *log2L = c->segl;
+    if (taps_out) *taps_out = c->bank ? c->bank->T : 0;
+    if (valid_per_segment) *valid_per_segment = c->path == MFB_PATH_SEGMENT ? c->V : 0;
+    if (segments) *segments = c->path == MFB_PATH_SEGMENT ? c->Q : 0;
+    return MFB_OK;
+}
+
+extern "C" int mfb_analyze_filters(const float *masks, int M, int N, int *support_start, int *support_len) {
+    if (!masks || M < 1 || N < 2 || (N & (N - 1))) return MFB_ERR_ARG;
+    taps::Bank b;
+    taps::analyse(masks, M, N, &b);
+    if (support_start) *support_start = b.start;
+    if (support_len) *support_len = b.T;
     return MFB_OK;
 }
 
@@ -929,13 +1159,20 @@ extern "C" int mfb_set_filters(mfb_ctx *c, const float *masks, int M, int N) {
     c->MU = (int)uniq.size();
     HIPCHK(hipMemcpyAsync(c->d_uniq, uniq.data(), uniq.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_rep, rep.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    // impulse-response window and taps of every filter (double precision, host threads)
+    if (!c->bank) c->bank = new taps::Bank();
+    taps::analyse(masks, M, N, c->bank);
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->chunk_auto) c->chunk = default_chunk(c);
-    if (c->chunk * c->MU > 65535) c->chunk = 65535 / c->MU;
-    int rcz = alloc_Z(c);
-    if (rcz) return rcz;
     c->have_filters = true;
-    return MFB_OK;
+    c->have_xc = false;
+    c->segl = 0;    // force G to be rebuilt for the new bank
+    int rc = resolve_path(c);
+    if (rc == MFB_ERR_UNSUPPORTED) {   // a segment path was demanded but this bank has no short support
+        c->path_req = MFB_PATH_AUTO;
+        rc = resolve_path(c);
+    }
+    if (rc) c->have_filters = false;
+    return rc;
 }
 
 extern "C" int mfb_set_shifts(mfb_ctx *c, const int32_t *shifts, int count) {
@@ -975,14 +1212,7 @@ static void prof_mark(mfb_ctx *c, int which) {
 
 template <int L1, int KIND>
 static int launch_p1_t(mfb_ctx *c, const P1Args &a, dim3 grid) {
-    const size_t lds = P1Cfg<L1>::lds_bytes;
-    if (lds > 48 * 1024) {
-        static bool done = false;  // per instantiation
-        if (!done) {
-            HIPCHK(hipFuncSetAttribute((const void *)k_pass1<L1, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            done = true;
-        }
-    }
+    const size_t lds = P1Cfg<L1>::lds_bytes;   // > 48 KiB cases: set_kernel_attributes (per device)
     hipLaunchKernelGGL((k_pass1<L1, KIND>), grid, dim3((L1 / 16) * TILE), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return MFB_OK;
@@ -1002,14 +1232,7 @@ template <int L2, int MODE>
 static int launch_p2_t(mfb_ctx *c, const P2Args &a, dim3 grid) {
     constexpr int NT = L2 / 16;
     constexpr int RB = P2Cfg<L2>::RB;
-    const size_t lds = P2Cfg<L2>::lds_bytes;
-    if (lds > 48 * 1024) {
-        static bool done = false;  // per instantiation
-        if (!done) {
-            HIPCHK(hipFuncSetAttribute((const void *)k_pass2<L2, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            done = true;
-        }
-    }
+    const size_t lds = P2Cfg<L2>::lds_bytes;   // > 48 KiB cases: set_kernel_attributes (per device)
     hipLaunchKernelGGL((k_pass2<L2, MODE>), grid, dim3(NT * RB), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return MFB_OK;
@@ -1079,7 +1302,8 @@ static int launch_transpose(mfb_ctx *c, cf *dst, int rows, int conj) {
 }
 
 // forward FFT of one row: complex (src_c) or real (src_r) input -> dst natural order
-static int forward_fft(mfb_ctx *c, const cf *src_c, const float *src_r, cf *dst) {
+static int forward_fft(mfb_ctx *c, const cf *src_c, const float *src_r, cf *dst, int conj_out = 1);
+static int forward_fft(mfb_ctx *c, const cf *src_c, const float *src_r, cf *dst, int conj_out) {
     P1Args a = p1_base(c);
     a.X = src_c;
     a.Xr = src_r;
@@ -1094,7 +1318,87 @@ static int forward_fft(mfb_ctx *c, const cf *src_c, const float *src_r, cf *dst)
     dim3 g2(b.parts, 1, 1);
     rc = launch_p2<MODE_STORE>(c, b, g2);
     if (rc) return rc;
-    return launch_transpose(c, dst, 1, 1);
+    return launch_transpose(c, dst, 1, conj_out);   // conj_out = 0 leaves conj(fft(src)) (real input only)
+}
+
+
+// ---- single-pass overlap-save launches -------------------------------------------------------------
+template <int L, int MODE>
+static int launch_seg_t(mfb_ctx *c, const SegArgs &a, int grid) {
+    const size_t lds = SegCfg<L>::lds_bytes(MODE == SEG_REDUCE ? a.mpb : 0);
+    hipLaunchKernelGGL((k_seg<L, MODE>), dim3(grid), dim3(256), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return MFB_OK;
+}
+template <int MODE>
+static int launch_seg(mfb_ctx *c, const SegArgs &a, int grid) {
+    switch (c->segl) {
+        case 8: return launch_seg_t<256, MODE>(c, a, grid);
+        case 9: return launch_seg_t<512, MODE>(c, a, grid);
+        case 10: return launch_seg_t<1024, MODE>(c, a, grid);
+        case 11: return launch_seg_t<2048, MODE>(c, a, grid);
+        case 12: return launch_seg_t<4096, MODE>(c, a, grid);
+    }
+    return MFB_ERR_UNSUPPORTED;
+}
+
+// Decomposition of one launch: nsg = 8 segment groups (one per XCD under round-robin placement), each
+// with wpg workgroups = bsplit Doppler streams x ssplit segment sub-ranges (x TPW teams).
+struct SegPlan {
+    int nsg, wpg, bsplit, ssplit, mpb, mgroups, nslots, parts, grid;
+};
+static SegPlan plan_seg(const mfb_ctx *c, int dc, int nfilters, bool reduce) {
+    const int L = 1 << c->segl;
+    const int NT = L / 16;
+    const int TEAM = NT < 64 ? 64 : NT;
+    const int CT = TEAM / NT, TPW = 256 / TEAM, WPT = TEAM / 64;
+    SegPlan p;
+    p.nsg = 8;
+    p.nslots = (c->Q + CT - 1) / CT;
+    int mpb = c->seg_mpb > 0 ? c->seg_mpb : SEG_MPB_MAX;
+    if (!reduce) mpb = 4;                       // demodulation: few bins, spread the filters over the chip
+    if (mpb > nfilters) mpb = nfilters;
+    p.mgroups = (nfilters + mpb - 1) / mpb;
+    p.mpb = (nfilters + p.mgroups - 1) / p.mgroups;   // balanced
+    const int wpc = c->seg_wpc > 0 ? c->seg_wpc : MFB_SEG_WAVES;
+    int wpg = wpc * 32;                          // workgroups per group: wpc per CU, 32 CUs per XCD
+    // never more teams than (bin, slot) units in a group
+    const long long units = (long long)dc * ((p.nslots + p.nsg - 1) / p.nsg);
+    while (wpg > 1 && (long long)wpg * TPW > units) wpg >>= 1;
+    p.wpg = wpg;
+    const bool wave_sync = NT <= 64;
+    // bsplit * ssplit = wpg * TPW teams; barrier teams of one workgroup must share the Doppler stream
+    const int tg = wave_sync ? wpg * TPW : wpg;
+    int bs = 1;
+    for (int d = 1; d <= tg; ++d)
+        if (tg % d == 0 && d <= dc) bs = d;
+    p.bsplit = bs;
+    p.ssplit = wave_sync ? tg / bs : (wpg / bs) * TPW;
+    p.parts = p.nsg * p.ssplit * WPT;
+    p.grid = p.nsg * p.mgroups * p.wpg;
+    return p;
+}
+
+static SegArgs seg_base(mfb_ctx *c, const SegPlan &p) {
+    SegArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = c->d_in;
+    a.G = c->d_G;
+    a.twL = c->d_twL;
+    a.twLo = c->d_twLo;
+    a.twHi = c->d_twHi;
+    a.N = c->N;
+    a.lo = c->lo;
+    a.V = c->V;
+    a.nslots = p.nslots;
+    a.mpb = p.mpb;
+    a.mgroups = p.mgroups;
+    a.nsg = p.nsg;
+    a.bsplit = p.bsplit;
+    a.ssplit = p.ssplit;
+    a.parts = p.parts;
+    a.scale = 1.0f / 262144.0f;
+    return a;
 }
 
 extern "C" int mfb_upload(mfb_ctx *c) {
@@ -1135,6 +1439,27 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
     if (!c->have_filters || !c->have_shifts || !c->have_input) return MFB_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
     const int MU = c->MU;
+    if (c->path == MFB_PATH_SEGMENT) {
+        // all bins in ONE launch: nothing of length N is written, so there is nothing to chunk
+        const SegPlan p = plan_seg(c, c->Dtot, MU, true);
+        int rc = reserve_partials(c, (size_t)c->Dtot * MU * p.parts);
+        if (rc) return rc;
+        SegArgs a = seg_base(c, p);
+        a.rows = (MU < c->M) ? c->d_uniq : nullptr;
+        a.shifts = c->d_shifts;
+        a.partials = c->d_part;
+        a.MU = MU;
+        a.j0 = 0;
+        a.dc = c->Dtot;
+        prof_mark(c, 0);
+        rc = launch_seg<SEG_REDUCE>(c, a, p.grid);
+        prof_mark(c, 0);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_finalize, dim3((c->Dtot + 63) / 64), dim3(64), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, MU,
+                           (const int *)c->d_rep, p.parts, c->sum_all);
+        HIPCHK(hipGetLastError());
+        return MFB_OK;
+    }
     const int mpb = c->mpb < MU ? c->mpb : MU;
     const int mgroups = (MU + mpb - 1) / mpb;
     for (int j0 = 0; j0 < c->Dtot; j0 += c->chunk) {
@@ -1224,23 +1549,37 @@ extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, fl
     HIPCHK(hipSetDevice(c->device));
     shift = ((shift % c->N) + c->N) % c->N;
     // A9: matched filters at one shift -> xc[M][N] natural order
-    P1Args a = p1_base(c);
-    a.X = c->d_X;
-    a.shifts = nullptr;
-    a.fixed_shift = shift;
-    a.dc = 1;
-    const int mgroups = (c->M + c->mpb - 1) / c->mpb;
-    a.ntiles = c->N2 / TILE;
-    a.mgroups = mgroups;
-    a.jsplit = 1;
-    int rc = launch_p1<KIND_BANK>(c, a, dim3(a.ntiles * mgroups, 1, 1));
-    if (rc) return rc;
-    P2Args b = p2_base(c);
-    p2_store_split(c, b, c->M);
-    rc = launch_p2<MODE_STORE>(c, b, dim3(b.parts, c->M, 1));
-    if (rc) return rc;
-    rc = launch_transpose(c, c->d_xc, c->M, 0);
-    if (rc) return rc;
+    int rc;
+    if (c->path == MFB_PATH_SEGMENT) {
+        // the same segment kernel, storing y in natural order instead of reducing it (no transpose)
+        const SegPlan p = plan_seg(c, 1, c->M, false);
+        SegArgs sa = seg_base(c, p);
+        sa.out = c->d_xc;
+        sa.MU = c->M;
+        sa.dc = 1;
+        sa.fixed_shift = shift;
+        sa.out_off = (c->win_start + c->T - 1) & (c->N - 1);
+        rc = launch_seg<SEG_STORE>(c, sa, p.grid);
+        if (rc) return rc;
+    } else {
+        P1Args a = p1_base(c);
+        a.X = c->d_X;
+        a.shifts = nullptr;
+        a.fixed_shift = shift;
+        a.dc = 1;
+        const int mgroups = (c->M + c->mpb - 1) / c->mpb;
+        a.ntiles = c->N2 / TILE;
+        a.mgroups = mgroups;
+        a.jsplit = 1;
+        rc = launch_p1<KIND_BANK>(c, a, dim3(a.ntiles * mgroups, 1, 1));
+        if (rc) return rc;
+        P2Args b = p2_base(c);
+        p2_store_split(c, b, c->M);
+        rc = launch_p2<MODE_STORE>(c, b, dim3(b.parts, c->M, 1));
+        if (rc) return rc;
+        rc = launch_transpose(c, c->d_xc, c->M, 0);
+        if (rc) return rc;
+    }
     // A10: envelope, spectrum of the envelope, windowed argmax
     hipLaunchKernelGGL(k_envelope, dim3(1024), dim3(256), 0, c->stream, c->d_xc, c->d_env, c->N, c->M, c->cs_off);
     HIPCHK(hipGetLastError());
@@ -1296,8 +1635,12 @@ extern "C" int mfb_get_envelope(mfb_ctx *c, float *host) {
     return MFB_OK;
 }
 
-// grow-only device workspace of the (handle-less) sync correlator, one per device
+// Workspaces of the (handle-less) sync correlator.  Every call borrows a workspace -- device buffers
+// that only grow, plus a stream of its own -- from a per-device pool and returns it afterwards, so
+// concurrent callers (two decoder threads, two demodulator instances on one device) never share
+// buffers or serialise on the null stream.  The pool itself is guarded by a mutex.
 struct SyncWs {
+    hipStream_t stream = nullptr;
     uint8_t *bits = nullptr;
     int8_t *tmpl = nullptr;
     int32_t *out = nullptr;
@@ -1305,7 +1648,38 @@ struct SyncWs {
     int32_t *hits = nullptr;  // hit_idx | hit_score
     size_t cap_bits = 0, cap_tmpl = 0, cap_out = 0, cap_seg = 0, cap_hits = 0;
 };
-static SyncWs g_sync_ws[16];
+#define SYNC_MAX_DEVICES 64
+static std::mutex g_sync_mu;
+static std::vector<SyncWs *> g_sync_pool[SYNC_MAX_DEVICES];
+
+static SyncWs *ws_acquire(int device) {
+    {
+        std::lock_guard<std::mutex> lk(g_sync_mu);
+        auto &pool = g_sync_pool[device];
+        if (!pool.empty()) {
+            SyncWs *w = pool.back();
+            pool.pop_back();
+            return w;
+        }
+    }
+    SyncWs *w = new SyncWs();
+    if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete w;
+        return nullptr;
+    }
+    return w;
+}
+static void ws_release(int device, SyncWs *w) {
+    std::lock_guard<std::mutex> lk(g_sync_mu);
+    g_sync_pool[device].push_back(w);
+}
+struct WsLease {   // returns the workspace on every exit path
+    int device;
+    SyncWs *w;
+    ~WsLease() {
+        if (w) ws_release(device, w);
+    }
+};
 
 template <class T>
 static int ws_reserve(T **p, size_t *cap, size_t need) {
@@ -1318,25 +1692,33 @@ static int ws_reserve(T **p, size_t *cap, size_t need) {
     return MFB_OK;
 }
 
-extern "C" int mfb_sync_correlate(int device, const uint8_t *bits, int B, int L, const int8_t *tmpl, int T, int32_t *scores) {
-    if (!bits || !tmpl || !scores || B < 1 || L < 1 || T < 1 || T > 4096) return MFB_ERR_ARG;
+static int sync_device_ok(int device) {
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
-    if (device < 0 || device >= ndev || device >= 16) return MFB_ERR_ARG;
+    if (device < 0 || device >= ndev || device >= SYNC_MAX_DEVICES) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(device));
+    return MFB_OK;
+}
+
+extern "C" int mfb_sync_correlate(int device, const uint8_t *bits, int B, int L, const int8_t *tmpl, int T, int32_t *scores) {
+    if (!bits || !tmpl || !scores || B < 1 || L < 1 || T < 1 || T > 4096) return MFB_ERR_ARG;
+    int rc = sync_device_ok(device);
+    if (rc) return rc;
     const int outLen = L + T - 1;
-    SyncWs &w = g_sync_ws[device];
-    int rc;
+    WsLease lease{device, ws_acquire(device)};
+    if (!lease.w) return MFB_ERR_HIP;
+    SyncWs &w = *lease.w;
     if ((rc = ws_reserve(&w.bits, &w.cap_bits, (size_t)B * L))) return rc;
     if ((rc = ws_reserve(&w.tmpl, &w.cap_tmpl, (size_t)T))) return rc;
     if ((rc = ws_reserve(&w.out, &w.cap_out, (size_t)B * outLen * sizeof(int32_t)))) return rc;
-    HIPCHK(hipMemcpy(w.bits, bits, (size_t)B * L, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(w.tmpl, tmpl, (size_t)T, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(w.bits, bits, (size_t)B * L, hipMemcpyHostToDevice, w.stream));
+    HIPCHK(hipMemcpyAsync(w.tmpl, tmpl, (size_t)T, hipMemcpyHostToDevice, w.stream));
     const int bs = 256;
     const size_t lds = (size_t)T + bs + T - 1;
-    hipLaunchKernelGGL(k_sync_corr, dim3((outLen + bs - 1) / bs, B), dim3(bs), lds, 0, w.bits, w.tmpl, w.out, L, T);
+    hipLaunchKernelGGL(k_sync_corr, dim3((outLen + bs - 1) / bs, B), dim3(bs), lds, w.stream, w.bits, w.tmpl, w.out, L, T);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(scores, w.out, (size_t)B * outLen * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(scores, w.out, (size_t)B * outLen * sizeof(int32_t), hipMemcpyDeviceToHost, w.stream));
+    HIPCHK(hipStreamSynchronize(w.stream));
     return MFB_OK;
 }
 
@@ -1344,32 +1726,84 @@ extern "C" int mfb_sync_find(int device, const uint8_t *bits, int B, int L, cons
                              int max_hits, int32_t *hit_idx, int32_t *hit_score, int32_t *counts) {
     if (!bits || !tmpl || !hit_idx || !hit_score || !counts || B < 1 || L < 1 || T < 1 || T > 4096 || max_hits < 1)
         return MFB_ERR_ARG;
-    int ndev = 0;
-    HIPCHK(hipGetDeviceCount(&ndev));
-    if (device < 0 || device >= ndev || device >= 16) return MFB_ERR_ARG;
-    HIPCHK(hipSetDevice(device));
+    int rc = sync_device_ok(device);
+    if (rc) return rc;
     const int outLen = L + T - 1;
     const int nseg = (outLen + SYNC_SEG - 1) / SYNC_SEG;
-    SyncWs &w = g_sync_ws[device];
-    int rc;
+    WsLease lease{device, ws_acquire(device)};
+    if (!lease.w) return MFB_ERR_HIP;
+    SyncWs &w = *lease.w;
     if ((rc = ws_reserve(&w.bits, &w.cap_bits, (size_t)B * L))) return rc;
     if ((rc = ws_reserve(&w.tmpl, &w.cap_tmpl, (size_t)T))) return rc;
     if ((rc = ws_reserve(&w.seg, &w.cap_seg, ((size_t)2 * B * nseg + B) * sizeof(int)))) return rc;
     if ((rc = ws_reserve(&w.hits, &w.cap_hits, (size_t)2 * B * max_hits * sizeof(int32_t)))) return rc;
     int *segcnt = w.seg, *segoff = w.seg + (size_t)B * nseg, *d_counts = w.seg + (size_t)2 * B * nseg;
     int32_t *d_idx = w.hits, *d_sc = w.hits + (size_t)B * max_hits;
-    HIPCHK(hipMemcpy(w.bits, bits, (size_t)B * L, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(w.tmpl, tmpl, (size_t)T, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(w.bits, bits, (size_t)B * L, hipMemcpyHostToDevice, w.stream));
+    HIPCHK(hipMemcpyAsync(w.tmpl, tmpl, (size_t)T, hipMemcpyHostToDevice, w.stream));
     const size_t lds = (size_t)T + SYNC_SEG + T - 1;
-    hipLaunchKernelGGL((k_sync_find<false>), dim3(nseg, B), dim3(256), lds, 0, w.bits, w.tmpl, L, T, threshold, nseg, segcnt,
+    hipLaunchKernelGGL((k_sync_find<false>), dim3(nseg, B), dim3(256), lds, w.stream, w.bits, w.tmpl, L, T, threshold, nseg, segcnt,
                        (const int *)nullptr, max_hits, (int32_t *)nullptr, (int32_t *)nullptr);
-    hipLaunchKernelGGL(k_sync_scan, dim3((B + 63) / 64), dim3(64), 0, 0, (const int *)segcnt, segoff, d_counts, B, nseg);
-    hipLaunchKernelGGL((k_sync_find<true>), dim3(nseg, B), dim3(256), lds, 0, w.bits, w.tmpl, L, T, threshold, nseg, segcnt,
+    hipLaunchKernelGGL(k_sync_scan, dim3((B + 63) / 64), dim3(64), 0, w.stream, (const int *)segcnt, segoff, d_counts, B, nseg);
+    hipLaunchKernelGGL((k_sync_find<true>), dim3(nseg, B), dim3(256), lds, w.stream, w.bits, w.tmpl, L, T, threshold, nseg, segcnt,
                        (const int *)segoff, max_hits, d_idx, d_sc);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(counts, d_counts, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(hit_idx, d_idx, (size_t)B * max_hits * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(hit_score, d_sc, (size_t)B * max_hits * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(counts, d_counts, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, w.stream));
+    HIPCHK(hipMemcpyAsync(hit_idx, d_idx, (size_t)B * max_hits * sizeof(int32_t), hipMemcpyDeviceToHost, w.stream));
+    HIPCHK(hipMemcpyAsync(hit_score, d_sc, (size_t)B * max_hits * sizeof(int32_t), hipMemcpyDeviceToHost, w.stream));
+    HIPCHK(hipStreamSynchronize(w.stream));
+    return MFB_OK;
+}
+
+// ---- N4: bit-stream alignment cross-correlation (reference lib/customXCorr.py:5-18) -----------------
+// out = ifft( fft(a, N) * conj(fft(b, N)) ) with N the handle's block length: a and b are real
+// sequences, truncated or zero-padded to N exactly as np.fft.fft(a, N) does.  Built from the handle's
+// forward / inverse transform passes; the handle's spectrum, filter row 0 and matched-filter buffers
+// serve as scratch, so this is meant for a handle of its own (M = 1), which is how the Python helper
+// uses it.
+__global__ void k_scale_c(cf *p, float s, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = p[i] * s;
+}
+
+extern "C" int mfb_xcorr(mfb_ctx *c, const float *a, int Na, const float *b, int Nb, float *out_c64) {
+    if (!c || !a || !b || !out_c64 || Na < 1 || Nb < 1) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    const int N = c->N;
+    auto stage = [&](const float *src, int n) -> int {   // real sequence -> d_env, zero-padded / truncated to N
+        const int k = n < N ? n : N;
+        HIPCHK(hipMemcpyAsync(c->d_env, src, (size_t)k * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        if (k < N) HIPCHK(hipMemsetAsync(c->d_env + k, 0, (size_t)(N - k) * sizeof(float), c->stream));
+        return MFB_OK;
+    };
+    int rc;
+    if ((rc = stage(a, Na))) return rc;
+    if ((rc = forward_fft(c, nullptr, c->d_env, c->d_X, 1))) return rc;        // A = fft(a, N)
+    HIPCHK(hipStreamSynchronize(c->stream));                                    // d_env is reused
+    if ((rc = stage(b, Nb))) return rc;
+    if ((rc = forward_fft(c, nullptr, c->d_env, c->d_masks, 0))) return rc;    // conj(fft(b, N)) into filter row 0
+    // inverse transform of A * conj(B): the two-pass bank kernels at shift 0, one filter row
+    P1Args p1 = p1_base(c);
+    p1.X = c->d_X;
+    p1.shifts = nullptr;
+    p1.fixed_shift = 0;
+    p1.dc = 1;
+    p1.M = 1;
+    p1.mpb = 1;
+    p1.ntiles = c->N2 / TILE;
+    p1.mgroups = 1;
+    p1.jsplit = 1;
+    if ((rc = launch_p1<KIND_BANK>(c, p1, dim3(p1.ntiles, 1, 1)))) return rc;
+    P2Args p2 = p2_base(c);
+    p2_store_split(c, p2, 1);
+    if ((rc = launch_p2<MODE_STORE>(c, p2, dim3(p2.parts, 1, 1)))) return rc;
+    if ((rc = launch_transpose(c, c->d_xc, 1, 0))) return rc;
+    hipLaunchKernelGGL(k_scale_c, dim3(256), dim3(256), 0, c->stream, c->d_xc, 1.0f / (float)N, N);   // numpy's ifft is 1/N
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_c64, c->d_xc, (size_t)N * sizeof(cf), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_filters = false;   // the scratch use clobbered the bank, the spectrum and the outputs
+    c->have_input = false;
+    c->have_xc = false;
     return MFB_OK;
 }
 

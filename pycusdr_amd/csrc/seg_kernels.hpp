@@ -1,0 +1,234 @@
+// seg_kernels.hpp -- single-pass overlap-save Doppler search / matched filtering for gfx950.
+//
+// The reference forms  y[s][m][n] = IFFT_N( X[(k + s) mod N] * H_m[k] )  (cuda_kernels.cu:339-373 +
+// batched cuFFT, demodulator_base.py:578-591) -- a length-N circular convolution of
+//     x_s[n] = x[n] * e^{-2 pi i s n / N}          (the spectrum shift, done in time)
+// with the impulse response h_m = ifft(H_m).  When h_m is T taps long (every shipped protocol: 48...640,
+// filter_taps.hpp) the same y is obtained from L-point segments, L >= 2T:
+//     segment q covers samples b0 = q*V ... b0 + L - 1 (circular in N),  V = L - T + 1 outputs each
+//     U = FFT_L(x_s[b0 ...]),  v_m = IFFT_L(U * G_m),  y[s][m][(b0 + i + off) mod N] = v_m[i], 0 <= i < V
+// with G_m the (N/L)-scaled L-point spectrum of the rotated taps.  Nothing of length N is ever written:
+// a segment lives in registers + LDS from the x load to the |.|^2 sum (Doppler search, MODE_REDUCE) or
+// to the natural-order store of y (demodulation, MODE_STORE).  HBM traffic of the whole search is the
+// 8 MiB block (served from L2 / Infinity Cache thereafter) plus a few KiB of partial sums, so the kernel
+// is bound by the fp32 vector rate, not by HBM.
+//
+// Work layout.  One transform is run by NT = L/16 threads holding 16 points each (fft_core.hpp).  A
+// "team" is the set of threads that must synchronise for a transform: one wavefront carrying CT = 64/NT
+// segments side by side for L <= 1024 (no s_barrier anywhere: LDS exchanges are wave-local), or NT
+// threads (2 or 4 waves, workgroup barrier) for L = 2048 / 4096.  Teams never talk to each other: every
+// wave writes its own partial sums, added up in fixed order by k_finalize (bit-reproducible).
+// The grid is decoded XCD-aware: workgroups with equal blockIdx % nsg share a contiguous range of
+// segments, i.e. one eighth of the block, which stays in that XCD's L2 while every Doppler bin passes
+// over it (placement affects speed only).
+#pragma once
+#include "fft_core.hpp"
+
+#define SEG_REDUCE 0
+#define SEG_STORE 1
+#define SEG_MPB_MAX 16   // filters per team pass (per-lane accumulators live in LDS)
+
+#ifndef MFB_SEG_WAVES
+#define MFB_SEG_WAVES 2
+#endif
+#ifndef MFB_SEG_PREFETCH
+#define MFB_SEG_PREFETCH 1
+#endif
+
+struct SegArgs {
+    const cf *x;         // time-domain block, complex64 [N]
+    const cf *G;         // segment spectra, complex64 [M][L]
+    const int *rows;     // bank row of filter slot m (nullptr: identity)
+    const int *shifts;   // device shift table (nullptr: fixed_shift)
+    const cf *twL;       // W_L^j, j < L (inverse sign)
+    const cf *twLo;      // W_N^j, j < 2^lo
+    const cf *twHi;      // W_N^(j * 2^lo)
+    float *partials;     // REDUCE: [rows][parts]
+    cf *out;             // STORE: complex64 [M][N], natural order
+    int N, lo;
+    int V;               // valid outputs per segment (L - T + 1)
+    int nslots;          // ceil(Q / CT): team-iterations needed to cover all Q = ceil(N / V) segments
+    int MU;              // filter slots per Doppler bin
+    int mpb, mgroups;    // filters per team pass, passes (workgroup groups) needed for MU
+    int nsg;             // segment groups (blockIdx % nsg)
+    int bsplit, ssplit;  // a group's teams = bsplit Doppler streams x ssplit segment sub-ranges
+    int j0, dc;          // Doppler bins [j0, j0 + dc) of the shift table
+    int fixed_shift;
+    int out_off;         // STORE: (window start + T - 1) mod N
+    int part_row0, parts;
+    float scale;         // REDUCE: 1 / 2^18
+};
+
+template <int L>
+struct SegCfg {
+    static constexpr int NT = L / 16;
+    static constexpr int TEAM = NT < 64 ? 64 : NT;
+    static constexpr int CT = TEAM / NT;          // segments side by side in a team
+    static constexpr int TPW = 256 / TEAM;        // teams per workgroup
+    static constexpr int WPT = TEAM / 64;         // waves per team
+    static constexpr int SYNC = NT <= 64 ? 1 : 0;
+    static constexpr int LDS_PER_TEAM = padlen(L) * CT;
+    static constexpr int LDS_ELEMS = LDS_PER_TEAM * TPW;
+    static constexpr size_t lds_bytes(int mpb) { return (size_t)LDS_ELEMS * sizeof(cf) + (size_t)mpb * 256 * sizeof(float); }
+};
+
+DEVI float seg_wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+template <int L, int MODE>
+__global__ void __launch_bounds__(256, MFB_SEG_WAVES) k_seg(SegArgs a) {
+    using Cfg = SegCfg<L>;
+    constexpr int NT = Cfg::NT, CT = Cfg::CT, TPW = Cfg::TPW, TEAM = Cfg::TEAM, SYNC = Cfg::SYNC;
+    extern __shared__ __attribute__((aligned(16))) cf lds[];
+    float *lacc = reinterpret_cast<float *>(lds + Cfg::LDS_ELEMS);   // [mpb][256] per-lane |y|^2 sums
+
+    const int tid = threadIdx.x;
+    const int team = __builtin_amdgcn_readfirstlane(tid / TEAM);
+    const int lt = tid % TEAM;
+    const int g = lt % NT;
+    const int col = lt / NT;
+    cf *mylds = lds + team * Cfg::LDS_PER_TEAM + col * padlen(L);
+    int ebuf = 0;
+
+    TwRegs<L> twr;
+    load_twiddles<L>(twr, a.twL, g);
+
+    // ---- which Doppler bins and which segments this team owns -------------------------------
+    int grp, mg, bstream, ssub;
+    {
+        const int b = blockIdx.x;
+        grp = b % a.nsg;
+        int r = b / a.nsg;
+        mg = r % a.mgroups;
+        r /= a.mgroups;
+        if constexpr (SYNC) {            // independent waves: neighbours take neighbouring Doppler streams
+            const int tt = r * TPW + team;
+            bstream = tt % a.bsplit;
+            ssub = tt / a.bsplit;
+        } else {                         // barrier teams of one workgroup share the stream (equal trip counts)
+            bstream = r % a.bsplit;
+            ssub = (r / a.bsplit) * TPW + team;
+        }
+    }
+    const int gs0 = (int)((long long)grp * a.nslots / a.nsg);
+    const int glen = (int)((long long)(grp + 1) * a.nslots / a.nsg) - gs0;
+    const int s0 = gs0 + (int)((long long)ssub * glen / a.ssplit);
+    const int s1 = gs0 + (int)((long long)(ssub + 1) * glen / a.ssplit);
+    // barrier teams run the longest range of the group (surplus iterations are fully masked)
+    const int niter = SYNC ? (s1 - s0) : (glen + a.ssplit - 1) / a.ssplit;
+    const int m0 = mg * a.mpb;
+    const int m1 = min(m0 + a.mpb, a.MU);
+
+    const unsigned nmask = (unsigned)a.N - 1u;
+    const unsigned lomask = (1u << a.lo) - 1u;
+    const auto xr = mk_rsrc(a.x, (unsigned)a.N * sizeof(cf));
+    const auto lor = mk_rsrc(a.twLo, (unsigned)(1u << a.lo) * sizeof(cf));
+    const auto hir = mk_rsrc(a.twHi, (unsigned)(a.N >> a.lo) * sizeof(cf));
+    const int vo_g = g * (int)sizeof(cf);
+    constexpr int so_g = NT * (int)sizeof(cf);
+    const int pv_all = a.V / NT;                  // output slots k < pv_all are valid in every full segment
+    const int kmax_all = (a.V + NT - 1) / NT;     // slots >= kmax_all are valid in none
+
+    for (int jl = bstream; jl < a.dc; jl += a.bsplit) {
+        const int shift = a.shifts ? a.shifts[a.j0 + jl] : a.fixed_shift;
+        const unsigned dstep = ((unsigned)shift * (unsigned)NT) & nmask;
+        if constexpr (MODE == SEG_REDUCE) {
+            for (int mi = 0; mi < m1 - m0; ++mi) lacc[mi * 256 + tid] = 0.f;
+        }
+        for (int it = 0; it < niter; ++it) {
+            const int slot = s0 + it;
+            const bool active = slot < s1;        // team-uniform
+            const int seg = slot * CT + col;
+            const unsigned b0 = (unsigned)seg * (unsigned)a.V;
+            const int vseg = active ? min(a.V, a.N - (int)b0) : 0;     // <= 0 beyond the last segment
+            const int lim = vseg - g;             // output slot k is valid for this lane iff k*NT < lim
+            // fast path bounds, team-uniform: every segment of this slot complete?
+            const bool full = active && ((long long)(slot + 1) * CT * a.V <= (long long)a.N);
+            const int pv = __builtin_amdgcn_readfirstlane(full ? pv_all : 0);
+            const int kmax = __builtin_amdgcn_readfirstlane(full ? kmax_all : 16);
+
+            // ---- load the segment, mix with e^{-2 pi i s n / N}, conjugate (forward via inverse) ----
+            cf v[16];
+            {
+                const unsigned e0 = b0 + (unsigned)g;
+                const unsigned t0 = ((unsigned)shift * e0) & nmask;      // N | 2^32: wrap-around is harmless
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const unsigned idx = (e0 + (unsigned)(NT * i)) & nmask;
+                    const unsigned t = (t0 + (unsigned)i * dstep) & nmask;
+                    const cf xv = buf_load_cf(xr, (int)(idx * sizeof(cf)), 0);
+                    const cf ph = cmul(buf_load_cf(hir, (int)((t >> a.lo) * sizeof(cf)), 0),
+                                       buf_load_cf(lor, (int)((t & lomask) * sizeof(cf)), 0));
+                    v[i] = cmul_cj(xv, ph);       // conj(x) * W_N^{+t} = conj(x * e^{-2 pi i t / N})
+                }
+            }
+            cf A[16];                             // A[k] = conj(U[g + NT*k])
+            {
+                auto keep = [&](int, cf val, auto, auto nu) { A[decltype(nu)::value / NT] = val; };
+                fft_passes<L, 1, 0, true, false, 0, SYNC>(v, mylds, ebuf, g, 0, twr, a.twL, keep);
+            }
+
+            // ---- per filter: multiply by the segment spectrum, inverse transform, reduce or store ----
+            cf gk[16];
+            if constexpr (MFB_SEG_PREFETCH) {
+                const int r0 = a.rows ? a.rows[m0] : m0;
+                const auto gr = mk_rsrc(a.G + (size_t)r0 * L, (unsigned)L * sizeof(cf));
+#pragma unroll
+                for (int i = 0; i < 16; ++i) gk[i] = buf_load_cf(gr, vo_g, i * so_g);
+            }
+            for (int m = m0; m < m1; ++m) {
+                cf w[16];
+                if constexpr (MFB_SEG_PREFETCH) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) w[i] = cmul_cj(A[i], gk[i]);    // conj(A) * G = U * G
+                    const int mn = (m + 1 < m1) ? (m + 1) : m0;
+                    const int rn = a.rows ? a.rows[mn] : mn;
+                    const auto gr = mk_rsrc(a.G + (size_t)rn * L, (unsigned)L * sizeof(cf));
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) gk[i] = buf_load_cf(gr, vo_g, i * so_g);
+                } else {
+                    const int rm = a.rows ? a.rows[m] : m;
+                    const auto gr = mk_rsrc(a.G + (size_t)rm * L, (unsigned)L * sizeof(cf));
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) w[i] = cmul_cj(A[i], buf_load_cf(gr, vo_g, i * so_g));
+                }
+                if constexpr (MODE == SEG_REDUCE) {
+                    cf racc = mkc(0.f, 0.f);      // (sum re^2, sum im^2)
+                    auto acc = [&](int, cf val, auto, auto nu) {
+                        constexpr int k = decltype(nu)::value / NT;
+                        if (k < pv) {
+                            racc = __builtin_elementwise_fma(val, val, racc);
+                        } else if (k < kmax) {
+                            const float wgt = (k * NT < lim) ? 1.f : 0.f;
+                            racc = __builtin_elementwise_fma(val * wgt, val, racc);
+                        }
+                    };
+                    fft_passes<L, 1, 0, true, false, 0, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, acc);
+                    lacc[(m - m0) * 256 + tid] += racc.x + racc.y;
+                } else {
+                    const int rm = a.rows ? a.rows[m] : m;
+                    const auto orr = mk_rsrc(a.out + (size_t)rm * a.N, (unsigned)a.N * sizeof(cf));
+                    const unsigned o0 = b0 + (unsigned)g + (unsigned)a.out_off;
+                    auto put = [&](int, cf val, auto, auto nu) {
+                        constexpr int k = decltype(nu)::value / NT;
+                        if (k * NT < lim) buf_store_cf(orr, (int)(((o0 + (unsigned)(k * NT)) & nmask) * sizeof(cf)), 0, val);
+                    };
+                    fft_passes<L, 1, 0, true, false, 0, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, put);
+                }
+            }
+        }
+        if constexpr (MODE == SEG_REDUCE) {
+            // registers/LDS -> wavefront -> one float per (bin, filter, wave); fixed order, no atomics
+            const int wave_in_team = (lt >> 6);
+            const int pidx = ((grp * a.ssplit + ssub) * Cfg::WPT) + wave_in_team;
+            for (int mi = 0; mi < m1 - m0; ++mi) {
+                const float s = seg_wave_sum(lacc[mi * 256 + tid]);
+                if ((tid & 63) == 0)
+                    a.partials[((size_t)(a.part_row0 + jl) * a.MU + (m0 + mi)) * a.parts + pidx] = s * a.scale;
+            }
+        }
+    }
+}

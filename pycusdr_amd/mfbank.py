@@ -66,6 +66,33 @@ class MFBank:
         _lib.check(self._lib.mfb_get_info(self._h, C.byref(a), C.byref(b), C.byref(c)), 'mfb_get_info')
         return a.value, b.value, c.value
 
+    PATHS = {'auto': 0, 'twopass': 1, 'segment': 2}
+
+    def set_search_path(self, path='auto', log2L=0, wg_per_cu=0, filters_per_pass=0):
+        """Choose between the single-pass overlap-save search ('segment': short filters, no HBM
+        intermediate) and the length-N two-pass transforms ('twopass'); 'auto' takes the segment path
+        whenever the filter bank has a short impulse response.  Raises ValueError if 'segment' is
+        demanded for a bank that does not allow it."""
+        _lib.check(self._lib.mfb_set_search_path(self._h, self.PATHS[path] if isinstance(path, str) else int(path),
+                                                 int(log2L), int(wg_per_cu), int(filters_per_pass)), 'mfb_set_search_path')
+
+    def get_search_path(self):
+        """dict(path, log2L, taps, valid_per_segment, segments) in force."""
+        v = [C.c_int() for _ in range(5)]
+        _lib.check(self._lib.mfb_get_search_path(self._h, *[C.byref(x) for x in v]), 'mfb_get_search_path')
+        names = {1: 'twopass', 2: 'segment'}
+        return dict(path=names.get(v[0].value, 'twopass'), log2L=v[1].value, taps=v[2].value,
+                    valid_per_segment=v[3].value, segments=v[4].value)
+
+    def xcorr(self, a, b):
+        """ifft(fft(a, N) * conj(fft(b, N))) for real sequences a, b (reference lib/customXCorr.py:5-18);
+        N is this handle's block length.  The handle's filters and input are invalidated."""
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        out = np.empty(self.N, dtype=np.complex64)
+        _lib.check(self._lib.mfb_xcorr(self._h, _ptr(a), a.size, _ptr(b), b.size, _ptr(out)), 'mfb_xcorr')
+        return out
+
     def set_filters(self, masks):
         masks = np.asarray(masks)
         if masks.ndim != 2:
@@ -167,6 +194,36 @@ class MFBank:
 
     def sync(self):
         _lib.check(self._lib.mfb_sync(self._h), 'mfb_sync')
+
+
+def analyze_filters(masks):
+    """(start, length) of the common circular support window of the impulse responses of a filter bank
+    complex64 [M, N] -- host-only, no GPU needed (length == N: no short support)."""
+    lib = _lib.load()
+    masks = np.ascontiguousarray(masks, dtype=np.complex64)
+    st, ln = C.c_int(), C.c_int()
+    _lib.check(lib.mfb_analyze_filters(_ptr(masks), masks.shape[0], masks.shape[1], C.byref(st), C.byref(ln)),
+               'mfb_analyze_filters')
+    return st.value, ln.value
+
+
+_xcorr_banks = {}
+
+
+def customXCorr(a, b, N=None, device=0):
+    """Drop-in for the reference's lib/customXCorr.customXCorr on the HIP transforms: N must be a power
+    of two in [2^10, 2^22] (the soft combiner always pads to one, softCombiner.py:701-706)."""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    if N is None:
+        N = max(len(a), len(b))
+    N = int(N)
+    if N & (N - 1) or not (1 << 10) <= N <= (1 << 22):
+        raise ValueError(f'customXCorr on the GPU needs a power-of-two length in [2^10, 2^22], got {N}')
+    key = (N, int(device))
+    if key not in _xcorr_banks:
+        _xcorr_banks[key] = MFBank(N.bit_length() - 1, 1, 1, device=device)
+    return _xcorr_banks[key].xcorr(a, b)
 
 
 def _as_bits_and_template(bits, template):
