@@ -43,18 +43,24 @@ DEVI cf sub_i(cf a, cf b) {
     return d;
 }
 // complex product: (a.x*w.x - a.y*w.y, a.x*w.y + a.y*w.x) in two packed ops
+// (one asm statement: the hazard recogniser pads every use of an asm-defined register that follows
+// within one wait state with an s_nop, which between the two halves of a product is pure loss)
 DEVI cf cmul(cf a, cf w) {
     cf p, d;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "v"(a), "v"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "v"(w), "v"(p));
+    asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(d), "=&v"(p)
+        : "v"(a), "v"(w));
     return d;
 }
 // conj(a) * w = (a.x*w.x + a.y*w.y, a.x*w.y - a.y*w.x): the forward transform of the segment search is
 // run as conj(IFFT(conj(u))), and both conjugations fold into the multiplies next to it
 DEVI cf cmul_cj(cf a, cf w) {
     cf p, d;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "v"(a), "v"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "=v"(d) : "v"(a), "v"(w), "v"(p));
+    asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]"
+        : "=v"(d), "=&v"(p)
+        : "v"(a), "v"(w));
     return d;
 }
 // (x.x - x.y, x.x + x.y)  and  (-x.x - x.y, x.x - x.y)

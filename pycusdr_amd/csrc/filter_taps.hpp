@@ -178,17 +178,18 @@ static inline cd tap(const Bank &b, int m, int r) {
     return off < (int)row.c.size() ? row.c[off] : cd(0.0, 0.0);
 }
 
-// L-point segment spectra, complex64 [M][L]:  G_m = (N/L) * FFT_L(c'_m), c'_m[(r - (T-1)) mod L] = tap r.
-// With this rotation the valid outputs of a segment that starts at sample b0 are i = 0 .. L-T and
-// output i is y[(b0 + i + start + T - 1) mod N] of the length-N formulation.
-static inline void segment_spectra(const Bank &b, int L, std::vector<float> *out) {
+// L-point segment spectra, complex64 [M][L]:  G_m = (N/L) * FFT_L(c'_m), c'_m[(r - (Te-1)) mod L] = tap r,
+// for a layout length Te >= T (the kernel rounds the valid count L - Te + 1 down to whole register slots).
+// With this rotation the valid outputs of a segment that starts at sample b0 are i = 0 .. L-Te and
+// output i is y[(b0 + i + start + Te - 1) mod N] of the length-N formulation.
+static inline void segment_spectra(const Bank &b, int L, int Te, std::vector<float> *out) {
     const Fft plan(L);
     out->assign((size_t)b.M * 2 * L, 0.f);
     std::vector<cd> buf(L);
     const double scale = (double)b.N / (double)L;
     for (int m = 0; m < b.M; ++m) {
         std::fill(buf.begin(), buf.end(), cd(0.0, 0.0));
-        for (int r = 0; r < b.T; ++r) buf[(r - (b.T - 1)) & (L - 1)] = tap(b, m, r);
+        for (int r = 0; r < b.T; ++r) buf[(r - (Te - 1)) & (L - 1)] = tap(b, m, r);
         plan.run(buf.data(), -1);
         float *o = out->data() + (size_t)m * 2 * L;
         for (int k = 0; k < L; ++k) {

@@ -818,8 +818,19 @@ static int attr_p2() {
 template <int L>
 static int attr_seg() {
     const int b = (int)SegCfg<L>::lds_bytes(SEG_MPB_MAX);
-    HIPCHK(hipFuncSetAttribute((const void *)k_seg<L, SEG_REDUCE>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
-    HIPCHK(hipFuncSetAttribute((const void *)k_seg<L, SEG_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
+    HIPCHK(hipFuncSetAttribute((const void *)k_seg<L, SEG_STORE, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
+#define MFB_ATTR_PV(PV_) HIPCHK(hipFuncSetAttribute((const void *)k_seg<L, SEG_REDUCE, PV_>, hipFuncAttributeMaxDynamicSharedMemorySize, b))
+    MFB_ATTR_PV(-1);
+    MFB_ATTR_PV(8);
+    MFB_ATTR_PV(9);
+    MFB_ATTR_PV(10);
+    MFB_ATTR_PV(11);
+    MFB_ATTR_PV(12);
+    MFB_ATTR_PV(13);
+    MFB_ATTR_PV(14);
+    MFB_ATTR_PV(15);
+    MFB_ATTR_PV(16);
+#undef MFB_ATTR_PV
     return MFB_OK;
 }
 static int set_kernel_attributes(const mfb_ctx *c) {
@@ -1007,23 +1018,28 @@ extern "C" int mfb_get_info(mfb_ctx *c, int *N1, int *N2, int *unique_filters) {
 }
 
 // ---- search path ---------------------------------------------------------------------------------
+// Valid outputs per complete segment: the largest multiple of NT = L/16 not above L - T + 1, so that
+// they are whole register slots (seg_kernels.hpp); 0 if fewer than half of a segment would be valid.
+static int seg_valid(int l, int T) {
+    const int L = 1 << l, NT = L / 16;
+    const int pv = (L - T + 1) / NT;
+    return pv >= 8 ? pv * NT : 0;
+}
 // Cost of one valid output sample per filter, in packed-fp32 VALU instructions per thread-point: the
 // instruction count of an L-point transform (radix-16 passes + remainder + twiddles, counted from the
 // ISA) plus the pointwise work, divided by the segment efficiency V / L.
 static double seg_cost(int l, int T) {
     static const double ops[13] = {0, 0, 0, 0, 0, 0, 0, 0, 194, 240, 256, 280, 322};
-    const int L = 1 << l;
-    const int V = L - T + 1;
-    if (V < 1) return 1e30;
-    return (ops[l] + 55.0) * (double)L / (double)V;
+    const int V = seg_valid(l, T);
+    if (!V) return 1e30;
+    return (ops[l] + 50.0) * (double)(1 << l) / (double)V;
 }
 
 static int choose_segl(const mfb_ctx *c, int T) {
     int best = 0;
     double bc = 1e30;
     for (int l = 8; l <= 12; ++l) {
-        const int L = 1 << l;
-        if (2 * T > L || 4 * L > c->N) continue;    // at least half of every segment valid, >= 4 segments
+        if (!seg_valid(l, T) || (4 << l) > c->N) continue;    // at least half of every segment valid, >= 4 segments
         const double cost = seg_cost(l, T);
         if (cost < bc) {
             bc = cost;
@@ -1040,8 +1056,7 @@ static int resolve_path(mfb_ctx *c) {
     int l = 0;
     if (c->path_req != MFB_PATH_TWOPASS) {
         if (c->segl_req) {
-            const int L = 1 << c->segl_req;
-            if (c->segl_req >= 8 && c->segl_req <= 12 && T <= L && 2 * L <= c->N) l = c->segl_req;
+            if (c->segl_req >= 8 && c->segl_req <= 12 && seg_valid(c->segl_req, T) && (2 << c->segl_req) <= c->N) l = c->segl_req;
         } else {
             l = choose_segl(c, T);
         }
@@ -1055,7 +1070,7 @@ static int resolve_path(mfb_ctx *c) {
         const int L = 1 << l;
         if (c->segl != l || !c->d_G) {
             std::vector<float> G;
-            taps::segment_spectra(*c->bank, L, &G);
+            taps::segment_spectra(*c->bank, L, L - seg_valid(l, T) + 1, &G);
             if (c->d_G) HIPCHK(hipFree(c->d_G));
             c->d_G = nullptr;
             HIPCHK(hipMalloc((void **)&c->d_G, G.size() * sizeof(float)));
@@ -1073,9 +1088,9 @@ static int resolve_path(mfb_ctx *c) {
         }
         c->path = MFB_PATH_SEGMENT;
         c->segl = l;
-        c->T = T;
+        c->V = seg_valid(l, T);
+        c->T = L - c->V + 1;          // taps the segments are laid out for (>= the bank's T)
         c->win_start = c->bank->start;
-        c->V = L - T + 1;
         c->Q = (c->N + c->V - 1) / c->V;
     }
     if (c->path == MFB_PATH_TWOPASS) {
@@ -1323,58 +1338,86 @@ static int forward_fft(mfb_ctx *c, const cf *src_c, const float *src_r, cf *dst,
 
 
 // ---- single-pass overlap-save launches -------------------------------------------------------------
-template <int L, int MODE>
-static int launch_seg_t(mfb_ctx *c, const SegArgs &a, int grid) {
+template <int L, int MODE, int PV>
+static int launch_seg_k(mfb_ctx *c, const SegArgs &a, int grid) {
     const size_t lds = SegCfg<L>::lds_bytes(MODE == SEG_REDUCE ? a.mpb : 0);
-    hipLaunchKernelGGL((k_seg<L, MODE>), dim3(grid), dim3(256), lds, c->stream, a);
+    hipLaunchKernelGGL((k_seg<L, MODE, PV>), dim3(grid), dim3(256), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return MFB_OK;
 }
-template <int MODE>
-static int launch_seg(mfb_ctx *c, const SegArgs &a, int grid) {
+// pv: valid register slots of a complete segment (8..16) for the branch-free instantiation, -1 = masked
+template <int L>
+static int launch_seg_l(mfb_ctx *c, const SegArgs &a, int grid, int mode, int pv) {
+    if (mode == SEG_STORE) return launch_seg_k<L, SEG_STORE, -1>(c, a, grid);
+    switch (pv) {
+        case -1: return launch_seg_k<L, SEG_REDUCE, -1>(c, a, grid);
+        case 8: return launch_seg_k<L, SEG_REDUCE, 8>(c, a, grid);
+        case 9: return launch_seg_k<L, SEG_REDUCE, 9>(c, a, grid);
+        case 10: return launch_seg_k<L, SEG_REDUCE, 10>(c, a, grid);
+        case 11: return launch_seg_k<L, SEG_REDUCE, 11>(c, a, grid);
+        case 12: return launch_seg_k<L, SEG_REDUCE, 12>(c, a, grid);
+        case 13: return launch_seg_k<L, SEG_REDUCE, 13>(c, a, grid);
+        case 14: return launch_seg_k<L, SEG_REDUCE, 14>(c, a, grid);
+        case 15: return launch_seg_k<L, SEG_REDUCE, 15>(c, a, grid);
+        case 16: return launch_seg_k<L, SEG_REDUCE, 16>(c, a, grid);
+    }
+    return MFB_ERR_UNSUPPORTED;
+}
+static int launch_seg(mfb_ctx *c, const SegArgs &a, int grid, int mode, int pv) {
     switch (c->segl) {
-        case 8: return launch_seg_t<256, MODE>(c, a, grid);
-        case 9: return launch_seg_t<512, MODE>(c, a, grid);
-        case 10: return launch_seg_t<1024, MODE>(c, a, grid);
-        case 11: return launch_seg_t<2048, MODE>(c, a, grid);
-        case 12: return launch_seg_t<4096, MODE>(c, a, grid);
+        case 8: return launch_seg_l<256>(c, a, grid, mode, pv);
+        case 9: return launch_seg_l<512>(c, a, grid, mode, pv);
+        case 10: return launch_seg_l<1024>(c, a, grid, mode, pv);
+        case 11: return launch_seg_l<2048>(c, a, grid, mode, pv);
+        case 12: return launch_seg_l<4096>(c, a, grid, mode, pv);
     }
     return MFB_ERR_UNSUPPORTED;
 }
 
-// Decomposition of one launch: nsg = 8 segment groups (one per XCD under round-robin placement), each
-// with wpg workgroups = bsplit Doppler streams x ssplit segment sub-ranges (x TPW teams).
-struct SegPlan {
-    int nsg, wpg, bsplit, ssplit, mpb, mgroups, nslots, parts, grid;
+// Decomposition of one launch over `nslots` slots (a slot = CT neighbouring segments, one team
+// iteration): nsg segment groups (8 = one per XCD under round-robin placement), each with wpg workgroups
+// = bsplit Doppler streams x ssplit slot sub-ranges (x TPW teams).
+struct SegGeom {
+    int NT, TEAM, CT, TPW, WPT;
+    bool wave_sync;
 };
-static SegPlan plan_seg(const mfb_ctx *c, int dc, int nfilters, bool reduce) {
+static SegGeom seg_geom(const mfb_ctx *c) {
+    SegGeom g;
     const int L = 1 << c->segl;
-    const int NT = L / 16;
-    const int TEAM = NT < 64 ? 64 : NT;
-    const int CT = TEAM / NT, TPW = 256 / TEAM, WPT = TEAM / 64;
+    g.NT = L / 16;
+    g.TEAM = g.NT < 64 ? 64 : g.NT;
+    g.CT = g.TEAM / g.NT;
+    g.TPW = 256 / g.TEAM;
+    g.WPT = g.TEAM / 64;
+    g.wave_sync = g.NT <= 64;
+    return g;
+}
+struct SegPlan {
+    int nsg, wpg, bsplit, ssplit, mpb, mgroups, parts, grid;
+};
+static SegPlan plan_seg(const mfb_ctx *c, int dc, int nfilters, int nslots, int mpb_want) {
+    const SegGeom g = seg_geom(c);
     SegPlan p;
-    p.nsg = 8;
-    p.nslots = (c->Q + CT - 1) / CT;
-    int mpb = c->seg_mpb > 0 ? c->seg_mpb : SEG_MPB_MAX;
-    if (!reduce) mpb = 4;                       // demodulation: few bins, spread the filters over the chip
+    p.nsg = nslots >= 64 ? 8 : 1;
+    int mpb = mpb_want > 0 ? mpb_want : SEG_MPB_MAX;
+    if (mpb > SEG_MPB_MAX) mpb = SEG_MPB_MAX;
     if (mpb > nfilters) mpb = nfilters;
     p.mgroups = (nfilters + mpb - 1) / mpb;
     p.mpb = (nfilters + p.mgroups - 1) / p.mgroups;   // balanced
-    const int wpc = c->seg_wpc > 0 ? c->seg_wpc : MFB_SEG_WAVES;
-    int wpg = wpc * 32;                          // workgroups per group: wpc per CU, 32 CUs per XCD
+    const int wpc = c->seg_wpc > 0 ? c->seg_wpc : (c->segl <= 8 ? MFB_SEG_WAVES_SHORT : MFB_SEG_WAVES_LONG);
+    int wpg = wpc * 256 / p.nsg;                 // workgroups per group: wpc per CU, 256 CUs
     // never more teams than (bin, slot) units in a group
-    const long long units = (long long)dc * ((p.nslots + p.nsg - 1) / p.nsg);
-    while (wpg > 1 && (long long)wpg * TPW > units) wpg >>= 1;
+    const long long units = (long long)dc * ((nslots + p.nsg - 1) / p.nsg);
+    while (wpg > 1 && (long long)wpg * g.TPW > units) wpg >>= 1;
     p.wpg = wpg;
-    const bool wave_sync = NT <= 64;
     // bsplit * ssplit = wpg * TPW teams; barrier teams of one workgroup must share the Doppler stream
-    const int tg = wave_sync ? wpg * TPW : wpg;
+    const int tg = g.wave_sync ? wpg * g.TPW : wpg;
     int bs = 1;
     for (int d = 1; d <= tg; ++d)
         if (tg % d == 0 && d <= dc) bs = d;
     p.bsplit = bs;
-    p.ssplit = wave_sync ? tg / bs : (wpg / bs) * TPW;
-    p.parts = p.nsg * p.ssplit * WPT;
+    p.ssplit = g.wave_sync ? tg / bs : (wpg / bs) * g.TPW;
+    p.parts = p.nsg * p.ssplit * g.WPT;
     p.grid = p.nsg * p.mgroups * p.wpg;
     return p;
 }
@@ -1384,22 +1427,30 @@ static SegArgs seg_base(mfb_ctx *c, const SegPlan &p) {
     memset(&a, 0, sizeof(a));
     a.x = c->d_in;
     a.G = c->d_G;
+    a.Grows = c->M;
     a.twL = c->d_twL;
     a.twLo = c->d_twLo;
     a.twHi = c->d_twHi;
     a.N = c->N;
     a.lo = c->lo;
     a.V = c->V;
-    a.nslots = p.nslots;
     a.mpb = p.mpb;
     a.mgroups = p.mgroups;
     a.nsg = p.nsg;
     a.bsplit = p.bsplit;
     a.ssplit = p.ssplit;
-    a.parts = p.parts;
     a.scale = 1.0f / 262144.0f;
     return a;
 }
+
+// slots whose segments are all complete (branch-free kernel) and the rest (masked kernel)
+static void seg_slots(const mfb_ctx *c, int *full, int *total) {
+    const SegGeom g = seg_geom(c);
+    const int qfull = c->N / c->V;                    // complete segments
+    *full = qfull / g.CT;
+    *total = (c->Q + g.CT - 1) / g.CT;
+}
+
 
 extern "C" int mfb_upload(mfb_ctx *c) {
     if (!c) return MFB_ERR_ARG;
@@ -1440,23 +1491,48 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
     HIPCHK(hipSetDevice(c->device));
     const int MU = c->MU;
     if (c->path == MFB_PATH_SEGMENT) {
-        // all bins in ONE launch: nothing of length N is written, so there is nothing to chunk
-        const SegPlan p = plan_seg(c, c->Dtot, MU, true);
-        int rc = reserve_partials(c, (size_t)c->Dtot * MU * p.parts);
+        // all bins in ONE launch: nothing of length N is written, so there is nothing to chunk.  A second,
+        // tiny launch of the masked instantiation covers the slots that hold incomplete segments.
+        int nfull, ntotal;
+        seg_slots(c, &nfull, &ntotal);
+        const SegPlan pm = plan_seg(c, c->Dtot, MU, nfull > 0 ? nfull : 1, c->seg_mpb);
+        const SegPlan pt = plan_seg(c, c->Dtot, MU, ntotal - nfull > 0 ? ntotal - nfull : 1, c->seg_mpb);
+        const int parts_main = nfull > 0 ? pm.parts : 0;
+        const int parts = parts_main + (ntotal > nfull ? pt.parts : 0);
+        int rc = reserve_partials(c, (size_t)c->Dtot * MU * parts);
         if (rc) return rc;
-        SegArgs a = seg_base(c, p);
-        a.rows = (MU < c->M) ? c->d_uniq : nullptr;
-        a.shifts = c->d_shifts;
-        a.partials = c->d_part;
-        a.MU = MU;
-        a.j0 = 0;
-        a.dc = c->Dtot;
         prof_mark(c, 0);
-        rc = launch_seg<SEG_REDUCE>(c, a, p.grid);
+        if (nfull > 0) {
+            SegArgs a = seg_base(c, pm);
+            a.rows = (MU < c->M) ? c->d_uniq : nullptr;
+            a.shifts = c->d_shifts;
+            a.partials = c->d_part;
+            a.MU = MU;
+            a.dc = c->Dtot;
+            a.slot0 = 0;
+            a.nslots = nfull;
+            a.parts = parts;
+            a.part0 = 0;
+            rc = launch_seg(c, a, pm.grid, SEG_REDUCE, c->V / seg_geom(c).NT);
+            if (rc) return rc;
+        }
+        if (ntotal > nfull) {
+            SegArgs a = seg_base(c, pt);
+            a.rows = (MU < c->M) ? c->d_uniq : nullptr;
+            a.shifts = c->d_shifts;
+            a.partials = c->d_part;
+            a.MU = MU;
+            a.dc = c->Dtot;
+            a.slot0 = nfull;
+            a.nslots = ntotal - nfull;
+            a.parts = parts;
+            a.part0 = parts_main;
+            rc = launch_seg(c, a, pt.grid, SEG_REDUCE, -1);
+            if (rc) return rc;
+        }
         prof_mark(c, 0);
-        if (rc) return rc;
         hipLaunchKernelGGL(k_finalize, dim3((c->Dtot + 63) / 64), dim3(64), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, MU,
-                           (const int *)c->d_rep, p.parts, c->sum_all);
+                           (const int *)c->d_rep, parts, c->sum_all);
         HIPCHK(hipGetLastError());
         return MFB_OK;
     }
@@ -1552,14 +1628,18 @@ extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, fl
     int rc;
     if (c->path == MFB_PATH_SEGMENT) {
         // the same segment kernel, storing y in natural order instead of reducing it (no transpose)
-        const SegPlan p = plan_seg(c, 1, c->M, false);
+        int nfull, ntotal;
+        seg_slots(c, &nfull, &ntotal);
+        const SegPlan p = plan_seg(c, 1, c->M, ntotal, 4);    // one bin: spread filters and slots over the chip
         SegArgs sa = seg_base(c, p);
         sa.out = c->d_xc;
         sa.MU = c->M;
         sa.dc = 1;
+        sa.slot0 = 0;
+        sa.nslots = ntotal;
         sa.fixed_shift = shift;
         sa.out_off = (c->win_start + c->T - 1) & (c->N - 1);
-        rc = launch_seg<SEG_STORE>(c, sa, p.grid);
+        rc = launch_seg(c, sa, p.grid, SEG_STORE, -1);
         if (rc) return rc;
     } else {
         P1Args a = p1_base(c);

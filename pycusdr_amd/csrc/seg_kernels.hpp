@@ -5,11 +5,11 @@
 //     x_s[n] = x[n] * e^{-2 pi i s n / N}          (the spectrum shift, done in time)
 // with the impulse response h_m = ifft(H_m).  When h_m is T taps long (every shipped protocol: 48...640,
 // filter_taps.hpp) the same y is obtained from L-point segments, L >= 2T:
-//     segment q covers samples b0 = q*V ... b0 + L - 1 (circular in N),  V = L - T + 1 outputs each
+//     segment q covers samples b0 = q*V ... b0 + L - 1 (circular in N),  V <= L - T + 1 outputs each
 //     U = FFT_L(x_s[b0 ...]),  v_m = IFFT_L(U * G_m),  y[s][m][(b0 + i + off) mod N] = v_m[i], 0 <= i < V
 // with G_m the (N/L)-scaled L-point spectrum of the rotated taps.  Nothing of length N is ever written:
-// a segment lives in registers + LDS from the x load to the |.|^2 sum (Doppler search, MODE_REDUCE) or
-// to the natural-order store of y (demodulation, MODE_STORE).  HBM traffic of the whole search is the
+// a segment lives in registers + LDS from the x load to the |.|^2 sum (Doppler search, SEG_REDUCE) or
+// to the natural-order store of y (demodulation, SEG_STORE).  HBM traffic of the whole search is the
 // 8 MiB block (served from L2 / Infinity Cache thereafter) plus a few KiB of partial sums, so the kernel
 // is bound by the fp32 vector rate, not by HBM.
 //
@@ -21,6 +21,17 @@
 // The grid is decoded XCD-aware: workgroups with equal blockIdx % nsg share a contiguous range of
 // segments, i.e. one eighth of the block, which stays in that XCD's L2 while every Doppler bin passes
 // over it (placement affects speed only).
+//
+// Issue-slot economy (the kernel is bound by instruction issue, measured: rocprofv3 SQ counters).
+//   * V is a multiple of NT, so the valid outputs of a complete segment are exactly the register slots
+//     k < PV = V / NT of every lane: PV is a TEMPLATE parameter, the |y|^2 accumulation has no masks and
+//     no branches, and the butterflies feeding dead slots are pruned by the compiler.  Incomplete
+//     segments (the last one of the block, padding of barrier teams) go through the PV = -1 instantiation,
+//     which masks per lane; the host launches it separately over the few slots that need it.
+//   * The mixing phasor of point i of a lane is  W_N^(s*e0) * W_N^(s*NT*i): one gathered base phasor per
+//     lane and unit, times 15 step phasors that depend on the Doppler bin only and are kept in LDS
+//     (broadcast reads) -- instead of two table gathers and ~9 integer ops per point.
+//   * x is read with immediate offsets (no per-point index arithmetic) unless the slot wraps past N.
 #pragma once
 #include "fft_core.hpp"
 
@@ -28,8 +39,13 @@
 #define SEG_STORE 1
 #define SEG_MPB_MAX 16   // filters per team pass (per-lane accumulators live in LDS)
 
-#ifndef MFB_SEG_WAVES
-#define MFB_SEG_WAVES 2
+// waves per SIMD the register budget is pinned to: 3 for L = 256 (one twiddled pass: 149 VGPRs), 2 for the
+// longer transforms (two twiddled passes: ~210 VGPRs; 3 waves would spill)
+#ifndef MFB_SEG_WAVES_SHORT
+#define MFB_SEG_WAVES_SHORT 3
+#endif
+#ifndef MFB_SEG_WAVES_LONG
+#define MFB_SEG_WAVES_LONG 2
 #endif
 #ifndef MFB_SEG_PREFETCH
 #define MFB_SEG_PREFETCH 1
@@ -46,16 +62,17 @@ struct SegArgs {
     float *partials;     // REDUCE: [rows][parts]
     cf *out;             // STORE: complex64 [M][N], natural order
     int N, lo;
-    int V;               // valid outputs per segment (L - T + 1)
-    int nslots;          // ceil(Q / CT): team-iterations needed to cover all Q = ceil(N / V) segments
+    int V;               // valid outputs per complete segment (multiple of NT)
+    int slot0, nslots;   // this launch covers team-iterations (slots) [slot0, slot0 + nslots); a slot = CT segments
     int MU;              // filter slots per Doppler bin
+    int Grows;           // rows of G (all M filters)
     int mpb, mgroups;    // filters per team pass, passes (workgroup groups) needed for MU
     int nsg;             // segment groups (blockIdx % nsg)
     int bsplit, ssplit;  // a group's teams = bsplit Doppler streams x ssplit segment sub-ranges
     int j0, dc;          // Doppler bins [j0, j0 + dc) of the shift table
     int fixed_shift;
-    int out_off;         // STORE: (window start + T - 1) mod N
-    int part_row0, parts;
+    int out_off;         // STORE: (window start + T_eff - 1) mod N
+    int part_row0, parts, part0;   // REDUCE: row of bin 0, row stride, first column of this launch
     float scale;         // REDUCE: 1 / 2^18
 };
 
@@ -69,7 +86,11 @@ struct SegCfg {
     static constexpr int SYNC = NT <= 64 ? 1 : 0;
     static constexpr int LDS_PER_TEAM = padlen(L) * CT;
     static constexpr int LDS_ELEMS = LDS_PER_TEAM * TPW;
-    static constexpr size_t lds_bytes(int mpb) { return (size_t)LDS_ELEMS * sizeof(cf) + (size_t)mpb * 256 * sizeof(float); }
+    static constexpr int STEP_ELEMS = 4 * 16;     // 16 step phasors per wave
+    static constexpr int WAVES = L <= 256 ? MFB_SEG_WAVES_SHORT : MFB_SEG_WAVES_LONG;   // per SIMD = workgroups per CU
+    static constexpr size_t lds_bytes(int mpb) {
+        return (size_t)(LDS_ELEMS + STEP_ELEMS) * sizeof(cf) + (size_t)mpb * 256 * sizeof(float);
+    }
 };
 
 DEVI float seg_wave_sum(float x) {
@@ -78,25 +99,36 @@ DEVI float seg_wave_sum(float x) {
     return x;
 }
 
-template <int L, int MODE>
-__global__ void __launch_bounds__(256, MFB_SEG_WAVES) k_seg(SegArgs a) {
+// PV >= 0: every segment this launch touches is complete; valid outputs = register slots k < PV.
+// PV < 0 : per-lane masking (incomplete / padding segments, any V).
+// amdgpu_waves_per_eu pins the register budget: without the upper bound the scheduler chases a fourth
+// wave per SIMD (which the LDS footprint does not admit anyway) by serialising every load behind an
+// s_waitcnt vmcnt(0).
+template <int L, int MODE, int PV>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SegCfg<L>::WAVES, SegCfg<L>::WAVES))) k_seg(SegArgs a) {
     using Cfg = SegCfg<L>;
     constexpr int NT = Cfg::NT, CT = Cfg::CT, TPW = Cfg::TPW, TEAM = Cfg::TEAM, SYNC = Cfg::SYNC;
+    constexpr bool MASKED = PV < 0;
+    static_assert(MODE == SEG_REDUCE || MASKED, "the STORE mode masks per lane");
     extern __shared__ __attribute__((aligned(16))) cf lds[];
-    float *lacc = reinterpret_cast<float *>(lds + Cfg::LDS_ELEMS);   // [mpb][256] per-lane |y|^2 sums
+    cf *lstep = lds + Cfg::LDS_ELEMS;                                         // [4 waves][16]
+    float *lacc = reinterpret_cast<float *>(lds + Cfg::LDS_ELEMS + Cfg::STEP_ELEMS);   // [mpb][256]
 
     const int tid = threadIdx.x;
     const int team = __builtin_amdgcn_readfirstlane(tid / TEAM);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
     const int lt = tid % TEAM;
     const int g = lt % NT;
     const int col = lt / NT;
     cf *mylds = lds + team * Cfg::LDS_PER_TEAM + col * padlen(L);
+    cf *mystep = lstep + wave * 16;
     int ebuf = 0;
 
     TwRegs<L> twr;
     load_twiddles<L>(twr, a.twL, g);
 
-    // ---- which Doppler bins and which segments this team owns -------------------------------
+    // ---- which Doppler bins and which slots this team owns -----------------------------------
     int grp, mg, bstream, ssub;
     {
         const int b = blockIdx.x;
@@ -115,55 +147,58 @@ __global__ void __launch_bounds__(256, MFB_SEG_WAVES) k_seg(SegArgs a) {
     }
     const int gs0 = (int)((long long)grp * a.nslots / a.nsg);
     const int glen = (int)((long long)(grp + 1) * a.nslots / a.nsg) - gs0;
-    const int s0 = gs0 + (int)((long long)ssub * glen / a.ssplit);
-    const int s1 = gs0 + (int)((long long)(ssub + 1) * glen / a.ssplit);
-    // barrier teams run the longest range of the group (surplus iterations are fully masked)
-    const int niter = SYNC ? (s1 - s0) : (glen + a.ssplit - 1) / a.ssplit;
+    const int s0 = a.slot0 + gs0 + (int)((long long)ssub * glen / a.ssplit);
+    const int s1 = a.slot0 + gs0 + (int)((long long)(ssub + 1) * glen / a.ssplit);
+    // barrier teams run the longest range of the group (surplus iterations contribute nothing)
+    const int niter = __builtin_amdgcn_readfirstlane(SYNC ? (s1 - s0) : (glen + a.ssplit - 1) / a.ssplit);
     const int m0 = mg * a.mpb;
-    const int m1 = min(m0 + a.mpb, a.MU);
+    const int nm = __builtin_amdgcn_readfirstlane(min(a.mpb, a.MU - m0));
 
     const unsigned nmask = (unsigned)a.N - 1u;
     const unsigned lomask = (1u << a.lo) - 1u;
     const auto xr = mk_rsrc(a.x, (unsigned)a.N * sizeof(cf));
     const auto lor = mk_rsrc(a.twLo, (unsigned)(1u << a.lo) * sizeof(cf));
     const auto hir = mk_rsrc(a.twHi, (unsigned)(a.N >> a.lo) * sizeof(cf));
+    const auto gr = mk_rsrc(a.G, (unsigned)a.Grows * (unsigned)(L * sizeof(cf)));   // whole G; rows via the scalar offset
     const int vo_g = g * (int)sizeof(cf);
     constexpr int so_g = NT * (int)sizeof(cf);
-    const int pv_all = a.V / NT;                  // output slots k < pv_all are valid in every full segment
-    const int kmax_all = (a.V + NT - 1) / NT;     // slots >= kmax_all are valid in none
+    auto phasor = [&](unsigned t) {
+        return cmul(buf_load_cf(hir, (int)((t >> a.lo) * sizeof(cf)), 0), buf_load_cf(lor, (int)((t & lomask) * sizeof(cf)), 0));
+    };
 
     for (int jl = bstream; jl < a.dc; jl += a.bsplit) {
         const int shift = a.shifts ? a.shifts[a.j0 + jl] : a.fixed_shift;
-        const unsigned dstep = ((unsigned)shift * (unsigned)NT) & nmask;
+        // step phasors W_N^(shift * NT * i), i < 16: the same for every lane, segment and filter of this bin
+        if (lane < 16) mystep[lane] = phasor(((unsigned)shift * (unsigned)(NT * lane)) & nmask);
         if constexpr (MODE == SEG_REDUCE) {
-            for (int mi = 0; mi < m1 - m0; ++mi) lacc[mi * 256 + tid] = 0.f;
+            for (int mi = 0; mi < nm; ++mi) lacc[mi * 256 + tid] = 0.f;
         }
+        xsync<1>();     // wave-local: every wave fills and reads its own copy
+
         for (int it = 0; it < niter; ++it) {
             const int slot = s0 + it;
-            const bool active = slot < s1;        // team-uniform
+            const bool active = slot < s1;        // team-uniform; false only on padding iterations of barrier teams
             const int seg = slot * CT + col;
             const unsigned b0 = (unsigned)seg * (unsigned)a.V;
-            const int vseg = active ? min(a.V, a.N - (int)b0) : 0;     // <= 0 beyond the last segment
-            const int lim = vseg - g;             // output slot k is valid for this lane iff k*NT < lim
-            // fast path bounds, team-uniform: every segment of this slot complete?
-            const bool full = active && ((long long)(slot + 1) * CT * a.V <= (long long)a.N);
-            const int pv = __builtin_amdgcn_readfirstlane(full ? pv_all : 0);
-            const int kmax = __builtin_amdgcn_readfirstlane(full ? kmax_all : 16);
+            const unsigned e0 = b0 + (unsigned)g;
 
             // ---- load the segment, mix with e^{-2 pi i s n / N}, conjugate (forward via inverse) ----
             cf v[16];
             {
-                const unsigned e0 = b0 + (unsigned)g;
-                const unsigned t0 = ((unsigned)shift * e0) & nmask;      // N | 2^32: wrap-around is harmless
+                const unsigned last = (unsigned)(slot * CT + CT - 1) * (unsigned)a.V + (unsigned)L;   // team-uniform
+                if (__builtin_amdgcn_readfirstlane(last <= (unsigned)a.N ? 1 : 0)) {
+                    const int vo_x = (int)(e0 * sizeof(cf));
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const unsigned idx = (e0 + (unsigned)(NT * i)) & nmask;
-                    const unsigned t = (t0 + (unsigned)i * dstep) & nmask;
-                    const cf xv = buf_load_cf(xr, (int)(idx * sizeof(cf)), 0);
-                    const cf ph = cmul(buf_load_cf(hir, (int)((t >> a.lo) * sizeof(cf)), 0),
-                                       buf_load_cf(lor, (int)((t & lomask) * sizeof(cf)), 0));
-                    v[i] = cmul_cj(xv, ph);       // conj(x) * W_N^{+t} = conj(x * e^{-2 pi i t / N})
+                    for (int i = 0; i < 16; ++i) v[i] = buf_load_cf(xr, vo_x, i * so_g);
+                } else {                          // the slot wraps past the end of the block
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        v[i] = buf_load_cf(xr, (int)(((e0 + (unsigned)(NT * i)) & nmask) * sizeof(cf)), 0);
                 }
+                const cf ph0 = phasor(((unsigned)shift * e0) & nmask);     // N | 2^32: wrap-around is harmless
+                v[0] = cmul_cj(v[0], ph0);        // conj(x) * W_N^{+t} = conj(x * e^{-2 pi i t / N})
+#pragma unroll
+                for (int i = 1; i < 16; ++i) v[i] = cmul_cj(v[i], cmul(ph0, mystep[i]));
             }
             cf A[16];                             // A[k] = conj(U[g + NT*k])
             {
@@ -172,46 +207,50 @@ __global__ void __launch_bounds__(256, MFB_SEG_WAVES) k_seg(SegArgs a) {
             }
 
             // ---- per filter: multiply by the segment spectrum, inverse transform, reduce or store ----
-            cf gk[16];
+            [[maybe_unused]] int lim = 0;
+            if constexpr (MASKED) {
+                const int vseg = active ? min(a.V, a.N - (int)b0) : 0;     // <= 0 beyond the last segment
+                lim = vseg - g;                   // output slot k is valid for this lane iff k*NT < lim
+            }
+            [[maybe_unused]] cf gk[16];
             if constexpr (MFB_SEG_PREFETCH) {
                 const int r0 = a.rows ? a.rows[m0] : m0;
-                const auto gr = mk_rsrc(a.G + (size_t)r0 * L, (unsigned)L * sizeof(cf));
 #pragma unroll
-                for (int i = 0; i < 16; ++i) gk[i] = buf_load_cf(gr, vo_g, i * so_g);
+                for (int i = 0; i < 16; ++i) gk[i] = buf_load_cf(gr, vo_g, r0 * (L * (int)sizeof(cf)) + i * so_g);
             }
-            for (int m = m0; m < m1; ++m) {
+            for (int mi = 0; mi < nm; ++mi) {
+                const int rm = a.rows ? a.rows[m0 + mi] : (m0 + mi);
                 cf w[16];
                 if constexpr (MFB_SEG_PREFETCH) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) w[i] = cmul_cj(A[i], gk[i]);    // conj(A) * G = U * G
-                    const int mn = (m + 1 < m1) ? (m + 1) : m0;
+                    const int mn = (mi + 1 < nm) ? (m0 + mi + 1) : m0;
                     const int rn = a.rows ? a.rows[mn] : mn;
-                    const auto gr = mk_rsrc(a.G + (size_t)rn * L, (unsigned)L * sizeof(cf));
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) gk[i] = buf_load_cf(gr, vo_g, i * so_g);
+                    for (int i = 0; i < 16; ++i) gk[i] = buf_load_cf(gr, vo_g, rn * (L * (int)sizeof(cf)) + i * so_g);
                 } else {
-                    const int rm = a.rows ? a.rows[m] : m;
-                    const auto gr = mk_rsrc(a.G + (size_t)rm * L, (unsigned)L * sizeof(cf));
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) w[i] = cmul_cj(A[i], buf_load_cf(gr, vo_g, i * so_g));
+                    for (int i = 0; i < 16; ++i)
+                        w[i] = cmul_cj(A[i], buf_load_cf(gr, vo_g, rm * (L * (int)sizeof(cf)) + i * so_g));
                 }
                 if constexpr (MODE == SEG_REDUCE) {
                     cf racc = mkc(0.f, 0.f);      // (sum re^2, sum im^2)
                     auto acc = [&](int, cf val, auto, auto nu) {
                         constexpr int k = decltype(nu)::value / NT;
-                        if (k < pv) {
-                            racc = __builtin_elementwise_fma(val, val, racc);
-                        } else if (k < kmax) {
+                        if constexpr (MASKED) {
                             const float wgt = (k * NT < lim) ? 1.f : 0.f;
                             racc = __builtin_elementwise_fma(val * wgt, val, racc);
+                        } else if constexpr (k < PV) {
+                            racc = __builtin_elementwise_fma(val, val, racc);
                         }
                     };
                     fft_passes<L, 1, 0, true, false, 0, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, acc);
-                    lacc[(m - m0) * 256 + tid] += racc.x + racc.y;
+                    float s = racc.x + racc.y;
+                    if constexpr (!MASKED && !SYNC) s = active ? s : 0.f;
+                    lacc[mi * 256 + tid] += s;
                 } else {
-                    const int rm = a.rows ? a.rows[m] : m;
                     const auto orr = mk_rsrc(a.out + (size_t)rm * a.N, (unsigned)a.N * sizeof(cf));
-                    const unsigned o0 = b0 + (unsigned)g + (unsigned)a.out_off;
+                    const unsigned o0 = e0 + (unsigned)a.out_off;
                     auto put = [&](int, cf val, auto, auto nu) {
                         constexpr int k = decltype(nu)::value / NT;
                         if (k * NT < lim) buf_store_cf(orr, (int)(((o0 + (unsigned)(k * NT)) & nmask) * sizeof(cf)), 0, val);
@@ -222,13 +261,12 @@ __global__ void __launch_bounds__(256, MFB_SEG_WAVES) k_seg(SegArgs a) {
         }
         if constexpr (MODE == SEG_REDUCE) {
             // registers/LDS -> wavefront -> one float per (bin, filter, wave); fixed order, no atomics
-            const int wave_in_team = (lt >> 6);
-            const int pidx = ((grp * a.ssplit + ssub) * Cfg::WPT) + wave_in_team;
-            for (int mi = 0; mi < m1 - m0; ++mi) {
+            const int pidx = a.part0 + ((grp * a.ssplit + ssub) * Cfg::WPT) + (lt >> 6);
+            for (int mi = 0; mi < nm; ++mi) {
                 const float s = seg_wave_sum(lacc[mi * 256 + tid]);
-                if ((tid & 63) == 0)
-                    a.partials[((size_t)(a.part_row0 + jl) * a.MU + (m0 + mi)) * a.parts + pidx] = s * a.scale;
+                if (lane == 0) a.partials[((size_t)(a.part_row0 + jl) * a.MU + (m0 + mi)) * a.parts + pidx] = s * a.scale;
             }
         }
+        xsync<1>();     // the step phasors are rewritten for the next bin
     }
 }

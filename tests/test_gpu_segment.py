@@ -47,7 +47,8 @@ def test_segment_scores_match_oracle_and_twopass(log2L, sum_all):
         assert bank.get_search_path()['path'] == 'segment' and bank.get_search_path()['taps'] == 48
         bank.set_search_path('segment', log2L)
         info = bank.get_search_path()
-        assert info['log2L'] == log2L and info['valid_per_segment'] == (1 << log2L) - 47
+        L = 1 << log2L
+        assert info['log2L'] == log2L and info['valid_per_segment'] == ((L - 47) // (L // 16)) * (L // 16)   # whole register slots
         bank.upload(x)
         idx, metric = bank.find_carrier()
         ds = bank.get_scores()
@@ -183,7 +184,7 @@ def test_segment_refused_for_long_filters_and_small_blocks():
         bank.set_filters(_short_masks(rs, M, N, 700, 0))       # 700 taps in a 4096-sample block: L would be 2048 > N/4
         assert bank.get_search_path()['path'] == 'twopass'
         bank.set_filters(_short_masks(rs, M, N, 20, 7))
-        assert bank.get_search_path() == dict(path='segment', log2L=8, taps=20, valid_per_segment=237, segments=18)
+        assert bank.get_search_path() == dict(path='segment', log2L=8, taps=20, valid_per_segment=224, segments=19)
     finally:
         bank.close()
 

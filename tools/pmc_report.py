@@ -1,6 +1,7 @@
 """Summarise rocprofv3 outputs under gpurun_out/<tag>/ per kernel."""
 import csv, collections, glob, sys
 tag = sys.argv[1]
+kpat = sys.argv[2] if len(sys.argv) > 2 else 'k_pass'
 for f in sorted(glob.glob(f'gpurun_out/{tag}/trace/*/*kernel_stats.csv')):
     for r in csv.DictReader(open(f)):
         if float(r['Percentage']) > 0.5:
@@ -9,11 +10,11 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
 for f in sorted(glob.glob(f'gpurun_out/{tag}/pmc*/*/*counter_collection.csv')):
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'][:32]
+        k = r['Kernel_Name'][:40]
         agg[k][r['Counter_Name']] += float(r['Counter_Value'])
         disp[(k, r['Counter_Name'])].add(r['Dispatch_Id'])
 for k, v in agg.items():
-    if 'k_pass' not in k:
+    if kpat not in k:
         continue
     print(k)
     for c, val in sorted(v.items()):
