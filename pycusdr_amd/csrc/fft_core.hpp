@@ -107,6 +107,15 @@ DEVI cf buf_load_cf(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX);
     return mkc(__uint_as_float(v.x), __uint_as_float(v.y));
 }
+// two adjacent complex values with ONE 16-byte load: the texture addresser spends 16 cycles on a wave64
+// buffer load whether a lane fetches 8 or 16 bytes (measured: TA_BUFFER_TOTAL_CYCLES / TA_BUFFER_WAVEFRONTS)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int AUX = 0>
+DEVI void buf_load_cf2(__amdgpu_buffer_rsrc_t r, int voff, int soff, cf &a, cf &b) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
+    a = mkc(__uint_as_float(v.x), __uint_as_float(v.y));
+    b = mkc(__uint_as_float(v.z), __uint_as_float(v.w));
+}
 DEVI float buf_load_f(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }

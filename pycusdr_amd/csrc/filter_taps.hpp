@@ -182,6 +182,8 @@ static inline cd tap(const Bank &b, int m, int r) {
 // for a layout length Te >= T (the kernel rounds the valid count L - Te + 1 down to whole register slots).
 // With this rotation the valid outputs of a segment that starts at sample b0 are i = 0 .. L-Te and
 // output i is y[(b0 + i + start + Te - 1) mod N] of the length-N formulation.
+// Storage order: [m][ii][g][e] = G_m[g + NT*(2*ii + e)], NT = L/16 -- the two register slots 2*ii, 2*ii+1
+// of transform lane g side by side, so that the kernel fetches them with one 16-byte load.
 static inline void segment_spectra(const Bank &b, int L, int Te, std::vector<float> *out) {
     const Fft plan(L);
     out->assign((size_t)b.M * 2 * L, 0.f);
@@ -192,10 +194,15 @@ static inline void segment_spectra(const Bank &b, int L, int Te, std::vector<flo
         for (int r = 0; r < b.T; ++r) buf[(r - (Te - 1)) & (L - 1)] = tap(b, m, r);
         plan.run(buf.data(), -1);
         float *o = out->data() + (size_t)m * 2 * L;
-        for (int k = 0; k < L; ++k) {
-            o[2 * k] = (float)(buf[k].real() * scale);
-            o[2 * k + 1] = (float)(buf[k].imag() * scale);
-        }
+        const int NT = L / 16;
+        for (int ii = 0; ii < 8; ++ii)
+            for (int g = 0; g < NT; ++g)
+                for (int e = 0; e < 2; ++e) {
+                    const cd v = buf[g + NT * (2 * ii + e)] * scale;
+                    const size_t pos = ((size_t)(ii * NT + g) * 2 + e) * 2;
+                    o[pos] = (float)v.real();
+                    o[pos + 1] = (float)v.imag();
+                }
     }
 }
 

@@ -1399,7 +1399,8 @@ static SegPlan plan_seg(const mfb_ctx *c, int dc, int nfilters, int nslots, int 
     const SegGeom g = seg_geom(c);
     SegPlan p;
     p.nsg = nslots >= 64 ? 8 : 1;
-    int mpb = mpb_want > 0 ? mpb_want : SEG_MPB_MAX;
+    // L = 256 runs three workgroups per CU only while a workgroup's LDS stays under 53 KiB: 8 filters per pass
+    int mpb = mpb_want > 0 ? mpb_want : (c->segl <= 8 ? 8 : SEG_MPB_MAX);
     if (mpb > SEG_MPB_MAX) mpb = SEG_MPB_MAX;
     if (mpb > nfilters) mpb = nfilters;
     p.mgroups = (nfilters + mpb - 1) / mpb;
@@ -1410,11 +1411,22 @@ static SegPlan plan_seg(const mfb_ctx *c, int dc, int nfilters, int nslots, int 
     const long long units = (long long)dc * ((nslots + p.nsg - 1) / p.nsg);
     while (wpg > 1 && (long long)wpg * g.TPW > units) wpg >>= 1;
     p.wpg = wpg;
-    // bsplit * ssplit = wpg * TPW teams; barrier teams of one workgroup must share the Doppler stream
+    // bsplit * ssplit = wpg * TPW teams; barrier teams of one workgroup must share the Doppler stream.
+    // Of all factorisations take the one whose busiest team has the least (bins x slots) to do;
+    // ties go to more Doppler streams (fewer partial-sum columns).
     const int tg = g.wave_sync ? wpg * g.TPW : wpg;
+    const int glen = (nslots + p.nsg - 1) / p.nsg;
     int bs = 1;
-    for (int d = 1; d <= tg; ++d)
-        if (tg % d == 0 && d <= dc) bs = d;
+    long long best = -1;
+    for (int d = 1; d <= tg; ++d) {
+        if (tg % d) continue;
+        const int ss = g.wave_sync ? tg / d : (wpg / d) * g.TPW;
+        const long long work = (long long)((dc + d - 1) / d) * ((glen + ss - 1) / ss);
+        if (best < 0 || work <= best) {
+            best = work;
+            bs = d;
+        }
+    }
     p.bsplit = bs;
     p.ssplit = g.wave_sync ? tg / bs : (wpg / bs) * g.TPW;
     p.parts = p.nsg * p.ssplit * g.WPT;
@@ -1496,7 +1508,8 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
         int nfull, ntotal;
         seg_slots(c, &nfull, &ntotal);
         const SegPlan pm = plan_seg(c, c->Dtot, MU, nfull > 0 ? nfull : 1, c->seg_mpb);
-        const SegPlan pt = plan_seg(c, c->Dtot, MU, ntotal - nfull > 0 ? ntotal - nfull : 1, c->seg_mpb);
+        // the tail is a handful of units: spread the filters too (2 per pass) so that it is short
+        const SegPlan pt = plan_seg(c, c->Dtot, MU, ntotal - nfull > 0 ? ntotal - nfull : 1, c->seg_mpb > 0 && c->seg_mpb < 2 ? c->seg_mpb : 2);
         const int parts_main = nfull > 0 ? pm.parts : 0;
         const int parts = parts_main + (ntotal > nfull ? pt.parts : 0);
         int rc = reserve_partials(c, (size_t)c->Dtot * MU * parts);

@@ -30,7 +30,11 @@
 //     which masks per lane; the host launches it separately over the few slots that need it.
 //   * The mixing phasor of point i of a lane is  W_N^(s*e0) * W_N^(s*NT*i): one gathered base phasor per
 //     lane and unit, times 15 step phasors that depend on the Doppler bin only and are kept in LDS
-//     (broadcast reads) -- instead of two table gathers and ~9 integer ops per point.
+//     (broadcast reads) -- instead of two table gathers and ~9 integer ops per point.  The Doppler
+//     search goes further: a phase that is constant over a segment multiplies every output of that
+//     segment by a unit phasor and drops out of |y|^2, so only the phase RELATIVE to the segment start
+//     is applied, W_N^(s*(g + NT*i)) -- a function of the lane and the bin alone, built once per bin
+//     (per-wave table in LDS for L = 256, lane phasor in registers otherwise): no gathers per segment.
 //   * x is read with immediate offsets (no per-point index arithmetic) unless the slot wraps past N.
 #pragma once
 #include "fft_core.hpp"
@@ -53,7 +57,8 @@
 
 struct SegArgs {
     const cf *x;         // time-domain block, complex64 [N]
-    const cf *G;         // segment spectra, complex64 [M][L]
+    const cf *G;         // segment spectra, complex64 [M][8][NT][2]: element (ii, g, e) = G_m[g + NT*(2*ii + e)],
+                         // i.e. register slots 2*ii and 2*ii+1 of lane g side by side (one 16-byte load)
     const int *rows;     // bank row of filter slot m (nullptr: identity)
     const int *shifts;   // device shift table (nullptr: fixed_shift)
     const cf *twL;       // W_L^j, j < L (inverse sign)
@@ -87,9 +92,12 @@ struct SegCfg {
     static constexpr int LDS_PER_TEAM = padlen(L) * CT;
     static constexpr int LDS_ELEMS = LDS_PER_TEAM * TPW;
     static constexpr int STEP_ELEMS = 4 * 16;     // 16 step phasors per wave
+    // Doppler search, L = 256: per-wave table of the relative mixing phasors W_N^(s*j), j < L (2 KiB a wave)
+    static constexpr bool PHASE_TABLE = L <= 256;
+    static constexpr int PHASE_ELEMS = PHASE_TABLE ? 4 * L : 0;
     static constexpr int WAVES = L <= 256 ? MFB_SEG_WAVES_SHORT : MFB_SEG_WAVES_LONG;   // per SIMD = workgroups per CU
-    static constexpr size_t lds_bytes(int mpb) {
-        return (size_t)(LDS_ELEMS + STEP_ELEMS) * sizeof(cf) + (size_t)mpb * 256 * sizeof(float);
+    static constexpr size_t lds_bytes(int mpb) {   // mpb = 0: STORE mode (no accumulators, no phase table)
+        return (size_t)(LDS_ELEMS + STEP_ELEMS + (mpb ? PHASE_ELEMS : 0)) * sizeof(cf) + (size_t)mpb * 256 * sizeof(float);
     }
 };
 
@@ -111,8 +119,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SegCfg
     constexpr bool MASKED = PV < 0;
     static_assert(MODE == SEG_REDUCE || MASKED, "the STORE mode masks per lane");
     extern __shared__ __attribute__((aligned(16))) cf lds[];
+    constexpr bool REL = MODE == SEG_REDUCE;                  // phase relative to the segment start suffices
+    constexpr bool PTAB = REL && Cfg::PHASE_TABLE;
     cf *lstep = lds + Cfg::LDS_ELEMS;                                         // [4 waves][16]
-    float *lacc = reinterpret_cast<float *>(lds + Cfg::LDS_ELEMS + Cfg::STEP_ELEMS);   // [mpb][256]
+    cf *lphase = lstep + Cfg::STEP_ELEMS;                                     // [4 waves][L] (PTAB)
+    float *lacc = reinterpret_cast<float *>(lphase + (REL ? Cfg::PHASE_ELEMS : 0));   // [mpb][256]
 
     const int tid = threadIdx.x;
     const int team = __builtin_amdgcn_readfirstlane(tid / TEAM);
@@ -123,6 +134,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SegCfg
     const int col = lt / NT;
     cf *mylds = lds + team * Cfg::LDS_PER_TEAM + col * padlen(L);
     cf *mystep = lstep + wave * 16;
+    [[maybe_unused]] cf *myphase = lphase + wave * L;
     int ebuf = 0;
 
     TwRegs<L> twr;
@@ -162,14 +174,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SegCfg
     const auto gr = mk_rsrc(a.G, (unsigned)a.Grows * (unsigned)(L * sizeof(cf)));   // whole G; rows via the scalar offset
     const int vo_g = g * (int)sizeof(cf);
     constexpr int so_g = NT * (int)sizeof(cf);
+    const int vo_g2 = g * 2 * (int)sizeof(cf);          // slot-pair layout of G
+    constexpr int so_g2 = NT * 2 * (int)sizeof(cf);
     auto phasor = [&](unsigned t) {
         return cmul(buf_load_cf(hir, (int)((t >> a.lo) * sizeof(cf)), 0), buf_load_cf(lor, (int)((t & lomask) * sizeof(cf)), 0));
     };
 
     for (int jl = bstream; jl < a.dc; jl += a.bsplit) {
         const int shift = a.shifts ? a.shifts[a.j0 + jl] : a.fixed_shift;
-        // step phasors W_N^(shift * NT * i), i < 16: the same for every lane, segment and filter of this bin
-        if (lane < 16) mystep[lane] = phasor(((unsigned)shift * (unsigned)(NT * lane)) & nmask);
+        [[maybe_unused]] cf pg = mkc(1.f, 0.f);
+        if constexpr (PTAB) {
+            // relative mixing phasors of all L positions of a segment, shared by the wave's columns
+#pragma unroll
+            for (int r = 0; r < L / 64; ++r) myphase[lane + 64 * r] = phasor(((unsigned)shift * (unsigned)(lane + 64 * r)) & nmask);
+        } else {
+            // step phasors W_N^(shift * NT * i), i < 16: the same for every lane, segment and filter of this bin
+            if (lane < 16) mystep[lane] = phasor(((unsigned)shift * (unsigned)(NT * lane)) & nmask);
+            if constexpr (REL) pg = phasor(((unsigned)shift * (unsigned)g) & nmask);
+        }
         if constexpr (MODE == SEG_REDUCE) {
             for (int mi = 0; mi < nm; ++mi) lacc[mi * 256 + tid] = 0.f;
         }
@@ -195,10 +217,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SegCfg
                     for (int i = 0; i < 16; ++i)
                         v[i] = buf_load_cf(xr, (int)(((e0 + (unsigned)(NT * i)) & nmask) * sizeof(cf)), 0);
                 }
-                const cf ph0 = phasor(((unsigned)shift * e0) & nmask);     // N | 2^32: wrap-around is harmless
-                v[0] = cmul_cj(v[0], ph0);        // conj(x) * W_N^{+t} = conj(x * e^{-2 pi i t / N})
+                // conj(x) * W_N^{+t} = conj(x * e^{-2 pi i t / N})
+                if constexpr (PTAB) {
 #pragma unroll
-                for (int i = 1; i < 16; ++i) v[i] = cmul_cj(v[i], cmul(ph0, mystep[i]));
+                    for (int i = 0; i < 16; ++i) v[i] = cmul_cj(v[i], myphase[g + NT * i]);
+                } else {
+                    cf ph0 = pg;
+                    if constexpr (!REL) ph0 = phasor(((unsigned)shift * e0) & nmask);   // N | 2^32: wrap-around is harmless
+                    v[0] = cmul_cj(v[0], ph0);
+#pragma unroll
+                    for (int i = 1; i < 16; ++i) v[i] = cmul_cj(v[i], cmul(ph0, mystep[i]));
+                }
             }
             cf A[16];                             // A[k] = conj(U[g + NT*k])
             {
@@ -216,7 +245,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SegCfg
             if constexpr (MFB_SEG_PREFETCH) {
                 const int r0 = a.rows ? a.rows[m0] : m0;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) gk[i] = buf_load_cf(gr, vo_g, r0 * (L * (int)sizeof(cf)) + i * so_g);
+                for (int ii = 0; ii < 8; ++ii) buf_load_cf2(gr, vo_g2, r0 * (L * (int)sizeof(cf)) + ii * so_g2, gk[2 * ii], gk[2 * ii + 1]);
             }
             for (int mi = 0; mi < nm; ++mi) {
                 const int rm = a.rows ? a.rows[m0 + mi] : (m0 + mi);
@@ -227,11 +256,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SegCfg
                     const int mn = (mi + 1 < nm) ? (m0 + mi + 1) : m0;
                     const int rn = a.rows ? a.rows[mn] : mn;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) gk[i] = buf_load_cf(gr, vo_g, rn * (L * (int)sizeof(cf)) + i * so_g);
+                    for (int ii = 0; ii < 8; ++ii)
+                        buf_load_cf2(gr, vo_g2, rn * (L * (int)sizeof(cf)) + ii * so_g2, gk[2 * ii], gk[2 * ii + 1]);
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        w[i] = cmul_cj(A[i], buf_load_cf(gr, vo_g, rm * (L * (int)sizeof(cf)) + i * so_g));
+                    for (int ii = 0; ii < 8; ++ii) {
+                        cf g0, g1;
+                        buf_load_cf2(gr, vo_g2, rm * (L * (int)sizeof(cf)) + ii * so_g2, g0, g1);
+                        w[2 * ii] = cmul_cj(A[2 * ii], g0);
+                        w[2 * ii + 1] = cmul_cj(A[2 * ii + 1], g1);
+                    }
                 }
                 if constexpr (MODE == SEG_REDUCE) {
                     cf racc = mkc(0.f, 0.f);      // (sum re^2, sum im^2)
