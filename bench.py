@@ -2,18 +2,23 @@
 """bench.py -- IQ Msamples/s through the Doppler matched-filter bank on MI355X.
 
 One "step" = one pass of the hot path over one N-sample block already resident in HBM:
-forward FFT -> shift-multiply -> D*M inverse FFTs -> |.|^2 row sums -> Doppler pick, including the
-8-byte result read-back the reference blocks on (A3..A7 of SURVEY.md section 8).
+forward FFT -> Doppler search over D bins x M matched filters -> |.|^2 row sums -> Doppler pick,
+including the 8-byte result read-back the reference blocks on (A3..A7 of SURVEY.md section 8).
 
   N=1 : config C2  (D=256 Doppler bins, M=8 GMSK matched filters, N=2^20, ov=2^10)
-  N>1 : config C4  (256 bins per GPU, D=256*G sharded by bin; every rank sees the same block;
-        one RCCL all-reduce of the [D, M] float32 scores per block, then the pick on every rank).
+  N>1 : config C4  (256 bins per GPU, D=256*G sharded by bin; rank 0's block is broadcast over RCCL,
+        one RCCL all-reduce of the per-bin scores per block, then the pick on every rank).
         Weak scaling: per-GPU work is fixed.  `value` counts the samples every rank pushed through
-        its 256-bin bank, i.e. (N-ov) * G per step ("Msamples/s of 256-bin-bank work").
+        its 256-bin bank, i.e. (N-ov) * G per step; `stream_msamples` is the physical IQ stream rate.
+
+Search paths (--path): `segment` = single-pass overlap-save in registers/LDS (no HBM intermediate; bound
+by the fp32 vector rate), `twopass` = length-N two-pass transforms through HBM (bound by HBM).  `auto`
+(default) takes the segment path for short filters -- every shipped protocol.  The JSON line carries the
+roofline of the path that ran the timed steps and, at N=1, a short measurement of the other one.
 
 Launch for N>1 (driver):  python -m torch.distributed.run --nnodes=1 --nproc-per-node N
                           --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  Exits non-zero if the full-size parity spot check fails.
 """
 import argparse
 import json
@@ -26,17 +31,27 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK = 8.0e12   # B/s, MI355X spec (MI355X_MICROARCH.md)
+HBM_PEAK = 8.0e12        # B/s, MI355X spec (MI355X_MICROARCH.md)
+VALU_FP32_PEAK = 157.3e12  # FLOP/s, MI355X fp32 vector peak (MI355X_MICROARCH.md)
+PARITY_TOL = 1e-5        # north_star: correlation magnitudes within 1e-5
 
 
 def b_alg(D, M, N):
-    """Algorithmic bytes of one block through A3..A7."""
+    """Algorithmic bytes of one block through A3..A7 in the two-pass formulation."""
     return 16.0 * D * M * N + 8.0 * N * (1 + M) + 16.0 * N + 4.0 * D
 
 
 def b_ref(D, M, N):
     """Traffic of the reference's unfused four-stage formulation, for context."""
     return 32.0 * D * M * N + 8.0 * N * (3 + M) + 4.0 * D * (1 + M)
+
+
+def seg_flops(D, Q, Mu, L, V):
+    """Nominal flops of one block on the segment path: per segment one forward transform of the mixed
+    input and, per filter, a pointwise product, an inverse transform and the |.|^2 sums.
+    5 L log2 L per transform, 6 per complex multiply, 4 per accumulated output."""
+    fft = 5.0 * L * np.log2(L)
+    return float(D) * Q * ((6.0 * L + fft) + Mu * (6.0 * L + fft + 4.0 * V))
 
 
 def widen_range_rate(conf, radio, N, D):
@@ -50,10 +65,21 @@ def widen_range_rate(conf, radio, N, D):
         rr *= 1.25
 
 
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(masks, shifts, x_block, N, ov, D, budget_bins=None):
-    """The oracle's Doppler search (numpy/scipy restatement, float32 arithmetic) timed on this
-    host's cores on a bounded sample of the same workload: the first `nb` of the D Doppler bins of
-    one block; the per-block figure is scaled by D/nb.  Reported baseline, not a target."""
+    """The oracle's Doppler search (numpy/scipy restatement) timed on this host's cores on a bounded
+    sample of the same workload: the first `nb` of the D Doppler bins of one block; the per-block figure
+    is scaled by D/nb.  Two modes: all cores (scipy.fft complex64, workers = cores) and one
+    thread (numpy pocketfft, complex128, row at a time).  Reported baseline, not a target."""
     import scipy.fft as sfft
     from oracle import mfbank_oracle as orc
     cores = os.cpu_count() or 1
@@ -69,14 +95,22 @@ def cpu_baseline(masks, shifts, x_block, N, ov, D, budget_bins=None):
             out[j] = (y.real.astype(np.float64) ** 2 + y.imag.astype(np.float64) ** 2).sum() / orc.SCALE_2_18
         return time.perf_counter() - t0, out
     t1, _ = run(1)                       # warm-up + calibration
-    nb = budget_bins or int(max(2, min(D, round(12.0 / max(t1, 1e-3)))))
+    nb = budget_bins or int(max(2, min(D, round(10.0 / max(t1, 1e-3)))))
     t, scores = run(nb)
     t_block = t * D / nb
+    # single thread, numpy: two bins
+    ns = 2
+    t0 = time.perf_counter()
+    single = orc.doppler_scores(X, masks, shifts[:ns], True)[:, 0]
+    ts = time.perf_counter() - t0
     return {
         'value': round((N - ov) / t_block / 1e6, 5), 'unit': 'Msamples/s', 'cores': cores, 'kind': 'port',
+        'cpu': cpu_model(),
         'sample': f'{nb} of {D} Doppler bins of one 2^{int(np.log2(N))}-sample block (M={masks.shape[0]}), '
                   f'{t:.1f} s of scipy.fft complex64 work with workers={cores}; per-block time scaled by D/{nb}',
-    }, scores
+        'single_thread': {'value': round((N - ov) / (ts * D / ns) / 1e6, 6), 'unit': 'Msamples/s', 'cores': 1,
+                          'sample': f'{ns} of {D} bins, numpy.fft complex128, {ts:.1f} s; scaled by D/{ns}'},
+    }, scores, single
 
 
 def main():
@@ -87,11 +121,14 @@ def main():
     ap.add_argument('--log2n', type=int, default=20)
     ap.add_argument('--bins', type=int, default=256, help='Doppler bins per GPU')
     ap.add_argument('--protocol', default='bench_GMSK')
+    ap.add_argument('--path', choices=['auto', 'segment', 'twopass'], default='auto')
+    ap.add_argument('--seg', default='', help='segment path tuning: log2L,wg_per_cu,filters_per_pass (0 = default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-demod-leg', action='store_true', help='skip the untimed find_carrier+demodulate figure (profiling runs)')
-    ap.add_argument('--tuning', default='', help='chunk,mpb,rows,jsplit (0 = default)')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the untimed secondary figures (demodulation leg, other path, S2, sync correlator): profiling runs')
+    ap.add_argument('--tuning', default='', help='two-pass path: chunk,mpb,rows,jsplit (0 = default)')
     ap.add_argument('--shard', choices=['bins', 'blocks'], default='bins',
-                    help='N>1: bins = C4, Doppler bins sharded 256/GPU + RCCL all-reduce per block (default); '
+                    help='N>1: bins = C4, Doppler bins sharded 256/GPU + RCCL exchange per block (default); '
                          'blocks = every GPU runs the full 256-bin bank on different time blocks, no collective')
     ap.add_argument('--force-dist', action='store_true', help='run the sharded/RCCL path even with one rank (rehearsal)')
     args = ap.parse_args()
@@ -100,7 +137,7 @@ def main():
     import __graft_entry__
     __graft_entry__.build()
     from pycusdr_amd import config as cfg, signals as sg
-    from pycusdr_amd.mfbank import MFBank
+    from pycusdr_amd.mfbank import MFBank, sync_find
     from pycusdr_amd.protocol import loadProtocol
     from pycusdr_amd.dist import DopplerShard, bin_slice
 
@@ -138,12 +175,16 @@ def main():
     bank = MFBank(log2N, hi - lo, M, window_width=7, sum_all_masks=True, device=local_rank)
     bank.set_filters(masks)
     bank.set_shifts(shifts[lo:hi])
+    seg = [int(v) for v in args.seg.split(',')] if args.seg else []
+    if args.path != 'auto' or seg:
+        bank.set_search_path(args.path if args.path != 'auto' or not seg else 'segment', *seg)
     if args.tuning:
         bank.set_tuning(*[int(v) for v in args.tuning.split(',')])
+    pinfo = bank.get_search_path()
     shard = None
     if (G > 1 or args.force_dist) and not by_blocks:
         shard = DopplerShard(rank=rank, world=G, device=dev)
-        shard.attach(bank, D_total, M)
+        shard.attach(bank, D_total, M, sum_all=True)
 
     # synthetic input S1: the reference's GMSK bench packet at +fs/4, tiled, AWGN 10 dB, resident in HBM
     nblocks = 16
@@ -153,18 +194,23 @@ def main():
     esz = blocks.element_size() * 2 * N
     torch.cuda.synchronize(dev)        # the blocks are resident before any other stream reads them
 
-    def step(i):
-        bank.upload_device(blocks.data_ptr() + ((i * (G if by_blocks else 1) + (rank if by_blocks else 0)) % nblocks) * esz)
+    def block_index(i):
+        return (i * (G if by_blocks else 1) + (rank if by_blocks else 0)) % nblocks
+
+    def step(i, src=None):
+        src = blocks if src is None else src
         if shard is None:
+            bank.upload_device(src.data_ptr() + block_index(i) * esz)
             return bank.find_carrier()
-        return shard.search_and_pick(bank, lo)
+        # sharded: rank 0 owns the stream; its block goes to every rank over RCCL, then search + exchange + pick
+        return shard.step(bank, lo, src[block_index(i)] if rank == 0 else None)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    step(0)            # initialisation: first launches load the code objects and touch the 8 GiB workspace
+    step(0)            # initialisation: first launches load the code objects and touch the workspaces
     for i in range(args.warmup):
         res = step(i)
     barrier()
@@ -178,30 +224,13 @@ def main():
     ev_ms = bank.timer_stop()
     counts, kms = bank.profile_read()
     bank.profile_enable(False)
+    # scores of the LAST timed block, read before anything else touches the handle (parity spot check)
+    last_block = block_index(args.steps - 1)
+    gscores = bank.get_scores()[:, 0].astype(np.float64)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
-    # secondary figure: find_carrier + demodulate (A3..A11 device part), outside the timed steps
-    full_ms = None
-    if shard is None and not args.no_demod_leg:
-        # host arithmetic of the demodulation stage, as Demodulator.findCodeRateAndPhaseGPU does it
-        k_off = int(N / (1.1 * 16))
-        k_len = int(N / (0.9 * 16)) - k_off
-        reps = 5
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for i in range(reps):
-            r = step(i)
-            k, arg, _ = bank.demodulate(N // 4, k_off, k_len)
-            spS = N / float(k) if float(k) else 10.0
-            cOff = -float(arg) / np.pi * spS / 2
-            if cOff < 0:
-                cOff += spS - 1
-            bank.find_centres(np.float32(spS), np.float32(cOff), 0, int(N / spS))
-        torch.cuda.synchronize(dev)
-        full_ms = (time.perf_counter() - t1) / reps * 1e3
 
     # live sanity: the pick must land on the +fs/4 carrier
     frac_idx = float(res[0])
@@ -209,77 +238,198 @@ def main():
     spacing = float(np.median(np.diff(np.sort(shifts))))
     carrier_ok = abs(pick_shift - N / 4) <= 1.5 * spacing
 
+    # ---- untimed secondary figures -----------------------------------------------------
+    extras = {}
+    other = None
+    if shard is None and not args.no_extras:
+        # find_carrier + demodulate (A3..A11 device part), host arithmetic as Demodulator.findCodeRateAndPhaseGPU
+        k_off = int(N / (1.1 * 16))
+        k_len = int(N / (0.9 * 16)) - k_off
+        reps = 5
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for i in range(reps):
+            step(i)
+            k, arg, _ = bank.demodulate(N // 4, k_off, k_len)
+            spS = N / float(k) if float(k) else 10.0
+            cOff = -float(arg) / np.pi * spS / 2
+            if cOff < 0:
+                cOff += spS - 1
+            bank.find_centres(np.float32(spS), np.float32(cOff), 0, int(N / spS))
+        torch.cuda.synchronize(dev)
+        extras['find_carrier_plus_demodulate_ms'] = round((time.perf_counter() - t1) / reps * 1e3, 4)
+        # S2: pure-throughput signal (unit-variance white noise, RandomState(0)), same step
+        s2 = sg.s2_noise(4, N)
+        if s2 is not None:
+            s2_dev = torch.from_numpy(s2.view(np.float32).reshape(4, 2 * N)).to(dev)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for i in range(8):
+                bank.upload_device(s2_dev.data_ptr() + (i % 4) * esz)
+                bank.find_carrier()
+            torch.cuda.synchronize(dev)
+            extras['S2_white_noise_msamples'] = round((N - ov) / ((time.perf_counter() - t1) / 8) / 1e6, 2)
+        # the other search path, same blocks, a few steps (its own roofline accounting)
+        if G == 1:
+            try:
+                bank.set_search_path('twopass' if pinfo['path'] == 'segment' else 'segment')
+                o_info = bank.get_search_path()
+                step(0)
+                torch.cuda.synchronize(dev)
+                bank.profile_enable(True)
+                t1 = time.perf_counter()
+                osteps = 4
+                for i in range(osteps):
+                    step(i)
+                torch.cuda.synchronize(dev)
+                o_el = time.perf_counter() - t1
+                o_counts, o_kms = bank.profile_read()
+                bank.profile_enable(False)
+                other = (o_info, o_el / osteps, o_counts, o_kms, bank.get_tuning(), osteps)
+            except ValueError:
+                other = None
+            bank.set_search_path(args.path if args.path != 'auto' or not seg else 'segment', *seg)
+        # sync/preamble correlator (A14): B = 1024 streams of 67 584 bits x 64 taps, thresholded on the device
+        rsb = np.random.RandomState(2)
+        B, Lb = 1024, 65536 + 2048
+        bits = rsb.randint(0, 2, (B, Lb)).astype(np.uint8)
+        tmpl = (2 * rsb.randint(0, 2, 64) - 1).astype(np.int8)
+        header = ((tmpl[::-1] + 1) // 2).astype(np.uint8)
+        for pos in range(100, Lb - 64, 4000):
+            bits[:, pos:pos + 64] = header
+        thr = int((tmpl == 1).sum()) - 5                      # numOnes - tolerance, as decoder.py:101
+        sync_find(bits, tmpl, thr, device=local_rank)      # warm-up (allocations)
+        t1 = time.perf_counter()
+        hits = sync_find(bits, tmpl, thr, device=local_rank)
+        dt = time.perf_counter() - t1
+        extras['sync_correlator'] = {'streams_per_s': round(B / dt, 1), 'B': B, 'bits_per_stream': Lb, 'taps': 64,
+                                     'hits_per_stream': int(len(hits[0][0])), 'includes': 'H2D of the bit streams, D2H of the hits'}
+
     out = None
+    rc = 0
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = (N - ov) * G / (elapsed / args.steps) / 1e6
         Dl = hi - lo
         tun = bank.get_tuning()
         Mu = bank.get_info()[2]          # filter rows the search really transforms (exact duplicates/negatives once)
-        # dominant kernel of the search and its own algorithmic bytes per launch
-        dom = 0 if kms[0] >= kms[1] else 1
-        names = ['k_pass1<256,BANK> (shift-multiply + column FFT + twiddle -> Z)',
-                 'k_pass2<4096,REDUCE> (row FFT + |.|^2 reduction)']
-        launches = max(counts[dom], 1)
-        bins_per_launch = Dl * args.steps / launches
-        if dom == 0:
-            k_bytes = 8.0 * bins_per_launch * Mu * N + 8.0 * N * (1 + Mu)   # Z write + spectrum + filter bank read once
-        else:
-            k_bytes = 8.0 * bins_per_launch * Mu * N + 4.0 * bins_per_launch * Mu  # Z read + partial sums
-        k_avg_s = kms[dom] / launches * 1e-3
-        achieved = k_bytes / k_avg_s
-        traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(tfile):
-            try:
-                rec = json.load(open(tfile))
-                key = f'D{Dl}_M{M}_N{log2N}_chunk{tun[0]}'
-                traffic = rec.get(key, {}).get('pass1' if dom == 0 else 'pass2')
-            except Exception:
-                traffic = None
         t_block_dev = ev_ms / args.steps * 1e-3
+
+        def twopass_roofline(Dl_, counts_, kms_, tun_, nsteps):
+            dom = 0 if kms_[0] >= kms_[1] else 1
+            names = ['k_pass1<256,BANK> (shift-multiply + column FFT + twiddle -> Z)',
+                     'k_pass2<4096,REDUCE> (row FFT + |.|^2 reduction)']
+            launches = max(counts_[dom], 1)
+            bins_per_launch = Dl_ * nsteps / launches
+            if dom == 0:
+                k_bytes = 8.0 * bins_per_launch * Mu * N + 8.0 * N * (1 + Mu)   # Z write + spectrum + filter bank read once
+            else:
+                k_bytes = 8.0 * bins_per_launch * Mu * N + 4.0 * bins_per_launch * Mu  # Z read + partial sums
+            k_avg_s = kms_[dom] / launches * 1e-3
+            traffic = None
+            tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+            if os.path.exists(tfile):
+                try:
+                    rec = json.load(open(tfile))
+                    key = f'D{Dl_}_M{M}_N{log2N}_chunk{tun_[0]}'
+                    traffic = rec.get(key, {}).get('pass1' if dom == 0 else 'pass2')
+                except Exception:
+                    traffic = None
+            return {'bound': 'hbm', 'kernel': names[dom], 'achieved': round(k_bytes / k_avg_s / 1e9, 2), 'peak': HBM_PEAK / 1e9,
+                    'unit': 'GB/s', 'frac': round(k_bytes / k_avg_s / HBM_PEAK, 4), 'traffic': traffic,
+                    'traffic_source': 'profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round 1 '
+                                      '(commit 717e07a), not measured by this run',
+                    'launches': launches, 'avg_launch_ms': round(k_avg_s * 1e3, 4), 'alg_bytes_per_launch': k_bytes,
+                    'other_kernel_avg_ms': round(kms_[1 - dom] / max(counts_[1 - dom], 1), 4)}
+
+        def segment_roofline(info, Dl_, counts_, kms_):
+            L, V, Q = 1 << info['log2L'], info['valid_per_segment'], info['segments']
+            fl = seg_flops(Dl_, Q, Mu, L, V)
+            launches = max(counts_[0], 1)
+            k_avg_s = kms_[0] / launches * 1e-3
+            traffic, tsrc = None, None
+            tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+            if os.path.exists(tfile):
+                try:
+                    rec = json.load(open(tfile)).get(f'segment_D{Dl_}_M{M}_N{log2N}_L{info["log2L"]}', {})
+                    traffic, tsrc = rec.get('bytes'), rec.get('source')
+                except Exception:
+                    pass
+            return {'bound': 'valu_fp32', 'kernel': f'k_seg<{L},REDUCE,{V // (L // 16)}> (mix + forward FFT + per filter: product, inverse FFT, '
+                                                    f'|.|^2 sums; segments of {L} points, {V} valid outputs, {Q} segments per bin)',
+                    'achieved': round(fl / k_avg_s / 1e12, 2), 'peak': VALU_FP32_PEAK / 1e12, 'unit': 'TFLOP/s',
+                    'frac': round(fl / k_avg_s / VALU_FP32_PEAK, 4), 'traffic': traffic, 'traffic_source': tsrc,
+                    'launches': launches, 'avg_launch_ms': round(k_avg_s * 1e3, 4), 'flops_per_launch': fl,
+                    'flops_formula': 'D*Q*((6L + 5L log2 L) + Mu*(6L + 5L log2 L + 4V))',
+                    'hbm_note': 'no length-N intermediate exists on this path: HBM traffic per launch is the 8 MiB block plus partial sums '
+                                '(see traffic); the two-pass algorithmic bytes below are context, not bytes moved',
+                    'twopass_formulation_alg_bytes_per_block': b_alg(Dl_, Mu, N),
+                    'twopass_formulation_alg_bytes_over_time_GBps': round(b_alg(Dl_, Mu, N) / t_block_dev / 1e9, 1)}
+
+        if pinfo['path'] == 'segment':
+            roof = segment_roofline(pinfo, Dl, counts, kms)
+        else:
+            roof = twopass_roofline(Dl, counts, kms, tun, args.steps)
+        roof['pipeline'] = {'device_ms_per_block': round(t_block_dev * 1e3, 4),
+                            'B_alg_twopass_per_block': b_alg(Dl, Mu, N), 'B_ref_unfused_per_block': b_ref(Dl, M, N)}
+        if G == 1 and log2N == 20 and args.bins == 256:
+            workload = ('C2: single MI355X, D=256 Doppler bins, M=8 GMSK matched filters (bench_GMSK), N=2^20 complex64 chunk, '
+                        f'ov=2^10; search path: {pinfo["path"]}'
+                        + (f' (L=2^{pinfo["log2L"]}, {pinfo["taps"]} taps)' if pinfo['path'] == 'segment' else ''))
+        elif by_blocks:
+            workload = (f'block round-robin: every one of {G} GPUs runs the full D={D_total} bank on different time blocks, M={M}, '
+                        f'N=2^{log2N}, no data-path collective; search path: {pinfo["path"]}')
+        else:
+            workload = (f'C4-style: D={D_total} Doppler bins sharded {Dl}/GPU over {G} GPUs, M={M}, N=2^{log2N}; rank 0 broadcasts the '
+                        f'block, one RCCL all-reduce of the per-bin scores per block; search path: {pinfo["path"]}')
         out = {
             'metric': 'IQ Msamples/sec through Doppler matched-filter bank (256 bins, 2^20 chunk)',
             'value': round(value, 3), 'unit': 'Msamples/s', 'n_gpus': G, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {
-                'workload': ('C2: single MI355X, D=256 Doppler bins, M=8 GMSK matched filters (bench_GMSK), '
-                             'N=2^20 complex64 chunk, ov=2^10' if G == 1 and log2N == 20 and args.bins == 256 else
-                             (f'block round-robin: every one of {G} GPUs runs the full D={D_total} bank on different time '
-                              f'blocks, M={M}, N=2^{log2N}, no data-path collective') if by_blocks else
-                             f'C4-style: D={D_total} Doppler bins sharded {Dl}/GPU over {G} GPUs, M={M}, N=2^{log2N}, '
-                             'RCCL all-reduce of the [D,M] scores per block'),
+                'workload': workload, 'path': pinfo,
                 'D_total': D_total, 'D_per_gpu': Dl, 'M': M, 'M_unique': Mu, 'log2N': log2N, 'overlap': ov,
                 'signal': 'S1: GMSK bench packet at +fs/4, tiled, AWGN 10 dB (RandomState(1)), resident in HBM',
-                'rangeRateMax_used': rr, 'tuning(chunk,mpb,rows,jsplit)': list(tun),
+                'rangeRateMax_used': rr, 'twopass_tuning(chunk,mpb,rows,jsplit)': list(tun),
                 'units': 'samples through a 256-bin bank, summed over ranks',
+                'stream_msamples': round((N - ov) / (elapsed / args.steps) / 1e6, 3) if not by_blocks else round(value, 3),
+                'world_size': G, 'backend': ('nccl (RCCL)' if dist is not None else None),
                 'carrier_found': bool(carrier_ok),
-                'find_carrier_plus_demodulate_ms': None if full_ms is None else round(full_ms, 4),
             },
-            'roofline': {
-                'bound': 'hbm', 'kernel': names[dom], 'achieved': round(achieved / 1e9, 2), 'peak': HBM_PEAK / 1e9,
-                'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK, 4), 'traffic': traffic,
-                'launches': launches, 'avg_launch_ms': round(k_avg_s * 1e3, 4), 'alg_bytes_per_launch': k_bytes,
-                'other_kernel_avg_ms': round(kms[1 - dom] / max(counts[1 - dom], 1), 4),
-                'pipeline': {'B_alg_per_block': b_alg(Dl, Mu, N), 'B_ref_unfused_per_block': b_ref(Dl, M, N), 'device_ms_per_block': round(t_block_dev * 1e3, 4),
-                             'achieved_GBps': round(b_alg(Dl, Mu, N) / t_block_dev / 1e9, 2),
-                             'frac': round(b_alg(Dl, Mu, N) / t_block_dev / HBM_PEAK, 4)},
-            },
+            'roofline': roof,
         }
+        out['config'].update(extras)
+        if other is not None:
+            o_info, o_t, o_counts, o_kms, o_tun, osteps = other
+            o_roof = (segment_roofline(o_info, Dl, o_counts, o_kms) if o_info['path'] == 'segment'
+                      else twopass_roofline(Dl, o_counts, o_kms, o_tun, osteps))
+            o_roof['ms_per_step'] = round(o_t * 1e3, 4)
+            o_roof['msamples'] = round((N - ov) / o_t / 1e6, 2)
+            out['roofline_other_path'] = {'path': o_info['path'], **o_roof}
         if not args.no_cpu_baseline and G == 1:
-            cb, cscores = cpu_baseline(masks, shifts[lo:hi], host_blocks[(args.steps - 1) % nblocks], N, ov, Dl)
-            # the bounded CPU sample doubles as a full-size parity spot check of the last block
-            gscores = bank.get_scores()[:len(cscores), 0]
-            cb['max_rel_diff_vs_gpu'] = float(np.abs(gscores - cscores).max() / cscores.max())
+            cb, cscores, single = cpu_baseline(masks, shifts[lo:hi], host_blocks[last_block], N, ov, Dl)
+            # the bounded CPU sample doubles as a full-size parity spot check of the last timed block
+            rel = float(np.abs(gscores[:len(cscores)] - cscores).max() / cscores.max())
+            rel1 = float(np.abs(gscores[:len(single)] - single).max() / single.max())
+            cb['max_rel_diff_vs_gpu'] = rel
+            cb['max_rel_diff_vs_gpu_fp64_oracle'] = rel1
+            cb['parity_tolerance'] = PARITY_TOL
             out['cpu_baseline'] = cb
+            if not (rel < PARITY_TOL and rel1 < PARITY_TOL):
+                rc = 1
         else:
             out['cpu_baseline'] = None
+        if not carrier_ok:
+            rc = 1
         print(json.dumps(out), flush=True)
     bank.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rc:
+        sys.stderr.write('bench.py: parity spot check or carrier check FAILED\n')
+        sys.exit(rc)
     return out
 
 

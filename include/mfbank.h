@@ -138,6 +138,12 @@ int mfb_export_scores_async(mfb_ctx *ctx, void *dev_dst, int row_offset);
  * top-2 weighted index and metric; synchronises and returns res = {idx, metric}.
  * Replaces findDopplerEst + memcpy_dtoh (DB:601-605; CU:502-597). */
 int mfb_pick(mfb_ctx *ctx, const void *dev_scores, int num, int offset, float res[2]);
+/* The same two steps for the SUM_ALL_MASKS case, in which only column 0 of doppSum is populated
+ * (CU:453-464): copy that column into dev_dst float32[*] at [row_offset, row_offset+count), and pick on a
+ * device vector float32[offset+num] -- the sharded exchange then moves D floats instead of D*M.
+ * mfb_pick_column returns MFB_ERR_STATE on a handle created without sum_all_masks. */
+int mfb_export_column_async(mfb_ctx *ctx, void *dev_dst, int row_offset);
+int mfb_pick_column(mfb_ctx *ctx, const void *dev_column, int num, int offset, float res[2]);
 /* mfb_search_async + mfb_pick on the handle's own bins: the device part of __findUHF
  * (DB:567-605). */
 int mfb_find_carrier(mfb_ctx *ctx, float res[2]);

@@ -56,6 +56,8 @@ PROTOTYPES = {
     'mfb_search_async': (_i, [_vp]),
     'mfb_export_scores_async': (_i, [_vp, _vp, _i]),
     'mfb_pick': (_i, [_vp, _vp, _i, _i, _fp]),
+    'mfb_export_column_async': (_i, [_vp, _vp, _i]),
+    'mfb_pick_column': (_i, [_vp, _vp, _i, _i, _fp]),
     'mfb_find_carrier': (_i, [_vp, _fp]),
     'mfb_get_scores': (_i, [_vp, _vp]),
     'mfb_get_spectrum': (_i, [_vp, _vp, _i, _i]),

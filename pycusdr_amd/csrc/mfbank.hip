@@ -1107,7 +1107,7 @@ static int resolve_path(mfb_ctx *c) {
 }
 
 extern "C" int mfb_set_search_path(mfb_ctx *c, int path, int log2L, int wg_per_cu, int filters_per_pass) {
-    if (!c || path < 0 || path > MFB_PATH_SEGMENT || log2L < 0 || wg_per_cu < 0 || wg_per_cu > 8 || filters_per_pass < 0 ||
+    if (!c || path < 0 || path > MFB_PATH_SEGMENT || log2L < 0 || wg_per_cu < 0 || wg_per_cu > 16 || filters_per_pass < 0 ||
         filters_per_pass > SEG_MPB_MAX)
         return MFB_ERR_ARG;
     if (log2L && (log2L < 8 || log2L > 12)) return MFB_ERR_UNSUPPORTED;
@@ -1405,7 +1405,10 @@ static SegPlan plan_seg(const mfb_ctx *c, int dc, int nfilters, int nslots, int 
     if (mpb > nfilters) mpb = nfilters;
     p.mgroups = (nfilters + mpb - 1) / mpb;
     p.mpb = (nfilters + p.mgroups - 1) / p.mgroups;   // balanced
-    const int wpc = c->seg_wpc > 0 ? c->seg_wpc : (c->segl <= 8 ? MFB_SEG_WAVES_SHORT : MFB_SEG_WAVES_LONG);
+    // Workgroups in the grid per CU.  More than are resident at once (3 / 2 per CU) on purpose: the surplus
+    // is dealt out as workgroups retire, which evens out CUs that run at different speeds (measured at C2,
+    // L = 256: 3 per CU 1.85 ms, 6: 1.75, 12: 1.60, 16: 1.60; L = 1024: 2: 2.26, 6: 2.20; L = 4096: 4: 2.75)
+    const int wpc = c->seg_wpc > 0 ? c->seg_wpc : (c->segl <= 8 ? 12 : (c->segl <= 10 ? 6 : 4));
     int wpg = wpc * 256 / p.nsg;                 // workgroups per group: wpc per CU, 256 CUs
     // never more teams than (bin, slot) units in a group
     const long long units = (long long)dc * ((nslots + p.nsg - 1) / p.nsg);
@@ -1514,35 +1517,27 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
         const int parts = parts_main + (ntotal > nfull ? pt.parts : 0);
         int rc = reserve_partials(c, (size_t)c->Dtot * MU * parts);
         if (rc) return rc;
+        SegArgs am = seg_base(c, pm), at = seg_base(c, pt);
+        for (SegArgs *q : {&am, &at}) {
+            q->rows = (MU < c->M) ? c->d_uniq : nullptr;
+            q->shifts = c->d_shifts;
+            q->partials = c->d_part;
+            q->MU = MU;
+            q->dc = c->Dtot;
+            q->parts = parts;
+        }
+        am.slot0 = 0;
+        am.nslots = nfull;
+        am.part0 = 0;
+        at.slot0 = nfull;
+        at.nslots = ntotal - nfull;
+        at.part0 = parts_main;
+        const int pv = c->V / seg_geom(c).NT;
         prof_mark(c, 0);
-        if (nfull > 0) {
-            SegArgs a = seg_base(c, pm);
-            a.rows = (MU < c->M) ? c->d_uniq : nullptr;
-            a.shifts = c->d_shifts;
-            a.partials = c->d_part;
-            a.MU = MU;
-            a.dc = c->Dtot;
-            a.slot0 = 0;
-            a.nslots = nfull;
-            a.parts = parts;
-            a.part0 = 0;
-            rc = launch_seg(c, a, pm.grid, SEG_REDUCE, c->V / seg_geom(c).NT);
-            if (rc) return rc;
-        }
-        if (ntotal > nfull) {
-            SegArgs a = seg_base(c, pt);
-            a.rows = (MU < c->M) ? c->d_uniq : nullptr;
-            a.shifts = c->d_shifts;
-            a.partials = c->d_part;
-            a.MU = MU;
-            a.dc = c->Dtot;
-            a.slot0 = nfull;
-            a.nslots = ntotal - nfull;
-            a.parts = parts;
-            a.part0 = parts_main;
-            rc = launch_seg(c, a, pt.grid, SEG_REDUCE, -1);
-            if (rc) return rc;
-        }
+        // (both roles inside one grid were tried: the merged kernel ran 8-10 % slower than two launches)
+        if (nfull > 0) rc = launch_seg(c, am, pm.grid, SEG_REDUCE, pv);
+        if (!rc && ntotal > nfull) rc = launch_seg(c, at, pt.grid, SEG_REDUCE, -1);
+        if (rc) return rc;
         prof_mark(c, 0);
         hipLaunchKernelGGL(k_finalize, dim3((c->Dtot + 63) / 64), dim3(64), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, MU,
                            (const int *)c->d_rep, parts, c->sum_all);
@@ -1588,6 +1583,26 @@ extern "C" int mfb_export_scores_async(mfb_ctx *c, void *dst, int row_offset) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync((float *)dst + (size_t)row_offset * c->M, c->d_sum, (size_t)c->Dtot * c->M * sizeof(float),
                           hipMemcpyDeviceToDevice, c->stream));
+    return MFB_OK;
+}
+
+extern "C" int mfb_export_column_async(mfb_ctx *c, void *dst, int row_offset) {
+    if (!c || !dst || row_offset < 0) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    // column 0 of doppSum [Dtot][M] -> dst[row_offset + j]
+    HIPCHK(hipMemcpy2DAsync((float *)dst + row_offset, sizeof(float), c->d_sum, (size_t)c->M * sizeof(float), sizeof(float),
+                            (size_t)c->Dtot, hipMemcpyDeviceToDevice, c->stream));
+    return MFB_OK;
+}
+
+extern "C" int mfb_pick_column(mfb_ctx *c, const void *column, int num, int offset, float res[2]) {
+    if (!c || !column || !res || num < 1 || offset < 0) return MFB_ERR_ARG;
+    if (!c->sum_all) return MFB_ERR_STATE;   // a single column is the whole table only under SUM_ALL_MASKS
+    HIPCHK(hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_pick, dim3(1), dim3(256), 0, c->stream, (const float *)column, c->d_res, num, offset, 1, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(res, c->d_res, 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return MFB_OK;
 }
 

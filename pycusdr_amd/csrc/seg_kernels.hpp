@@ -107,13 +107,11 @@ DEVI float seg_wave_sum(float x) {
     return x;
 }
 
-// PV >= 0: every segment this launch touches is complete; valid outputs = register slots k < PV.
+// PV >= 0: every segment this role touches is complete; valid outputs = register slots k < PV.
 // PV < 0 : per-lane masking (incomplete / padding segments, any V).
-// amdgpu_waves_per_eu pins the register budget: without the upper bound the scheduler chases a fourth
-// wave per SIMD (which the LDS footprint does not admit anyway) by serialising every load behind an
-// s_waitcnt vmcnt(0).
+// `blk` is the workgroup's index in the launch.
 template <int L, int MODE, int PV>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SegCfg<L>::WAVES, SegCfg<L>::WAVES))) k_seg(SegArgs a) {
+DEVI void seg_body(const SegArgs &a, const int blk) {
     using Cfg = SegCfg<L>;
     constexpr int NT = Cfg::NT, CT = Cfg::CT, TPW = Cfg::TPW, TEAM = Cfg::TEAM, SYNC = Cfg::SYNC;
     constexpr bool MASKED = PV < 0;
@@ -143,7 +141,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SegCfg
     // ---- which Doppler bins and which slots this team owns -----------------------------------
     int grp, mg, bstream, ssub;
     {
-        const int b = blockIdx.x;
+        const int b = blk;
         grp = b % a.nsg;
         int r = b / a.nsg;
         mg = r % a.mgroups;
@@ -303,4 +301,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SegCfg
         }
         xsync<1>();     // the step phasors are rewritten for the next bin
     }
+}
+
+// amdgpu_waves_per_eu pins the register budget: without the upper bound the scheduler chases a fourth
+// wave per SIMD (which the LDS footprint does not admit anyway) by serialising every load behind an
+// s_waitcnt vmcnt(0).
+#define SEG_KERNEL_ATTRS(L_) __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SegCfg<L_>::WAVES, SegCfg<L_>::WAVES)))
+
+template <int L, int MODE, int PV>
+__global__ void SEG_KERNEL_ATTRS(L) k_seg(SegArgs a) {
+    seg_body<L, MODE, PV>(a, (int)blockIdx.x);
 }

@@ -60,6 +60,7 @@ def doppler_bin_table(confRadio, rangeRateMax, Nfft):
 
 class Demodulator:
     """One receive channel: Doppler search + symbol demodulation of N-sample blocks."""
+    backend = None
 
     def __init__(self, conf, protocol, radioName, shard=None):
         self.protocol = protocol
@@ -145,7 +146,8 @@ class Demodulator:
         self.bank.set_filters(masks)
         self.bank.set_shifts(self.doppCyperSymNorm[self._bin_lo:self._bin_hi])
         if shard is not None:
-            shard.attach(self.bank, self.num_dopplers, self.num_masks)
+            shard.attach(self.bank, self.num_dopplers, self.num_masks, sum_all=self.SUM_ALL_MASKS_PYTHON)
+        self._pick_bin = 0
 
         # windowed argmax range of the symbol-rate estimate (reference DB:508-512)
         self.symsTolLow = 0.9 * spsym
@@ -182,8 +184,19 @@ class Demodulator:
 
     # ---- input ---------------------------------------------------------------------------------
     def uploadToGPU(self, samples):
-        """H2D copy + forward FFT (reference DB:548-558)."""
-        self.bank.upload(samples)
+        """H2D copy + forward FFT (reference DB:548-558).  Sharded: rank 0 owns the IQ stream; its block is
+        broadcast to every rank (``samples`` is ignored on the other ranks and may be None)."""
+        if self.shard is None:
+            self.bank.upload(samples)
+            return
+        sh = self.shard
+        if sh.rank == 0:
+            src = sh.torch.from_numpy(np.ascontiguousarray(samples, dtype=np.complex64).view(np.float32))
+            with sh._on_stream():
+                sh.block.copy_(src, non_blocking=False)
+            sh.broadcast_block(self.bank, sh.block)
+        else:
+            sh.broadcast_block(self.bank)
 
     def thresholdInput(self, samples):
         self._thresholdInput(samples)
@@ -231,6 +244,7 @@ class Demodulator:
         best[0], best[1] = self._device_search()
         try:
             lowIdx = int(best[0])
+            self._pick_bin = lowIdx
             highIdx = int(np.ceil(best[0]))
             frac = float(best[0]) % 1
             lowVal, highVal = self.doppHzLUT[lowIdx], self.doppHzLUT[highIdx]
@@ -301,6 +315,11 @@ class Demodulator:
     def _demodulate(self):
         """Symbols of the uploaded block at the found shift (reference DB:765-859).  Returns
         (bits uint8[], centres uint8[] (mod 256), trust uint8[], spSym)."""
+        if self.shard is not None and self.shard.world > 1 and self.backend == 'UHF' \
+                and self.shard.owner(min(max(self._pick_bin, 0), self.num_dopplers - 1)) != self.shard.rank:
+            # sharded: the demodulation stage (1/D of the work) runs on the rank that owns the picked bin
+            empty = np.empty(0, dtype=np.uint8)
+            return empty, empty, empty, 0.0
         spSym, codeOffset = self.findCodeRateAndPhaseGPU()
         idxSymbol, _, centres, _, _, trustSymbol = self.cudaFindCentres(spSym, codeOffset, Operations.CENTRES_ABS)
         dataBits, symError_t = self.extractBits(centres, idxSymbol)

@@ -133,6 +133,15 @@ class MFBank:
         _lib.check(self._lib.mfb_pick(self._h, C.c_void_p(int(dev_scores) if dev_scores else 0), num, offset, res), 'mfb_pick')
         return np.float32(res[0]), np.float32(res[1])
 
+    def export_column_async(self, dev_ptr, row_offset):
+        _lib.check(self._lib.mfb_export_column_async(self._h, C.c_void_p(int(dev_ptr)), int(row_offset)),
+                   'mfb_export_column_async')
+
+    def pick_column(self, dev_column, num, offset=0):
+        res = (C.c_float * 2)()
+        _lib.check(self._lib.mfb_pick_column(self._h, C.c_void_p(int(dev_column)), int(num), int(offset), res), 'mfb_pick_column')
+        return np.float32(res[0]), np.float32(res[1])
+
     def find_carrier(self):
         res = (C.c_float * 2)()
         _lib.check(self._lib.mfb_find_carrier(self._h, res), 'mfb_find_carrier')

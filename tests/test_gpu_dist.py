@@ -37,7 +37,7 @@ def test_sharded_search_equals_local_search_one_rank():
             b = sharded.uploadAndFindCarrier(x)
             assert a[0] == b[0] and a[1] == b[1] and a[3] == b[3]
             assert int(plain.dopplerIdxlast) == int(sharded.dopplerIdxlast) == N // 4
-            full = sharded.shard.scores.cpu().numpy()
+            full = sharded.shard.full_scores()
             assert np.array_equal(full, plain.bank.get_scores())
             ra, rb = plain.demodulate(), sharded.demodulate()
             assert all(np.array_equal(u, v) for u, v in zip(ra[:3], rb[:3])) and ra[3] == rb[3]
