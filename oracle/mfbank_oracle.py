@@ -364,3 +364,15 @@ def find_carrier(x, masks, shifts, num_dopplers, element_offset=0, sum_all_masks
     ds = doppler_scores(X, masks, shifts, sum_all_masks, dtype=dtype).astype(np.float32)
     idx, metric = find_doppler_est(ds, num_dopplers, element_offset, sum_all_masks)
     return X, ds, idx, metric
+
+
+# --------------------------------------------------------------------------------------------
+# N4  bit-stream alignment cross-correlation                       lib/customXCorr.py:5-18
+# --------------------------------------------------------------------------------------------
+def custom_xcorr(a, b, N=None):
+    """ifft(fft(a, N) * conj(fft(b, N))), N = max(len) by default (fft truncates or zero-pads to N).
+    Pinned by fixture G13 (the reference's own soft-combiner test streams)."""
+    a, b = np.asarray(a), np.asarray(b)
+    if N is None:
+        N = max(len(a), len(b))
+    return np.fft.ifft(np.fft.fft(a, N) * np.conj(np.fft.fft(b, N)), N)

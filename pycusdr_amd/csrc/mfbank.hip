@@ -357,26 +357,33 @@ __global__ void __launch_bounds__((L2 / 16) * P2Cfg<L2>::RB, (L2 == 4096 && MODE
 // ------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------
-// doppSum[j][m] from the per-workgroup partials (fixed order).  SUM_ALL_MASKS: column 0 gets the
-// sum over masks, the other columns stay 0 (cuda_kernels.cu:453-464); else per mask (472-475).
+// doppSum[j][m] from the per-workgroup partials.  One wavefront per Doppler bin: lane l adds partials
+// l, l+64, ... of a filter, then a fixed butterfly over the 64 lanes -- the order depends on nothing but
+// `parts`, so results are bit-reproducible (no float atomics, unlike cuda_kernels.cu:463,474).
+// SUM_ALL_MASKS: column 0 gets the sum over masks (added in filter order), the other columns stay 0
+// (cuda_kernels.cu:453-464); else per mask (472-475).
 // The partials hold MU <= M rows per bin (filters that are exact copies or exact negatives of an
 // earlier filter are transformed once: |.|^2 is identical bit for bit); rep[m] names filter m's row.
-__global__ void k_finalize(const float *partials, float *dsum, int D, int M, int MU, const int *rep, int parts, int sum_all) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(64) k_finalize(const float *partials, float *dsum, int D, int M, int MU, const int *rep, int parts,
+                                                 int sum_all) {
+    const int j = blockIdx.x;
+    const int lane = threadIdx.x;
     if (j >= D) return;
     float tot = 0.f;
     for (int m = 0; m < M; ++m) {
-        float s = 0.f;
         const float *p = partials + ((size_t)j * MU + rep[m]) * parts;
-        for (int q = 0; q < parts; ++q) s += p[q];
+        float s = 0.f;
+        for (int q = lane; q < parts; q += 64) s += p[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         if (sum_all) {
             tot += s;
-            dsum[j * M + m] = 0.f;
-        } else {
+            if (lane == 0) dsum[j * M + m] = 0.f;
+        } else if (lane == 0) {
             dsum[j * M + m] = s;
         }
     }
-    if (sum_all) dsum[j * M] = tot;
+    if (sum_all && lane == 0) dsum[j * M] = tot;
 }
 
 // Z[row][n1][n2] -> out[row][n1 + N1*n2] (natural order), optional conjugation (forward transform).
@@ -399,69 +406,80 @@ __global__ void __launch_bounds__(256) k_transpose(const cf *Z, cf *out, int N1,
     }
 }
 
-// findDopplerEst (cuda_kernels.cu:502-597).  One wavefront; lane x < M owns column x.
+// findDopplerEst (cuda_kernels.cu:502-597).  The reference scans every column sequentially: a value
+// replaces the smaller of the two kept maxima when it is strictly greater (first come wins ties), and
+// which of the two slots a maximum sits in -- it matters for the fp32 rounding of the weighted index --
+// depends on the whole history.  One wavefront reproduces that scan exactly but skips what cannot change
+// the state: 64 rows are compared against the current threshold at once (ballot); only lanes that beat
+// it are visited, in row order, each visit updating the threshold for the lanes behind it.
 // fp32 evaluation order is pinned with explicit intrinsics (see oracle/mfbank_oracle.py).
-__global__ void __launch_bounds__(256) k_pick(const float *in, float *res, int num, int offset, int M, int sum_all) {
+__global__ void __launch_bounds__(64) k_pick(const float *in, float *res, int num, int offset, int M, int sum_all) {
     __shared__ float sIdx[64], sVal[64];
-    __shared__ float stage[8192];   // chunk of rows x M scores, staged with all 256 threads
-    const int x = threadIdx.x;
-    float idxL = 0.f, valL = 0.f;
-    float maxVal[2] = {0.f, 0.f};
-    int maxIdx[2] = {0, 0};
-    int cur = 0;
-    const int rows_per_chunk = 8192 / M;
-    for (int r0 = offset; r0 < num + offset; r0 += rows_per_chunk) {
-        const int nr = min(rows_per_chunk, num + offset - r0);
-        __syncthreads();
-        for (int q = x; q < nr * M; q += 256) stage[q] = in[(size_t)r0 * M + q];
-        __syncthreads();
-        if (x < M) {
-            // the reference's sequential scan (strict '>', slot of the smaller value is replaced)
-#pragma unroll 8
-            for (int r = 0; r < nr; ++r) {
-                const float tmp = stage[r * M + x];
-                if (tmp > maxVal[cur]) {
-                    maxVal[cur] = tmp;
-                    maxIdx[cur] = r0 + r;
-                    cur = (maxVal[0] >= maxVal[1]) ? 1 : 0;
+    const int lane = threadIdx.x;
+    const int ncol = sum_all ? 1 : M;
+    for (int x = 0; x < ncol; ++x) {
+        float mv0 = 0.f, mv1 = 0.f;
+        int mi0 = 0, mi1 = 0, cur = 0;
+        for (int r0 = offset; r0 < num + offset; r0 += 64) {
+            const int r = r0 + lane;
+            const bool inside = r < num + offset;
+            const float v = inside ? in[(size_t)r * M + x] : 0.f;
+            unsigned long long todo = ~0ull;
+            while (true) {
+                const float thr = cur ? mv1 : mv0;
+                const unsigned long long hit = __ballot(inside && v > thr) & todo;     // strict '>' (NaN never enters)
+                if (!hit) break;
+                const int l = __builtin_ctzll(hit);
+                const float tmp = __shfl(v, l, 64);
+                if (cur) {
+                    mv1 = tmp;
+                    mi1 = r0 + l;
+                } else {
+                    mv0 = tmp;
+                    mi0 = r0 + l;
                 }
+                cur = (mv0 >= mv1) ? 1 : 0;          // the slot of the smaller value is replaced next
+                todo = (l == 63) ? 0ull : (~0ull << (l + 1));
             }
         }
-    }
-    if (x < M) {
-        const float numr = __fmaf_rn((float)maxIdx[0], maxVal[0], __fmul_rn((float)maxIdx[1], maxVal[1]));
-        idxL = __fdiv_rn(numr, __fadd_rn(maxVal[0], maxVal[1]));
-        valL = __fdiv_rn(numr, (float)(maxIdx[0] + maxIdx[1]));
-        if (offset > 0) valL = __fdiv_rn(maxVal[(cur + 1) % 2], in[x]);
-    }
-    if (sum_all) {
-        if (x == 0) {
-            res[0] = idxL;
-            res[1] = 10.f * log10f(valL);
+        const float numr = __fmaf_rn((float)mi0, mv0, __fmul_rn((float)mi1, mv1));
+        const float idxL = __fdiv_rn(numr, __fadd_rn(mv0, mv1));
+        float valL = __fdiv_rn(numr, (float)(mi0 + mi1));
+        if (offset > 0) valL = __fdiv_rn(cur ? mv0 : mv1, in[x]);     // maxVal[(cur + 1) % 2] / noise-bin score
+        if (sum_all) {
+            if (lane == 0) {
+                res[0] = idxL;
+                res[1] = 10.f * log10f(valL);
+            }
+            return;
         }
-        return;
+        if (lane == 0) {
+            sIdx[x] = idxL;
+            sVal[x] = valL;
+        }
     }
     int n = 1;
     while (n < M) n <<= 1;
-    if (x < 64) {
-        sIdx[x] = (x < M) ? idxL : 0.f;
-        sVal[x] = (x < M) ? valL : 0.f;
+    __syncthreads();
+    if (lane >= M) {
+        sIdx[lane] = 0.f;
+        sVal[lane] = 0.f;
     }
     __syncthreads();
     for (int step = n >> 1; step >= 1; step >>= 1) {
         float a = 0.f, b = 0.f;
-        if (x < n) {
-            a = __fadd_rn(sIdx[x], sIdx[x ^ step]);
-            b = __fadd_rn(sVal[x], sVal[x ^ step]);
+        if (lane < n) {
+            a = __fadd_rn(sIdx[lane], sIdx[lane ^ step]);
+            b = __fadd_rn(sVal[lane], sVal[lane ^ step]);
         }
         __syncthreads();
-        if (x < n) {
-            sIdx[x] = a;
-            sVal[x] = b;
+        if (lane < n) {
+            sIdx[lane] = a;
+            sVal[lane] = b;
         }
         __syncthreads();
     }
-    if (x == 0) {
+    if (lane == 0) {
         res[0] = __fdiv_rn(sIdx[0], (float)M);
         res[1] = 10.f * log10f(__fdiv_rn(sVal[0], (float)M));
     }
@@ -1539,7 +1557,7 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
         if (!rc && ntotal > nfull) rc = launch_seg(c, at, pt.grid, SEG_REDUCE, -1);
         if (rc) return rc;
         prof_mark(c, 0);
-        hipLaunchKernelGGL(k_finalize, dim3((c->Dtot + 63) / 64), dim3(64), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, MU,
+        hipLaunchKernelGGL(k_finalize, dim3(c->Dtot), dim3(64), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, MU,
                            (const int *)c->d_rep, parts, c->sum_all);
         HIPCHK(hipGetLastError());
         return MFB_OK;
@@ -1572,7 +1590,7 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
         prof_mark(c, 1);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_finalize, dim3((c->Dtot + 63) / 64), dim3(64), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, MU,
+    hipLaunchKernelGGL(k_finalize, dim3(c->Dtot), dim3(64), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, MU,
                        (const int *)c->d_rep, c->parts, c->sum_all);
     HIPCHK(hipGetLastError());
     return MFB_OK;
@@ -1599,7 +1617,7 @@ extern "C" int mfb_pick_column(mfb_ctx *c, const void *column, int num, int offs
     if (!c || !column || !res || num < 1 || offset < 0) return MFB_ERR_ARG;
     if (!c->sum_all) return MFB_ERR_STATE;   // a single column is the whole table only under SUM_ALL_MASKS
     HIPCHK(hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_pick, dim3(1), dim3(256), 0, c->stream, (const float *)column, c->d_res, num, offset, 1, 1);
+    hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, c->stream, (const float *)column, c->d_res, num, offset, 1, 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(res, c->d_res, 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1611,7 +1629,7 @@ extern "C" int mfb_pick(mfb_ctx *c, const void *scores, int num, int offset, flo
     if (!scores && (num != c->D || offset != c->Doff)) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     const float *in = scores ? (const float *)scores : c->d_sum;
-    hipLaunchKernelGGL(k_pick, dim3(1), dim3(256), 0, c->stream, in, c->d_res, num, offset, c->M, c->sum_all);
+    hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, c->stream, in, c->d_res, num, offset, c->M, c->sum_all);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(res, c->d_res, 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

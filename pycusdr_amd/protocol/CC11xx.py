@@ -1,11 +1,19 @@
-"""CC11xx (TI sub-GHz transceiver framing) receive plugin: 2-FSK filters, centre-bit LUT,
-preamble+sync template.  Mirrors the parts of the reference's protocol/CC11xx.py the hot path uses
-(:42-146); the packet class keeps the length-byte cut (:254-266) but no CRC / PN9 de-whitening of
-the payload (next scope row N2).
+"""CC11xx (TI sub-GHz transceiver framing) receive plugin: 2-FSK (or Gaussian 2-FSK) filters,
+centre-bit LUT, preamble+sync template, and the packet class with the length-byte cut, PN9
+de-whitening and the CRC flag (reference protocol/CC11xx.py:42-146, 216-300).
+
+Two things the reference fixes at import time are selectable here:
+  * modulation (reference ``modIDX``, CC11xx.py:30-32,42): ``CC11xx`` is FSK-2, ``CC11xx_GFSK2`` the
+    GFSK-2 flavour (``loadProtocol('CC11xx_GFSK2')``);
+  * where the CRC is looked for (``CRC_CHECK``): ``'reference'`` (default) reproduces the reference's
+    ``getBinaryData`` bit for bit -- the flag compares crc16([len | packetLen bytes]) with the two RAW
+    bytes that follow them; ``'framer'`` checks the CRC where the reference's own TX framer puts it
+    (inside the length-counted bytes, modulator/encoders/CC11xx.py:82-96).
 """
 import numpy as np
 
 from .FSK2_base import FSK2
+from .GFSK2_base import GFSK2
 from .protocolBase import Packet, PacketEndDetect, PacketLenEndianness, bit_patterns
 
 DEFAULT_SYNC = [0xAB, 0x35, 0xAB, 0x35]
@@ -64,8 +72,9 @@ def frame_bits(payload, preamble=(0xAA,) * 4, sync=(0xD6, 0xBA, 0xD6, 0xBA), whi
     return np.unpackbits(np.r_[np.asarray(preamble, np.uint8), np.asarray(sync, np.uint8), body])
 
 
-class CC11xx(FSK2):
-    name = 'CC11xx FSK-2'
+class _CC11xxFraming:
+    """Everything of the plugin but the filter generator (mixed into an FSK2 / GFSK2 base)."""
+    CRC_CHECK = 'reference'      # or 'framer'
     packetEndDetectMode = PacketEndDetect.FIXED
     packetLen = (256 + 9 + 2) * 8
     packetEndLenField = 9
@@ -121,6 +130,14 @@ class CC11xx(FSK2):
         return PacketCC11xx(self, *args, **kwargs)
 
 
+class CC11xx(_CC11xxFraming, FSK2):
+    name = 'CC11xx FSK-2'
+
+
+class CC11xx_GFSK2(_CC11xxFraming, GFSK2):
+    name = 'CC11xx GFSK-2'
+
+
 class PacketCC11xx(Packet):
     """flags | sync | length byte | address | data | CRC -- cut to the length the (whitened)
     length byte announces (reference CC11xx.py:226-266)."""
@@ -141,19 +158,27 @@ class PacketCC11xx(Packet):
         self._pre = DEFAULT_NUM_PREAMBLE + self.maskLen + self.pLen      # bytes before the length-counted part
 
     def getBinaryData(self):
-        """(bytes after the length byte, de-whitened; CRC error flag; the same bytes).
+        """(packetLen bytes after the length byte, de-whitened; CRC flag; the same bytes) -- the return
+        shape of the reference (CC11xx.py:274-300).
 
-        Same return shape as the reference (CC11xx.py:274-300): ``packetLen`` bytes follow the length
-        byte, the last two of them are the CRC (low byte first).  The reference compares its CRC with the
-        two bytes *behind* the frame and runs it over the CRC bytes too, so its flag is always set; here
-        the CRC is checked where the TX framer puts it (over [len | payload])."""
-        n = int(self.packetLen)
+        ``CRC_CHECK == 'reference'``: the flag is the reference's, bit for bit: crc16 over
+        [len | the packetLen de-whitened bytes] compared with the last two bytes of the cut frame taken RAW
+        (still whitened), low byte first; True means mismatch.  For frames of the reference's own TX
+        framer (length byte counts the CRC) that flag is set on every good frame.
+        ``CRC_CHECK == 'framer'``: the CRC is the last two of the packetLen bytes, computed over
+        [len | payload]; True means CRC error."""
+        n = int(np.uint8(self.packetLen))
         body = np.asarray(self.bits[self._pre * 8:(self._pre + n) * 8]).astype(np.int64)
         data = np.dot(body.reshape(-1, 8), 2 ** np.arange(7, -1, -1)).astype(np.uint8)
         if self.protocol.deWhiten:
-            data = np.bitwise_xor(data, pn9_bytes(len(data) + 1)[1:].astype(np.uint8))
-        if len(data) < 2 or len(data) < n:
-            return data, True, data
-        crc_rx = int(data[-2]) | (int(data[-1]) << 8)
-        crc_ok = crc16_cc11xx(np.r_[n, data[:-2]]) == crc_rx
-        return data, (not crc_ok), data
+            k = min(len(data), int(self.packetLen))
+            data[:k] = np.bitwise_xor(data[:k], pn9_bytes(k + 1)[1:].astype(np.uint8))
+        if getattr(self.protocol, 'CRC_CHECK', 'reference') == 'framer':
+            if len(data) < 2 or len(data) < n:
+                return data, True, data
+            crc_rx = int(data[-2]) | (int(data[-1]) << 8)
+            return data, crc16_cc11xx(np.r_[n, data[:-2]]) != crc_rx, data
+        tail = np.asarray(self.bits[-self.CRClen * 8:]).astype(np.int64).reshape(self.CRClen, 8)
+        crc_bytes = np.dot(tail, 2 ** np.arange(7, -1, -1))
+        crc_rx = int(crc_bytes[0]) + 256 * int(crc_bytes[1])
+        return data, crc_rx != crc16_cc11xx(np.r_[n, data].astype(np.uint8)), data

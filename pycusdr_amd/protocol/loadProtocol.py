@@ -9,6 +9,7 @@ import importlib
 # name -> (module relative to this package, class name)
 _REGISTRY = {
     'CC11xx': ('.CC11xx', 'CC11xx'),
+    'CC11xx_GFSK2': ('.CC11xx', 'CC11xx_GFSK2'),     # the reference's modIDX = 1 flavour (CC11xx.py:30-32)
     'bench_GMSK': ('.benchmark.bench_GMSK', 'Bench_GMSK'),
     'bench_BPSK': ('.benchmark.bench_BPSK', 'Bench_BPSK'),
     'bench_FSK': ('.benchmark.bench_FSK', 'Bench_FSK'),

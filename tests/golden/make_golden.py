@@ -15,11 +15,21 @@ What is captured (SURVEY.md section 8c, G1..G5 + host-logic KATs):
   G7  host-logic KATs         Demodulator.checkSymbolOverlap / extractBitsNRZs (pure numpy
                               methods, called unbound on a plain namespace object)
   G8  PN9 whitening bytes     lib.shift_registers.PN9 (CC11xx framing, next-scope row N2)
+  G9  peak clipping           Demodulator.__thresholdInput (name-mangled, unbound on a namespace)
+  G10 SNR estimate            Demodulator.computeSNR on a numpy spectrum (cuda.Context.synchronize stubbed)
+  G11 FLAGS-mode decoder      Decoder.findFrames with packetEndDetectMode = FLAGS (frame inside one call,
+                              across calls, overflow past maxPacketLenBits)
+  G12 CC11xx packet parsing   PacketCC11xx: length cut, PN9 de-whitening, CRC flag
+  G13 bit-stream alignment    lib.customXCorr.customXCorr on the reference's own unit-test streams
+                              (test/test_trustProcessor/bitData_test.npz) -- next-scope row N4
 
 Harness-side shims (the same ones SURVEY.md 8c lists): numpy aliases removed in numpy>=1.24
-(np.float, np.int), an empty ``crcmod`` module (packet CRC only; off the hot path) and, for G7
-only, empty ``pycuda`` / ``lib.cufft`` modules so that the module holding the two pure-numpy methods
-imports (both are glue to closed-source CUDA libraries that cannot exist here).
+(np.float, np.int); a ``crcmod`` module whose ``mkCrcFun`` is this harness's own bitwise CRC (crcmod
+1.7 is a third-party dependency absent from this image; its published algorithm -- polynomial with the
+leading 1, MSB-first when rev=False, initial value, final XOR -- is restated below and checked against
+the catalogue value 0xAEE7 of CRC-16/CMS); and, for G7/G9/G10 only, empty ``pycuda`` / ``lib.cufft``
+modules so that the module holding the pure-numpy methods imports (both are glue to closed-source CUDA
+libraries that cannot exist here; ``cuda.Context.synchronize`` is a no-op stub).
 No GPU code of the reference is executed (none can be: there is no CUDA here).
 
 Usage:  python tests/golden/make_golden.py      (writes tests/golden/*.npz)
@@ -40,12 +50,28 @@ def _install_shims():
     np.float = float  # noqa: removed aliases the reference still uses
     np.int = int
     crc = types.ModuleType('crcmod')
-    crc.mkCrcFun = lambda *a, **k: (lambda b: 0)
+
+    def mkCrcFun(poly, initCrc=0, rev=True, xorOut=0):
+        """crcmod.mkCrcFun restated for the non-reflected 16-bit case the reference uses."""
+        assert not rev and poly >> 16 == 1, 'only the rev=False, 16-bit form is restated'
+        p16 = poly & 0xFFFF
+
+        def fun(data):
+            c = initCrc
+            for byte in bytes(data):
+                c ^= byte << 8
+                for _ in range(8):
+                    c = ((c << 1) ^ p16) & 0xFFFF if c & 0x8000 else (c << 1) & 0xFFFF
+            return np.int64(c ^ xorOut)      # numpy scalar: np.uint8(...) of it wraps as it did under numpy 1.x
+        return fun
+    assert mkCrcFun(0x18005, rev=False, initCrc=0xFFFF, xorOut=0)(b'123456789') == 0xAEE7
+    crc.mkCrcFun = mkCrcFun
     sys.modules['crcmod'] = crc
     # pycuda is imported at module level by demodulator_base; only needed so the module object
     # exists -- none of its functions are called by the pure-numpy methods we exercise.
     pc = types.ModuleType('pycuda')
     drv = types.ModuleType('pycuda.driver')
+    drv.Context = types.SimpleNamespace(synchronize=lambda: None)     # computeSNR calls it before reading the spectrum
     comp = types.ModuleType('pycuda.compiler')
     comp.SourceModule = object
     pc.driver = drv
@@ -264,6 +290,157 @@ def g8_pn9(out):
     out['g8/pn9_300'] = np.asarray(PN9()).astype(np.int64)
 
 
+def g9_threshold(out):
+    """Demodulator.__thresholdInput (DB:670-707): two clipping rounds, gap filling below 100 samples."""
+    import demodulator.demodulator_base as db
+    fn = db.Demodulator._Demodulator__thresholdInput
+    rs = np.random.RandomState(21)
+    N = 1 << 12
+    cases = {'none': [], 'one': [(700, 5, 60.0)], 'close': [(500, 4, 80.0), (560, 3, 50.0), (1900, 6, 200.0)],
+             'far': [(300, 2, 90.0), (450, 2, 70.0), (3000, 8, 40.0)], 'loud': [(1000, 20, 5000.0), (1050, 1, 30.0)]}
+    for name, bursts in cases.items():
+        x = (rs.standard_normal(N) + 1j * rs.standard_normal(N)).astype(np.complex64)
+        for pos, ln, amp in bursts:
+            x[pos:pos + ln] *= amp
+        for scale in (4.5, 40.5):
+            s = types.SimpleNamespace(peakThresholdScale=scale, Nfft=N)
+            y = x.copy()
+            fn(s, y)
+            out[f'g9/{name}/s{scale}/in'] = x
+            out[f'g9/{name}/s{scale}/out'] = y
+            out[f'g9/{name}/s{scale}/clippedPeakIPure'] = np.asarray(s.clippedPeakIPure, dtype=np.int64)
+            out[f'g9/{name}/s{scale}/clippedPeakI'] = np.asarray(s.clippedPeakI, dtype=np.int64)
+
+
+def g10_snr(out):
+    """Demodulator.computeSNR (DB:635-667) on a numpy spectrum; bands that wrap around bin 0 included."""
+    import demodulator.demodulator_base as db
+    rs = np.random.RandomState(22)
+    N = 1 << 12
+    X = (rs.standard_normal(N) + 1j * rs.standard_normal(N)).astype(np.complex64)
+    X[1000:1040] *= 30
+    X[N - 8:] *= 12
+    X[:12] *= 12
+    shifts = np.array([990, 1010, 1030, N - 6, 4, 2046, 2050, 20], dtype=np.int32)
+    s = types.SimpleNamespace(doppCyperSymNorm=shifts, Nfft=N, GPU_bufSignalFreq_cpu_handle=X)
+    out['g10/X'] = X
+    out['g10/shifts'] = shifts
+    pairs = [(0, 1, 5), (1, 2, 5), (3, 4, 5), (5, 6, 5), (0, 0, 3), (7, 7, 5), (4, 7, 2)]
+    out['g10/pairs'] = np.array(pairs)
+    with np.errstate(all='ignore'):
+        out['g10/snr'] = np.array([db.Demodulator.computeSNR(s, lo, hi, w) for lo, hi, w in pairs], dtype=np.float64)
+
+
+def g11_flags(out, cases):
+    """Decoder.findFrames in FLAGS mode (DEC:122-243).  The bench plugin (128-bit header, 16-bit sync flag)
+    with packetEndDetectMode switched to FLAGS on the instance."""
+    import decoder as refdec
+    from protocol.protocolBase import PacketEndDetect
+    p = cases[0][1]
+    hdr = ((np.flipud(np.asarray(p.get_mask())) + 1) // 2).astype(np.float64)
+    flag = ((np.flipud(np.asarray(p.get_syncFlag())) + 1) // 2).astype(np.float64)
+    p.packetEndDetectMode = PacketEndDetect.FLAGS
+    try:
+        scen = {
+            # header, two flags behind it (the frame ends at the first, the reference needs a later one too)
+            'inside': dict(L=6000, hdr=[900], flags=[2500, 2900], cuts=[0, 6000]),
+            # header in call 0 without any flag; flags arrive in call 1
+            'across': dict(L=9000, hdr=[3800], flags=[5600, 6100], cuts=[0, 4500, 9000]),
+            # header, then silence for more than maxPacketLenBits = 8192 bits: forced end
+            'overflow': dict(L=16000, hdr=[700], flags=[], cuts=[0, 3000, 6000, 9000, 12000, 16000]),
+            # two frames in one call, the second one too short a tail (< 120 bits to its flag)
+            'two': dict(L=9000, hdr=[400, 4000], flags=[1500, 2100, 4090, 6000, 6600], cuts=[0, 9000]),
+        }
+        for name, sc in scen.items():
+            rs = np.random.RandomState(sum(map(ord, name)))
+            stream = np.zeros(sc['L'])
+            stream[rs.choice(sc['L'], sc['L'] // 10, replace=False)] = 1      # sparse background: no chance matches
+            for h in sc['hdr']:
+                stream[h:h + len(hdr)] = hdr
+            for f in sc['flags']:
+                stream[f:f + len(flag)] = flag
+            d = refdec.Decoder({}, p)
+            out[f'g11/{name}/stream'] = stream.astype(np.uint8)
+            out[f'g11/{name}/cuts'] = np.array(sc['cuts'])
+            for ci in range(len(sc['cuts']) - 1):
+                pk, bits, nsync = d.findFrames(stream[sc['cuts'][ci]:sc['cuts'][ci + 1]], 1000 * ci)
+                out[f'g11/{name}/call{ci}/numSyncSig'] = np.int64(nsync)
+                out[f'g11/{name}/call{ci}/npackets'] = np.int64(len(pk))
+                out[f'g11/{name}/call{ci}/pending'] = np.int64(-1 if d.headerFrameStartIdx is None else d.headerFrameStartIdx)
+                for i, q in enumerate(pk):
+                    out[f'g11/{name}/call{ci}/p{i}/bits'] = np.asarray(q.bits).astype(np.uint8)
+                    out[f'g11/{name}/call{ci}/p{i}/start'] = np.int64(q.frameStartIdx)
+                    out[f'g11/{name}/call{ci}/p{i}/maskBitErrors'] = np.float64(q.maskBitErrors)
+                    out[f'g11/{name}/call{ci}/p{i}/split'] = np.int64(q.frameSplitIdx)
+    finally:
+        del p.packetEndDetectMode      # back to the class attribute (FIXED)
+
+
+def g12_cc11xx_packet(out, cases):
+    """PacketCC11xx (CC11xx.py:216-300): length cut, de-whitening, the CRC flag as the reference computes it."""
+    from lib.shift_registers import PN9
+    p = cases[4][1]
+    pn9 = np.asarray(PN9()).astype(np.uint8)
+    crcf = sys.modules['crcmod'].mkCrcFun(0x18005, rev=False, initCrc=0xFFFF, xorOut=0)
+    rs = np.random.RandomState(31)
+    hdr = np.array([0xAA] * 4 + [0xD6, 0xBA, 0xD6, 0xBA], dtype=np.uint8)
+    frames = {}
+    # (a) the reference TX framer's layout: len = n + 2 counts the CRC
+    pay = rs.randint(0, 256, 10).astype(np.uint8)
+    body = np.r_[len(pay) + 2, pay].astype(np.uint8)
+    c = crcf(body.tobytes())
+    body = np.r_[body, c & 0xFF, c >> 8].astype(np.uint8)
+    frames['framer'] = np.r_[hdr, body ^ pn9[:len(body)], rs.randint(0, 256, 40).astype(np.uint8)]
+    # (b) hardware packet mode: len counts the payload only; CRC over [len | payload] follows, whitened
+    pay = rs.randint(0, 256, 17).astype(np.uint8)
+    body = np.r_[len(pay), pay].astype(np.uint8)
+    c = crcf(body.tobytes())
+    body = np.r_[body, c & 0xFF, c >> 8].astype(np.uint8)
+    frames['hardware'] = np.r_[hdr, body ^ pn9[:len(body)], rs.randint(0, 256, 40).astype(np.uint8)]
+    # (c) the layout for which the reference's own flag reads False: the two bytes behind the data are the
+    #     RAW (un-whitened) CRC of [len | data], low byte first
+    pay = rs.randint(0, 256, 9).astype(np.uint8)
+    body = np.r_[len(pay), pay].astype(np.uint8)
+    c = crcf(body.tobytes())
+    frames['rawcrc'] = np.r_[hdr, body ^ pn9[:len(body)], c & 0xFF, c >> 8, rs.randint(0, 256, 40).astype(np.uint8)].astype(np.uint8)
+    # (d) (c) with one payload bit flipped
+    bad = frames['rawcrc'].copy()
+    bad[12] ^= 0x10
+    frames['rawcrc_bad'] = bad
+    for name, fr in frames.items():
+        bits = np.unpackbits(fr.astype(np.uint8)).astype(np.float64)
+        pk = p.Packet(bits, 5, 1.0)
+        data, flag, again = pk.getBinaryData()
+        out[f'g12/{name}/bits_in'] = bits.astype(np.uint8)
+        out[f'g12/{name}/packetLen'] = np.int64(pk.packetLen)
+        out[f'g12/{name}/bits_cut'] = np.asarray(pk.bits).astype(np.uint8)
+        out[f'g12/{name}/data'] = np.asarray(data).astype(np.uint8)
+        out[f'g12/{name}/flag'] = np.bool_(flag)
+
+
+def g13_xcorr(out):
+    """lib.customXCorr on the streams the reference's own soft-combiner tests use, with the call shape of
+    softCombiner.py:701-706 (a zero-padded to the next power of two, b truncated to len(a))."""
+    from lib.customXCorr import customXCorr
+    z = np.load(os.path.join(REF, 'test', 'test_trustProcessor', 'bitData_test.npz'))
+    for tag, (ka, kb, cut) in {'r1_vs_d1': ('ddR1', 'dd1', 58834), 'r2_vs_d2_16k': ('ddR2', 'dd2', 16000),
+                               'r1_shifted': ('ddR1', 'ddR1', 20000)}.items():
+        a = np.asarray(z[ka], dtype=np.float64)[:cut]
+        b = np.asarray(z[kb], dtype=np.float64)
+        if tag == 'r1_shifted':
+            b = np.asarray(z[kb], dtype=np.float64)[1234:1234 + cut]
+        n = len(a)
+        nAdd = int(2 ** (np.ceil(np.log2(n))))
+        ax = np.r_[a, np.zeros(nAdd - n)]
+        r = customXCorr(ax, b[:n])
+        out[f'g13/{tag}/a'] = ax.astype(np.uint8)
+        out[f'g13/{tag}/b'] = b[:n].astype(np.uint8)
+        out[f'g13/{tag}/abs_c64'] = np.abs(r).astype(np.float32)
+        top = np.argsort(-np.abs(r), kind='stable')[:15]
+        out[f'g13/{tag}/top15_idx'] = top.astype(np.int64)
+        out[f'g13/{tag}/head'] = r[:64].astype(np.complex128)
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit('reference not mounted; fixtures can only be regenerated in the authoring container')
@@ -274,6 +451,11 @@ def main():
     g5_stimulus(out)
     g7_hostlogic(out, cases)
     g8_pn9(out)
+    g9_threshold(out)
+    g10_snr(out)
+    g11_flags(out, cases)
+    g12_cc11xx_packet(out, cases)
+    g13_xcorr(out)
     flat = {k.replace('/', '__'): v for k, v in out.items()}
     path = os.path.join(HERE, 'ref_goldens.npz')
     np.savez_compressed(path, **flat)

@@ -216,6 +216,7 @@ def test_cc11xx_frame_received_and_crc_ok():
     bs, sps = 17, 128
     conf = cfg.cc11xx_config(blockSize=bs, doppCarrierSteps=64, samplesPerSym=sps)
     p = loadProtocol('CC11xx')(conf=conf)
+    p.CRC_CHECK = 'framer'        # the stimulus is a TX-framer frame: CRC inside the length-counted bytes
     run = DemodulatorRunner(conf, p, 'UHF-H')
     payload = np.arange(1, 41, dtype=np.uint8)
     sig = _cc11xx_stimulus(bs, sps, payload)

@@ -1,0 +1,113 @@
+"""Host functions pinned by fixtures recorded from the importable numpy parts of the reference
+(tests/golden/make_golden.py, G9-G13): peak clipping, SNR estimate, FLAGS-mode packet search, CC11xx
+packet parsing, and the soft combiner's alignment cross-correlation (oracle restatement)."""
+import types
+
+import numpy as np
+import pytest
+
+from oracle import mfbank_oracle as orc
+from pycusdr_amd import config as cfg
+from pycusdr_amd.decoder import Decoder
+from pycusdr_amd.demodulator.demodulator_base import Demodulator
+from pycusdr_amd.protocol import PacketEndDetect, loadProtocol
+
+G9_CASES = [(n, s) for n in ('none', 'one', 'close', 'far', 'loud') for s in (4.5, 40.5)]
+
+
+@pytest.mark.parametrize('name,scale', G9_CASES)
+def test_threshold_input_matches_reference(goldens, name, scale):
+    """_thresholdInput == the reference's Demodulator.__thresholdInput (DB:670-707): clipped samples,
+    clippedPeakIPure, clippedPeakI (gaps below 100 samples filled, larger gaps kept)."""
+    k = f'g9/{name}/s{scale}'
+    s = types.SimpleNamespace(peakThresholdScale=scale, Nfft=len(goldens[k + '/in']))
+    y = goldens[k + '/in'].copy()
+    Demodulator._thresholdInput(s, y)
+    assert np.array_equal(y, goldens[k + '/out'])
+    assert np.array_equal(np.asarray(s.clippedPeakIPure), goldens[k + '/clippedPeakIPure'])
+    assert np.array_equal(np.asarray(s.clippedPeakI), goldens[k + '/clippedPeakI'])
+
+
+def test_compute_snr_matches_reference(goldens):
+    """computeSNR == the reference's (DB:635-667), signal or noise band wrapping around bin 0 included; the
+    spectrum windows come through the same get_spectrum(start, count) call the HIP path serves."""
+    X, shifts = goldens['g10/X'], goldens['g10/shifts']
+    N = len(X)
+    bank = types.SimpleNamespace(get_spectrum=lambda start, count: X[(start + np.arange(count)) % N])
+    s = types.SimpleNamespace(doppCyperSymNorm=shifts, Nfft=N, bank=bank)
+    s._spectrum_slice = lambda a, b: Demodulator._spectrum_slice(s, a, b)
+    got = np.array([Demodulator.computeSNR(s, int(lo), int(hi), int(w)) for lo, hi, w in goldens['g10/pairs']])
+    assert np.array_equal(np.isnan(got), np.isnan(goldens['g10/snr']))
+    ok = ~np.isnan(got)
+    assert np.allclose(got[ok], goldens['g10/snr'][ok], rtol=1e-6, atol=1e-6)
+    # and the oracle's statement of the same function
+    ref = np.array([orc.compute_snr(X, shifts, int(lo), int(hi), int(w), N) for lo, hi, w in goldens['g10/pairs']])
+    assert np.allclose(ref[ok], goldens['g10/snr'][ok], rtol=1e-6, atol=1e-6)
+
+
+def run_flags_kat(goldens, name, correlator):
+    p = loadProtocol('bench_GMSK')(conf=cfg.bench_config())
+    p.packetEndDetectMode = PacketEndDetect.FLAGS
+    d = Decoder({}, p, correlator=correlator)
+    stream = goldens[f'g11/{name}/stream'].astype(np.float64)
+    cuts = goldens[f'g11/{name}/cuts']
+    seen = 0
+    for ci in range(len(cuts) - 1):
+        packets, bits, nsync = d.findFrames(stream[cuts[ci]:cuts[ci + 1]], 1000 * ci)
+        k = f'g11/{name}/call{ci}'
+        assert nsync == int(goldens[k + '/numSyncSig'])
+        assert len(packets) == int(goldens[k + '/npackets'])
+        assert (-1 if d.headerFrameStartIdx is None else d.headerFrameStartIdx) == int(goldens[k + '/pending'])
+        for i, q in enumerate(packets):
+            assert np.array_equal(np.asarray(q.bits).astype(np.uint8), goldens[k + f'/p{i}/bits'])
+            assert q.frameStartIdx == int(goldens[k + f'/p{i}/start'])
+            assert q.maskBitErrors == float(goldens[k + f'/p{i}/maskBitErrors'])
+            assert q.frameSplitIdx == int(goldens[k + f'/p{i}/split'])
+            seen += 1
+    return seen
+
+
+@pytest.mark.parametrize('name', ['inside', 'across', 'overflow', 'two'])
+def test_flags_mode_findframes_matches_reference(goldens, name):
+    """FLAGS-mode packet search (DEC:122-243): frame inside one call, across calls (frameSplitIdx), forced end
+    past maxPacketLenBits, two frames in one call."""
+    assert run_flags_kat(goldens, name, orc.sync_correlate) >= 1
+
+
+@pytest.mark.parametrize('name', ['framer', 'hardware', 'rawcrc', 'rawcrc_bad'])
+def test_cc11xx_packet_matches_reference(goldens, name):
+    """PacketCC11xx: length byte, cut, PN9 de-whitening and -- by default -- the reference's CRC flag, bit for
+    bit (CC11xx.py:226-300).  The flag of the reference reads 'no error' only for a frame whose two bytes behind
+    the data are the RAW crc16([len | data]); frames of its own TX framer and hardware-mode frames both read
+    'error'.  CRC_CHECK = 'framer' is the opt-in check at the framer's CRC position."""
+    p = loadProtocol('CC11xx')(conf=cfg.cc11xx_config())
+    k = f'g12/{name}'
+    pk = p.Packet(goldens[k + '/bits_in'].astype(np.float64), 5, 1.0)
+    assert int(pk.packetLen) == int(goldens[k + '/packetLen'])
+    assert np.array_equal(np.asarray(pk.bits).astype(np.uint8), goldens[k + '/bits_cut'])
+    data, flag, again = pk.getBinaryData()
+    assert np.array_equal(data, goldens[k + '/data']) and bool(flag) == bool(goldens[k + '/flag'])
+    p.CRC_CHECK = 'framer'
+    data2, err, _ = p.Packet(goldens[k + '/bits_in'].astype(np.float64), 5, 1.0).getBinaryData()
+    assert np.array_equal(data2, data)
+    assert bool(err) == (name != 'framer')      # only the TX framer's layout carries its CRC inside the counted bytes
+
+
+def test_cc11xx_gfsk2_flavour_selectable(goldens):
+    """The reference's modIDX = 1 build (CC11xx over GFSK2, CC11xx.py:30-32,42) is a registry entry here; its
+    filter bank is GFSK2.get_filter (pinned by G1 'GFSK2_sps16'), the framing is shared."""
+    p = loadProtocol('CC11xx_GFSK2')(conf=cfg.cc11xx_config())
+    M, bank = p.get_filter(1 << 10, 16, 3)
+    assert M == 8 and np.array_equal(bank, goldens['g1/GFSK2_sps16/bank_n1024'])
+    q = loadProtocol('CC11xx')(conf=cfg.cc11xx_config())
+    assert np.array_equal(p.get_mask(), q.get_mask()) and p.packetLen == q.packetLen and p.name == 'CC11xx GFSK-2'
+
+
+@pytest.mark.parametrize('tag', ['r1_vs_d1', 'r2_vs_d2_16k', 'r1_shifted'])
+def test_oracle_custom_xcorr_matches_reference(goldens, tag):
+    """oracle.custom_xcorr == lib.customXCorr.customXCorr on the reference's own soft-combiner test streams."""
+    a, b = goldens[f'g13/{tag}/a'].astype(np.float64), goldens[f'g13/{tag}/b'].astype(np.float64)
+    r = orc.custom_xcorr(a, b)
+    assert np.allclose(r[:64], goldens[f'g13/{tag}/head'], rtol=1e-12, atol=1e-9)
+    assert np.allclose(np.abs(r), goldens[f'g13/{tag}/abs_c64'], rtol=1e-5, atol=1e-3)
+    assert np.array_equal(np.argsort(-np.abs(r), kind='stable')[:3], goldens[f'g13/{tag}/top15_idx'][:3])

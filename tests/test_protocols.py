@@ -121,6 +121,7 @@ def test_cc11xx_pn9_crc_and_framing(goldens):
     assert np.array_equal(np.packbits(bits[:64]), [0xAA] * 4 + [0xD6, 0xBA, 0xD6, 0xBA])
     assert np.packbits(bits[64:72])[0] == (22 ^ 0xFF)     # whitened length byte
     p = loadProtocol('CC11xx')(conf=CCONF)
+    p.CRC_CHECK = 'framer'        # opt-in: check the CRC where the TX framer puts it (default = the reference's flag, G12)
     pk = p.Packet(np.r_[bits, np.zeros(64, np.uint8)].astype(np.float64), 0, 0)
     data, err, _ = pk.getBinaryData()
     assert pk.packetLen == 22 and not err and np.array_equal(data[:-2], payload)
