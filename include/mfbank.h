@@ -94,6 +94,10 @@ int mfb_set_search_path(mfb_ctx *ctx, int path, int log2L, int wg_per_cu, int fi
  * support), valid outputs per segment and number of segments (0 on the two-pass path).  Any pointer
  * may be NULL. */
 int mfb_get_search_path(mfb_ctx *ctx, int *path, int *log2L, int *taps, int *valid_per_segment, int *segments);
+/* Fault injection for tests: the nth device allocation made on behalf of a handle by the calling thread
+ * from now on fails as if the device were out of memory (0 disarms).  Lets a test walk the free-on-error
+ * path of mfb_create allocation by allocation. */
+int mfb_debug_fail_alloc(int nth);
 /* Host-only helper (no device work): common circular support window [start, start+len) of the impulse
  * responses ifft(H_m) of a filter bank complex64 [M][N]; len == N when some filter has no short support.
  * This is the analysis mfb_set_filters runs; exported so it can be checked without a GPU. */

@@ -727,6 +727,22 @@ struct mfb_ctx {
         }                                                                                    \
     } while (0)
 
+// Device allocations of a handle go through dev_alloc so that a test can make the n-th one fail
+// (mfb_debug_fail_alloc): the only way to exercise the free-on-error path of mfb_create without driving
+// a 288 GB device out of memory.
+static thread_local int g_fail_alloc_countdown = 0;
+static hipError_t dev_alloc(void **p, size_t bytes) {
+    if (g_fail_alloc_countdown > 0 && --g_fail_alloc_countdown == 0) {
+        *p = nullptr;
+        return hipErrorOutOfMemory;
+    }
+    return hipMalloc(p, bytes);
+}
+extern "C" int mfb_debug_fail_alloc(int nth) {
+    g_fail_alloc_countdown = nth > 0 ? nth : 0;
+    return MFB_OK;
+}
+
 extern "C" const char *mfb_strerror(int s) {
     switch (s) {
         case MFB_OK: return "ok";
@@ -750,7 +766,7 @@ static void make_twiddles(std::vector<cf> &v, int count, double denom, double st
 }
 
 static int upload_tw(cf **dst, const std::vector<cf> &v) {
-    HIPCHK(hipMalloc((void **)dst, v.size() * sizeof(cf)));
+    HIPCHK(dev_alloc((void **)dst, v.size() * sizeof(cf)));
     HIPCHK(hipMemcpy(*dst, v.data(), v.size() * sizeof(cf), hipMemcpyHostToDevice));
     return MFB_OK;
 }
@@ -793,7 +809,7 @@ static int alloc_Z(mfb_ctx *c) {
         c->d_Z = nullptr;
         c->z_rows = 0;
     }
-    HIPCHK(hipMalloc((void **)&c->d_Z, need * c->N * sizeof(cf)));
+    HIPCHK(dev_alloc((void **)&c->d_Z, need * c->N * sizeof(cf)));
     c->z_rows = need;
     return MFB_OK;
 }
@@ -806,7 +822,7 @@ static int reserve_partials(mfb_ctx *c, size_t floats) {
         c->d_part = nullptr;
         c->part_cap = 0;
     }
-    HIPCHK(hipMalloc((void **)&c->d_part, floats * sizeof(float)));
+    HIPCHK(dev_alloc((void **)&c->d_part, floats * sizeof(float)));
     c->part_cap = floats;
     return MFB_OK;
 }
@@ -884,24 +900,24 @@ static int create_impl(mfb_ctx *c) {
     const size_t nb = (size_t)c->N * sizeof(cf);
     HIPCHK(hipHostMalloc((void **)&c->h_in, nb, hipHostMallocDefault));
     memset(c->h_in, 0, nb);
-    HIPCHK(hipMalloc((void **)&c->d_x, nb));
-    HIPCHK(hipMalloc((void **)&c->d_X, nb));
-    HIPCHK(hipMalloc((void **)&c->d_masks, nb * M));
-    HIPCHK(hipMalloc((void **)&c->d_xc, nb * M));
-    HIPCHK(hipMalloc((void **)&c->d_P, nb));
-    HIPCHK(hipMalloc((void **)&c->d_env, (size_t)c->N * sizeof(float)));
-    HIPCHK(hipMalloc((void **)&c->d_shifts, (size_t)c->Dtot * sizeof(int)));
+    HIPCHK(dev_alloc((void **)&c->d_x, nb));
+    HIPCHK(dev_alloc((void **)&c->d_X, nb));
+    HIPCHK(dev_alloc((void **)&c->d_masks, nb * M));
+    HIPCHK(dev_alloc((void **)&c->d_xc, nb * M));
+    HIPCHK(dev_alloc((void **)&c->d_P, nb));
+    HIPCHK(dev_alloc((void **)&c->d_env, (size_t)c->N * sizeof(float)));
+    HIPCHK(dev_alloc((void **)&c->d_shifts, (size_t)c->Dtot * sizeof(int)));
     if ((rc = reserve_partials(c, (size_t)c->Dtot * M * c->N1))) return rc;
-    HIPCHK(hipMalloc((void **)&c->d_sum, (size_t)c->Dtot * M * sizeof(float)));
+    HIPCHK(dev_alloc((void **)&c->d_sum, (size_t)c->Dtot * M * sizeof(float)));
     HIPCHK(hipMemset(c->d_sum, 0, (size_t)c->Dtot * M * sizeof(float)));
-    HIPCHK(hipMalloc((void **)&c->d_res, 2 * sizeof(float)));
-    HIPCHK(hipMalloc((void **)&c->d_uniq, (size_t)M * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&c->d_rep, (size_t)M * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&c->d_cr, 3 * sizeof(float)));
+    HIPCHK(dev_alloc((void **)&c->d_res, 2 * sizeof(float)));
+    HIPCHK(dev_alloc((void **)&c->d_uniq, (size_t)M * sizeof(int)));
+    HIPCHK(dev_alloc((void **)&c->d_rep, (size_t)M * sizeof(int)));
+    HIPCHK(dev_alloc((void **)&c->d_cr, 3 * sizeof(float)));
     c->cap = c->N / 2;  // symbols never shorter than 2 samples
-    HIPCHK(hipMalloc((void **)&c->d_sym, (size_t)c->cap * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&c->d_cen, (size_t)c->cap * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&c->d_mag, (size_t)c->cap * sizeof(float)));
+    HIPCHK(dev_alloc((void **)&c->d_sym, (size_t)c->cap * sizeof(int)));
+    HIPCHK(dev_alloc((void **)&c->d_cen, (size_t)c->cap * sizeof(int)));
+    HIPCHK(dev_alloc((void **)&c->d_mag, (size_t)c->cap * sizeof(float)));
     // one row for the plain forward transforms; the search's share is sized when the filters arrive
     if ((rc = alloc_Z(c))) return rc;
 
@@ -1091,7 +1107,7 @@ static int resolve_path(mfb_ctx *c) {
             taps::segment_spectra(*c->bank, L, L - seg_valid(l, T) + 1, &G);
             if (c->d_G) HIPCHK(hipFree(c->d_G));
             c->d_G = nullptr;
-            HIPCHK(hipMalloc((void **)&c->d_G, G.size() * sizeof(float)));
+            HIPCHK(dev_alloc((void **)&c->d_G, G.size() * sizeof(float)));
             HIPCHK(hipMemcpy(c->d_G, G.data(), G.size() * sizeof(float), hipMemcpyHostToDevice));
             if (c->twL_len != L) {
                 if (c->d_twL) HIPCHK(hipFree(c->d_twL));

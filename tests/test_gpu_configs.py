@@ -1,0 +1,209 @@
+"""BASELINE.json configurations at their own workload: C5 (two concurrent demodulator instances, 512 bins
+each, N=2^20; both handles in one process and as two processes on one device), C3 (1024 bins, real GMSK bank,
+widened Doppler span), the multi-GPU sharded search (runs when >= 2 devices are visible), and the C-ABI's
+resource handling (failed creation leaks nothing, concurrent sync-correlator calls)."""
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import mfbank_oracle as orc
+from pycusdr_amd import config as cfg, signals as sg
+from pycusdr_amd.mfbank import MFBank, sync_correlate, sync_find
+from pycusdr_amd.protocol import loadProtocol
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ok(res, name):
+    assert res['parseval'] < 1e-5, (name, res)           # north_star tolerance on magnitudes, all 512 bins
+    assert res['real'] < 1e-5, (name, res)                # real oracle IFFTs on a sample of bins
+    assert res['pick_exact'] and res['zeros_ok'], (name, res)
+    assert res['carrier_err_bins'] <= 1.0, (name, res)    # the carrier sits where the stimulus puts it
+
+
+def test_c5_two_instances_one_process():
+    """C5: CC11xx FSK-2 (sps 128, M=8) and BPSK (M=32, 16 unique up to sign), D=512 each, N=2^20, matching
+    stimuli, both handles alive and used alternately."""
+    from c5_common import c5_instance, check_instance
+    a = c5_instance('CC11xx', 20, 512)
+    b = c5_instance('bench_BPSK', 20, 512)
+    ba = MFBank(20, 512, a['M'])
+    bb = MFBank(20, 512, b['M'])
+    try:
+        ba.set_filters(a['masks'])
+        bb.set_filters(b['masks'])
+        ba.set_shifts(a['shifts'])
+        bb.set_shifts(b['shifts'])
+        assert ba.get_search_path()['path'] == 'segment' and ba.get_search_path()['taps'] == 384
+        assert bb.get_search_path()['path'] == 'segment' and bb.get_search_path()['taps'] == 80 and bb.get_info()[2] == 16
+        ba.upload(a['x'])
+        bb.upload(b['x'])
+        ia = ba.find_carrier()
+        ib = bb.find_carrier()
+        ra = check_instance(ba, a)
+        rb = check_instance(bb, b)
+        assert float(ia[0]) == ra['idx'] and float(ib[0]) == rb['idx']      # interleaving changes nothing
+    finally:
+        ba.close()
+        bb.close()
+    _ok(ra, 'CC11xx')
+    _ok(rb, 'bench_BPSK')
+
+
+def test_c5_two_processes_one_device():
+    """C5 as the reference deploys it: one OS process (and device context) per demodulator instance, both on
+    the same device at the same time."""
+    child = os.path.join(ROOT, 'tests', 'children', 'c5_child.py')
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, child, name, '20', '512', '6'], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              env=env, text=True) for name in ('CC11xx', 'bench_BPSK')]
+    outs = [p.communicate(timeout=500) for p in procs]
+    for p, (so, se), name in zip(procs, outs, ('CC11xx', 'bench_BPSK')):
+        assert p.returncode == 0, se[-2000:]
+        res = json.loads(so.strip().splitlines()[-1])
+        _ok(res, name)
+        assert res['picks_equal'] and res['path']['path'] == 'segment'
+
+
+@pytest.mark.parametrize('path', ['segment', 'twopass'])
+def test_c3_1024_bins_gmsk_bank(path):
+    """C3: D=1024 at N=2^20 with the real GMSK bank and the Doppler span widened until the 1024 shifts are
+    distinct, S1 stimulus; both search paths."""
+    from bench import widen_range_rate
+    log2N, D = 20, 1024
+    N = 1 << log2N
+    conf = cfg.bench_config('bench_GMSK', blockSize=log2N, doppCarrierSteps=D)
+    rr, shifts = widen_range_rate(conf, 'UHF-H', N, D)
+    assert len(np.unique(shifts)) == D
+    M, masks = loadProtocol('bench_GMSK')(conf=conf).get_filter(N, 16, 3)
+    x = sg.s1_stream(1, N, 1 << 10, 'GMSK', snr_db=10.0, seed=1)[:N]
+    bank = MFBank(log2N, D, M)
+    try:
+        bank.set_filters(masks)
+        bank.set_shifts(shifts)
+        bank.set_search_path(path)
+        bank.upload(x)
+        idx, metric = bank.find_carrier()
+        ds = bank.get_scores()
+        X = bank.get_spectrum()
+    finally:
+        bank.close()
+    pv = orc.doppler_scores_parseval(X, masks, shifts)
+    assert np.abs(ds[:, 0] - pv).max() / pv.max() < 1e-5
+    sel = [0, 1, 300, 511, 512, 1023]
+    ref = orc.doppler_scores(X, masks, shifts[sel], True)[:, 0]
+    assert np.abs(ds[sel, 0] - ref).max() / ref.max() < 1e-5
+    oidx, _ = orc.find_doppler_est(ds, D, 0, True)
+    assert idx == oidx
+    pick = orc.interpolate_doppler(idx, shifts, np.zeros(D))
+    assert abs(pick['dopplerIdxlast'] - N // 4) <= np.median(np.diff(np.sort(shifts)))
+
+
+def test_multi_gpu_sharded_pick_equals_unsharded():
+    """Sharded search on every visible GPU (one fresh process per rank via torch.distributed.run, RCCL):
+    broadcast of rank 0's block, search, one all-reduce, pick -- equal, bit for bit, to the unsharded search;
+    the demodulation stage runs on the owner rank only."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip('needs >= 2 GPUs (the driver runs it on the 8-GPU node)')
+    n = min(n, 4)
+    child = os.path.join(ROOT, 'tests', 'children', 'dist_child.py')
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', '29577', child, 'nccl']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = [json.loads(line) for line in r.stdout.splitlines() if line.startswith('{')]
+    assert len(res) == n and all(q['ok'] for q in res), res
+
+
+def test_failed_create_frees_everything():
+    """mfb_create that fails at ANY of its allocations must hand back every byte it took -- the caller gets no
+    handle to destroy (reference teardown DB:517-530).  mfb_debug_fail_alloc makes the n-th allocation fail."""
+    import torch
+    from pycusdr_amd import _lib
+    lib = _lib.load()
+    MFBank(14, 8, 4).close()                 # code objects, context: resident before the baseline is read
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    failed = 0
+    for nth in range(1, 40):
+        lib.mfb_debug_fail_alloc(nth)
+        try:
+            MFBank(18, 64, 8).close()        # past the last allocation: creation succeeds
+            break
+        except MemoryError:
+            failed += 1
+        finally:
+            lib.mfb_debug_fail_alloc(0)
+    assert failed >= 15                      # every buffer of the handle was walked
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert abs(free0 - free1) < (32 << 20), (free0, free1)
+    # the same walk through mfb_set_filters (segment spectra, intermediate): a failed call leaves a usable handle
+    rs = np.random.RandomState(1)
+    bank = MFBank(14, 4, 2)
+    masks = (rs.standard_normal((2, 1 << 14)) + 1j * rs.standard_normal((2, 1 << 14))).astype(np.complex64)
+    lib.mfb_debug_fail_alloc(1)
+    with pytest.raises(MemoryError):
+        bank.set_filters(masks)
+    lib.mfb_debug_fail_alloc(0)
+    bank.set_filters(masks)
+    bank.set_shifts([1, 2, 3, 4])
+    bank.upload(masks[0])
+    bank.find_carrier()
+    bank.close()
+
+
+def test_two_handles_and_concurrent_sync_calls():
+    """Two handles on one device used from two threads, each interleaving searches with sync-correlator
+    calls: per-call workspaces and streams, results equal to the single-threaded ones."""
+    rs = np.random.RandomState(8)
+    log2N, D, M = 14, 9, 4
+    N = 1 << log2N
+    jobs = []
+    for t in range(2):
+        masks = (rs.standard_normal((M, N)) + 1j * rs.standard_normal((M, N))).astype(np.complex64)
+        x = (rs.standard_normal(N) + 1j * rs.standard_normal(N)).astype(np.complex64)
+        shifts = rs.randint(0, N, D).astype(np.int32)
+        bits = rs.randint(0, 2, (64, 30000 + 777 * t)).astype(np.uint8)
+        tmpl = (2 * rs.randint(0, 2, 64) - 1).astype(np.int8)
+        jobs.append((masks, x, shifts, bits, tmpl))
+    expect = []
+    for masks, x, shifts, bits, tmpl in jobs:
+        X = orc.forward_fft(x)
+        expect.append((orc.doppler_scores(X, masks, shifts, True), np.stack([np.convolve(b.astype(np.int64), tmpl) for b in bits])))
+    errors = []
+
+    def work(t):
+        try:
+            masks, x, shifts, bits, tmpl = jobs[t]
+            bank = MFBank(log2N, D, M)
+            bank.set_filters(masks)
+            bank.set_shifts(shifts)
+            for _ in range(6):
+                bank.upload(x)
+                bank.find_carrier()
+                ds = bank.get_scores()
+                sc = sync_correlate(bits, tmpl)
+                hits = sync_find(bits, tmpl, 20)
+                assert np.abs(ds - expect[t][0]).max() / expect[t][0].max() < 1e-5
+                assert np.array_equal(sc, expect[t][1])
+                for b in range(0, 64, 13):
+                    assert np.array_equal(hits[b][0], np.where(expect[t][1][b] >= 20)[0])
+            bank.close()
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors

@@ -62,3 +62,34 @@ def test_sync_find_equals_where_of_convolve():
     i1, s1 = sync_find(bits[0], tmpl, 3.5)                   # 1-D input, fractional threshold
     ref = orc.sync_correlate(bits[0], tmpl)
     assert np.array_equal(i1, np.where(ref >= 3.5)[0]) and np.array_equal(s1, ref[ref >= 3.5])
+
+
+@pytest.mark.parametrize('name', ['inside', 'across', 'overflow', 'two'])
+def test_flags_mode_kats_on_hip_correlator(goldens, name):
+    """The reference's FLAGS-mode findFrames KATs (fixture G11) with both correlations on the GPU."""
+    from test_pins_round2 import run_flags_kat
+    assert run_flags_kat(goldens, name, None) >= 1
+
+
+@pytest.mark.parametrize('tag', ['r1_vs_d1', 'r2_vs_d2_16k', 'r1_shifted'])
+def test_custom_xcorr_on_hip_matches_reference(goldens, tag):
+    """N4: the soft combiner's alignment cross-correlation on the HIP transforms (mfb_xcorr) against the
+    fixture recorded from the reference's customXCorr on its own unit-test streams: peak index exact,
+    magnitudes within 1e-5 of the peak, complex values against the oracle restatement."""
+    from oracle import mfbank_oracle as orc
+    from pycusdr_amd.mfbank import customXCorr
+    a, b = goldens[f'g13/{tag}/a'].astype(np.float64), goldens[f'g13/{tag}/b'].astype(np.float64)
+    r = customXCorr(a, b)
+    assert r.dtype == np.complex64 and len(r) == len(a)
+    mag = np.abs(r)
+    ref = goldens[f'g13/{tag}/abs_c64']
+    assert int(np.argmax(mag)) == int(goldens[f'g13/{tag}/top15_idx'][0])
+    assert np.abs(mag - ref).max() / ref.max() < 1e-5
+    full = orc.custom_xcorr(a, b)
+    assert np.abs(r - full).max() / np.abs(full).max() < 1e-5
+    # N given explicitly, b longer than N (fft truncates), and a non-power-of-two N refused
+    r2 = customXCorr(a[:5000], b, N=4096)
+    f2 = orc.custom_xcorr(a[:5000], b, 4096)
+    assert np.abs(r2 - f2).max() / np.abs(f2).max() < 1e-5
+    with pytest.raises(ValueError):
+        customXCorr(a, b, N=5000)

@@ -48,7 +48,7 @@ def test_compute_snr_matches_reference(goldens):
 def run_flags_kat(goldens, name, correlator):
     p = loadProtocol('bench_GMSK')(conf=cfg.bench_config())
     p.packetEndDetectMode = PacketEndDetect.FLAGS
-    d = Decoder({}, p, correlator=correlator)
+    d = Decoder({}, p, correlator=correlator) if correlator is not None else Decoder({}, p)     # None: the HIP correlator
     stream = goldens[f'g11/{name}/stream'].astype(np.float64)
     cuts = goldens[f'g11/{name}/cuts']
     seen = 0
