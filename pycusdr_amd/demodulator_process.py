@@ -71,11 +71,15 @@ class DemodulatorRunner:
         raw = self.raw
         raw[self.overlap:] = new_samples
         stamp = time.time()
+        # every key of the reference's result dict (DP:259-276), including the two it initialises and never
+        # updates ('rangerateEst', 'baudRate_est': its loop writes 'rangerate' and 'baudrate_est' instead, DP:299,303)
         data = {'workerId': self.workerId, 'count': self.count, 'timestamp': stamp, 'voteGroup': self.voteGroup,
-                'baudRate': self.baudRate, 'sample_rate': self.Fs, 'protocol': self.decoderProtocol}
+                'doppler': 0, 'doppler_std': 0, 'data': np.array([]), 'trust': np.array([]), 'spSymEst': 0, 'SNR': float(0),
+                'rangerateEst': 0, 'baudRate': self.baudRate, 'baudRate_est': 0, 'sample_rate': self.Fs,
+                'protocol': self.decoderProtocol}
         data['doppler'], data['doppler_std'], _, data['SNR'] = self.demod.uploadAndFindCarrier(raw)
         data['data'], centres, data['trust'], data['spSymEst'] = self.demod.demodulate()
-        data['baudrate_est'] = self.Fs / data['spSymEst']
+        data['baudrate_est'] = self.Fs / data['spSymEst'] if data['spSymEst'] else 0.0
         # range rate implied by the measured frequency offset (reference computeTxFreqOffset, DP:359-379)
         fc = self.confRadio['frequency_Hz']
         data['rangerate'] = -data['doppler'] / fc * 299792458.0
@@ -87,6 +91,21 @@ class DemodulatorRunner:
         raw[:self.overlap] = raw[-self.overlap:]      # overlap carry for the next block
         self.count += 1
         return data
+
+    def run_stream(self, chunk_source, sink=None, decoder=None):
+        """The reference's loop shape (DP:284-338): chunks of ANY size (GNU Radio ~4096 samples, the BER bench
+        2^14) go through a SigFIFO that hands out blocks of blockSize - overlap new samples; ends when the
+        chunk source is exhausted."""
+        from .sigFIFO import SigFIFO
+        fifo = SigFIFO(chunk_source, self.samplesPerSlice)
+
+        def blocks():
+            while True:
+                try:
+                    yield fifo.getBlock()
+                except TimeoutError:
+                    return
+        return self.run(blocks(), sink=sink, decoder=decoder)
 
     def run(self, sample_source, sink=None, decoder=None):
         """Drive the loop over an iterable of new-sample slices.  With a ``decoder`` every block's

@@ -20,6 +20,7 @@ What is captured (SURVEY.md section 8c, G1..G5 + host-logic KATs):
   G11 FLAGS-mode decoder      Decoder.findFrames with packetEndDetectMode = FLAGS (frame inside one call,
                               across calls, overflow past maxPacketLenBits)
   G12 CC11xx packet parsing   PacketCC11xx: length cut, PN9 de-whitening, CRC flag
+  G14 ring buffer             sigFIFO.RingBuffer insert / popBlock traces (zmq stubbed: the class is pure numpy)
   G13 bit-stream alignment    lib.customXCorr.customXCorr on the reference's own unit-test streams
                               (test/test_trustProcessor/bitData_test.npz) -- next-scope row N4
 
@@ -79,6 +80,7 @@ def _install_shims():
     sys.modules['pycuda'] = pc
     sys.modules['pycuda.driver'] = drv
     sys.modules['pycuda.compiler'] = comp
+    sys.modules['zmq'] = types.ModuleType('zmq')      # sigFIFO imports it at module level; RingBuffer never touches it
     sys.path.insert(0, os.path.join(REF, 'pyCuSDR'))
     sys.path.insert(0, os.path.join(REF, 'examples', 'benchmark'))
     # lib/cufft.py raises OSError at import when libcufft is absent (lib/cufft.py:45-46); give the
@@ -441,6 +443,45 @@ def g13_xcorr(out):
         out[f'g13/{tag}/head'] = r[:64].astype(np.complex128)
 
 
+def g14_ringbuffer(out):
+    """sigFIFO.RingBuffer (sigFIFO.py:13-103) driven by a seeded trace of inserts and pops: chunk sizes that
+    divide nothing, wrap-around of head and tail, pops while too little is buffered, the overflow flush."""
+    import sigFIFO as ref
+    rs = np.random.RandomState(41)
+    for name, (outLen, bufLen, chunks) in {'grc': (15360, 30720, [4095, 4096] * 12), 'bench': (15360, 30720, [16384] * 6),
+                                            'odd': (1000, 2500, list(rs.randint(1, 900, 40))),
+                                            'tight': (1000, 2000, [900, 900, 900, 300, 700])}.items():
+        rb = ref.RingBuffer(outLen, bufLen=bufLen, dtype=np.complex64)
+        sizes, popped, state = [], [], []
+        v = 0
+        for n in chunks:
+            n = int(n)
+            data = (np.arange(v, v + n) + 1j * (np.arange(v, v + n) % 7)).astype(np.complex64)
+            v += n
+            sizes.append(rb.insert(data))
+            blk = rb.popBlock(outLen)
+            popped.append(np.array(blk, dtype=np.complex64).copy() if len(blk) else np.empty(0, np.complex64))
+            state.append((rb.headIdx, rb.tailIdx, rb.currentBufSize))
+        out[f'g14/{name}/outLen'] = np.int64(outLen)
+        out[f'g14/{name}/bufLen'] = np.int64(bufLen)
+        out[f'g14/{name}/chunks'] = np.array(chunks, dtype=np.int64)
+        out[f'g14/{name}/sizes'] = np.array(sizes, dtype=np.int64)
+        out[f'g14/{name}/state'] = np.array(state, dtype=np.int64)
+        out[f'g14/{name}/npop'] = np.array([len(q) for q in popped], dtype=np.int64)
+        out[f'g14/{name}/popped'] = np.concatenate(popped) if popped else np.empty(0, np.complex64)
+    # overflow: the reference logs 'buffer full: Flush', flushes -- and then stores with the end index it computed
+    # BEFORE the flush (sigFIFO.py:49-65), which raises ValueError.  Recorded as a fact, not reproduced.
+    rb = ref.RingBuffer(1900, bufLen=2000, dtype=np.complex64)
+    rb.insert(np.zeros(900, np.complex64))
+    rb.insert(np.zeros(900, np.complex64))
+    try:
+        rb.insert(np.zeros(900, np.complex64))
+        raised = False
+    except ValueError:
+        raised = True
+    out['g14/overflow_raises_in_reference'] = np.bool_(raised)
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit('reference not mounted; fixtures can only be regenerated in the authoring container')
@@ -456,6 +497,7 @@ def main():
     g11_flags(out, cases)
     g12_cc11xx_packet(out, cases)
     g13_xcorr(out)
+    g14_ringbuffer(out)
     flat = {k.replace('/', '__'): v for k, v in out.items()}
     path = os.path.join(HERE, 'ref_goldens.npz')
     np.savez_compressed(path, **flat)

@@ -196,6 +196,21 @@ def test_streaming_runner_on_oracle_backend(oracle_backend):
     d = seen[1]
     assert d['voteGroup'] == 0 and d['protocol'] == 'UHF' and d['sample_rate'] == 153600 and abs(d['spSymEst'] - 16) < 0.1
     assert abs(d['doppler']) < 50 and d['rate_ksps'] > 0
+    # every key of the reference's result dict (DP:259-276 + the two its loop adds), and it survives the pickle
+    # round trip of demodOut.send_pyobj (DP:309)
+    import pickle
+    for key in ('workerId', 'count', 'timestamp', 'voteGroup', 'doppler', 'doppler_std', 'data', 'trust', 'spSymEst', 'SNR',
+                'rangerateEst', 'baudRate', 'baudRate_est', 'sample_rate', 'protocol', 'baudrate_est', 'rangerate'):
+        assert key in d, key
+    back = pickle.loads(pickle.dumps(d, protocol=pickle.HIGHEST_PROTOCOL))
+    assert set(back) == set(d) and np.array_equal(back['data'], d['data']) and back['data'].dtype == np.uint8
+    assert back['doppler'] == d['doppler'] and back['workerId'] == d['workerId']
+    # the same stream in chunks of 2^14 samples (the BER bench's size) through the ring buffer: same blocks
+    run2 = DemodulatorRunner(conf, p, 'UHF-H')
+    seen2 = []
+    run2.run_stream((sig[i:i + (1 << 14)] for i in range(0, 3 * step, 1 << 14)), sink=seen2.append)
+    assert len(seen2) == 3 and all(np.array_equal(a['data'], b['data']) and a['doppler'] == b['doppler']
+                                   for a, b in zip(seen, seen2))
     assert radioBackendVoteGroupIDX('STX')[1] == 1
     with pytest.raises(TypeError):
         radioBackendVoteGroupIDX('LBAND')

@@ -111,3 +111,46 @@ def test_oracle_custom_xcorr_matches_reference(goldens, tag):
     assert np.allclose(r[:64], goldens[f'g13/{tag}/head'], rtol=1e-12, atol=1e-9)
     assert np.allclose(np.abs(r), goldens[f'g13/{tag}/abs_c64'], rtol=1e-5, atol=1e-3)
     assert np.array_equal(np.argsort(-np.abs(r), kind='stable')[:3], goldens[f'g13/{tag}/top15_idx'][:3])
+
+
+@pytest.mark.parametrize('name', ['grc', 'bench', 'odd', 'tight'])
+def test_ring_buffer_matches_reference(goldens, name):
+    """RingBuffer == the reference's sigFIFO.RingBuffer (sigFIFO.py:13-103) on seeded insert/pop traces: GNU
+    Radio sized chunks (4095/4096), the BER bench's 2^14, odd sizes with wrap-around, the overflow flush."""
+    from pycusdr_amd.sigFIFO import RingBuffer
+    k = f'g14/{name}'
+    rb = RingBuffer(int(goldens[k + '/outLen']), bufLen=int(goldens[k + '/bufLen']), dtype=np.complex64)
+    v, pos = 0, 0
+    for i, n in enumerate(goldens[k + '/chunks']):
+        n = int(n)
+        data = (np.arange(v, v + n) + 1j * (np.arange(v, v + n) % 7)).astype(np.complex64)
+        v += n
+        assert rb.insert(data) == int(goldens[k + '/sizes'][i])
+        blk = rb.popBlock(rb.outLen)
+        assert len(blk) == int(goldens[k + '/npop'][i])
+        assert np.array_equal(np.asarray(blk, dtype=np.complex64), goldens[k + '/popped'][pos:pos + len(blk)])
+        pos += len(blk)
+        assert (rb.headIdx, rb.tailIdx, rb.currentBufSize) == tuple(int(q) for q in goldens[k + '/state'][i])
+    with pytest.raises(IndexError):
+        RingBuffer(100, bufLen=50)
+    # overflow: the reference raises ValueError after its flush (stale end index, fixture records it); here the
+    # flush is followed by a clean store
+    assert bool(goldens['g14/overflow_raises_in_reference'])
+    rb = RingBuffer(1900, bufLen=2000, dtype=np.complex64)
+    rb.insert(np.zeros(900, np.complex64))
+    rb.insert(np.ones(900, np.complex64))
+    assert rb.insert(np.full(900, 2, np.complex64)) == 900 and np.all(rb.buf[:900] == 2)
+
+
+def test_sigfifo_blocks_from_arbitrary_chunks():
+    """SigFIFO.getBlock: the stream comes out unchanged, cut into fixed blocks, whatever the chunk size."""
+    from pycusdr_amd.sigFIFO import SigFIFO
+    rs = np.random.RandomState(3)
+    x = (rs.standard_normal(70000) + 1j * rs.standard_normal(70000)).astype(np.complex64)
+    for chunk in (16384, 4095, 1000, 15360, 20000):
+        fifo = SigFIFO((x[i:i + chunk] for i in range(0, len(x), chunk)), 15360)
+        got = []
+        with pytest.raises(TimeoutError):
+            while True:
+                got.append(np.array(fifo.getBlock()))
+        assert len(got) == len(x) // 15360 and np.array_equal(np.concatenate(got), x[:len(got) * 15360])
