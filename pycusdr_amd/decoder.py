@@ -17,26 +17,41 @@ from .protocol import PacketEndDetect
 log = logging.getLogger('pycusdr_amd.decoder')
 
 
-def _hip_correlator(bits, template):
+def _hip_correlator(bits, template, device=0):
     from .mfbank import sync_correlate
-    return sync_correlate(bits, template)
+    return sync_correlate(bits, template, device=device)
 
 
-def _hip_finder(bits, template, threshold):
+def _hip_finder(bits, template, threshold, device=0):
     from .mfbank import sync_find
-    return sync_find(bits, template, threshold)
+    return sync_find(bits, template, threshold, device=device)
+
+
+def _config_device(config):
+    """HIP device of this process: ``config['GPU'][<set>]['CUDA']['device']`` (the key the Demodulator reads,
+    reference DB:178) of the first GPU set that names one; 0 otherwise."""
+    try:
+        for gpu_set in config.get('GPU', {}).values():
+            dev = gpu_set.get('CUDA', {}).get('device')
+            if dev is not None:
+                return int(dev)
+    except AttributeError:
+        pass
+    return 0
 
 
 class Decoder:
     maxPacketLenBits = int(2 ** 13)
     minNumBitsBeforeProcessing = int(2 ** 10)
 
-    def __init__(self, config, protocol, correlator=None):
+    def __init__(self, config, protocol, correlator=None, device=None):
         self.conf = config
         self.protocol = protocol
+        # one process per GPU: the correlations run on this process's device, not on device 0
+        self.device = _config_device(config) if device is None else int(device)
         # default: thresholded correlation on the GPU (positions + scores only come back); an injected
         # correlator returns the full np.convolve-style score array and is thresholded on the host
-        self.correlate = correlator if correlator is not None else _hip_correlator
+        self.correlate = correlator if correlator is not None else (lambda b, t: _hip_correlator(b, t, device=self.device))
         self._finder = _hip_finder if correlator is None else None
         self.preprocessor = protocol.decoderPreprocessor
         self.postprocessor = protocol.decoderPostprocessor
@@ -61,7 +76,7 @@ class Decoder:
         """(positions, scores there) where the correlation with ``template`` reaches ``threshold`` --
         np.where(np.convolve(bits, template) >= threshold) of the reference (decoder.py:96-113)."""
         if self._finder is not None:
-            return self._finder(bits, template, threshold)
+            return self._finder(bits, template, threshold, device=self.device)
         score = self.correlate(bits, template)
         idx = np.where(score >= threshold)[0]
         return idx, score[idx]

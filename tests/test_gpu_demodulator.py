@@ -29,9 +29,9 @@ def _pair(pname, bs, D, monkeypatch):
 # 60 dB stands for "noiseless": with exactly-zero padding the matched-filter outputs there are pure FFT
 # round-off and the per-symbol argmax is arbitrary in both implementations; a whisper of noise makes
 # every decision well defined without disturbing the packet.
-@pytest.mark.parametrize('mod,pname,snr', [('GMSK', 'bench_GMSK', 60.0), ('GMSK', 'bench_GMSK', 10.0),
-                                           ('FSK', 'bench_FSK', 60.0), ('GFSK', 'bench_GFSK', 12.0),
-                                           ('BPSK', 'bench_BPSK', 60.0)])
+@pytest.mark.parametrize('mod,pname,snr', [('GMSK', 'bench_GMSK', 60.0), ('GMSK', 'bench_GMSK', 10.0), ('GMSK', 'bench_GMSK', 6.0),
+                                           ('FSK', 'bench_FSK', 60.0), ('FSK', 'bench_FSK', 12.0), ('GFSK', 'bench_GFSK', 12.0),
+                                           ('BPSK', 'bench_BPSK', 60.0), ('BPSK', 'bench_BPSK', 12.0)])
 def test_stream_bits_identical_to_oracle_and_packet_error_free(monkeypatch, mod, pname, snr):
     bs, ov, D = 15, 1 << 10, 32
     N = 1 << bs
@@ -67,16 +67,15 @@ def test_stream_bits_identical_to_oracle_and_packet_error_free(monkeypatch, mod,
         bc, cc, tc, spc = cpu.demodulate()
         assert spg == spc                                                 # same FFT bin -> same float
         if snr <= 20:
-            # noise floor far above fp32 round-off: decisions agree except at numerical ties between
-            # two candidates (fp32 device vs fp64 oracle FFTs; at most 1 symbol in 1000).  Exact
-            # equality on identical matched-filter outputs is asserted in tests/test_gpu_kernels.py.
-            assert len(bg) == len(bc)
-            assert np.count_nonzero(bg != bc) <= max(1, len(bg) // 1000), f'block {b}: symbol decisions differ'
-            # peak sample index: equal except where two neighbouring |xc|^2 samples tie to within
-            # fp32-vs-fp64 round-off (the kernel itself is bit-exact against the oracle on its own
-            # matched-filter outputs: tests/test_gpu_kernels.py)
+            # noise floor far above fp32 round-off: symbol decisions are BIT-EXACT (north_star), fp32 device
+            # transforms against the fp64 oracle (measured with tools/decision_slack.py: 0 of ~12 000 symbols
+            # differ for every modulation at 6-12 dB).
+            assert np.array_equal(bg, bc), f'block {b}: symbol decisions differ'
+            # peak sample index: equal except where two neighbouring |xc|^2 samples tie to within fp32-vs-fp64
+            # round-off -- measured: at most one centre per packet, by one sample (the kernel itself is
+            # bit-exact against the oracle on its own matched-filter outputs: tests/test_gpu_kernels.py)
             dcen = gpu._centresWin - cpu._centresWin
-            assert np.abs(dcen).max() <= 6 and np.count_nonzero(dcen) <= 0.02 * len(dcen)
+            assert np.abs(dcen).max() <= 1 and np.count_nonzero(dcen) <= 2
         else:
             # quiet padding: the matched-filter outputs there are fp32 FFT round-off of the strong
             # packet, so the argmax is arbitrary in BOTH implementations; decisions must agree on
