@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(64) k_pick(const float *in, float *res, int nu
                 const unsigned long long hit = __ballot(inside && v > thr) & todo;     // strict '>' (NaN never enters)
                 if (!hit) break;
                 const int l = __builtin_ctzll(hit);
-                const float tmp = __shfl(v, l, 64);
+                const float tmp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));   // l is wave-uniform
                 if (cur) {
                     mv1 = tmp;
                     mi1 = r0 + l;
@@ -1059,14 +1059,17 @@ static int seg_valid(int l, int T) {
     const int pv = (L - T + 1) / NT;
     return pv >= 8 ? pv * NT : 0;
 }
-// Cost of one valid output sample per filter, in packed-fp32 VALU instructions per thread-point: the
-// instruction count of an L-point transform (radix-16 passes + remainder + twiddles, counted from the
-// ISA) plus the pointwise work, divided by the segment efficiency V / L.
+// Relative cost of one segment point per filter, MEASURED on MI355X at C2 (time x V / L, 48 taps, D = 256,
+// M = 8; tools/seg_probe.py): the 256-point kernel is by far the cheapest per point (one twiddled pass,
+// three waves per SIMD, phase table in LDS), so it wins whenever at least ~2/3 of a segment is valid; the
+// cost of a valid output is this divided by the segment efficiency V / L.  Checked against the other
+// shipped banks: 80 taps (BPSK) -> 256 (7.7 ms at D = 512 vs 8.9 ms at 1024), 384 taps (CC11xx at 128
+// samples per symbol) -> 4096 (5.9 ms at D = 512 vs 6.1 ms at 2048, 6.7 ms at 1024).
 static double seg_cost(int l, int T) {
-    static const double ops[13] = {0, 0, 0, 0, 0, 0, 0, 0, 194, 240, 256, 280, 322};
+    static const double per_point[13] = {0, 0, 0, 0, 0, 0, 0, 0, 1.37, 2.10, 2.06, 2.80, 2.58};
     const int V = seg_valid(l, T);
     if (!V) return 1e30;
-    return (ops[l] + 50.0) * (double)(1 << l) / (double)V;
+    return per_point[l] * (double)(1 << l) / (double)V;
 }
 
 static int choose_segl(const mfb_ctx *c, int T) {

@@ -54,6 +54,11 @@
 #ifndef MFB_SEG_PREFETCH
 #define MFB_SEG_PREFETCH 1
 #endif
+// issue the first filter's spectrum loads BEFORE the forward transform (keeps 32 more registers live through
+// it: spills at the 3-wave budget of L = 256, so off)
+#ifndef MFB_SEG_G0EARLY
+#define MFB_SEG_G0EARLY 0
+#endif
 
 struct SegArgs {
     const cf *x;         // time-domain block, complex64 [N]
@@ -195,6 +200,30 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
         }
         xsync<1>();     // wave-local: every wave fills and reads its own copy
 
+        // x of a slot -> 16 registers (immediate offsets unless the slot wraps past the end of the block)
+        auto load_x = [&](cf (&dst)[16], int slot_) {
+            const unsigned e0_ = (unsigned)(slot_ * CT + col) * (unsigned)a.V + (unsigned)g;
+            const unsigned last = (unsigned)(slot_ * CT + CT - 1) * (unsigned)a.V + (unsigned)L;   // team-uniform
+            if (__builtin_amdgcn_readfirstlane(last <= (unsigned)a.N ? 1 : 0)) {
+                const int vo_x = (int)(e0_ * sizeof(cf));
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dst[i] = buf_load_cf(xr, vo_x, i * so_g);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dst[i] = buf_load_cf(xr, (int)(((e0_ + (unsigned)(NT * i)) & nmask) * sizeof(cf)), 0);
+            }
+        };
+        auto load_g = [&](cf (&dst)[16], int row) {
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii) buf_load_cf2(gr, vo_g2, row * (L * (int)sizeof(cf)) + ii * so_g2, dst[2 * ii], dst[2 * ii + 1]);
+        };
+        // One set of 16 prefetch registers (MFB_SEG_PREFETCH) receives the next filter's spectrum during every
+        // inverse transform and the x of the NEXT slot while the last filter of a slot is transformed, so the
+        // L2 round trip of the x loads is never waited for; only the first filter's spectrum (L1-resident) is
+        // loaded right where it is needed.
+        [[maybe_unused]] cf gk[16];
+        if constexpr (MFB_SEG_PREFETCH) load_x(gk, s0);
+
         for (int it = 0; it < niter; ++it) {
             const int slot = s0 + it;
             const bool active = slot < s1;        // team-uniform; false only on padding iterations of barrier teams
@@ -202,18 +231,14 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
             const unsigned b0 = (unsigned)seg * (unsigned)a.V;
             const unsigned e0 = b0 + (unsigned)g;
 
-            // ---- load the segment, mix with e^{-2 pi i s n / N}, conjugate (forward via inverse) ----
+            // ---- the segment, mixed with e^{-2 pi i s n / N} and conjugated (forward via inverse) ----
             cf v[16];
             {
-                const unsigned last = (unsigned)(slot * CT + CT - 1) * (unsigned)a.V + (unsigned)L;   // team-uniform
-                if (__builtin_amdgcn_readfirstlane(last <= (unsigned)a.N ? 1 : 0)) {
-                    const int vo_x = (int)(e0 * sizeof(cf));
+                if constexpr (MFB_SEG_PREFETCH) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = buf_load_cf(xr, vo_x, i * so_g);
-                } else {                          // the slot wraps past the end of the block
-#pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        v[i] = buf_load_cf(xr, (int)(((e0 + (unsigned)(NT * i)) & nmask) * sizeof(cf)), 0);
+                    for (int i = 0; i < 16; ++i) v[i] = gk[i];
+                } else {
+                    load_x(v, slot);
                 }
                 // conj(x) * W_N^{+t} = conj(x * e^{-2 pi i t / N})
                 if constexpr (PTAB) {
@@ -227,11 +252,14 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                     for (int i = 1; i < 16; ++i) v[i] = cmul_cj(v[i], cmul(ph0, mystep[i]));
                 }
             }
+            const int r0 = a.rows ? a.rows[m0] : m0;
+            if constexpr (MFB_SEG_PREFETCH && MFB_SEG_G0EARLY) load_g(gk, r0);    // lands while the forward transform runs
             cf A[16];                             // A[k] = conj(U[g + NT*k])
             {
                 auto keep = [&](int, cf val, auto, auto nu) { A[decltype(nu)::value / NT] = val; };
                 fft_passes<L, 1, 0, true, false, 0, SYNC>(v, mylds, ebuf, g, 0, twr, a.twL, keep);
             }
+            if constexpr (MFB_SEG_PREFETCH && !MFB_SEG_G0EARLY) load_g(gk, r0);
 
             // ---- per filter: multiply by the segment spectrum, inverse transform, reduce or store ----
             [[maybe_unused]] int lim = 0;
@@ -239,23 +267,18 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                 const int vseg = active ? min(a.V, a.N - (int)b0) : 0;     // <= 0 beyond the last segment
                 lim = vseg - g;                   // output slot k is valid for this lane iff k*NT < lim
             }
-            [[maybe_unused]] cf gk[16];
-            if constexpr (MFB_SEG_PREFETCH) {
-                const int r0 = a.rows ? a.rows[m0] : m0;
-#pragma unroll
-                for (int ii = 0; ii < 8; ++ii) buf_load_cf2(gr, vo_g2, r0 * (L * (int)sizeof(cf)) + ii * so_g2, gk[2 * ii], gk[2 * ii + 1]);
-            }
+            const int next_slot = (it + 1 < niter) ? slot + 1 : s0;
             for (int mi = 0; mi < nm; ++mi) {
                 const int rm = a.rows ? a.rows[m0 + mi] : (m0 + mi);
                 cf w[16];
                 if constexpr (MFB_SEG_PREFETCH) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) w[i] = cmul_cj(A[i], gk[i]);    // conj(A) * G = U * G
-                    const int mn = (mi + 1 < nm) ? (m0 + mi + 1) : m0;
-                    const int rn = a.rows ? a.rows[mn] : mn;
-#pragma unroll
-                    for (int ii = 0; ii < 8; ++ii)
-                        buf_load_cf2(gr, vo_g2, rn * (L * (int)sizeof(cf)) + ii * so_g2, gk[2 * ii], gk[2 * ii + 1]);
+                    if (mi + 1 < nm) {
+                        load_g(gk, a.rows ? a.rows[m0 + mi + 1] : (m0 + mi + 1));
+                    } else {
+                        load_x(gk, next_slot);
+                    }
                 } else {
 #pragma unroll
                     for (int ii = 0; ii < 8; ++ii) {
@@ -266,6 +289,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                     }
                 }
                 if constexpr (MODE == SEG_REDUCE) {
+                    const float before = lacc[mi * 256 + tid];     // read early: its latency hides behind the transform
                     cf racc = mkc(0.f, 0.f);      // (sum re^2, sum im^2)
                     auto acc = [&](int, cf val, auto, auto nu) {
                         constexpr int k = decltype(nu)::value / NT;
@@ -279,7 +303,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                     fft_passes<L, 1, 0, true, false, 0, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, acc);
                     float s = racc.x + racc.y;
                     if constexpr (!MASKED && !SYNC) s = active ? s : 0.f;
-                    lacc[mi * 256 + tid] += s;
+                    lacc[mi * 256 + tid] = before + s;
                 } else {
                     const auto orr = mk_rsrc(a.out + (size_t)rm * a.N, (unsigned)a.N * sizeof(cf));
                     const unsigned o0 = e0 + (unsigned)a.out_off;

@@ -185,6 +185,8 @@ def test_segment_refused_for_long_filters_and_small_blocks():
         assert bank.get_search_path()['path'] == 'twopass'
         bank.set_filters(_short_masks(rs, M, N, 20, 7))
         assert bank.get_search_path() == dict(path='segment', log2L=8, taps=20, valid_per_segment=224, segments=19)
+        bank.set_filters(_short_masks(rs, M, N, 90, 4000))       # 90 taps: 256-point segments still win (V = 160)
+        assert bank.get_search_path()['log2L'] == 8 and bank.get_search_path()['valid_per_segment'] == 160
     finally:
         bank.close()
 
