@@ -54,10 +54,15 @@
 #ifndef MFB_SEG_PREFETCH
 #define MFB_SEG_PREFETCH 1
 #endif
-// issue the first filter's spectrum loads BEFORE the forward transform (keeps 32 more registers live through
-// it: spills at the 3-wave budget of L = 256, so off)
+// prefetch the NEXT slot's x into the prefetch registers while the last filter of a slot is transformed
+// (A/B on one MI355X: same time within noise as loading x at the slot's start, but the registers it keeps live
+// across the slot loop spill 20 VGPRs at the 3-wave budget -> off)
+#ifndef MFB_SEG_XNEXT
+#define MFB_SEG_XNEXT 0
+#endif
+// issue the first filter's spectrum loads BEFORE the forward transform, so that they land while it runs
 #ifndef MFB_SEG_G0EARLY
-#define MFB_SEG_G0EARLY 0
+#define MFB_SEG_G0EARLY 1
 #endif
 
 struct SegArgs {
@@ -217,12 +222,11 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
 #pragma unroll
             for (int ii = 0; ii < 8; ++ii) buf_load_cf2(gr, vo_g2, row * (L * (int)sizeof(cf)) + ii * so_g2, dst[2 * ii], dst[2 * ii + 1]);
         };
-        // One set of 16 prefetch registers (MFB_SEG_PREFETCH) receives the next filter's spectrum during every
-        // inverse transform and the x of the NEXT slot while the last filter of a slot is transformed, so the
-        // L2 round trip of the x loads is never waited for; only the first filter's spectrum (L1-resident) is
-        // loaded right where it is needed.
+        // One set of 16 prefetch registers (MFB_SEG_PREFETCH) receives the first filter's spectrum while the forward
+        // transform runs and the next filter's spectrum during every inverse transform (optionally the x of the
+        // next slot during the last one, MFB_SEG_XNEXT).
         [[maybe_unused]] cf gk[16];
-        if constexpr (MFB_SEG_PREFETCH) load_x(gk, s0);
+        if constexpr (MFB_SEG_PREFETCH && MFB_SEG_XNEXT) load_x(gk, s0);
 
         for (int it = 0; it < niter; ++it) {
             const int slot = s0 + it;
@@ -234,7 +238,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
             // ---- the segment, mixed with e^{-2 pi i s n / N} and conjugated (forward via inverse) ----
             cf v[16];
             {
-                if constexpr (MFB_SEG_PREFETCH) {
+                if constexpr (MFB_SEG_PREFETCH && MFB_SEG_XNEXT) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) v[i] = gk[i];
                 } else {
@@ -276,7 +280,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                     for (int i = 0; i < 16; ++i) w[i] = cmul_cj(A[i], gk[i]);    // conj(A) * G = U * G
                     if (mi + 1 < nm) {
                         load_g(gk, a.rows ? a.rows[m0 + mi + 1] : (m0 + mi + 1));
-                    } else {
+                    } else if constexpr (MFB_SEG_XNEXT) {
                         load_x(gk, next_slot);
                     }
                 } else {
@@ -330,9 +334,16 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
 // amdgpu_waves_per_eu pins the register budget: without the upper bound the scheduler chases a fourth
 // wave per SIMD (which the LDS footprint does not admit anyway) by serialising every load behind an
 // s_waitcnt vmcnt(0).
-#define SEG_KERNEL_ATTRS(L_) __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SegCfg<L_>::WAVES, SegCfg<L_>::WAVES)))
+// The masked instantiations (tail of the search, demodulation) carry the per-lane limits and are not on the
+// critical path: they get the 2-wave budget (no spills).
+template <int L, int PV>
+struct SegWaves {
+    static constexpr int value = PV < 0 ? 2 : SegCfg<L>::WAVES;
+};
+#define SEG_KERNEL_ATTRS(L_, PV_) \
+    __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SegWaves<L_, PV_>::value, SegWaves<L_, PV_>::value)))
 
 template <int L, int MODE, int PV>
-__global__ void SEG_KERNEL_ATTRS(L) k_seg(SegArgs a) {
+__global__ void SEG_KERNEL_ATTRS(L, PV) k_seg(SegArgs a) {
     seg_body<L, MODE, PV>(a, (int)blockIdx.x);
 }
