@@ -51,6 +51,35 @@ class OracleBank:
     def get_scores(self):
         return self.ds
 
+    # -- the device-pointer calls DopplerShard uses; "device" memory here is host memory of CPU tensors ----------
+    @staticmethod
+    def _view(ptr, count, dtype=np.float32):
+        import ctypes
+        nbytes = count * np.dtype(dtype).itemsize
+        return np.frombuffer((ctypes.c_char * nbytes).from_address(int(ptr)), dtype=dtype)
+
+    def upload_device(self, ptr):
+        self.upload(self._view(ptr, 2 * self.N).view(np.complex64).copy())
+
+    def search_async(self):
+        self.ds = orc.doppler_scores(self.X, self.masks, self.shifts, self.sum_all).astype(np.float32)
+
+    def export_scores_async(self, ptr, row_offset):
+        self._view(ptr, (row_offset + self.Dtot) * self.M)[row_offset * self.M:] = self.ds.ravel()
+
+    def export_column_async(self, ptr, row_offset):
+        self._view(ptr, row_offset + self.Dtot)[row_offset:] = self.ds[:, 0]
+
+    def pick(self, ptr=None, num=None, offset=None):
+        num = self.D if num is None else num
+        offset = self.Doff if offset is None else offset
+        table = self.ds if not ptr else self._view(ptr, (num + offset) * self.M).reshape(num + offset, self.M)
+        return orc.find_doppler_est(table, num, offset, self.sum_all)
+
+    def pick_column(self, ptr, num, offset=0):
+        col = self._view(ptr, num + offset).reshape(-1, 1)
+        return orc.find_doppler_est(col, num, offset, True)
+
     def get_spectrum(self, start=0, count=None):
         count = self.N if count is None else count
         idx = (start + np.arange(count)) % self.N

@@ -30,29 +30,49 @@ def _free_port():
 
 
 def _worker(rank, world, port, q):
+    """One rank: DopplerShard itself (CPU tensors over gloo) around the OracleBank stand-in: rank 0 broadcasts the
+    block, every rank searches its bin slice, one all-reduce, the pick on every rank."""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    import torch
     import torch.distributed as dist
     from oracle import mfbank_oracle as orc
-    from pycusdr_amd.dist import allreduce_scores_host, bin_slice as bs
+    from oracle_bank import OracleBank
+    from pycusdr_amd.dist import DopplerShard, allreduce_scores_host, bin_owner
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    rs = np.random.RandomState(5)              # same block and filters on every rank
-    N, M, D = 1 << 12, 4, 10
+    rs = np.random.RandomState(5)              # same filters on every rank; the block lives on rank 0 only
+    log2N, M, D = 12, 4, 10
+    N = 1 << log2N
     x = (rs.standard_normal(N) + 1j * rs.standard_normal(N)).astype(np.complex64)
     masks = (rs.standard_normal((M, N)) + 1j * rs.standard_normal((M, N))).astype(np.complex64)
     shifts = rs.randint(0, N, D)
     X = orc.forward_fft(x)
-    lo, hi = bs(D, rank, world)
+    ok = True
+    for sum_all in (True, False):
+        shard = DopplerShard(device=torch.device('cpu'))
+        lo, hi = shard.bin_range(D)
+        bank = OracleBank(log2N, hi - lo, M, sum_all_masks=sum_all)
+        bank.set_filters(masks)
+        bank.set_shifts(shifts[lo:hi])
+        shard.attach(bank, D, M, sum_all=sum_all)
+        block = torch.from_numpy(x.view(np.float32).copy()) if rank == 0 else None
+        idx, metric = shard.step(bank, lo, block)
+        single = orc.doppler_scores(X, masks, shifts, sum_all).astype(np.float32)
+        sidx, smetric = orc.find_doppler_est(single, D, 0, sum_all)
+        ok &= bool(np.array_equal(shard.full_scores(), single))       # adding exact zeros
+        ok &= bool(idx == sidx and metric == smetric)
+        ok &= shard.owner(int(float(idx))) == bin_owner(D, world, int(float(idx)))
+        if sum_all:
+            ok &= shard.scores.numel() == D                            # only the populated column travels
+    # the documented numpy statement of the same exchange
+    lo, hi = lo, hi
     local = orc.doppler_scores(X, masks, shifts[lo:hi], True).astype(np.float32)
-    full = allreduce_scores_host(local, lo, D)
-    idx, metric = orc.find_doppler_est(full, D, 0, True)
-    single = orc.doppler_scores(X, masks, shifts, True).astype(np.float32)
-    sidx, smetric = orc.find_doppler_est(single, D, 0, True)
-    ok = bool(np.array_equal(full, single) and idx == sidx and metric == smetric)   # adding exact zeros
-    q.put((rank, ok, float(idx)))
+    ok &= bool(np.array_equal(allreduce_scores_host(local, lo, D), orc.doppler_scores(X, masks, shifts, True).astype(np.float32)))
+    q.put((rank, bool(ok), float(idx)))
     dist.destroy_process_group()
 
 
