@@ -130,6 +130,7 @@ def main():
     ap.add_argument('--shard', choices=['bins', 'blocks'], default='bins',
                     help='N>1: bins = C4, Doppler bins sharded 256/GPU + RCCL exchange per block (default); '
                          'blocks = every GPU runs the full 256-bin bank on different time blocks, no collective')
+    ap.add_argument('--no-prefetch', action='store_true', help='N>1: broadcast every block right before its search instead of one block ahead')
     ap.add_argument('--force-dist', action='store_true', help='run the sharded/RCCL path even with one rank (rehearsal)')
     args = ap.parse_args()
 
@@ -202,8 +203,10 @@ def main():
         if shard is None:
             bank.upload_device(src.data_ptr() + block_index(i) * esz)
             return bank.find_carrier()
-        # sharded: rank 0 owns the stream; its block goes to every rank over RCCL, then search + exchange + pick
-        return shard.step(bank, lo, src[block_index(i)] if rank == 0 else None)
+        # sharded: rank 0 owns the stream; its block goes to every rank over RCCL (the next block's broadcast is
+        # started beside this block's search), then search + exchange + pick
+        return shard.step(bank, lo, src[block_index(i)] if rank == 0 else None,
+                          next_block=src[block_index(i + 1)] if rank == 0 else None, prefetch_next=not args.no_prefetch)
 
     def barrier():
         if dist is not None:
@@ -211,13 +214,14 @@ def main():
         torch.cuda.synchronize(dev)
 
     step(0)            # initialisation: first launches load the code objects and touch the workspaces
-    for i in range(args.warmup):
+    for i in range(1, 1 + args.warmup):     # one running block counter: a prefetched block is always the next one used
         res = step(i)
     barrier()
     bank.profile_enable(True)
     bank.timer_start()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    first = 1 + args.warmup
+    for i in range(first, first + args.steps):
         res = step(i)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -225,7 +229,7 @@ def main():
     counts, kms = bank.profile_read()
     bank.profile_enable(False)
     # scores of the LAST timed block, read before anything else touches the handle (parity spot check)
-    last_block = block_index(args.steps - 1)
+    last_block = block_index(first + args.steps - 1)
     gscores = bank.get_scores()[:, 0].astype(np.float64)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)

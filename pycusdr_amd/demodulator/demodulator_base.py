@@ -192,9 +192,7 @@ class Demodulator:
         sh = self.shard
         if sh.rank == 0:
             src = sh.torch.from_numpy(np.ascontiguousarray(samples, dtype=np.complex64).view(np.float32))
-            with sh._on_stream():
-                sh.block.copy_(src, non_blocking=False)
-            sh.broadcast_block(self.bank, sh.block)
+            sh.broadcast_block(self.bank, src.to(sh.device, non_blocking=False) if sh.on_gpu else src)
         else:
             sh.broadcast_block(self.bank)
 

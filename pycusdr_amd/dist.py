@@ -4,11 +4,14 @@ over xGMI on ROCm; "gloo" on CPU for tests).
 The reference has no distributed runtime.  The hot path shards by Doppler bin:
 rank r of G owns the contiguous slice [r*D/G, (r+1)*D/G) of the bin table and holds a full replica of
 the filter bank.  Per block:
-  1. rank 0 owns the IQ stream; its N-sample block is broadcast to every rank (8 MiB over xGMI, on the
-     shard's side stream, SURVEY 8e) -- ranks need no feeder process of their own;
+  1. rank 0 owns the IQ stream; its N-sample block is broadcast to every rank (8 MiB over xGMI) --
+     ranks need no feeder process of their own.  The broadcast of block i+1 can be started while block i is
+     searched (``prefetch``: a communication stream and a communicator of its own, two block buffers), so in
+     a stream of blocks the transfer costs nothing;
   2. every rank searches its bins (libmfbank, same stream);
-  3. ONE all-reduce (sum) of the per-bin scores in which every rank has zeros outside its slice --
-     adding exact zeros, so the result is bit-identical on all ranks.  With SUM_ALL_MASKS (every shipped
+  3. ONE collective on the per-bin scores: an all-gather of the ranks' slices when the bins divide evenly
+     (the C4 layout), otherwise an all-reduce (sum) in which every rank has zeros outside its slice -- adding
+     exact zeros; either way the table is bit-identical on all ranks.  With SUM_ALL_MASKS (every shipped
      protocol) only column 0 of doppSum is populated (reference cuda_kernels.cu:453-464), so only that
      column travels: D floats instead of D*M;
   4. the Doppler pick on the full table on every rank (identical everywhere);
@@ -56,9 +59,14 @@ class DopplerShard:
         # a dedicated side stream: the bank's kernels, the buffer clear and the collectives are all
         # ordered on it (an RCCL op is synchronised against the *current* torch stream)
         self.stream = torch.cuda.Stream(self.device) if self.on_gpu else None
+        # block distribution ahead of time: its own stream and its own communicator, so that the broadcast of
+        # the next block runs beside the search and the all-reduce of the current one
+        self.comm = torch.cuda.Stream(self.device) if self.on_gpu else None
+        self.bcast_group = dist.new_group(backend=dist.get_backend(group)) if (self.world > 1 and group is None) else group
 
-    def _on_stream(self):
-        return self.torch.cuda.stream(self.stream) if self.on_gpu else contextlib.nullcontext()
+    def _on_stream(self, which=None):
+        which = self.stream if which is None else which
+        return self.torch.cuda.stream(which) if self.on_gpu else contextlib.nullcontext()
 
     def bin_range(self, num_bins):
         return bin_slice(num_bins, self.rank, self.world)
@@ -73,7 +81,16 @@ class DopplerShard:
         self.D, self.M, self.sum_all = int(num_bins_total), int(M), bool(sum_all)
         shape = (self.D,) if self.sum_all else (self.D, self.M)
         self.scores = torch.zeros(shape, dtype=torch.float32, device=self.device)
-        self.block = torch.empty(2 * bank.N, dtype=torch.float32, device=self.device)   # complex64 block, interleaved
+        # equal slices: every rank exports into a slice-sized buffer and the table is all-gathered (no clearing,
+        # no additions); uneven slices: all-reduce of the zero-padded table
+        self.even = self.D % self.world == 0
+        self.local = torch.zeros((self.D // self.world,) + shape[1:], dtype=torch.float32, device=self.device) if self.even else None
+        # complex64 blocks, interleaved: two buffers so that one can be filled while the other is searched
+        self.blocks = [torch.empty(2 * bank.N, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.block = self.blocks[0]
+        self.cur, self.pending = 0, None
+        self.ready = [None, None]      # events: buffer k holds a complete block
+        self.free = [None, None]       # events: the search that read buffer k has been enqueued and finished
         if self.on_gpu:
             torch.cuda.synchronize(self.device)
             bank.set_stream(self.stream.cuda_stream)
@@ -87,37 +104,71 @@ class DopplerShard:
         out[:, 0] = s
         return out
 
-    def broadcast_block(self, bank, block=None):
-        """Rank 0 passes the block (a float32 view of N complex64 samples, on the shard's device); every rank
-        receives it and runs the forward FFT on it."""
-        with self._on_stream():
+    def _fill(self, k, block, stream):
+        """Enqueue on ``stream``: buffer k <- rank 0's block, on every rank."""
+        with self._on_stream(stream):
+            if self.on_gpu and self.free[k] is not None:
+                stream.wait_event(self.free[k])               # the previous search on this buffer is done
             if self.rank == 0:
                 if block is None:
                     raise ValueError('rank 0 must supply the block')
-                buf = block if block.is_contiguous() else block.contiguous()
-            else:
-                buf = self.block
+                self.blocks[k].copy_(block.reshape(-1), non_blocking=True)
             if self.world > 1:
-                self.dist.broadcast(buf, src=0, group=self.group)
-            bank.upload_device(buf.data_ptr())
-            self._live = buf      # keep the source alive until the next block
+                self.dist.broadcast(self.blocks[k], src=0, group=self.bcast_group)
+            if self.on_gpu:
+                ev = self.torch.cuda.Event()
+                ev.record(stream)
+                self.ready[k] = ev
+
+    def prefetch(self, block=None):
+        """Start distributing the NEXT block (rank 0 passes it) while the current one is being searched."""
+        k = 1 - self.cur
+        self._fill(k, block, self.comm if self.on_gpu else None)
+        self.pending = k
+
+    def broadcast_block(self, bank, block=None):
+        """Make rank 0's block (a float32 view of N complex64 samples on the shard's device) the bank's input on
+        every rank and run the forward FFT on it.  Uses the block a preceding ``prefetch`` distributed, if any."""
+        if self.pending is not None:
+            k, self.pending = self.pending, None
+        else:
+            k = 1 - self.cur
+            self._fill(k, block, self.stream)
+        self.cur = k
+        self.block = self.blocks[k]
+        with self._on_stream():
+            if self.on_gpu and self.ready[k] is not None:
+                self.stream.wait_event(self.ready[k])
+            bank.upload_device(self.blocks[k].data_ptr())
 
     def search_and_pick(self, bank, row_offset):
         with self._on_stream():
-            self.scores.zero_()
+            if not self.even:
+                self.scores.zero_()
             bank.search_async()
+            if self.on_gpu:                       # from here on the block buffer may be refilled
+                ev = self.torch.cuda.Event()
+                ev.record(self.stream)
+                self.free[self.cur] = ev
+            dst, off = (self.local, 0) if self.even else (self.scores, row_offset)
             if self.sum_all:
-                bank.export_column_async(self.scores.data_ptr(), row_offset)
+                bank.export_column_async(dst.data_ptr(), off)
             else:
-                bank.export_scores_async(self.scores.data_ptr(), row_offset)
-            self.dist.all_reduce(self.scores, op=self.dist.ReduceOp.SUM, group=self.group)
+                bank.export_scores_async(dst.data_ptr(), off)
+            if self.even:
+                self.dist.all_gather_into_tensor(self.scores, self.local, group=self.group)
+            else:
+                self.dist.all_reduce(self.scores, op=self.dist.ReduceOp.SUM, group=self.group)
             if self.sum_all:
                 return bank.pick_column(self.scores.data_ptr(), num=self.D, offset=0)
             return bank.pick(self.scores.data_ptr(), num=self.D, offset=0)
 
-    def step(self, bank, row_offset, block=None):
-        """One block of the sharded hot path: broadcast, search, exchange, pick."""
+    def step(self, bank, row_offset, block=None, next_block=None, prefetch_next=False):
+        """One block of the sharded hot path: (take the prefetched block or broadcast now), start the next block's
+        broadcast if the caller knows it, search, exchange, pick."""
         self.broadcast_block(bank, block)
+        if prefetch_next:
+            self.prefetch(next_block)
         return self.search_and_pick(bank, row_offset)
 
 

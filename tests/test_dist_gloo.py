@@ -52,7 +52,8 @@ def _worker(rank, world, port, q):
     shifts = rs.randint(0, N, D)
     X = orc.forward_fft(x)
     ok = True
-    for sum_all in (True, False):
+    for sum_all, D in ((True, 10), (False, 10), (True, 7), (False, 7)):    # even slices: all-gather; uneven: all-reduce
+        shifts = rs.randint(0, N, D)
         shard = DopplerShard(device=torch.device('cpu'))
         lo, hi = shard.bin_range(D)
         bank = OracleBank(log2N, hi - lo, M, sum_all_masks=sum_all)
@@ -68,8 +69,16 @@ def _worker(rank, world, port, q):
         ok &= shard.owner(int(float(idx))) == bin_owner(D, world, int(float(idx)))
         if sum_all:
             ok &= shard.scores.numel() == D                            # only the populated column travels
+        # a stream of blocks: the next block is distributed while the current one is searched
+        b1 = torch.from_numpy(x.view(np.float32).copy()) if rank == 0 else None
+        b2 = torch.from_numpy((x * np.complex64(2)).view(np.float32).copy()) if rank == 0 else None
+        i1, _ = shard.step(bank, lo, b1, next_block=b2, prefetch_next=True)
+        ok &= bool(np.array_equal(shard.full_scores(), single))
+        i2, _ = shard.step(bank, lo, None, next_block=b1, prefetch_next=True)      # block 2 is already there
+        ok &= bool(np.array_equal(shard.full_scores(), single * np.float32(4))) and i1 == sidx and i2 == sidx
+        i3, _ = shard.step(bank, lo, None)                                         # and block 1 again
+        ok &= bool(np.array_equal(shard.full_scores(), single)) and i3 == sidx
     # the documented numpy statement of the same exchange
-    lo, hi = lo, hi
     local = orc.doppler_scores(X, masks, shifts[lo:hi], True).astype(np.float32)
     ok &= bool(np.array_equal(allreduce_scores_host(local, lo, D), orc.doppler_scores(X, masks, shifts, True).astype(np.float32)))
     q.put((rank, bool(ok), float(idx)))
