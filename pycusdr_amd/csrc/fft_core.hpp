@@ -333,7 +333,11 @@ DEVI void fft_passes(cf (&v)[16], cf *lds, int &ebuf, const int g, const int col
                     buf[padi(prefix * Lnext + t + Lnn * decltype(i)::value) * T + col];
             });
         });
-        if constexpr (S == 0) mid();
+        if constexpr (S == 0 && !std::is_same<Mid, NoMid>::value) {
+            __builtin_amdgcn_sched_barrier(0);      // keep the caller's work between the reads' issue and their use
+            mid();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if constexpr (!PP) xsync<SYNC>();
         fft_passes<L, T, S + 1, HOIST, PP, HALF, SYNC>(v, lds, ebuf, g, col, twr, table, store);
     }

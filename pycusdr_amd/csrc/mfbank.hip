@@ -264,7 +264,7 @@ struct P2Cfg {
     static constexpr int RB = NT >= 256 ? 1 : 256 / NT;
     static constexpr int HALF = padlen(L2) * RB;
     static constexpr bool PP = MFB_P2_PP && (size_t)HALF * 2 * sizeof(cf) <= 72 * 1024;
-    static constexpr bool HOIST = L2 <= 8192;  // 16384-point rows run 1024 threads: 128-VGPR budget
+    static constexpr bool HOIST = L2 <= 8192;  // (16384-point rows would run 1024 threads on a 128-VGPR budget and spill: N = 2^22 is split 512 x 8192 instead)
     static constexpr size_t lds_bytes = (size_t)HALF * (PP ? 2 : 1) * sizeof(cf);
 };
 
@@ -874,11 +874,11 @@ static int set_kernel_attributes(const mfb_ctx *c) {
         case 6: rc = attr_p1<64>(); break;
         case 7: rc = attr_p1<128>(); break;
         case 8: rc = attr_p1<256>(); break;
+        case 9: rc = attr_p1<512>(); break;
     }
     if (rc) return rc;
     switch (c->l2) {
         case 13: rc = attr_p2<8192>(); break;
-        case 14: rc = attr_p2<16384>(); break;
         default: break;   // <= 4096 points: 35 KiB
     }
     if (rc) return rc;
@@ -952,7 +952,10 @@ extern "C" int mfb_create(mfb_ctx **out, int device, int log2N, int num_dopplers
     c->device = device;
     c->log2N = log2N;
     c->N = 1 << log2N;
+    // N = N1 * N2: columns of at most 256 points, rows of at most 8192 (2^22 = 512 x 8192: a 16384-point row would
+    // need 1024 threads at 128 VGPRs and spilled > 100 registers)
     c->l1 = log2N / 2 < 8 ? log2N / 2 : 8;
+    if (log2N - c->l1 > 13) c->l1 = log2N - 13;
     c->l2 = log2N - c->l1;
     c->N1 = 1 << c->l1;
     c->N2 = 1 << c->l2;
@@ -1276,6 +1279,7 @@ static int launch_p1(mfb_ctx *c, const P1Args &a, dim3 grid) {
         case 6: return launch_p1_t<64, KIND>(c, a, grid);
         case 7: return launch_p1_t<128, KIND>(c, a, grid);
         case 8: return launch_p1_t<256, KIND>(c, a, grid);
+        case 9: return launch_p1_t<512, KIND>(c, a, grid);
     }
     return MFB_ERR_UNSUPPORTED;
 }
@@ -1301,7 +1305,6 @@ static int launch_p2(mfb_ctx *c, const P2Args &a, dim3 grid) {
         case 11: return launch_p2_t<2048, MODE>(c, a, grid);
         case 12: return launch_p2_t<4096, MODE>(c, a, grid);
         case 13: return launch_p2_t<8192, MODE>(c, a, grid);
-        case 14: return launch_p2_t<16384, MODE>(c, a, grid);
     }
     return MFB_ERR_UNSUPPORTED;
 }

@@ -60,6 +60,11 @@
 #ifndef MFB_SEG_XNEXT
 #define MFB_SEG_XNEXT 0
 #endif
+// multiply the NEXT filter's spectrum into the prefetch registers in the shadow of the current transform's LDS
+// exchange (fft_passes' mid hook) instead of at the top of the next iteration
+#ifndef MFB_SEG_SHADOW
+#define MFB_SEG_SHADOW 0
+#endif
 // issue the first filter's spectrum loads BEFORE the forward transform, so that they land while it runs
 #ifndef MFB_SEG_G0EARLY
 #define MFB_SEG_G0EARLY 1
@@ -272,10 +277,26 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                 lim = vseg - g;                   // output slot k is valid for this lane iff k*NT < lim
             }
             const int next_slot = (it + 1 < niter) ? slot + 1 : s0;
+            if constexpr (MFB_SEG_PREFETCH && MFB_SEG_SHADOW) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) gk[i] = cmul_cj(A[i], gk[i]);       // first filter: product in place
+            }
             for (int mi = 0; mi < nm; ++mi) {
                 const int rm = a.rows ? a.rows[m0 + mi] : (m0 + mi);
                 cf w[16];
-                if constexpr (MFB_SEG_PREFETCH) {
+                [[maybe_unused]] auto shadow = [&]() {
+                    if constexpr (MFB_SEG_PREFETCH && MFB_SEG_SHADOW) {
+                        if (mi + 1 < nm) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) gk[i] = cmul_cj(A[i], gk[i]);
+                        }
+                    }
+                };
+                if constexpr (MFB_SEG_PREFETCH && MFB_SEG_SHADOW) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) w[i] = gk[i];                   // already U * G
+                    if (mi + 1 < nm) load_g(gk, a.rows ? a.rows[m0 + mi + 1] : (m0 + mi + 1));
+                } else if constexpr (MFB_SEG_PREFETCH) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) w[i] = cmul_cj(A[i], gk[i]);    // conj(A) * G = U * G
                     if (mi + 1 < nm) {
@@ -304,7 +325,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                             racc = __builtin_elementwise_fma(val, val, racc);
                         }
                     };
-                    fft_passes<L, 1, 0, true, false, 0, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, acc);
+                    fft_passes<L, 1, 0, true, false, 0, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, acc, shadow);
                     float s = racc.x + racc.y;
                     if constexpr (!MASKED && !SYNC) s = active ? s : 0.f;
                     lacc[mi * 256 + tid] = before + s;
@@ -315,7 +336,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                         constexpr int k = decltype(nu)::value / NT;
                         if (k * NT < lim) buf_store_cf(orr, (int)(((o0 + (unsigned)(k * NT)) & nmask) * sizeof(cf)), 0, val);
                     };
-                    fft_passes<L, 1, 0, true, false, 0, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, put);
+                    fft_passes<L, 1, 0, true, false, 0, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, put, shadow);
                 }
             }
         }
