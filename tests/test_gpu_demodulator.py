@@ -227,3 +227,32 @@ def test_cc11xx_frame_received_and_crc_ok():
     data, crc_err, _ = packets[0].getBinaryData()
     assert packets[0].packetLen == 42 and not crc_err and np.array_equal(data[:-2], payload)
     run.close()
+
+
+def test_runner_stream_of_arbitrary_chunks_on_hip():
+    """N1 on the HIP path: the BER bench's 2^14-sample chunks (and GNU Radio's 4095/4096) go through the ring
+    buffer into blocks; results equal the block-fed run, the dict carries every reference key and pickles."""
+    import pickle
+    from pycusdr_amd.demodulator_process import DemodulatorRunner
+    bs, ov = 15, 1 << 10
+    N = 1 << bs
+    conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=32)
+    p = loadProtocol('bench_GMSK')(conf=conf)
+    sig = sg.awgn(np.concatenate((sg.get_padded_packet('GMSK')[0], np.zeros(2 * N))), 12.0, rng=np.random.RandomState(4)).astype(np.complex64)
+    step = N - ov
+    nblk = len(sig) // step
+    ref_run = DemodulatorRunner(conf, p, 'UHF-H')
+    ref, _ = ref_run.run([sig[i * step:(i + 1) * step] for i in range(nblk)])
+    ref_run.close()
+    for chunk in (1 << 14, 4095):
+        run = DemodulatorRunner(conf, p, 'UHF-H')
+        got, packets = run.run_stream((sig[i:i + chunk] for i in range(0, nblk * step, chunk)), decoder=Decoder(conf, p))
+        run.close()
+        assert len(got) == nblk and len(packets) == 1 and packets[0].checkPacketData() == 0
+        for a, b in zip(ref, got):
+            assert np.array_equal(a['data'], b['data']) and np.array_equal(a['trust'], b['trust'])
+            assert a['doppler'] == b['doppler'] and a['spSymEst'] == b['spSymEst']
+            assert np.array_equal(np.float64(a['SNR']), np.float64(b['SNR']), equal_nan=True)
+        d = pickle.loads(pickle.dumps(got[3], protocol=pickle.HIGHEST_PROTOCOL))
+        assert {'rangerateEst', 'baudRate_est', 'baudrate_est', 'rangerate', 'data', 'trust', 'doppler', 'SNR'} <= set(d)
+        assert np.array_equal(d['data'], got[3]['data'])

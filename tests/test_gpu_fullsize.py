@@ -15,8 +15,8 @@ def _rc(rs, *s):
     return (rs.standard_normal(s) + 1j * rs.standard_normal(s)).astype(np.complex64)
 
 
-@pytest.fixture(scope='module')
-def c2():
+@pytest.fixture(scope='module', params=['segment', 'twopass'])
+def c2(request):
     """C2: D=256, M=8 GMSK filters, N=2^20, bench geometry, S1 signal."""
     log2N, D = 20, 256
     N = 1 << log2N
@@ -28,6 +28,8 @@ def c2():
     bank = MFBank(log2N, D, M)
     bank.set_filters(masks)
     bank.set_shifts(shifts)
+    bank.set_search_path(request.param)          # both search paths go through every C2 test
+    assert bank.get_search_path()['path'] == request.param
     bank.upload(x)
     yield dict(bank=bank, masks=masks, shifts=shifts, x=x, N=N, D=D, M=M)
     bank.close()
@@ -214,8 +216,8 @@ def test_error_behaviour():
 
 @pytest.mark.parametrize('log2N', [19, 21, 22])
 def test_largest_supported_blocks(log2N):
-    """Maximum sizes: N = 2^21 runs 8192-point rows (512 threads), N = 2^22 runs 16384-point rows
-    (1024 threads, twiddles re-read instead of hoisted).  Real inverse FFTs of the oracle, D=3, M=2."""
+    """Maximum sizes: N = 2^21 = 256 x 8192 and N = 2^22 = 512 x 8192 (8192-point rows run 512 threads; a
+    16384-point row would spill).  Real inverse FFTs of the oracle, D=3, M=2 (white spectra: two-pass path)."""
     N = 1 << log2N
     rs = np.random.RandomState(log2N)
     D, M = 3, 2
@@ -225,6 +227,7 @@ def test_largest_supported_blocks(log2N):
     try:
         bank.set_filters(masks)
         bank.set_shifts(shifts)
+        assert bank.get_info()[:2] == {19: (256, 2048), 21: (256, 8192), 22: (512, 8192)}[log2N]
         bank.upload(x)
         X = bank.get_spectrum()
         bank.find_carrier()
