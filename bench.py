@@ -293,6 +293,28 @@ def main():
             except ValueError:
                 other = None
             bank.set_search_path(args.path if args.path != 'auto' or not seg else 'segment', *seg)
+        # opt-in span basis of the SUM_ALL search (rank(bank) filters instead of M) -- never the headline
+        if G == 1 and pinfo['path'] == 'segment':
+            try:
+                bank.set_search_basis('span')
+                sb = bank.get_search_basis()
+                step(0)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for i in range(8):
+                    step(i)
+                torch.cuda.synchronize(dev)
+                dt_sb = (time.perf_counter() - t1) / 8
+                sc_sb = bank.get_scores()[:, 0].astype(np.float64)
+                bank.set_search_basis('filters')
+                step(7)
+                sc_f = bank.get_scores()[:, 0].astype(np.float64)
+                extras['span_basis_search'] = {'filters_transformed': sb[1], 'of': M, 'ms_per_step': round(dt_sb * 1e3, 4),
+                                               'msamples': round((N - ov) / dt_sb / 1e6, 2),
+                                               'max_rel_diff_vs_default_search': float(np.abs(sc_sb - sc_f).max() / sc_f.max()),
+                                               'note': 'opt-in (mfb_set_search_basis): exact identity for the SUM_ALL_MASKS score; not the headline'}
+            except (ValueError, RuntimeError):
+                bank.set_search_basis('filters')
         # sync/preamble correlator (A14): B = 1024 streams of 67 584 bits x 64 taps, thresholded on the device
         rsb = np.random.RandomState(2)
         B, Lb = 1024, 65536 + 2048

@@ -94,6 +94,22 @@ int mfb_set_search_path(mfb_ctx *ctx, int path, int log2L, int wg_per_cu, int fi
  * support), valid outputs per segment and number of segments (0 on the two-pass path).  Any pointer
  * may be NULL. */
 int mfb_get_search_path(mfb_ctx *ctx, int *path, int *log2L, int *taps, int *valid_per_segment, int *segments);
+/* Search basis (opt-in; segment path with SUM_ALL_MASKS only).  With SUM_ALL_MASKS the search needs
+ * sum_m |y_m[n]|^2 only, which is invariant under any unitary mixing of the filters; the shipped banks (all 2^k
+ * bit patterns of a smooth modulation) span far fewer dimensions than they have filters (GMSK 6 of 8, FSK-2 and
+ * CC11xx 4 of 8, BPSK 5 of 32; directions below 1e-10 of the energy are dropped).  MFB_BASIS_SPAN makes the search transform an orthogonalised basis F of that span
+ * with F F^H = C C^H (C = the taps): the same doppSum to fp32 rounding from rank(C) inverse transforms per
+ * segment instead of M.  It is an algorithmic shortcut, so it is OFF by default (MFB_BASIS_FILTERS: every unique
+ * filter is transformed, as the reference does, DB:578-588) and bench.py reports it as a separate figure.
+ * The demodulation stage always uses the M filters.  Returns MFB_ERR_STATE on a handle created without
+ * sum_all_masks (per-filter sums need every filter); on the two-pass path the request stays pending. */
+#define MFB_BASIS_FILTERS 0
+#define MFB_BASIS_SPAN    1
+int mfb_set_search_basis(mfb_ctx *ctx, int basis);
+/* Basis in force and the number of filters the search transforms per Doppler bin. */
+int mfb_get_search_basis(mfb_ctx *ctx, int *basis, int *transformed_filters);
+/* Host-only helper: dimension of the span of a bank's impulse responses (M if it has no short support). */
+int mfb_analyze_rank(const float *masks_c64, int M, int N, int *rank);
 /* Fault injection for tests: the nth device allocation made on behalf of a handle by the calling thread
  * from now on fails as if the device were out of memory (0 disarms).  Lets a test walk the free-on-error
  * path of mfb_create allocation by allocation. */

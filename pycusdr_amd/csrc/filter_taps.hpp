@@ -206,4 +206,109 @@ static inline void segment_spectra(const Bank &b, int L, int Te, std::vector<flo
     }
 }
 
+// ---- span basis (opt-in, SUM_ALL_MASKS search only) ---------------------------------------------------------
+// With SUM_ALL_MASKS the search needs  sum_m |y_m[n]|^2 = x_n^H (C C^H) x_n  only, C = [c_1 ... c_M] the taps.
+// Any F with F F^H = C C^H gives the same number from rank(C) filters instead of M.  The shipped banks are
+// strongly rank-deficient (all 2^k bit patterns of a smooth modulation: GMSK 6 of 8, FSK-2 / CC11xx 4 of 8,
+// BPSK 5 of 32).  F = Q L with C = Q R (pivoted modified Gram-Schmidt, Q orthonormal) and R R^H = L L^H
+// (Cholesky): F F^H = Q R R^H Q^H = C C^H.  Directions whose residual energy is below SPAN_REL = 1e-10 of the
+// largest column are dropped: exact dependencies (the complex64 rounding of the spectra leaves ~1e-15 there) and
+// the two directions of the GMSK bank that carry 3e-12 of the energy -- they change doppSum by < 1e-10 relative,
+// three orders below the fp32 rounding of the transforms themselves.
+static constexpr double SPAN_REL = 1e-10;
+static inline int span_basis(const Bank &b, Bank *out) {
+    const int M = b.M, T = b.T;
+    std::vector<std::vector<cd>> C(M, std::vector<cd>(T));
+    double emax = 0.0;
+    for (int m = 0; m < M; ++m) {
+        double e = 0.0;
+        for (int r = 0; r < T; ++r) {
+            C[m][r] = tap(b, m, r);
+            e += std::norm(C[m][r]);
+        }
+        emax = std::max(emax, e);
+    }
+    out->N = b.N;
+    out->start = b.start;
+    out->T = b.T;
+    out->rows.clear();
+    if (emax == 0.0) {
+        out->M = 0;
+        return 0;
+    }
+    std::vector<std::vector<cd>> Q;                 // orthonormal columns
+    std::vector<std::vector<cd>> work = C;          // residuals
+    std::vector<uint8_t> used(M, 0);
+    for (;;) {
+        int best = -1;
+        double be = SPAN_REL * emax;
+        for (int m = 0; m < M; ++m) {
+            if (used[m]) continue;
+            double e = 0.0;
+            for (int r = 0; r < T; ++r) e += std::norm(work[m][r]);
+            if (e > be) {
+                be = e;
+                best = m;
+            }
+        }
+        if (best < 0) break;
+        used[best] = 1;
+        std::vector<cd> q = work[best];
+        for (int pass = 0; pass < 2; ++pass)          // re-orthogonalise once (twice is enough)
+            for (const auto &p : Q) {
+                cd d(0.0, 0.0);
+                for (int r = 0; r < T; ++r) d += std::conj(p[r]) * q[r];
+                for (int r = 0; r < T; ++r) q[r] -= d * p[r];
+            }
+        double n2 = 0.0;
+        for (int r = 0; r < T; ++r) n2 += std::norm(q[r]);
+        const double inv = 1.0 / sqrt(n2);
+        for (int r = 0; r < T; ++r) q[r] *= inv;
+        for (int m = 0; m < M; ++m) {
+            if (used[m]) continue;
+            cd d(0.0, 0.0);
+            for (int r = 0; r < T; ++r) d += std::conj(q[r]) * work[m][r];
+            for (int r = 0; r < T; ++r) work[m][r] -= d * q[r];
+        }
+        Q.push_back(q);
+    }
+    const int R = (int)Q.size();
+    // Rm = Q^H C (R x M), S = Rm Rm^H (R x R), Cholesky S = L L^H
+    std::vector<std::vector<cd>> Rm(R, std::vector<cd>(M));
+    for (int k = 0; k < R; ++k)
+        for (int m = 0; m < M; ++m) {
+            cd d(0.0, 0.0);
+            for (int r = 0; r < T; ++r) d += std::conj(Q[k][r]) * C[m][r];
+            Rm[k][m] = d;
+        }
+    std::vector<std::vector<cd>> S(R, std::vector<cd>(R)), Lc(R, std::vector<cd>(R, cd(0.0, 0.0)));
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < R; ++j) {
+            cd d(0.0, 0.0);
+            for (int m = 0; m < M; ++m) d += Rm[i][m] * std::conj(Rm[j][m]);
+            S[i][j] = d;
+        }
+    for (int j = 0; j < R; ++j) {
+        double d = S[j][j].real();
+        for (int k = 0; k < j; ++k) d -= std::norm(Lc[j][k]);
+        const double ljj = sqrt(d > 0.0 ? d : 0.0);
+        Lc[j][j] = cd(ljj, 0.0);
+        for (int i = j + 1; i < R; ++i) {
+            cd v = S[i][j];
+            for (int k = 0; k < j; ++k) v -= Lc[i][k] * std::conj(Lc[j][k]);
+            Lc[i][j] = ljj > 0.0 ? v / ljj : cd(0.0, 0.0);
+        }
+    }
+    // F = Q L: column k of F = sum_i Q_i * L[i][k]
+    out->M = R;
+    out->rows.assign(R, RowTaps());
+    for (int k = 0; k < R; ++k) {
+        out->rows[k].start = b.start;
+        out->rows[k].c.assign(T, cd(0.0, 0.0));
+        for (int i = k; i < R; ++i)
+            for (int r = 0; r < T; ++r) out->rows[k].c[r] += Q[i][r] * Lc[i][k];
+    }
+    return R;
+}
+
 }  // namespace taps

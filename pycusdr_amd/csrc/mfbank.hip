@@ -370,15 +370,18 @@ __global__ void __launch_bounds__(64) k_finalize(const float *partials, float *d
     const int lane = threadIdx.x;
     if (j >= D) return;
     float tot = 0.f;
-    for (int m = 0; m < M; ++m) {
-        const float *p = partials + ((size_t)j * MU + rep[m]) * parts;
+    const int nrows = rep ? M : MU;       // rep == nullptr: sum every transformed row (span basis, SUM_ALL only)
+    if (!rep && lane == 0)
+        for (int m = 0; m < M; ++m) dsum[j * M + m] = 0.f;
+    for (int m = 0; m < nrows; ++m) {
+        const float *p = partials + ((size_t)j * MU + (rep ? rep[m] : m)) * parts;
         float s = 0.f;
         for (int q = lane; q < parts; q += 64) s += p[q];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         if (sum_all) {
             tot += s;
-            if (lane == 0) dsum[j * M + m] = 0.f;
+            if (rep && lane == 0) dsum[j * M + m] = 0.f;
         } else if (lane == 0) {
             dsum[j * M + m] = s;
         }
@@ -714,6 +717,10 @@ struct mfb_ctx {
     int twL_len;
     size_t part_cap;          // floats allocated in d_part
     taps::Bank *bank;         // host copy of the taps (kept so that L can be changed)
+    int basis_req, basis;     // MFB_BASIS_*: requested / in force
+    int MB;                   // filters of the span basis
+    cf *d_Gb;                 // their segment spectra [MB][L] (slot-pair layout)
+    int gb_l;                 // segment length d_Gb was built for
     std::vector<hipEvent_t> ev[2];
     std::vector<hipEvent_t> ev_pool;
 };
@@ -999,7 +1006,7 @@ extern "C" int mfb_destroy(mfb_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_uniq, c->d_rep, c->d_x,  c->d_X,    c->d_masks, c->d_Z,   c->d_xc,  c->d_P,   c->d_env, c->d_shifts, c->d_tw1,
                     c->d_tw2, c->d_twLo, c->d_twHi,  c->d_part, c->d_sum, c->d_res, c->d_cr,  c->d_sym,    c->d_cen, c->d_mag,
-                    c->d_G, c->d_twL};
+                    c->d_G, c->d_twL, c->d_Gb};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (c->h_in) (void)hipHostFree(c->h_in);
@@ -1106,6 +1113,7 @@ static int resolve_path(mfb_ctx *c) {
     if (!l) {
         c->path = MFB_PATH_TWOPASS;
         c->segl = 0;
+        c->basis = MFB_BASIS_FILTERS;
     } else {
         const int L = 1 << l;
         if (c->segl != l || !c->d_G) {
@@ -1125,6 +1133,25 @@ static int resolve_path(mfb_ctx *c) {
                 if (rc) return rc;
                 c->twL_len = L;
             }
+        }
+        // opt-in span basis of the SUM_ALL search (filter_taps.hpp): rank(C) filters instead of M
+        c->basis = MFB_BASIS_FILTERS;
+        if (c->basis_req == MFB_BASIS_SPAN && c->sum_all) {
+            if (c->gb_l != l || !c->d_Gb) {
+                taps::Bank sb;
+                c->MB = taps::span_basis(*c->bank, &sb);
+                std::vector<float> G;
+                if (c->MB > 0) taps::segment_spectra(sb, L, L - seg_valid(l, T) + 1, &G);
+                if (c->d_Gb) HIPCHK(hipFree(c->d_Gb));
+                c->d_Gb = nullptr;
+                c->gb_l = 0;
+                if (c->MB > 0) {
+                    HIPCHK(dev_alloc((void **)&c->d_Gb, G.size() * sizeof(float)));
+                    HIPCHK(hipMemcpy(c->d_Gb, G.data(), G.size() * sizeof(float), hipMemcpyHostToDevice));
+                    c->gb_l = l;
+                }
+            }
+            if (c->MB > 0) c->basis = MFB_BASIS_SPAN;
         }
         c->path = MFB_PATH_SEGMENT;
         c->segl = l;
@@ -1164,6 +1191,31 @@ extern "C" int mfb_set_search_path(mfb_ctx *c, int path, int log2L, int wg_per_c
         (void)resolve_path(c);
     }
     return rc;
+}
+
+extern "C" int mfb_set_search_basis(mfb_ctx *c, int basis) {
+    if (!c || (basis != MFB_BASIS_FILTERS && basis != MFB_BASIS_SPAN)) return MFB_ERR_ARG;
+    if (basis == MFB_BASIS_SPAN && !c->sum_all) return MFB_ERR_STATE;   // per-filter sums need every filter
+    HIPCHK(hipSetDevice(c->device));
+    c->basis_req = basis;
+    return resolve_path(c);
+}
+extern "C" int mfb_get_search_basis(mfb_ctx *c, int *basis, int *transformed_filters) {
+    if (!c) return MFB_ERR_ARG;
+    if (basis) *basis = c->basis;
+    if (transformed_filters) *transformed_filters = (c->path == MFB_PATH_SEGMENT && c->basis == MFB_BASIS_SPAN) ? c->MB : c->MU;
+    return MFB_OK;
+}
+extern "C" int mfb_analyze_rank(const float *masks, int M, int N, int *rank) {
+    if (!masks || !rank || M < 1 || N < 2 || (N & (N - 1))) return MFB_ERR_ARG;
+    taps::Bank b, sb;
+    taps::analyse(masks, M, N, &b);
+    if (b.T > taps::ROW_TAPS_MAX) {
+        *rank = M;          // no short support: not analysed
+        return MFB_OK;
+    }
+    *rank = taps::span_basis(b, &sb);
+    return MFB_OK;
 }
 
 extern "C" int mfb_get_search_path(mfb_ctx *c, int *path, int *log2L, int *taps_out, int *valid_per_segment, int *segments) {
@@ -1221,6 +1273,7 @@ extern "C" int mfb_set_filters(mfb_ctx *c, const float *masks, int M, int N) {
     c->have_filters = true;
     c->have_xc = false;
     c->segl = 0;    // force G to be rebuilt for the new bank
+    c->gb_l = 0;
     int rc = resolve_path(c);
     if (rc == MFB_ERR_UNSUPPORTED) {   // a segment path was demanded but this bank has no short support
         c->path_req = MFB_PATH_AUTO;
@@ -1548,6 +1601,8 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
     if (c->path == MFB_PATH_SEGMENT) {
         // all bins in ONE launch: nothing of length N is written, so there is nothing to chunk.  A second,
         // tiny launch of the masked instantiation covers the slots that hold incomplete segments.
+        const bool span = c->basis == MFB_BASIS_SPAN;
+        const int MU = span ? c->MB : c->MU;     // filters transformed per bin
         int nfull, ntotal;
         seg_slots(c, &nfull, &ntotal);
         const SegPlan pm = plan_seg(c, c->Dtot, MU, nfull > 0 ? nfull : 1, c->seg_mpb);
@@ -1559,7 +1614,11 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
         if (rc) return rc;
         SegArgs am = seg_base(c, pm), at = seg_base(c, pt);
         for (SegArgs *q : {&am, &at}) {
-            q->rows = (MU < c->M) ? c->d_uniq : nullptr;
+            if (span) {
+                q->G = c->d_Gb;
+                q->Grows = c->MB;
+            }
+            q->rows = (!span && MU < c->M) ? c->d_uniq : nullptr;
             q->shifts = c->d_shifts;
             q->partials = c->d_part;
             q->MU = MU;
@@ -1580,7 +1639,7 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
         if (rc) return rc;
         prof_mark(c, 0);
         hipLaunchKernelGGL(k_finalize, dim3(c->Dtot), dim3(64), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, MU,
-                           (const int *)c->d_rep, parts, c->sum_all);
+                           span ? (const int *)nullptr : (const int *)c->d_rep, parts, c->sum_all);
         HIPCHK(hipGetLastError());
         return MFB_OK;
     }

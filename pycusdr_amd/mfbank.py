@@ -76,6 +76,18 @@ class MFBank:
         _lib.check(self._lib.mfb_set_search_path(self._h, self.PATHS[path] if isinstance(path, str) else int(path),
                                                  int(log2L), int(wg_per_cu), int(filters_per_pass)), 'mfb_set_search_path')
 
+    def set_search_basis(self, basis='filters'):
+        """'filters' (default): the search transforms every unique filter, as the reference does.  'span'
+        (opt-in; SUM_ALL_MASKS on the segment path): it transforms an orthogonalised basis of the bank's span --
+        the same doppSum to fp32 rounding from rank(bank) instead of M inverse transforms per segment."""
+        _lib.check(self._lib.mfb_set_search_basis(self._h, {'filters': 0, 'span': 1}[basis]), 'mfb_set_search_basis')
+
+    def get_search_basis(self):
+        """(basis in force, filters transformed per Doppler bin)."""
+        b, n = C.c_int(), C.c_int()
+        _lib.check(self._lib.mfb_get_search_basis(self._h, C.byref(b), C.byref(n)), 'mfb_get_search_basis')
+        return ('span' if b.value == 1 else 'filters'), n.value
+
     def get_search_path(self):
         """dict(path, log2L, taps, valid_per_segment, segments) in force."""
         v = [C.c_int() for _ in range(5)]
@@ -214,6 +226,15 @@ def analyze_filters(masks):
     _lib.check(lib.mfb_analyze_filters(_ptr(masks), masks.shape[0], masks.shape[1], C.byref(st), C.byref(ln)),
                'mfb_analyze_filters')
     return st.value, ln.value
+
+
+def analyze_rank(masks):
+    """Dimension of the span of a filter bank's impulse responses -- host-only, no GPU needed."""
+    lib = _lib.load()
+    masks = np.ascontiguousarray(masks, dtype=np.complex64)
+    r = C.c_int()
+    _lib.check(lib.mfb_analyze_rank(_ptr(masks), masks.shape[0], masks.shape[1], C.byref(r)), 'mfb_analyze_rank')
+    return r.value
 
 
 _xcorr_banks = {}

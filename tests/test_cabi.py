@@ -74,3 +74,20 @@ def test_product_path_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
                 assert '/root/reference' not in src, f
+
+
+def test_bank_rank_analysis_host_only():
+    """mfb_analyze_rank (host-only): the shipped banks span far fewer dimensions than they have filters -- the
+    basis of the opt-in span search."""
+    import numpy as np
+    from pycusdr_amd import config as cfg
+    from pycusdr_amd.mfbank import analyze_rank
+    from pycusdr_amd.protocol import loadProtocol
+    expect = {'bench_GMSK': (8, 6), 'bench_FSK': (8, 4), 'bench_GFSK': (8, 4), 'bench_BPSK': (32, 5), 'CC11xx': (8, 4)}
+    for name, (M0, r0) in expect.items():
+        conf = cfg.cc11xx_config(blockSize=14) if name == 'CC11xx' else cfg.bench_config(name, blockSize=14)
+        sps, ms = (128, 3) if name == 'CC11xx' else (16, 5 if name == 'bench_BPSK' else 3)
+        M, masks = loadProtocol(name)(conf=conf).get_filter(1 << 14, sps, ms)
+        assert (M, analyze_rank(masks)) == (M0, r0), name
+    rs = np.random.RandomState(0)
+    assert analyze_rank((rs.standard_normal((3, 1024)) + 1j * rs.standard_normal((3, 1024))).astype(np.complex64)) == 3

@@ -214,3 +214,57 @@ def test_zero_and_single_tap_filters():
     e = float(N) * N * np.sum(np.abs(x.astype(np.complex128)) ** 2) / 262144.0
     assert np.all(ds[:, 0] == 0)
     assert np.allclose(ds[:, 1], e, rtol=1e-5) and np.allclose(ds[:, 2], 4 * e, rtol=1e-5)
+
+
+@pytest.mark.parametrize('name,sps,ms,rank', [('bench_GMSK', 16, 3, 6), ('bench_FSK', 16, 3, 4), ('bench_BPSK', 16, 5, 5),
+                                              ('CC11xx', 128, 3, 4)])
+def test_span_basis_search_equals_full_bank(name, sps, ms, rank):
+    """Opt-in span basis: the SUM_ALL search over an orthogonalised basis of the bank's span (rank filters instead
+    of M) gives the reference's doppSum -- against the oracle's FULL bank (1e-5) and against the default search of
+    the same handle (fp32 rounding); the pick is the same; demodulation still uses all M filters."""
+    log2N, D = 16, 9
+    N = 1 << log2N
+    rs = np.random.RandomState(rank)
+    M, masks = _bank_masks(name, log2N, sps, ms)
+    x = _rc(rs, N)
+    shifts = rs.randint(0, N, D).astype(np.int32)
+    bank = MFBank(log2N, D, M, sum_all_masks=True)
+    try:
+        bank.set_filters(masks)
+        bank.set_shifts(shifts)
+        bank.upload(x)
+        assert bank.get_search_basis()[0] == 'filters'
+        idx0, _ = bank.find_carrier()
+        ds0 = bank.get_scores()
+        bank.set_search_basis('span')
+        assert bank.get_search_basis() == ('span', rank)
+        idx1, _ = bank.find_carrier()
+        ds1 = bank.get_scores()
+        X = bank.get_spectrum()
+        bank.demodulate(int(shifts[2]), 10, 100)
+        xc = bank.get_xcorr()
+        bank.set_search_path('twopass')                       # the request stays pending off the segment path
+        assert bank.get_search_basis()[0] == 'filters'
+        bank.set_search_path('segment')
+        assert bank.get_search_basis() == ('span', rank)
+        bank.set_search_basis('filters')
+        assert bank.get_search_basis()[0] == 'filters'
+    finally:
+        bank.close()
+    ref = orc.doppler_scores(X, masks, shifts, True)
+    assert np.abs(ds1 - ref).max() / ref.max() < 1e-5
+    assert np.abs(ds1 - ds0).max() / ds0.max() < 2e-6
+    # white-noise input: all bins score alike, so the weighted top-2 index moves in its last bits with the scores'
+    assert int(idx0) == int(idx1) and abs(float(idx0) - float(idx1)) < 1e-5 * max(1.0, abs(float(idx0)))
+    assert np.all(ds1[:, 1:] == 0)
+    ref_xc = orc.demod_xcorr(X, masks, int(shifts[2]))
+    assert xc.shape == (M, N) and np.abs(xc - ref_xc).max() / np.abs(ref_xc).max() < 1e-5
+
+
+def test_span_basis_refused_without_sum_all():
+    bank = MFBank(12, 3, 2, sum_all_masks=False)
+    try:
+        with pytest.raises(RuntimeError):
+            bank.set_search_basis('span')
+    finally:
+        bank.close()
