@@ -270,15 +270,9 @@ DEVI void xsync() {
 // g    : thread index inside the FFT group, 0 <= g < L/16 ;  col: column inside the tile
 // store(n, value, slot, nu): natural output index n = nu + g; slot (register slot id) and nu are
 //        compile-time constants (std::integral_constant)
-// mid() : optional independent work of the caller, placed in program order right after the LDS reads of
-//        the FIRST exchange have been issued and before their results are used -- it runs in the shadow of
-//        the exchange's round trip (the segment search multiplies the next filter there)
-struct NoMid {
-    DEVI void operator()() const {}
-};
-template <int L, int T, int S, bool HOIST, bool PP, int HALF, int SYNC = 0, class Store, class Mid = NoMid>
+template <int L, int T, int S, bool HOIST, bool PP, int HALF, int SYNC = 0, class Store>
 DEVI void fft_passes(cf (&v)[16], cf *lds, int &ebuf, const int g, const int col, const TwRegs<L> &twr,
-                     const cf *__restrict__ table, Store &store, Mid mid = Mid()) {
+                     const cf *__restrict__ table, Store &store) {
     constexpr int l = ilog2c(L);
     constexpr int NP = npass(l);
     constexpr int R = radix_of(l, S);
@@ -333,11 +327,6 @@ DEVI void fft_passes(cf (&v)[16], cf *lds, int &ebuf, const int g, const int col
                     buf[padi(prefix * Lnext + t + Lnn * decltype(i)::value) * T + col];
             });
         });
-        if constexpr (S == 0 && !std::is_same<Mid, NoMid>::value) {
-            __builtin_amdgcn_sched_barrier(0);      // keep the caller's work between the reads' issue and their use
-            mid();
-            __builtin_amdgcn_sched_barrier(0);
-        }
         if constexpr (!PP) xsync<SYNC>();
         fft_passes<L, T, S + 1, HOIST, PP, HALF, SYNC>(v, lds, ebuf, g, col, twr, table, store);
     }

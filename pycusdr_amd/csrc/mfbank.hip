@@ -1602,7 +1602,7 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
         // all bins in ONE launch: nothing of length N is written, so there is nothing to chunk.  A second,
         // tiny launch of the masked instantiation covers the slots that hold incomplete segments.
         const bool span = c->basis == MFB_BASIS_SPAN;
-        const int MU = span ? c->MB : c->MU;     // filters transformed per bin
+        const int MU = span ? c->MB : c->MU;     // filters transformed per bin (shadows the two-pass count above on purpose)
         int nfull, ntotal;
         seg_slots(c, &nfull, &ntotal);
         const SegPlan pm = plan_seg(c, c->Dtot, MU, nfull > 0 ? nfull : 1, c->seg_mpb);

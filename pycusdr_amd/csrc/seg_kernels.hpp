@@ -54,17 +54,6 @@
 #ifndef MFB_SEG_PREFETCH
 #define MFB_SEG_PREFETCH 1
 #endif
-// prefetch the NEXT slot's x into the prefetch registers while the last filter of a slot is transformed
-// (A/B on one MI355X: same time within noise as loading x at the slot's start, but the registers it keeps live
-// across the slot loop spill 20 VGPRs at the 3-wave budget -> off)
-#ifndef MFB_SEG_XNEXT
-#define MFB_SEG_XNEXT 0
-#endif
-// multiply the NEXT filter's spectrum into the prefetch registers in the shadow of the current transform's LDS
-// exchange (fft_passes' mid hook) instead of at the top of the next iteration
-#ifndef MFB_SEG_SHADOW
-#define MFB_SEG_SHADOW 0
-#endif
 // issue the first filter's spectrum loads BEFORE the forward transform, so that they land while it runs
 #ifndef MFB_SEG_G0EARLY
 #define MFB_SEG_G0EARLY 1
@@ -228,10 +217,11 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
             for (int ii = 0; ii < 8; ++ii) buf_load_cf2(gr, vo_g2, row * (L * (int)sizeof(cf)) + ii * so_g2, dst[2 * ii], dst[2 * ii + 1]);
         };
         // One set of 16 prefetch registers (MFB_SEG_PREFETCH) receives the first filter's spectrum while the forward
-        // transform runs and the next filter's spectrum during every inverse transform (optionally the x of the
-        // next slot during the last one, MFB_SEG_XNEXT).
+        // transform runs and the next filter's spectrum during every inverse transform.  (Also tried, one MI355X,
+        // A/B of two builds: the next slot's x in the same registers during the last filter -- no gain, 20 spilled
+        // VGPRs at the 3-wave budget; the next filter's product in the shadow of the LDS exchange -- 7 % slower than
+        // the compiler's own schedule.)
         [[maybe_unused]] cf gk[16];
-        if constexpr (MFB_SEG_PREFETCH && MFB_SEG_XNEXT) load_x(gk, s0);
 
         for (int it = 0; it < niter; ++it) {
             const int slot = s0 + it;
@@ -243,12 +233,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
             // ---- the segment, mixed with e^{-2 pi i s n / N} and conjugated (forward via inverse) ----
             cf v[16];
             {
-                if constexpr (MFB_SEG_PREFETCH && MFB_SEG_XNEXT) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = gk[i];
-                } else {
-                    load_x(v, slot);
-                }
+                load_x(v, slot);
                 // conj(x) * W_N^{+t} = conj(x * e^{-2 pi i t / N})
                 if constexpr (PTAB) {
 #pragma unroll
@@ -276,34 +261,13 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                 const int vseg = active ? min(a.V, a.N - (int)b0) : 0;     // <= 0 beyond the last segment
                 lim = vseg - g;                   // output slot k is valid for this lane iff k*NT < lim
             }
-            const int next_slot = (it + 1 < niter) ? slot + 1 : s0;
-            if constexpr (MFB_SEG_PREFETCH && MFB_SEG_SHADOW) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) gk[i] = cmul_cj(A[i], gk[i]);       // first filter: product in place
-            }
             for (int mi = 0; mi < nm; ++mi) {
                 const int rm = a.rows ? a.rows[m0 + mi] : (m0 + mi);
                 cf w[16];
-                [[maybe_unused]] auto shadow = [&]() {
-                    if constexpr (MFB_SEG_PREFETCH && MFB_SEG_SHADOW) {
-                        if (mi + 1 < nm) {
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) gk[i] = cmul_cj(A[i], gk[i]);
-                        }
-                    }
-                };
-                if constexpr (MFB_SEG_PREFETCH && MFB_SEG_SHADOW) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) w[i] = gk[i];                   // already U * G
-                    if (mi + 1 < nm) load_g(gk, a.rows ? a.rows[m0 + mi + 1] : (m0 + mi + 1));
-                } else if constexpr (MFB_SEG_PREFETCH) {
+                if constexpr (MFB_SEG_PREFETCH) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) w[i] = cmul_cj(A[i], gk[i]);    // conj(A) * G = U * G
-                    if (mi + 1 < nm) {
-                        load_g(gk, a.rows ? a.rows[m0 + mi + 1] : (m0 + mi + 1));
-                    } else if constexpr (MFB_SEG_XNEXT) {
-                        load_x(gk, next_slot);
-                    }
+                    if (mi + 1 < nm) load_g(gk, a.rows ? a.rows[m0 + mi + 1] : (m0 + mi + 1));
                 } else {
 #pragma unroll
                     for (int ii = 0; ii < 8; ++ii) {
@@ -325,7 +289,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                             racc = __builtin_elementwise_fma(val, val, racc);
                         }
                     };
-                    fft_passes<L, 1, 0, true, false, 0, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, acc, shadow);
+                    fft_passes<L, 1, 0, true, false, 0, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, acc);
                     float s = racc.x + racc.y;
                     if constexpr (!MASKED && !SYNC) s = active ? s : 0.f;
                     lacc[mi * 256 + tid] = before + s;
@@ -336,7 +300,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                         constexpr int k = decltype(nu)::value / NT;
                         if (k * NT < lim) buf_store_cf(orr, (int)(((o0 + (unsigned)(k * NT)) & nmask) * sizeof(cf)), 0, val);
                     };
-                    fft_passes<L, 1, 0, true, false, 0, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, put, shadow);
+                    fft_passes<L, 1, 0, true, false, 0, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, put);
                 }
             }
         }
