@@ -279,18 +279,21 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                 }
                 if constexpr (MODE == SEG_REDUCE) {
                     const float before = lacc[mi * 256 + tid];     // read early: its latency hides behind the transform
-                    cf racc = mkc(0.f, 0.f);      // (sum re^2, sum im^2)
+                    // (sum re^2, sum im^2) in four independent chains: back-to-back dependent packed ops cost a
+                    // wait state each (the compiler pads them with s_nop)
+                    cf racc[4] = {mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f)};
                     auto acc = [&](int, cf val, auto, auto nu) {
                         constexpr int k = decltype(nu)::value / NT;
                         if constexpr (MASKED) {
                             const float wgt = (k * NT < lim) ? 1.f : 0.f;
-                            racc = __builtin_elementwise_fma(val * wgt, val, racc);
+                            racc[k & 3] = __builtin_elementwise_fma(val * wgt, val, racc[k & 3]);
                         } else if constexpr (k < PV) {
-                            racc = __builtin_elementwise_fma(val, val, racc);
+                            racc[k & 3] = __builtin_elementwise_fma(val, val, racc[k & 3]);
                         }
                     };
                     fft_passes<L, 1, 0, true, false, 0, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, acc);
-                    float s = racc.x + racc.y;
+                    const cf rsum = (racc[0] + racc[1]) + (racc[2] + racc[3]);
+                    float s = rsum.x + rsum.y;
                     if constexpr (!MASKED && !SYNC) s = active ? s : 0.f;
                     lacc[mi * 256 + tid] = before + s;
                 } else {
