@@ -25,6 +25,8 @@ else:
 _, _, shifts, _ = doppler_bin_table(conf['Radios']['Rx']['UHF-H'], conf['Radios']['rangeRateMax'], N)
 M, masks = loadProtocol(name)(conf=conf).get_filter(N, sps, ms)
 x = sg.s1_stream(1, N, 1 << 10, 'GMSK', snr_db=10.0, seed=1)[:N]
+if '--zeros' in sys.argv:      # power/clock experiment: the same instruction stream on all-zero data
+    x = np.zeros(N, dtype=np.complex64)
 bank = MFBank(log2N, D, M)
 bank.set_filters(masks)
 bank.set_shifts(shifts)
@@ -42,7 +44,7 @@ def run(tag):
         bank.search_async()
     ms_ = bank.timer_stop() / reps
     ds = bank.get_scores()[:, 0].astype(np.float64)
-    err = np.abs(ds - ref).max() / ref.max()
+    err = np.abs(ds - ref).max() / max(ref.max(), 1e-30)
     print(f'{tag:34s} {ms_:8.3f} ms/block  {(N - 1024) / ms_ / 1e3:8.2f} Msamp/s   parseval rel err {err:.2e}', flush=True)
 
 
