@@ -572,12 +572,11 @@ __global__ void k_centres(int *outSym, int *outIdx, float *mag, const cf *sig, f
         outSym[x] = maxIdx;
         outIdx[x] = (int)__fadd_rn(__fadd_rn(base, (float)maxCentreIdx), (float)offsetComp);
         mag[x] = maxVal;
+    } else {            // a symbol past the end of the block: the reference leaves its buffers untouched there
+        outSym[x] = INT32_MIN;
+        outIdx[x] = INT32_MIN;
+        mag[x] = 0.f;
     }
-}
-
-__global__ void k_fill_i32(int *p, int v, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
 }
 
 // batched sync-word correlation (decoder.py:96,112): full convolution, exact int32
@@ -1757,9 +1756,18 @@ extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, fl
         // the same segment kernel, storing y in natural order instead of reducing it (no transpose)
         int nfull, ntotal;
         seg_slots(c, &nfull, &ntotal);
-        const SegPlan p = plan_seg(c, 1, c->M, ntotal, 4);    // one bin: spread filters and slots over the chip
+        // one bin: spread the slots over the chip.  When a team takes all M filters of its segments (M <= 16) it also
+        // sums the symbol-energy envelope (sumXCorrBuffMasks, CU:191-205) in the same pass; otherwise the filters are
+        // spread too and k_envelope follows
+        const bool fused_env = c->M <= SEG_MPB_MAX;
+        const SegPlan p = plan_seg(c, 1, c->M, ntotal, fused_env ? c->M : 4);
         SegArgs sa = seg_base(c, p);
         sa.out = c->d_xc;
+        if (fused_env) {
+            sa.env = c->d_env;
+            sa.env_lo = c->cs_off;
+            sa.env_hi = c->M - c->cs_off;
+        }
         sa.MU = c->M;
         sa.dc = 1;
         sa.slot0 = 0;
@@ -1787,9 +1795,11 @@ extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, fl
         rc = launch_transpose(c, c->d_xc, c->M, 0);
         if (rc) return rc;
     }
-    // A10: envelope, spectrum of the envelope, windowed argmax
-    hipLaunchKernelGGL(k_envelope, dim3(1024), dim3(256), 0, c->stream, c->d_xc, c->d_env, c->N, c->M, c->cs_off);
-    HIPCHK(hipGetLastError());
+    // A10: envelope (unless the matched-filter launch already summed it), spectrum of the envelope, windowed argmax
+    if (!(c->path == MFB_PATH_SEGMENT && c->M <= SEG_MPB_MAX)) {
+        hipLaunchKernelGGL(k_envelope, dim3(1024), dim3(256), 0, c->stream, c->d_xc, c->d_env, c->N, c->M, c->cs_off);
+        HIPCHK(hipGetLastError());
+    }
     rc = forward_fft(c, nullptr, c->d_env, c->d_P);
     if (rc) return rc;
     hipLaunchKernelGGL(k_code_rate, dim3(1), dim3(1024), 0, c->stream, c->d_P, c->d_cr, k_offset, k_len);
@@ -1811,9 +1821,7 @@ extern "C" int mfb_find_centres(mfb_ctx *c, float spSym, float offset, int op, i
     if (nthreads > c->cap) nthreads = c->cap;
     if (nthreads < count) nthreads = count;
     const int nb = (nthreads + 255) / 256;
-    hipLaunchKernelGGL(k_fill_i32, dim3((c->cap + 255) / 256), dim3(256), 0, c->stream, c->d_sym, INT32_MIN, c->cap);
-    hipLaunchKernelGGL(k_fill_i32, dim3((c->cap + 255) / 256), dim3(256), 0, c->stream, c->d_cen, INT32_MIN, c->cap);
-    HIPCHK(hipMemsetAsync(c->d_mag, 0, (size_t)c->cap * sizeof(float), c->stream));
+    // (every one of the nthreads >= count entries is written by k_centres itself: no clearing launches)
     hipLaunchKernelGGL(k_centres, dim3(nb), dim3(256), 0, c->stream, c->d_sym, c->d_cen, c->d_mag, c->d_xc, spSym, offset, c->N,
                        c->M, c->W, op, c->cap);
     HIPCHK(hipGetLastError());

@@ -70,6 +70,8 @@ struct SegArgs {
     const cf *twHi;      // W_N^(j * 2^lo)
     float *partials;     // REDUCE: [rows][parts]
     cf *out;             // STORE: complex64 [M][N], natural order
+    float *env;          // STORE, optional: float32 [N] symbol-energy envelope sum_{env_lo <= m < env_hi} |y_m[n]|^2 (needs mgroups == 1)
+    int env_lo, env_hi;
     int N, lo;
     int V;               // valid outputs per complete segment (multiple of NT)
     int slot0, nslots;   // this launch covers team-iterations (slots) [slot0, slot0 + nslots); a slot = CT segments
@@ -261,6 +263,11 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                 const int vseg = active ? min(a.V, a.N - (int)b0) : 0;     // <= 0 beyond the last segment
                 lim = vseg - g;                   // output slot k is valid for this lane iff k*NT < lim
             }
+            [[maybe_unused]] float envacc[16];
+            if constexpr (MODE == SEG_STORE) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) envacc[k] = 0.f;
+            }
             for (int mi = 0; mi < nm; ++mi) {
                 const int rm = a.rows ? a.rows[m0 + mi] : (m0 + mi);
                 cf w[16];
@@ -299,11 +306,22 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                 } else {
                     const auto orr = mk_rsrc(a.out + (size_t)rm * a.N, (unsigned)a.N * sizeof(cf));
                     const unsigned o0 = e0 + (unsigned)a.out_off;
+                    const bool in_env = a.env && rm >= a.env_lo && rm < a.env_hi;      // team-uniform
                     auto put = [&](int, cf val, auto, auto nu) {
                         constexpr int k = decltype(nu)::value / NT;
                         if (k * NT < lim) buf_store_cf(orr, (int)(((o0 + (unsigned)(k * NT)) & nmask) * sizeof(cf)), 0, val);
+                        // same fp32 order as k_envelope: s = s + fma(re, re, im * im), filters ascending
+                        if (in_env) envacc[k] = __fadd_rn(envacc[k], __fmaf_rn(val.x, val.x, __fmul_rn(val.y, val.y)));
                     };
                     fft_passes<L, 1, 0, true, false, 0, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, put);
+                }
+            }
+            if constexpr (MODE == SEG_STORE) {
+                if (a.env) {
+                    const unsigned o0 = e0 + (unsigned)a.out_off;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        if (k * NT < lim) a.env[(o0 + (unsigned)(k * NT)) & nmask] = envacc[k];
                 }
             }
         }
