@@ -95,7 +95,7 @@ def cpu_baseline(masks, shifts, x_block, N, ov, D, budget_bins=None):
             out[j] = (y.real.astype(np.float64) ** 2 + y.imag.astype(np.float64) ** 2).sum() / orc.SCALE_2_18
         return time.perf_counter() - t0, out
     t1, _ = run(1)                       # warm-up + calibration
-    nb = budget_bins or int(max(2, min(D, round(10.0 / max(t1, 1e-3)))))
+    nb = budget_bins or int(max(2, min(D, round(14.0 / max(t1, 1e-3)))))     # the whole block when it fits ~14 s
     t, scores = run(nb)
     t_block = t * D / nb
     # single thread, numpy: two bins

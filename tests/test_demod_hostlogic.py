@@ -156,12 +156,12 @@ def _cc11xx_stimulus(bs, sps, payload, snr_db=15.0):
 
 
 def test_cc11xx_frame_received_and_crc_ok_on_oracle_backend(oracle_backend):
-    """CC11xx (FSK-2, 128 samples/symbol, IF offset 148.32 kHz, config/CC11xx.json geometry): a framed,
-    whitened, CRC-protected packet goes through Doppler search, demodulation, sync correlation and
-    the packet parser (next-scope row N2)."""
+    """BASELINE config C1 (CC11xx protocol, 32 Doppler bins, 2^16-sample chunks, CPU path -- plumbing, no GPU):
+    CC11xx FSK-2 at 128 samples/symbol, IF offset 148.32 kHz (config/CC11xx.json geometry); a framed, whitened,
+    CRC-protected packet goes through Doppler search, demodulation, sync correlation and the packet parser."""
     from pycusdr_amd.demodulator_process import DemodulatorRunner
     bs, sps = 16, 128
-    conf = cfg.cc11xx_config(blockSize=bs, doppCarrierSteps=64, samplesPerSym=sps)
+    conf = cfg.cc11xx_config(blockSize=bs, doppCarrierSteps=32, samplesPerSym=sps)
     p = loadProtocol('CC11xx')(conf=conf)
     p.CRC_CHECK = 'framer'        # the stimulus is a TX-framer frame: CRC inside the length-counted bytes
     run = DemodulatorRunner(conf, p, 'UHF-H')
