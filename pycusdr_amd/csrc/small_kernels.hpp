@@ -1,0 +1,234 @@
+// small_kernels.hpp -- the kernels around the transforms: partial-sum finalisation, transpose, Doppler pick,
+// envelope, symbol-rate search, symbol centres.  Reference semantics reproduced (file:line under pyCuSDR/):
+//   |.|^2 / 2^18 row sums  demodulator/cuda_kernels.cu:421-480      pick        cuda_kernels.cu:502-597
+//   envelope               cuda_kernels.cu:191-205                  rate/phase  cuda_kernels.cu:236-320
+//   centres                cuda_kernels.cu:78-146
+#pragma once
+#include <stdint.h>
+
+#include "fft_core.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------------
+// doppSum[j][m] from the per-workgroup partials.  One wavefront per Doppler bin: lane l adds partials
+// l, l+64, ... of a filter, then a fixed butterfly over the 64 lanes -- the order depends on nothing but
+// `parts`, so results are bit-reproducible (no float atomics, unlike cuda_kernels.cu:463,474).
+// SUM_ALL_MASKS: column 0 gets the sum over masks (added in filter order), the other columns stay 0
+// (cuda_kernels.cu:453-464); else per mask (472-475).
+// The partials hold MU <= M rows per bin (filters that are exact copies or exact negatives of an
+// earlier filter are transformed once: |.|^2 is identical bit for bit); rep[m] names filter m's row.
+__global__ void __launch_bounds__(64) k_finalize(const float *partials, float *dsum, int D, int M, int MU, const int *rep, int parts,
+                                                 int sum_all) {
+    const int j = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (j >= D) return;
+    float tot = 0.f;
+    const int nrows = rep ? M : MU;       // rep == nullptr: sum every transformed row (span basis, SUM_ALL only)
+    if (!rep && lane == 0)
+        for (int m = 0; m < M; ++m) dsum[j * M + m] = 0.f;
+    for (int m = 0; m < nrows; ++m) {
+        const float *p = partials + ((size_t)j * MU + (rep ? rep[m] : m)) * parts;
+        float s = 0.f;
+        for (int q = lane; q < parts; q += 64) s += p[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (sum_all) {
+            tot += s;
+            if (rep && lane == 0) dsum[j * M + m] = 0.f;
+        } else if (lane == 0) {
+            dsum[j * M + m] = s;
+        }
+    }
+    if (sum_all && lane == 0) dsum[j * M] = tot;
+}
+
+// Z[row][n1][n2] -> out[row][n1 + N1*n2] (natural order), optional conjugation (forward transform).
+// 32x32 tiles through LDS: coalesced reads along n2, coalesced writes along n1.
+__global__ void __launch_bounds__(256) k_transpose(const cf *Z, cf *out, int N1, int N2, int conj) {
+    __shared__ cf tile[32][33];
+    const size_t rowoff = (size_t)blockIdx.z * N1 * N2;
+    const int n2_0 = blockIdx.x * 32, n1_0 = blockIdx.y * 32;
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    for (int r = r0; r < 32; r += 8) {
+        if (n1_0 + r < N1 && n2_0 + c < N2) tile[r][c] = Z[rowoff + (size_t)(n1_0 + r) * N2 + n2_0 + c];
+    }
+    __syncthreads();
+    const float sgn = conj ? -1.f : 1.f;
+    for (int r = r0; r < 32; r += 8) {
+        if (n2_0 + r < N2 && n1_0 + c < N1) {
+            const cf z = tile[c][r];
+            out[rowoff + (size_t)(n2_0 + r) * N1 + n1_0 + c] = mkc(z.x, sgn * z.y);
+        }
+    }
+}
+
+// findDopplerEst (cuda_kernels.cu:502-597).  The reference scans every column sequentially: a value
+// replaces the smaller of the two kept maxima when it is strictly greater (first come wins ties), and
+// which of the two slots a maximum sits in -- it matters for the fp32 rounding of the weighted index --
+// depends on the whole history.  One wavefront reproduces that scan exactly but skips what cannot change
+// the state: 64 rows are compared against the current threshold at once (ballot); only lanes that beat
+// it are visited, in row order, each visit updating the threshold for the lanes behind it.
+// fp32 evaluation order is pinned with explicit intrinsics (see oracle/mfbank_oracle.py).
+__global__ void __launch_bounds__(64) k_pick(const float *in, float *res, int num, int offset, int M, int sum_all) {
+    __shared__ float sIdx[64], sVal[64];
+    const int lane = threadIdx.x;
+    const int ncol = sum_all ? 1 : M;
+    for (int x = 0; x < ncol; ++x) {
+        float mv0 = 0.f, mv1 = 0.f;
+        int mi0 = 0, mi1 = 0, cur = 0;
+        for (int r0 = offset; r0 < num + offset; r0 += 64) {
+            const int r = r0 + lane;
+            const bool inside = r < num + offset;
+            const float v = inside ? in[(size_t)r * M + x] : 0.f;
+            unsigned long long todo = ~0ull;
+            while (true) {
+                const float thr = cur ? mv1 : mv0;
+                const unsigned long long hit = __ballot(inside && v > thr) & todo;     // strict '>' (NaN never enters)
+                if (!hit) break;
+                const int l = __builtin_ctzll(hit);
+                const float tmp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));   // l is wave-uniform
+                if (cur) {
+                    mv1 = tmp;
+                    mi1 = r0 + l;
+                } else {
+                    mv0 = tmp;
+                    mi0 = r0 + l;
+                }
+                cur = (mv0 >= mv1) ? 1 : 0;          // the slot of the smaller value is replaced next
+                todo = (l == 63) ? 0ull : (~0ull << (l + 1));
+            }
+        }
+        const float numr = __fmaf_rn((float)mi0, mv0, __fmul_rn((float)mi1, mv1));
+        const float idxL = __fdiv_rn(numr, __fadd_rn(mv0, mv1));
+        float valL = __fdiv_rn(numr, (float)(mi0 + mi1));
+        if (offset > 0) valL = __fdiv_rn(cur ? mv0 : mv1, in[x]);     // maxVal[(cur + 1) % 2] / noise-bin score
+        if (sum_all) {
+            if (lane == 0) {
+                res[0] = idxL;
+                res[1] = 10.f * log10f(valL);
+            }
+            return;
+        }
+        if (lane == 0) {
+            sIdx[x] = idxL;
+            sVal[x] = valL;
+        }
+    }
+    int n = 1;
+    while (n < M) n <<= 1;
+    __syncthreads();
+    if (lane >= M) {
+        sIdx[lane] = 0.f;
+        sVal[lane] = 0.f;
+    }
+    __syncthreads();
+    for (int step = n >> 1; step >= 1; step >>= 1) {
+        float a = 0.f, b = 0.f;
+        if (lane < n) {
+            a = __fadd_rn(sIdx[lane], sIdx[lane ^ step]);
+            b = __fadd_rn(sVal[lane], sVal[lane ^ step]);
+        }
+        __syncthreads();
+        if (lane < n) {
+            sIdx[lane] = a;
+            sVal[lane] = b;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        res[0] = __fdiv_rn(sIdx[0], (float)M);
+        res[1] = 10.f * log10f(__fdiv_rn(sVal[0], (float)M));
+    }
+}
+
+// |z|^2 the way nvcc contracts in.x*in.x+in.y*in.y (cuda_kernels.cu:1022-1026): fma(x,x,y*y)
+DEVI float abs2c(cf z) { return __fmaf_rn(z.x, z.x, __fmul_rn(z.y, z.y)); }
+
+// sumXCorrBuffMasks (cuda_kernels.cu:191-205)
+__global__ void k_envelope(const cf *xc, float *env, int N, int M, int off) {
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < N; x += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int m = off; m < M - off; ++m) s = __fadd_rn(s, abs2c(xc[(size_t)m * N + x]));
+        env[x] = s;
+    }
+}
+
+// findCodeRateAndPhase (cuda_kernels.cu:236-320): argmax |P[k]|^2 over [offset, offset+len);
+// ties resolve to the lowest k (deterministic).  out = {k, atan2(im,re), |P|^2}
+__global__ void k_code_rate(const cf *P, float *out, int offset, int len) {
+    __shared__ float sv[1024];
+    __shared__ int si[1024];
+    const int tid = threadIdx.x;
+    float best = -1.f;
+    int bi = 0x7fffffff;
+    for (int x = tid; x < len; x += blockDim.x) {
+        const float v = abs2c(P[x + offset]);
+        if (v > best) {
+            best = v;
+            bi = x + offset;
+        }
+    }
+    sv[tid] = best;
+    si[tid] = bi;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float ov = sv[tid + s];
+            const int oi = si[tid + s];
+            if (ov > sv[tid] || (ov == sv[tid] && oi < si[tid])) {
+                sv[tid] = ov;
+                si[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int k = (len > 0) ? si[0] : 0;
+        const cf z = P[k];
+        out[0] = (float)k;
+        out[1] = atan2f(z.y, z.x);
+        out[2] = sv[0];
+    }
+}
+
+// findCentres (cuda_kernels.cu:78-146); thread = symbol index.
+__global__ void k_centres(int *outSym, int *outIdx, float *mag, const cf *sig, float spSym, float offset,
+                          int lenSig, int M, int W, int op, int capacity) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= capacity) return;
+    const float half = (float)(W / 2);  // WINDOW_WIDTH/2 is an integer division (demodulator_base.py:407)
+    const float base = __fmaf_rn((float)x, spSym, -half);
+    int arrayIdx = (int)__fadd_rn(base, offset);
+    int maxArrayIdx = arrayIdx + W;
+    int offsetComp = (int)offset;
+    if (arrayIdx < 0) {
+        offsetComp -= arrayIdx;
+        arrayIdx = 0;
+    }
+    if (maxArrayIdx > lenSig) maxArrayIdx = lenSig;
+    maxArrayIdx -= arrayIdx;
+    int maxIdx = -1, maxCentreIdx = -1;
+    if (arrayIdx < lenSig) {
+        float maxVal = 0.f;
+        for (int m = 0; m < M; ++m) {
+            const cf *row = sig + (size_t)m * lenSig + arrayIdx;
+            for (int k = 0; k < maxArrayIdx; ++k) {
+                const cf z = row[k];
+                const float tmp = (op == 0) ? abs2c(z) : (op == 1 ? fabsf(z.x) : fabsf(z.y));
+                if (tmp > maxVal) {
+                    maxVal = tmp;
+                    maxIdx = m;
+                    maxCentreIdx = k;
+                }
+            }
+        }
+        outSym[x] = maxIdx;
+        outIdx[x] = (int)__fadd_rn(__fadd_rn(base, (float)maxCentreIdx), (float)offsetComp);
+        mag[x] = maxVal;
+    } else {            // a symbol past the end of the block: the reference leaves its buffers untouched there
+        outSym[x] = INT32_MIN;
+        outIdx[x] = INT32_MIN;
+        mag[x] = 0.f;
+    }
+}
