@@ -131,6 +131,8 @@ def main():
                     help='N>1: bins = C4, Doppler bins sharded 256/GPU + RCCL exchange per block (default); '
                          'blocks = every GPU runs the full 256-bin bank on different time blocks, no collective')
     ap.add_argument('--no-prefetch', action='store_true', help='N>1: broadcast every block right before its search instead of one block ahead')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="process-group backend; 'gloo' lets several ranks share ONE GPU (rehearsal of the N>1 path on a 1-GPU box)")
     ap.add_argument('--force-dist', action='store_true', help='run the sharded/RCCL path even with one rank (rehearsal)')
     args = ap.parse_args()
 
@@ -153,8 +155,13 @@ def main():
         os.environ.setdefault('WORLD_SIZE', '1')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if args.backend == 'gloo':                      # rehearsal: ranks may share a device
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group('gloo')
         G = dist.get_world_size()
     else:
         dist = None
@@ -420,7 +427,7 @@ def main():
                 'rangeRateMax_used': rr, 'twopass_tuning(chunk,mpb,rows,jsplit)': list(tun),
                 'units': 'samples through a 256-bin bank, summed over ranks',
                 'stream_msamples': round((N - ov) / (elapsed / args.steps) / 1e6, 3) if not by_blocks else round(value, 3),
-                'world_size': G, 'backend': ('nccl (RCCL)' if dist is not None else None),
+                'world_size': G, 'backend': (('nccl (RCCL)' if args.backend == 'nccl' else 'gloo (rehearsal)') if dist is not None else None),
                 'carrier_found': bool(carrier_ok),
             },
             'roofline': roof,

@@ -83,7 +83,9 @@ class DopplerShard:
         self.scores = torch.zeros(shape, dtype=torch.float32, device=self.device)
         # equal slices: every rank exports into a slice-sized buffer and the table is all-gathered (no clearing,
         # no additions); uneven slices: all-reduce of the zero-padded table
-        self.even = self.D % self.world == 0
+        # (gloo moves device tensors through host staging and has no all_gather_into_tensor for them: all-reduce there)
+        backend = self.dist.get_backend(self.group)
+        self.even = self.D % self.world == 0 and (backend == 'nccl' or not self.on_gpu)
         self.local = torch.zeros((self.D // self.world,) + shape[1:], dtype=torch.float32, device=self.device) if self.even else None
         # complex64 blocks, interleaved: two buffers so that one can be filled while the other is searched
         self.blocks = [torch.empty(2 * bank.N, dtype=torch.float32, device=self.device) for _ in range(2)]

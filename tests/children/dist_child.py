@@ -19,6 +19,8 @@ from pycusdr_amd.protocol import loadProtocol  # noqa: E402
 
 rank, world, local = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), int(os.environ['LOCAL_RANK'])
 backend = sys.argv[1] if len(sys.argv) > 1 else 'nccl'
+if backend == 'gloo':                      # rehearsal on a 1-GPU box: the ranks share the device
+    local = local % torch.cuda.device_count()
 torch.cuda.set_device(local)
 dist.init_process_group(backend, device_id=torch.device('cuda', local) if backend == 'nccl' else None)
 bs, D = 16, 64 * world
@@ -44,7 +46,7 @@ for b in range(3):
             pr = plain.demodulate()
             ok &= all(np.array_equal(u, v) for u, v in zip(out[:3], pr[:3]))
     ok &= (len(out[0]) > 0) == (owner == rank)        # the demodulation stage runs on the owner only
-    t = torch.tensor([float(res[0]), float(res[1])], device='cuda')
+    t = torch.tensor([float(res[0]), float(res[1])], device='cuda' if backend == 'nccl' else 'cpu')
     g = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(g, t)
     ok &= all(bool(torch.equal(g[0], q)) for q in g)  # every rank picked the same

@@ -120,8 +120,24 @@ def test_multi_gpu_sharded_pick_equals_unsharded():
            '--master-port', '29577', child, 'nccl']
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
     assert r.returncode == 0, r.stderr[-3000:]
-    res = [json.loads(line) for line in r.stdout.splitlines() if line.startswith('{')]
-    assert len(res) == n and all(q['ok'] for q in res), res
+    import re
+    res = [json.loads(m) for m in re.findall(r'\{[^{}]*\}', r.stdout)]
+    assert len(res) == n and all(q['ok'] for q in res), (res, r.stderr[-2000:])
+
+
+def test_two_ranks_sharing_one_gpu_over_gloo():
+    """The sharded path with TWO ranks on the GPU box's single device (gloo moves the device tensors): broadcast of
+    rank 0's block, search of each rank's bin slice on its own handle, exchange, pick on both ranks -- equal, bit
+    for bit, to the unsharded search; demodulation on the owner only.  Everything but RCCL itself."""
+    child = os.path.join(ROOT, 'tests', 'children', 'dist_child.py')
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', '29578', child, 'gloo']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import re
+    res = [json.loads(m) for m in re.findall(r'\{[^{}]*\}', r.stdout)]      # the ranks' lines may interleave
+    assert len(res) == 2 and all(q['ok'] for q in res), (res, r.stderr[-2000:])
 
 
 def test_failed_create_frees_everything():
