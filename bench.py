@@ -300,7 +300,7 @@ def main():
             except ValueError:
                 other = None
             bank.set_search_path(args.path if args.path != 'auto' or not seg else 'segment', *seg)
-        # opt-in span basis of the SUM_ALL search (rank(bank) filters instead of M; DESIGN.md 4.4) -- never the headline
+        # opt-in span basis of the SUM_ALL search (rank(bank) filters instead of M; DESIGN.md 4.3) -- never the headline
         if G == 1 and pinfo['path'] == 'segment':
             try:
                 bank.set_search_basis('span')
@@ -322,6 +322,27 @@ def main():
                                                'note': 'opt-in (mfb_set_search_basis): exact identity for the SUM_ALL_MASKS score; not the headline'}
             except (ValueError, RuntimeError):
                 bank.set_search_basis('filters')
+        # opt-in spectral-energy search (Parseval: no inverse transform at all) -- never the headline
+        if G == 1:
+            try:
+                bank.set_search_mode('energy')
+                step(0)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for i in range(32):
+                    step(i)
+                torch.cuda.synchronize(dev)
+                dt_en = (time.perf_counter() - t1) / 32
+                sc_en = bank.get_scores()[:, 0].astype(np.float64)
+                bank.set_search_mode('transforms')
+                step(31)
+                sc_f = bank.get_scores()[:, 0].astype(np.float64)
+                extras['energy_search'] = {'ms_per_step': round(dt_en * 1e3, 4), 'msamples': round((N - ov) / dt_en / 1e6, 2),
+                                           'max_rel_diff_vs_default_search': float(np.abs(sc_en - sc_f).max() / sc_f.max()),
+                                           'note': 'opt-in (mfb_set_search_mode): Parseval identity on |X|^2 and the filters\' energy, D*N '
+                                                   'multiply-adds, the matched-filter bank does not run; not the headline'}
+            finally:
+                bank.set_search_mode('transforms')
         # sync/preamble correlator (A14): B = 1024 streams of 67 584 bits x 64 taps, thresholded on the device
         rsb = np.random.RandomState(2)
         B, Lb = 1024, 65536 + 2048

@@ -110,6 +110,17 @@ int mfb_set_search_basis(mfb_ctx *ctx, int basis);
 int mfb_get_search_basis(mfb_ctx *ctx, int *basis, int *transformed_filters);
 /* Host-only helper: dimension of the span of a bank's impulse responses (M if it has no short support). */
 int mfb_analyze_rank(const float *masks_c64, int M, int N, int *rank);
+/* Search mode (opt-in shortcut).  The search uses only the row sums of |y|^2 over all N outputs of each circular
+ * correlation (cuda_kernels.cu:421-480 after DB:578-588), and by Parseval's identity
+ *     doppSum[j][m] = N/2^18 . sum_k |X[(k + shift_j) mod N]|^2 . |H_m[k]|^2
+ * so MFB_SEARCH_ENERGY computes the table from the power spectrum of the block and the filters' energy spectrum
+ * (their sum over m under SUM_ALL_MASKS): D.N multiply-adds, no inverse transform.  Same table to fp32 rounding, any
+ * filter bank, either search path for the demodulation stage.  Because it no longer runs the matched-filter bank it
+ * is OFF by default (MFB_SEARCH_TRANSFORMS) and bench.py reports it as a separate figure, never as the headline. */
+#define MFB_SEARCH_TRANSFORMS 0
+#define MFB_SEARCH_ENERGY     1
+int mfb_set_search_mode(mfb_ctx *ctx, int mode);
+int mfb_get_search_mode(mfb_ctx *ctx, int *mode);
 /* Fault injection for tests: the nth device allocation made on behalf of a handle by the calling thread
  * from now on fails as if the device were out of memory (0 disarms).  Lets a test walk the free-on-error
  * path of mfb_create allocation by allocation. */

@@ -48,6 +48,8 @@ PROTOTYPES = {
     'mfb_get_search_path': (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     'mfb_set_search_basis': (_i, [_vp, _i]),
     'mfb_get_search_basis': (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    'mfb_set_search_mode': (_i, [_vp, _i]),
+    'mfb_get_search_mode': (_i, [_vp, C.POINTER(_i)]),
     'mfb_analyze_rank': (_i, [_vp, _i, _i, C.POINTER(_i)]),
     'mfb_debug_fail_alloc': (_i, [_i]),
     'mfb_analyze_filters': (_i, [_vp, _i, _i, C.POINTER(_i), C.POINTER(_i)]),

@@ -356,6 +356,7 @@ __global__ void __launch_bounds__((L2 / 16) * P2Cfg<L2>::RB, (L2 == 4096 && MODE
 
 #include "small_kernels.hpp"
 #include "sync_kernels.hpp"
+#include "energy_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -397,6 +398,9 @@ struct mfb_ctx {
     int MB;                   // filters of the span basis
     cf *d_Gb;                 // their segment spectra [MB][L] (slot-pair layout)
     int gb_l;                 // segment length d_Gb was built for
+    int search_mode;          // MFB_SEARCH_*: transforms (default) or the opt-in spectral-energy shortcut
+    float *d_pow, *d_W;       // |X|^2 [N]; filter energy [R][N] (R = 1 under SUM_ALL_MASKS, else M)
+    bool W_valid;
     std::vector<hipEvent_t> ev[2];
     std::vector<hipEvent_t> ev_pool;
 };
@@ -480,6 +484,7 @@ static int default_chunk(const mfb_ctx *c) {
 // transforms of A3 / A10 still run two-pass); the two-pass search needs chunk * MU rows.
 static size_t z_rows_needed(const mfb_ctx *c) {
     if (!c->have_filters || c->path == MFB_PATH_SEGMENT) return 1;
+    if (c->search_mode == MFB_SEARCH_ENERGY) return (size_t)c->M;   // the demodulation stage only
     const size_t rows = (size_t)c->chunk * c->MU;   // the search stores only the unique filter rows
     return rows > (size_t)c->M ? rows : (size_t)c->M;
 }
@@ -682,7 +687,7 @@ extern "C" int mfb_destroy(mfb_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_uniq, c->d_rep, c->d_x,  c->d_X,    c->d_masks, c->d_Z,   c->d_xc,  c->d_P,   c->d_env, c->d_shifts, c->d_tw1,
                     c->d_tw2, c->d_twLo, c->d_twHi,  c->d_part, c->d_sum, c->d_res, c->d_cr,  c->d_sym,    c->d_cen, c->d_mag,
-                    c->d_G, c->d_twL, c->d_Gb};
+                    c->d_G, c->d_twL, c->d_Gb, c->d_pow, c->d_W};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (c->h_in) (void)hipHostFree(c->h_in);
@@ -876,6 +881,17 @@ extern "C" int mfb_set_search_basis(mfb_ctx *c, int basis) {
     c->basis_req = basis;
     return resolve_path(c);
 }
+extern "C" int mfb_set_search_mode(mfb_ctx *c, int mode) {
+    if (!c || (mode != MFB_SEARCH_TRANSFORMS && mode != MFB_SEARCH_ENERGY)) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    c->search_mode = mode;
+    return resolve_path(c);      // the two-pass intermediate is sized for what the search needs
+}
+extern "C" int mfb_get_search_mode(mfb_ctx *c, int *mode) {
+    if (!c || !mode) return MFB_ERR_ARG;
+    *mode = c->search_mode;
+    return MFB_OK;
+}
 extern "C" int mfb_get_search_basis(mfb_ctx *c, int *basis, int *transformed_filters) {
     if (!c) return MFB_ERR_ARG;
     if (basis) *basis = c->basis;
@@ -948,6 +964,7 @@ extern "C" int mfb_set_filters(mfb_ctx *c, const float *masks, int M, int N) {
     HIPCHK(hipStreamSynchronize(c->stream));
     c->have_filters = true;
     c->have_xc = false;
+    c->W_valid = false;
     c->segl = 0;    // force G to be rebuilt for the new bank
     c->gb_l = 0;
     int rc = resolve_path(c);
@@ -1274,6 +1291,31 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
     if (!c->have_filters || !c->have_shifts || !c->have_input) return MFB_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
     const int MU = c->MU;
+    if (c->search_mode == MFB_SEARCH_ENERGY) {
+        // opt-in shortcut (energy_kernels.hpp): no transform, D.N multiply-adds on |X|^2 and the filters' energy
+        const int R = c->sum_all ? 1 : c->M;
+        const int parts = c->N / EN_CHUNK;
+        int rc = reserve_partials(c, (size_t)c->Dtot * R * parts);
+        if (rc) return rc;
+        if (!c->d_pow) HIPCHK(dev_alloc((void **)&c->d_pow, (size_t)c->N * sizeof(float)));
+        if (!c->d_W) HIPCHK(dev_alloc((void **)&c->d_W, (size_t)c->N * (c->sum_all ? 1 : c->M) * sizeof(float)));
+        if (!c->W_valid) {
+            hipLaunchKernelGGL(k_filter_energy, dim3(c->N / 256, R), dim3(256), 0, c->stream, (const cf *)c->d_masks, c->d_W, c->N, c->M,
+                               c->sum_all);
+            HIPCHK(hipGetLastError());
+            c->W_valid = true;
+        }
+        prof_mark(c, 0);
+        hipLaunchKernelGGL(k_power, dim3(c->N / 256), dim3(256), 0, c->stream, (const cf *)c->d_X, c->d_pow, c->N);
+        hipLaunchKernelGGL(k_energy, dim3(parts, R), dim3(256), 0, c->stream, (const float *)c->d_pow, (const float *)c->d_W,
+                           (const int *)c->d_shifts, c->d_part, c->N, c->Dtot, R, parts, (float)c->N / 262144.f);
+        HIPCHK(hipGetLastError());
+        prof_mark(c, 0);
+        hipLaunchKernelGGL(k_finalize, dim3(c->Dtot), dim3(64), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, R, (const int *)nullptr,
+                           parts, c->sum_all);
+        HIPCHK(hipGetLastError());
+        return MFB_OK;
+    }
     if (c->path == MFB_PATH_SEGMENT) {
         // all bins in ONE launch: nothing of length N is written, so there is nothing to chunk.  A second,
         // tiny launch of the masked instantiation covers the slots that hold incomplete segments.

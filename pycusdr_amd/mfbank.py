@@ -88,6 +88,17 @@ class MFBank:
         _lib.check(self._lib.mfb_get_search_basis(self._h, C.byref(b), C.byref(n)), 'mfb_get_search_basis')
         return ('span' if b.value == 1 else 'filters'), n.value
 
+    def set_search_mode(self, mode='transforms'):
+        """'transforms' (default): the search runs the matched-filter bank.  'energy' (opt-in): Parseval's identity --
+        doppSum from the block's power spectrum and the filters' energy spectrum, D.N multiply-adds and no inverse
+        transform; the same table to fp32 rounding.  The demodulation stage is unaffected."""
+        _lib.check(self._lib.mfb_set_search_mode(self._h, {'transforms': 0, 'energy': 1}[mode]), 'mfb_set_search_mode')
+
+    def get_search_mode(self):
+        m = C.c_int()
+        _lib.check(self._lib.mfb_get_search_mode(self._h, C.byref(m)), 'mfb_get_search_mode')
+        return 'energy' if m.value == 1 else 'transforms'
+
     def get_search_path(self):
         """dict(path, log2L, taps, valid_per_segment, segments) in force."""
         v = [C.c_int() for _ in range(5)]

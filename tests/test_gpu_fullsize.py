@@ -63,6 +63,24 @@ def test_c2_rows_against_oracle_sample(c2):
     assert np.abs(ds[sel] - ref).max() / ref.max() < 1e-5
 
 
+def test_c2_energy_search_fullsize(c2):
+    """Opt-in spectral-energy search at C2 against the bank itself (all 256 bins) and the oracle's real IFFTs (6 bins)."""
+    bank = c2['bank']
+    idx, _ = bank.find_carrier()
+    ds = bank.get_scores()
+    bank.set_search_mode('energy')
+    try:
+        idx_e, _ = bank.find_carrier()
+        de = bank.get_scores()
+    finally:
+        bank.set_search_mode('transforms')
+    assert np.abs(de - ds).max() / ds.max() < 1e-5 and np.all(de[:, 1:] == 0)
+    assert abs(idx_e - idx) < 1e-3
+    sel = [0, 1, 127, 128, 200, 255]
+    ref = orc.doppler_scores(bank.get_spectrum(), c2['masks'], c2['shifts'][sel], True)[:, 0]
+    assert np.abs(de[sel, 0] - ref).max() / ref.max() < 1e-5
+
+
 def test_c2_tuning_invariance_and_repeatability(c2):
     bank = c2['bank']
     base_t = bank.get_tuning()

@@ -41,6 +41,17 @@ for case in range(cases):
         X = bank.get_spectrum()
         ref = orc.doppler_scores(X, masks, shifts, sum_all)
         tags = []
+
+        def check(tag, idx_, ds):
+            global worst
+            err = float(np.abs(ds - ref).max() / ref.max())
+            worst = max(worst, err)
+            oidx, _ = orc.find_doppler_est(ds, D, doff, sum_all)
+            ok = err < 1e-5 and (idx_ == oidx or (np.isnan(idx_) and np.isnan(oidx)))
+            if not ok:
+                print('FAIL', dict(case=case, log2N=log2N, D=D, M=M, sum_all=sum_all, doff=doff, l=l, T=T, start=start, rank=rank, tag=tag,
+                                   err=err, idx=float(idx_), oidx=float(oidx), path=bank.get_search_path(), basis=bank.get_search_basis()))
+                sys.exit(1)
         try:
             bank.set_search_path('segment', l, int(rs.randint(0, 7)), int(rs.randint(0, 17)))
             tags.append('segment')
@@ -52,16 +63,12 @@ for case in range(cases):
             if tag == 'twopass2':
                 bank.set_search_basis('filters') if sum_all else None
                 bank.set_search_path('twopass')
-            idx_, met = bank.find_carrier()
-            ds = bank.get_scores()
-            err = float(np.abs(ds - ref).max() / ref.max())
-            worst = max(worst, err)
-            oidx, _ = orc.find_doppler_est(ds, D, doff, sum_all)
-            ok = err < 1e-5 and (idx_ == oidx or (np.isnan(idx_) and np.isnan(oidx)))
-            if not ok:
-                print('FAIL', dict(case=case, log2N=log2N, D=D, M=M, sum_all=sum_all, doff=doff, l=l, T=T, start=start, rank=rank, tag=tag,
-                                   err=err, idx=float(idx_), oidx=float(oidx), path=bank.get_search_path(), basis=bank.get_search_basis()))
-                sys.exit(1)
+            for mode in ('transforms', 'energy') if tag != 'span' else ('transforms',):
+                bank.set_search_mode(mode)
+                idx_, met = bank.find_carrier()
+                ds = bank.get_scores()
+                check(tag + '/' + mode, idx_, ds)
+        bank.set_search_mode('transforms')
         if tags[0] == 'segment':
             bank.set_search_path('segment', l)
             sh = int(shifts[-1])
