@@ -1,0 +1,94 @@
+"""Bit-error-rate benchmark through the demodulator and the decoder -- in-process counterpart of the reference's
+examples/benchmark/bench_modem.py (same arguments, same SNR bookkeeping and result table, bench_modem.py:150-280).
+
+    python examples/benchmark/bench_modem.py modscheme N SNR_low SNR_high SNR_step [--block-size 15] [--search energy]
+
+For every SNR the seed-123 bench packet (10 000 bits, create_signals.py:10-26) is sent N times, each copy with fresh
+white noise at SNR_r = SNR + 10 log10(bw / fs); the samples go in 2^14-sample chunks (bench_modem.py:32) through the
+ring buffer, the HIP Doppler search + demodulation and the decoder; every packet found is compared with the known bits
+(Packet_bench.checkPacketData).  The reference moves the samples and the packets over ZeroMQ between processes; here
+both ends are in this process.  Needs a GPU (libmfbank.so)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+from pycusdr_amd import config as cfg, signals as sg            # noqa: E402
+from pycusdr_amd.decoder import Decoder                          # noqa: E402
+from pycusdr_amd.demodulator_process import DemodulatorRunner    # noqa: E402
+from pycusdr_amd.protocol import loadProtocol                    # noqa: E402
+
+CHUNK = 2 ** 14
+
+
+def bandwidth(modulation, baud):
+    """Noise bandwidths the reference's bench uses (bench_modem.py:203-209)."""
+    return {'GMSK': baud / 0.7, 'BPSK': baud * 1.5, 'FSK': 2 * baud + 2 * (baud / 2), 'GFSK': 2 * baud + 2 * (baud / 2)}[modulation]
+
+
+def run_snr(modulation, n_runs, snr, block_size, search, seed):
+    spSym, baud = 16, 9600
+    fs = spSym * baud
+    pname = 'bench_' + modulation
+    conf = cfg.bench_config(pname, blockSize=block_size)
+    proto = loadProtocol(pname)(conf=conf)
+    sig, bit_data = sg.get_padded_packet(modulation, spSym, fs)
+    bw = bandwidth(modulation, baud)
+    snr_r = snr + 10 * np.log10(bw / fs)
+    rng = np.random.RandomState(seed)
+    run = DemodulatorRunner(conf, proto, 'UHF-H')
+    if search != 'transforms':
+        run.demod.bank.set_search_mode(search)
+    N = 1 << block_size
+
+    def chunks():
+        for _ in range(n_runs):
+            s = sg.awgn(sig, snr_r, rng=rng).astype(np.complex64)
+            for i in range(0, len(s), CHUNK):
+                yield s[i:i + CHUNK]
+        # push the last packet through the overlap buffers (noise floor only: an all-zero block has no Doppler pick)
+        flush = (1e-3 * (rng.standard_normal(2 * N) + 1j * rng.standard_normal(2 * N))).astype(np.complex64)
+        for i in range(0, len(flush), CHUNK):
+            yield flush[i:i + CHUNK]
+
+    t0 = time.perf_counter()
+    results, packets = run.run_stream(chunks(), decoder=Decoder(conf, proto))
+    dt = time.perf_counter() - t0
+    run.close()
+    errs = [p.checkPacketData() for p in packets]
+    errs = [e for e in errs if e >= 0]                  # too-short packets report -0.1 (bench_base.py:168-176)
+    nsamp = n_runs * len(sig)
+    return dict(SNR=float(snr), EBN0=float(snr + 10 * np.log10(bw / baud)), packets=len(errs), sent=n_runs,
+                bitErrors=[int(e) for e in errs], BER=float(np.mean(np.array(errs) / len(bit_data))) if errs else 1.0,
+                ksamples_per_s=nsamp / dt / 1e3, blocks=len(results))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('modulation', choices=['GMSK', 'FSK', 'BPSK', 'GFSK'])
+    ap.add_argument('nRuns', type=int)
+    ap.add_argument('SNR_low', type=float)
+    ap.add_argument('SNR_high', type=float)
+    ap.add_argument('SNR_step', type=float)
+    ap.add_argument('--block-size', type=int, default=15)
+    ap.add_argument('--search', choices=['transforms', 'energy'], default='transforms')
+    ap.add_argument('--out', default=None, help='write the table as JSON')
+    a = ap.parse_args()
+    rows = []
+    for k, snr in enumerate(np.arange(a.SNR_low, a.SNR_high + a.SNR_step / 2, a.SNR_step)):
+        r = run_snr(a.modulation, a.nRuns, snr, a.block_size, a.search, seed=1000 + k)
+        rows.append(r)
+        print(f"SNR {r['SNR']:5.1f} dB:\tEB/N0 {r['EBN0']:.2f} dB\tpackets {r['packets']}/{r['sent']}\tavg. BER {r['BER']:.3e}"
+              f"\t({r['ksamples_per_s']:.0f} ksamples/s through the chain)", flush=True)
+    if a.out:
+        with open(a.out, 'w') as f:
+            json.dump(dict(modulation=a.modulation, nRuns=a.nRuns, search=a.search, blockSize=a.block_size, rows=rows), f, indent=1)
+
+
+if __name__ == '__main__':
+    main()

@@ -256,3 +256,17 @@ def test_runner_stream_of_arbitrary_chunks_on_hip():
         d = pickle.loads(pickle.dumps(got[3], protocol=pickle.HIGHEST_PROTOCOL))
         assert {'rangerateEst', 'baudRate_est', 'baudrate_est', 'rangerate', 'data', 'trust', 'doppler', 'SNR'} <= set(d)
         assert np.array_equal(d['data'], got[3]['data'])
+
+
+def test_ber_bench_script_runs_the_whole_chain():
+    """examples/benchmark/bench_modem.py (the reference's BER bench, in-process): every packet found, error-free at high SNR."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples', 'benchmark', 'bench_modem.py')
+    spec = importlib.util.spec_from_file_location('bench_modem', path)
+    bm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bm)
+    for mod, search in (('FSK', 'transforms'), ('GMSK', 'energy')):
+        r = bm.run_snr(mod, 2, 14.0, 15, search, seed=5)
+        assert r['packets'] == 2 and r['BER'] < 1e-3, r
+    assert abs(bm.bandwidth('GMSK', 9600) - 9600 / 0.7) < 1e-9 and bm.bandwidth('FSK', 9600) == 28800
