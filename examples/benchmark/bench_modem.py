@@ -1,7 +1,7 @@
 """Bit-error-rate benchmark through the demodulator and the decoder -- in-process counterpart of the reference's
 examples/benchmark/bench_modem.py (same arguments, same SNR bookkeeping and result table, bench_modem.py:150-280).
 
-    python examples/benchmark/bench_modem.py modscheme N SNR_low SNR_high SNR_step [--block-size 15] [--search energy]
+    python examples/benchmark/bench_modem.py modscheme N SNR_low SNR_high SNR_step [--block-size 15] [--doppler-bins 64] [--search energy]
 
 For every SNR the seed-123 bench packet (10 000 bits, create_signals.py:10-26) is sent N times, each copy with fresh
 white noise at SNR_r = SNR + 10 log10(bw / fs); the samples go in 2^14-sample chunks (bench_modem.py:32) through the
@@ -31,11 +31,11 @@ def bandwidth(modulation, baud):
     return {'GMSK': baud / 0.7, 'BPSK': baud * 1.5, 'FSK': 2 * baud + 2 * (baud / 2), 'GFSK': 2 * baud + 2 * (baud / 2)}[modulation]
 
 
-def run_snr(modulation, n_runs, snr, block_size, search, seed):
+def run_snr(modulation, n_runs, snr, block_size, search, seed, doppler_bins=64, pipelined=False):
     spSym, baud = 16, 9600
     fs = spSym * baud
     pname = 'bench_' + modulation
-    conf = cfg.bench_config(pname, blockSize=block_size)
+    conf = cfg.bench_config(pname, blockSize=block_size, doppCarrierSteps=doppler_bins)
     proto = loadProtocol(pname)(conf=conf)
     sig, bit_data = sg.get_padded_packet(modulation, spSym, fs)
     bw = bandwidth(modulation, baud)
@@ -46,23 +46,19 @@ def run_snr(modulation, n_runs, snr, block_size, search, seed):
         run.demod.bank.set_search_mode(search)
     N = 1 << block_size
 
-    def chunks():
-        for _ in range(n_runs):
-            s = sg.awgn(sig, snr_r, rng=rng).astype(np.complex64)
-            for i in range(0, len(s), CHUNK):
-                yield s[i:i + CHUNK]
-        # push the last packet through the overlap buffers (noise floor only: an all-zero block has no Doppler pick)
-        flush = (1e-3 * (rng.standard_normal(2 * N) + 1j * rng.standard_normal(2 * N))).astype(np.complex64)
-        for i in range(0, len(flush), CHUNK):
-            yield flush[i:i + CHUNK]
-
+    # the stimulus is made before the clock starts: the rate below is the receive chain's, not the noise generator's
+    parts = [sg.awgn(sig, snr_r, rng=rng).astype(np.complex64) for _ in range(n_runs)]
+    # push the last packet through the overlap buffers (noise floor only: an all-zero block has no Doppler pick)
+    parts.append((1e-3 * (rng.standard_normal(2 * N) + 1j * rng.standard_normal(2 * N))).astype(np.complex64))
+    stream = np.concatenate(parts)
     t0 = time.perf_counter()
-    results, packets = run.run_stream(chunks(), decoder=Decoder(conf, proto))
+    results, packets = run.run_stream((stream[i:i + CHUNK] for i in range(0, len(stream), CHUNK)), decoder=Decoder(conf, proto),
+                                          pipelined=pipelined)
     dt = time.perf_counter() - t0
     run.close()
     errs = [p.checkPacketData() for p in packets]
     errs = [e for e in errs if e >= 0]                  # too-short packets report -0.1 (bench_base.py:168-176)
-    nsamp = n_runs * len(sig)
+    nsamp = len(stream)
     return dict(SNR=float(snr), EBN0=float(snr + 10 * np.log10(bw / baud)), packets=len(errs), sent=n_runs,
                 bitErrors=[int(e) for e in errs], BER=float(np.mean(np.array(errs) / len(bit_data))) if errs else 1.0,
                 ksamples_per_s=nsamp / dt / 1e3, blocks=len(results))
@@ -76,12 +72,15 @@ def main():
     ap.add_argument('SNR_high', type=float)
     ap.add_argument('SNR_step', type=float)
     ap.add_argument('--block-size', type=int, default=15)
+    ap.add_argument('--doppler-bins', type=int, default=64)
+    ap.add_argument('--pipelined', action='store_true', help='source, demodulator and decoder as three threads (the reference: three processes)')
     ap.add_argument('--search', choices=['transforms', 'energy'], default='transforms')
     ap.add_argument('--out', default=None, help='write the table as JSON')
     a = ap.parse_args()
     rows = []
     for k, snr in enumerate(np.arange(a.SNR_low, a.SNR_high + a.SNR_step / 2, a.SNR_step)):
-        r = run_snr(a.modulation, a.nRuns, snr, a.block_size, a.search, seed=1000 + k)
+        r = run_snr(a.modulation, a.nRuns, snr, a.block_size, a.search, seed=1000 + k, doppler_bins=a.doppler_bins,
+                    pipelined=a.pipelined)
         rows.append(r)
         print(f"SNR {r['SNR']:5.1f} dB:\tEB/N0 {r['EBN0']:.2f} dB\tpackets {r['packets']}/{r['sent']}\tavg. BER {r['BER']:.3e}"
               f"\t({r['ksamples_per_s']:.0f} ksamples/s through the chain)", flush=True)

@@ -92,7 +92,7 @@ class DemodulatorRunner:
         self.count += 1
         return data
 
-    def run_stream(self, chunk_source, sink=None, decoder=None):
+    def run_stream(self, chunk_source, sink=None, decoder=None, pipelined=False):
         """The reference's loop shape (DP:284-338): chunks of ANY size (GNU Radio ~4096 samples, the BER bench
         2^14) go through a SigFIFO that hands out blocks of blockSize - overlap new samples; ends when the
         chunk source is exhausted."""
@@ -105,14 +105,19 @@ class DemodulatorRunner:
                     yield fifo.getBlock()
                 except TimeoutError:
                     return
-        return self.run(blocks(), sink=sink, decoder=decoder)
+        return self.run(blocks(), sink=sink, decoder=decoder, pipelined=pipelined)
 
-    def run(self, sample_source, sink=None, decoder=None):
+    def run(self, sample_source, sink=None, decoder=None, pipelined=False):
         """Drive the loop over an iterable of new-sample slices.  With a ``decoder`` every block's
-        bits go through ``findFrames`` and the packets are collected."""
+        bits go through ``findFrames`` and the packets are collected.
+
+        ``pipelined``: the three stages the reference runs as three OS processes joined by ZeroMQ (sample source ->
+        Demodulator_process -> decoder process, pyCuSDR.py / DP:242-338) run as three threads joined by bounded queues:
+        the ring buffer assembles block i+1 and the decoder works on block i-1 while the device searches block i
+        (the library calls release the GIL).  Same results in the same order as the sequential loop."""
         results, packets = [], []
-        for chunk in sample_source:
-            d = self.feed(np.asarray(chunk, dtype=np.complex64))
+
+        def decode(d):
             if decoder is not None:
                 pk, _, nsync = decoder.findFrames(d['data'], 0)
                 d['numSyncSig'] = nsync
@@ -121,8 +126,77 @@ class DemodulatorRunner:
                 sink(d)
             else:
                 results.append(d)
+
+        def report(d):
             if d['count'] % 50 == 0:
                 log.info('[%s]: freq offset % 6.0f Hz, SNR % 2.1f dB, est spsym % 3.2f, time % 3.2f ms (avg % 3.2f ms), '
                          'rate %5.0f ksamples/s (avg %5.0f)', self.radioName, d['doppler'], d['SNR'], d['spSymEst'],
                          d['time_ms'], self.timeMA * 1e3, d['rate_ksps'], d['rate_ksps_avg'])
+
+        if not pipelined:
+            for chunk in sample_source:
+                d = self.feed(np.asarray(chunk, dtype=np.complex64))
+                decode(d)
+                report(d)
+            return results, packets
+
+        import queue
+        import threading
+        END = object()
+        q_in, q_out = queue.Queue(maxsize=2), queue.Queue(maxsize=4)
+        failure = []
+
+        def stage(body, q_to):
+            """Run ``body``; whatever happens, tell the next stage that the stream has ended."""
+            def target():
+                try:
+                    body()
+                except BaseException as e:      # noqa: BLE001 -- re-raised in the caller's thread below
+                    failure.append(e)
+                finally:
+                    if q_to is not None:
+                        q_to.put(END)
+            t = threading.Thread(target=target, daemon=True)
+            t.start()
+            return t
+
+        def source_body():
+            for chunk in sample_source:
+                if failure:
+                    return
+                q_in.put(np.array(chunk, dtype=np.complex64))      # own copy: the ring buffer reuses its storage
+
+        def decoder_body():
+            while True:
+                d = q_out.get()
+                if d is END:
+                    return
+                if not failure:                 # after a failure keep draining so that the producer never blocks
+                    try:
+                        decode(d)
+                    except BaseException as e:  # noqa: BLE001
+                        failure.append(e)
+
+        t_src = stage(source_body, q_in)
+        t_dec = stage(decoder_body, None)
+        try:
+            while True:
+                chunk = q_in.get()
+                if chunk is END:
+                    break
+                if failure:
+                    continue                                        # drain so that the source thread can finish
+                d = self.feed(chunk)
+                q_out.put(d)
+                report(d)
+        except BaseException as e:                                   # noqa: BLE001
+            failure.append(e)
+            while q_in.get() is not END:                            # let the source thread run out
+                pass
+        finally:
+            q_out.put(END)
+            t_dec.join()
+            t_src.join()
+        if failure:
+            raise failure[0]
         return results, packets
