@@ -220,6 +220,15 @@ int mfb_sync_correlate(int device, const uint8_t *bits, int B, int L,
 int mfb_sync_find(int device, const uint8_t *bits, int B, int L, const int8_t *tmpl, int T,
                   int threshold, int max_hits, int32_t *hit_idx, int32_t *hit_score, int32_t *counts);
 
+/* The same for several templates in one call: the decoder correlates every block's bit stream with the header mask
+ * AND the sync flag (DEC:96-101 and DEC:112-113).  Template t has T[t] taps at tmpls + T[0] + ... + T[t-1] and threshold
+ * thresholds[t]; its results are counts[t*B + b], hit_idx / hit_score[(t*B + b)*max_hits + ..].  ntmpl <= 16.  Small
+ * calls (<= 1 MiB of bits and of results) move inputs and results as one packed copy each through page-locked
+ * staging: one host-device round trip per block instead of two calls x five copies. */
+int mfb_sync_find_multi(int device, const uint8_t *bits, int B, int L, const int8_t *tmpls, const int *T,
+                        const int *thresholds, int ntmpl, int max_hits, int32_t *hit_idx, int32_t *hit_score,
+                        int32_t *counts);
+
 /* Bit-stream alignment cross-correlation of the soft combiner:
  *   out = ifft( fft(a, N) * conj(fft(b, N)) ),  N = the handle's block length,
  * a, b real float32 sequences truncated / zero-padded to N as np.fft.fft(a, N) does; out complex64 [N].

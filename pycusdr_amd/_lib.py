@@ -73,6 +73,7 @@ PROTOTYPES = {
     'mfb_get_envelope': (_i, [_vp, _vp]),
     'mfb_sync_correlate': (_i, [_i, _vp, _i, _i, _vp, _i, _vp]),
     'mfb_sync_find': (_i, [_i, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    'mfb_sync_find_multi': (_i, [_i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     'mfb_xcorr': (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     'mfb_timer_start': (_i, [_vp]),
     'mfb_timer_stop': (_i, [_vp, _fp]),

@@ -372,6 +372,10 @@ struct mfb_ctx {
     int parts, srb;
     hipStream_t own_stream, stream;
     cf *h_in;  // pinned
+    // page-locked landing zone of the small read-backs (pick, rate/phase, spectrum windows, symbol decisions): a
+    // copy into pageable memory is staged by the runtime with a round trip of its own per copy
+    uint8_t *h_back;
+    size_t back_cap;
     cf *d_x, *d_X, *d_masks, *d_Z, *d_xc, *d_P;
     const cf *d_in;  // current time-domain input (d_x or caller's device pointer)
     float *d_env;
@@ -588,6 +592,9 @@ static int create_impl(mfb_ctx *c) {
     const size_t nb = (size_t)c->N * sizeof(cf);
     HIPCHK(hipHostMalloc((void **)&c->h_in, nb, hipHostMallocDefault));
     memset(c->h_in, 0, nb);
+    c->back_cap = (size_t)3 * (c->N / 2) * sizeof(int) + 64;      // three arrays of at most N/2 symbol decisions
+    if (c->back_cap < ((size_t)64 << 10)) c->back_cap = (size_t)64 << 10;
+    HIPCHK(hipHostMalloc((void **)&c->h_back, c->back_cap, hipHostMallocDefault));
     HIPCHK(dev_alloc((void **)&c->d_x, nb));
     HIPCHK(dev_alloc((void **)&c->d_X, nb));
     HIPCHK(dev_alloc((void **)&c->d_masks, nb * M));
@@ -691,6 +698,7 @@ extern "C" int mfb_destroy(mfb_ctx *c) {
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (c->h_in) (void)hipHostFree(c->h_in);
+    if (c->h_back) (void)hipHostFree(c->h_back);
     for (auto &v : c->ev)
         for (auto e : v) (void)hipEventDestroy(e);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -1395,6 +1403,33 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
     return MFB_OK;
 }
 
+// device -> host through the page-locked landing zone when it fits (n pieces back to back, ONE synchronisation)
+struct BackPiece {
+    void *host;
+    const void *dev;
+    size_t bytes;
+};
+static int read_back(mfb_ctx *c, const BackPiece *p, int n) {
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += (p[i].bytes + 15) & ~(size_t)15;
+    const bool staged = c->h_back && total <= c->back_cap;
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!p[i].bytes) continue;
+        HIPCHK(hipMemcpyAsync(staged ? (void *)(c->h_back + off) : p[i].host, p[i].dev, p[i].bytes, hipMemcpyDeviceToHost, c->stream));
+        off += (p[i].bytes + 15) & ~(size_t)15;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (staged) {
+        off = 0;
+        for (int i = 0; i < n; ++i) {
+            if (p[i].bytes) memcpy(p[i].host, c->h_back + off, p[i].bytes);
+            off += (p[i].bytes + 15) & ~(size_t)15;
+        }
+    }
+    return MFB_OK;
+}
+
 extern "C" int mfb_export_scores_async(mfb_ctx *c, void *dst, int row_offset) {
     if (!c || !dst || row_offset < 0) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
@@ -1418,9 +1453,8 @@ extern "C" int mfb_pick_column(mfb_ctx *c, const void *column, int num, int offs
     HIPCHK(hipSetDevice(c->device));
     hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, c->stream, (const float *)column, c->d_res, num, offset, 1, 1);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(res, c->d_res, 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return MFB_OK;
+    const BackPiece bp = {res, c->d_res, 2 * sizeof(float)};
+    return read_back(c, &bp, 1);
 }
 
 extern "C" int mfb_pick(mfb_ctx *c, const void *scores, int num, int offset, float res[2]) {
@@ -1430,9 +1464,8 @@ extern "C" int mfb_pick(mfb_ctx *c, const void *scores, int num, int offset, flo
     const float *in = scores ? (const float *)scores : c->d_sum;
     hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, c->stream, in, c->d_res, num, offset, c->M, c->sum_all);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(res, c->d_res, 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return MFB_OK;
+    const BackPiece bp = {res, c->d_res, 2 * sizeof(float)};
+    return read_back(c, &bp, 1);
 }
 
 extern "C" int mfb_find_carrier(mfb_ctx *c, float res[2]) {
@@ -1455,12 +1488,9 @@ extern "C" int mfb_get_spectrum(mfb_ctx *c, float *host, int start, int count) {
     HIPCHK(hipSetDevice(c->device));
     start = ((start % c->N) + c->N) % c->N;
     const int first = (start + count <= c->N) ? count : c->N - start;
-    HIPCHK(hipMemcpyAsync(host, c->d_X + start, (size_t)first * sizeof(cf), hipMemcpyDeviceToHost, c->stream));
-    if (first < count)
-        HIPCHK(hipMemcpyAsync(host + 2 * (size_t)first, c->d_X, (size_t)(count - first) * sizeof(cf), hipMemcpyDeviceToHost,
-                              c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return MFB_OK;
+    const BackPiece bp[2] = {{host, c->d_X + start, (size_t)first * sizeof(cf)},
+                             {host + 2 * (size_t)first, c->d_X, (size_t)(count - first) * sizeof(cf)}};
+    return read_back(c, bp, 2);
 }
 
 extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, float res[3]) {
@@ -1523,8 +1553,8 @@ extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, fl
     if (rc) return rc;
     hipLaunchKernelGGL(k_code_rate, dim3(1), dim3(1024), 0, c->stream, c->d_P, c->d_cr, k_offset, k_len);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(res, c->d_cr, 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    const BackPiece bp = {res, c->d_cr, 3 * sizeof(float)};
+    if ((rc = read_back(c, &bp, 1))) return rc;
     c->have_xc = true;
     return MFB_OK;
 }
@@ -1544,11 +1574,10 @@ extern "C" int mfb_find_centres(mfb_ctx *c, float spSym, float offset, int op, i
     hipLaunchKernelGGL(k_centres, dim3(nb), dim3(256), 0, c->stream, c->d_sym, c->d_cen, c->d_mag, c->d_xc, spSym, offset, c->N,
                        c->M, c->W, op, c->cap);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(sym, c->d_sym, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(cen, c->d_cen, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(mag, c->d_mag, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return MFB_OK;
+    const BackPiece bp[3] = {{sym, c->d_sym, (size_t)count * sizeof(int)},
+                             {cen, c->d_cen, (size_t)count * sizeof(int)},
+                             {mag, c->d_mag, (size_t)count * sizeof(float)}};
+    return read_back(c, bp, 3);
 }
 
 extern "C" int mfb_get_xcorr(mfb_ctx *c, float *host) {
@@ -1581,7 +1610,12 @@ struct SyncWs {
     int *seg = nullptr;     // segcnt | segoff | counts
     int32_t *hits = nullptr;  // hit_idx | hit_score
     size_t cap_bits = 0, cap_tmpl = 0, cap_out = 0, cap_seg = 0, cap_hits = 0;
+    // small calls (one block's bit stream, a few templates): inputs and results each travel as ONE packed copy
+    // through page-locked staging -- every separate copy of pageable memory costs a round trip of its own
+    uint8_t *h_stage = nullptr, *d_stage = nullptr;
+    size_t cap_hstage = 0, cap_dstage = 0;
 };
+#define SYNC_STAGE_MAX ((size_t)1 << 20)
 #define SYNC_MAX_DEVICES 64
 static std::mutex g_sync_mu;
 static std::vector<SyncWs *> g_sync_pool[SYNC_MAX_DEVICES];
@@ -1656,37 +1690,100 @@ extern "C" int mfb_sync_correlate(int device, const uint8_t *bits, int B, int L,
     return MFB_OK;
 }
 
-extern "C" int mfb_sync_find(int device, const uint8_t *bits, int B, int L, const int8_t *tmpl, int T, int threshold,
-                             int max_hits, int32_t *hit_idx, int32_t *hit_score, int32_t *counts) {
-    if (!bits || !tmpl || !hit_idx || !hit_score || !counts || B < 1 || L < 1 || T < 1 || T > 4096 || max_hits < 1)
+static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// K templates against the same B bit streams; template t: T[t] taps at tmpls + sum(T[0..t)), threshold thr[t];
+// its results sit at counts + t*B, hit_idx / hit_score + t*B*max_hits.
+static int sync_find_impl(int device, const uint8_t *bits, int B, int L, const int8_t *tmpls, const int *T, const int *thr, int K,
+                          int max_hits, int32_t *hit_idx, int32_t *hit_score, int32_t *counts) {
+    if (!bits || !tmpls || !T || !thr || !hit_idx || !hit_score || !counts || B < 1 || L < 1 || K < 1 || K > 16 || max_hits < 1)
         return MFB_ERR_ARG;
+    size_t taps = 0;
+    int Tmax = 0;
+    for (int t = 0; t < K; ++t) {
+        if (T[t] < 1 || T[t] > 4096) return MFB_ERR_ARG;
+        taps += (size_t)T[t];
+        if (T[t] > Tmax) Tmax = T[t];
+    }
     int rc = sync_device_ok(device);
     if (rc) return rc;
-    const int outLen = L + T - 1;
-    const int nseg = (outLen + SYNC_SEG - 1) / SYNC_SEG;
+    const int nseg = (L + Tmax - 1 + SYNC_SEG - 1) / SYNC_SEG;      // segments of the longest output
     WsLease lease{device, ws_acquire(device)};
     if (!lease.w) return MFB_ERR_HIP;
     SyncWs &w = *lease.w;
-    if ((rc = ws_reserve(&w.bits, &w.cap_bits, (size_t)B * L))) return rc;
-    if ((rc = ws_reserve(&w.tmpl, &w.cap_tmpl, (size_t)T))) return rc;
-    if ((rc = ws_reserve(&w.seg, &w.cap_seg, ((size_t)2 * B * nseg + B) * sizeof(int)))) return rc;
-    if ((rc = ws_reserve(&w.hits, &w.cap_hits, (size_t)2 * B * max_hits * sizeof(int32_t)))) return rc;
-    int *segcnt = w.seg, *segoff = w.seg + (size_t)B * nseg, *d_counts = w.seg + (size_t)2 * B * nseg;
-    int32_t *d_idx = w.hits, *d_sc = w.hits + (size_t)B * max_hits;
-    HIPCHK(hipMemcpyAsync(w.bits, bits, (size_t)B * L, hipMemcpyHostToDevice, w.stream));
-    HIPCHK(hipMemcpyAsync(w.tmpl, tmpl, (size_t)T, hipMemcpyHostToDevice, w.stream));
-    const size_t lds = (size_t)T + SYNC_SEG + T - 1;
-    hipLaunchKernelGGL((k_sync_find<false>), dim3(nseg, B), dim3(256), lds, w.stream, w.bits, w.tmpl, L, T, threshold, nseg, segcnt,
-                       (const int *)nullptr, max_hits, (int32_t *)nullptr, (int32_t *)nullptr);
-    hipLaunchKernelGGL(k_sync_scan, dim3((B + 63) / 64), dim3(64), 0, w.stream, (const int *)segcnt, segoff, d_counts, B, nseg);
-    hipLaunchKernelGGL((k_sync_find<true>), dim3(nseg, B), dim3(256), lds, w.stream, w.bits, w.tmpl, L, T, threshold, nseg, segcnt,
-                       (const int *)segoff, max_hits, d_idx, d_sc);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(counts, d_counts, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, w.stream));
-    HIPCHK(hipMemcpyAsync(hit_idx, d_idx, (size_t)B * max_hits * sizeof(int32_t), hipMemcpyDeviceToHost, w.stream));
-    HIPCHK(hipMemcpyAsync(hit_score, d_sc, (size_t)B * max_hits * sizeof(int32_t), hipMemcpyDeviceToHost, w.stream));
-    HIPCHK(hipStreamSynchronize(w.stream));
+    const size_t nbits = (size_t)B * L;
+    const size_t res_ints = (size_t)K * B * (1 + 2 * (size_t)max_hits);       // counts | idx | score, template-major
+    const bool packed = align16(taps) + nbits <= SYNC_STAGE_MAX && res_ints * sizeof(int32_t) <= SYNC_STAGE_MAX;
+    if ((rc = ws_reserve(&w.seg, &w.cap_seg, ((size_t)2 * B * nseg) * sizeof(int)))) return rc;
+    if ((rc = ws_reserve(&w.hits, &w.cap_hits, res_ints * sizeof(int32_t)))) return rc;
+    int32_t *d_counts = w.hits, *d_idx = w.hits + (size_t)K * B, *d_sc = d_idx + (size_t)K * B * max_hits;
+    const uint8_t *d_bits;
+    const int8_t *d_tmpl;
+    if (packed) {
+        const size_t in_bytes = align16(taps) + nbits;
+        const size_t hneed = in_bytes > res_ints * sizeof(int32_t) ? in_bytes : res_ints * sizeof(int32_t);
+        if (w.cap_hstage < hneed) {
+            if (w.h_stage) HIPCHK(hipHostFree(w.h_stage));
+            w.h_stage = nullptr;
+            w.cap_hstage = 0;
+            HIPCHK(hipHostMalloc((void **)&w.h_stage, hneed, hipHostMallocDefault));
+            w.cap_hstage = hneed;
+        }
+        if ((rc = ws_reserve(&w.d_stage, &w.cap_dstage, in_bytes))) return rc;
+        memcpy(w.h_stage, tmpls, taps);
+        memcpy(w.h_stage + align16(taps), bits, nbits);
+        HIPCHK(hipMemcpyAsync(w.d_stage, w.h_stage, in_bytes, hipMemcpyHostToDevice, w.stream));
+        d_tmpl = (const int8_t *)w.d_stage;
+        d_bits = w.d_stage + align16(taps);
+    } else {
+        if ((rc = ws_reserve(&w.bits, &w.cap_bits, nbits))) return rc;
+        if ((rc = ws_reserve(&w.tmpl, &w.cap_tmpl, taps))) return rc;
+        HIPCHK(hipMemcpyAsync(w.bits, bits, nbits, hipMemcpyHostToDevice, w.stream));
+        HIPCHK(hipMemcpyAsync(w.tmpl, tmpls, taps, hipMemcpyHostToDevice, w.stream));
+        d_bits = w.bits;
+        d_tmpl = w.tmpl;
+    }
+    int *segcnt = w.seg, *segoff = w.seg + (size_t)B * nseg;
+    size_t toff = 0;
+    for (int t = 0; t < K; ++t) {
+        const int Tt = T[t];
+        const int ns = (L + Tt - 1 + SYNC_SEG - 1) / SYNC_SEG;
+        const size_t lds = (size_t)Tt + SYNC_SEG + Tt - 1;
+        int32_t *ci = d_counts + (size_t)t * B, *ii = d_idx + (size_t)t * B * max_hits, *si = d_sc + (size_t)t * B * max_hits;
+        hipLaunchKernelGGL((k_sync_find<false>), dim3(ns, B), dim3(256), lds, w.stream, d_bits, d_tmpl + toff, L, Tt, thr[t], ns, segcnt,
+                           (const int *)nullptr, max_hits, (int32_t *)nullptr, (int32_t *)nullptr);
+        hipLaunchKernelGGL(k_sync_scan, dim3((B + 63) / 64), dim3(64), 0, w.stream, (const int *)segcnt, segoff, ci, B, ns);
+        hipLaunchKernelGGL((k_sync_find<true>), dim3(ns, B), dim3(256), lds, w.stream, d_bits, d_tmpl + toff, L, Tt, thr[t], ns, segcnt,
+                           (const int *)segoff, max_hits, ii, si);
+        HIPCHK(hipGetLastError());
+        toff += (size_t)Tt;
+    }
+    const size_t nc = (size_t)K * B, nh = (size_t)K * B * max_hits;
+    if (packed) {
+        HIPCHK(hipMemcpyAsync(w.h_stage, w.hits, res_ints * sizeof(int32_t), hipMemcpyDeviceToHost, w.stream));
+        HIPCHK(hipStreamSynchronize(w.stream));
+        const int32_t *r = (const int32_t *)w.h_stage;
+        memcpy(counts, r, nc * sizeof(int32_t));
+        memcpy(hit_idx, r + nc, nh * sizeof(int32_t));
+        memcpy(hit_score, r + nc + nh, nh * sizeof(int32_t));
+    } else {
+        HIPCHK(hipMemcpyAsync(counts, d_counts, nc * sizeof(int32_t), hipMemcpyDeviceToHost, w.stream));
+        HIPCHK(hipMemcpyAsync(hit_idx, d_idx, nh * sizeof(int32_t), hipMemcpyDeviceToHost, w.stream));
+        HIPCHK(hipMemcpyAsync(hit_score, d_sc, nh * sizeof(int32_t), hipMemcpyDeviceToHost, w.stream));
+        HIPCHK(hipStreamSynchronize(w.stream));
+    }
     return MFB_OK;
+}
+
+extern "C" int mfb_sync_find(int device, const uint8_t *bits, int B, int L, const int8_t *tmpl, int T, int threshold,
+                             int max_hits, int32_t *hit_idx, int32_t *hit_score, int32_t *counts) {
+    return sync_find_impl(device, bits, B, L, tmpl, &T, &threshold, 1, max_hits, hit_idx, hit_score, counts);
+}
+
+extern "C" int mfb_sync_find_multi(int device, const uint8_t *bits, int B, int L, const int8_t *tmpls, const int *T,
+                                   const int *thresholds, int ntmpl, int max_hits, int32_t *hit_idx, int32_t *hit_score,
+                                   int32_t *counts) {
+    return sync_find_impl(device, bits, B, L, tmpls, T, thresholds, ntmpl, max_hits, hit_idx, hit_score, counts);
 }
 
 // ---- N4: bit-stream alignment cross-correlation (reference lib/customXCorr.py:5-18) -----------------

@@ -27,6 +27,11 @@ def _hip_finder(bits, template, threshold, device=0):
     return sync_find(bits, template, threshold, device=device)
 
 
+def _hip_finder_multi(bits, templates, thresholds, device=0):
+    from .mfbank import sync_find_multi
+    return sync_find_multi(bits, templates, thresholds, device=device)
+
+
 def _config_device(config):
     """HIP device of this process: ``config['GPU'][<set>]['CUDA']['device']`` (the key the Demodulator reads,
     reference DB:178) of the first GPU set that names one; 0 otherwise."""
@@ -87,9 +92,15 @@ class Decoder:
         rawBits_DS = np.concatenate((self.bitsOverlapBuf, bits_less_raw))
         self.bitsOverlapBuf = rawBits_DS[-self.numBitsOverlap:]
 
-        idxCand, candScore = self.hits(rawBits_DS, self.mask, p.numOnesHeader - p.headerTol)
+        if self._finder is not None:
+            # both searches of the block in one library call (one host-device round trip)
+            (idxCand, candScore), (syncSigStartIdx, _) = _hip_finder_multi(
+                rawBits_DS, (self.mask, self.syncSig), (p.numOnesHeader - p.headerTol, p.numOnesSyncSig - p.syncSigTol),
+                device=self.device)
+        else:
+            idxCand, candScore = self.hits(rawBits_DS, self.mask, p.numOnesHeader - p.headerTol)
+            syncSigStartIdx, _ = self.hits(rawBits_DS, self.syncSig, p.numOnesSyncSig - p.syncSigTol)
         packetIdx = idxCand - len(self.mask) + 1          # the peak sits on the template's last bit
-        syncSigStartIdx, _ = self.hits(rawBits_DS, self.syncSig, p.numOnesSyncSig - p.syncSigTol)
         numSyncSig = len(syncSigStartIdx)
 
         if self.packetEndDetectMode == PacketEndDetect.FLAGS:

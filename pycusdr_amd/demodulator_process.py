@@ -141,8 +141,13 @@ class DemodulatorRunner:
             return results, packets
 
         import queue
+        import sys
         import threading
         END = object()
+        # the stages hand the interpreter lock to each other once per block: with the default 5 ms switch interval a
+        # stage that returns from a library call can wait that long for a stage busy in Python code
+        old_switch = sys.getswitchinterval()
+        sys.setswitchinterval(min(old_switch, 1e-4))
         q_in, q_out = queue.Queue(maxsize=2), queue.Queue(maxsize=4)
         failure = []
 
@@ -197,6 +202,7 @@ class DemodulatorRunner:
             q_out.put(END)
             t_dec.join()
             t_src.join()
+            sys.setswitchinterval(old_switch)
         if failure:
             raise failure[0]
         return results, packets

@@ -303,6 +303,49 @@ def sync_find(bits, template, threshold, max_hits=1024, device=0):
     return out[0] if single else out
 
 
+def sync_find_multi(bits, templates, thresholds, max_hits=256, device=0):
+    """``sync_find`` for several templates against the same bit stream(s) in ONE library call (one host-device
+    round trip): the decoder's header-mask and sync-flag searches of a block (reference decoder.py:96-113).
+    Returns one ``sync_find`` result per template."""
+    lib = _lib.load()
+    b = np.asarray(bits)
+    single = b.ndim == 1
+    b2 = np.ascontiguousarray(b.reshape(1, -1) if single else b)
+    if b2.dtype != np.uint8:
+        u = b2.astype(np.uint8)
+        if not np.array_equal(u, b2) or u.max(initial=0) > 1:
+            raise ValueError('expected a 0/1 bit stream')
+        b2 = u
+    tis = []
+    for t in templates:
+        t = np.asarray(t)
+        ti = np.ascontiguousarray(t, dtype=np.int8)
+        if not np.array_equal(ti, t):
+            raise ValueError('template must hold small integers (int8)')
+        tis.append(ti)
+    K = len(tis)
+    packed = np.concatenate(tis)
+    T = np.array([t.size for t in tis], dtype=np.int32)
+    thr = np.array([int(np.ceil(x)) for x in thresholds], dtype=np.int32)
+    if len(thr) != K:
+        raise ValueError('one threshold per template')
+    B, L = b2.shape
+    while True:
+        idx = np.empty((K, B, max_hits), dtype=np.int32)
+        sc = np.empty((K, B, max_hits), dtype=np.int32)
+        cnt = np.empty((K, B), dtype=np.int32)
+        _lib.check(lib.mfb_sync_find_multi(int(device), _ptr(b2), B, L, _ptr(packed), _ptr(T), _ptr(thr), K, int(max_hits),
+                                           _ptr(idx), _ptr(sc), _ptr(cnt)), 'mfb_sync_find_multi')
+        if cnt.max() <= max_hits:
+            break
+        max_hits = int(cnt.max())
+    out = []
+    for k in range(K):
+        per = [(idx[k, s, :cnt[k, s]].copy(), sc[k, s, :cnt[k, s]].copy()) for s in range(B)]
+        out.append(per[0] if single else per)
+    return out
+
+
 def sync_correlate(bits, template, device=0):
     """Batched full convolution of 0/1 bit streams with an integer template on the GPU
     (reference decoder.py:96,112 does this with np.convolve).  ``bits`` uint8 [L] or [B, L];

@@ -64,6 +64,33 @@ def test_sync_find_equals_where_of_convolve():
     assert np.array_equal(i1, np.where(ref >= 3.5)[0]) and np.array_equal(s1, ref[ref >= 3.5])
 
 
+def test_sync_find_multi_equals_separate_searches():
+    """Several templates of different lengths in one call: small inputs take the packed single-copy route, large ones
+    the direct copies; both must equal np.where(np.convolve(...) >= thr) per template and stream."""
+    from pycusdr_amd.mfbank import sync_find_multi
+    rs = np.random.RandomState(21)
+    for B, L, Ts, thrs in ((1, 2304, (128, 16), (20, 6)), (1, 67584, (64, 32, 7), (18, 10, 5)), (40, 60000, (64, 200), (22, 40)),
+                           (3, 50, (64, 5), (-10, 2)), (2, 1024, (1, 4096), (1, 90))):
+        bits = rs.randint(0, 2, (B, L)).astype(np.uint8)
+        tmpls = [(rs.randint(0, 2, T) * 2 - 1).astype(np.int8) for T in Ts]
+        got = sync_find_multi(bits, tmpls, thrs, max_hits=4)          # small max_hits forces the regrow path
+        assert len(got) == len(Ts)
+        for k, (tm, thr) in enumerate(zip(tmpls, thrs)):
+            for b in range(B):
+                ref = orc.sync_correlate(bits[b], tm)
+                idx = np.where(ref >= thr)[0]
+                assert np.array_equal(got[k][b][0], idx) and np.array_equal(got[k][b][1], ref[idx]), (B, L, k, b)
+    # 1-D float bit stream, float templates, fractional thresholds: what Decoder.findFrames passes
+    fb = bits[0].astype(np.float64)
+    (i0, s0), (i1, s1) = sync_find_multi(fb, [tmpls[0].astype(float), tmpls[1].astype(float)], (0.5, 80.5))
+    r0, r1 = orc.sync_correlate(bits[0], tmpls[0]), orc.sync_correlate(bits[0], tmpls[1])
+    assert np.array_equal(i0, np.where(r0 >= 0.5)[0]) and np.array_equal(s1, r1[r1 >= 80.5]) and np.array_equal(i1, np.where(r1 >= 80.5)[0])
+    with pytest.raises(ValueError):
+        sync_find_multi(np.array([0., 0.5, 1.]), [tmpls[0]], (1,))
+    with pytest.raises(ValueError):
+        sync_find_multi(bits, tmpls, (1,))
+
+
 @pytest.mark.parametrize('name', ['inside', 'across', 'overflow', 'two'])
 def test_flags_mode_kats_on_hip_correlator(goldens, name):
     """The reference's FLAGS-mode findFrames KATs (fixture G11) with both correlations on the GPU."""
