@@ -11,10 +11,10 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 worst = 0.0
 for case in range(cases):
-    log2N = int(rs.randint(12, 17))
+    log2N = int(rs.randint(10, 17))
     N = 1 << log2N
-    D = int(rs.randint(1, 40))
-    M = int(rs.choice([1, 2, 3, 5, 8, 13, 16, 17, 33]))
+    D = int(rs.randint(1, 40)) if rs.randint(0, 8) else int(rs.randint(200, 600))
+    M = int(rs.choice([1, 2, 3, 5, 8, 13, 16, 17, 33, 64]))
     sum_all = bool(rs.randint(0, 2))
     doff = int(rs.randint(0, 2))
     lmax = min(12, log2N - 2)
