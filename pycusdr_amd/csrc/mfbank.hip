@@ -67,6 +67,14 @@ struct mfb_ctx {
     // copy into pageable memory is staged by the runtime with a round trip of its own per copy
     uint8_t *h_back;
     size_t back_cap;
+    // Host mirror of the spectrum for small blocks.  The reference keeps the spectrum in host-mapped memory and reads
+    // its SNR windows straight from there (DB:456-457, 651-661); here the first mfb_get_spectrum on a handle turns on
+    // an asynchronous copy of every new spectrum (own stream, beside the search), so that later window reads cost no
+    // host-device round trip.  Blocks above MIRROR_MAX_N keep fetching windows on demand.
+    cf *h_X;
+    bool mirror, mirror_valid;
+    hipStream_t copy_stream;
+    hipEvent_t ev_fft, ev_X;
     cf *d_x, *d_X, *d_masks, *d_Z, *d_xc, *d_P;
     const cf *d_in;  // current time-domain input (d_x or caller's device pointer)
     float *d_env;
@@ -383,6 +391,7 @@ extern "C" int mfb_destroy(mfb_ctx *c) {
     if (!c) return MFB_ERR_ARG;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     void *bufs[] = {c->d_uniq, c->d_rep, c->d_x,  c->d_X,    c->d_masks, c->d_Z,   c->d_xc,  c->d_P,   c->d_env, c->d_shifts, c->d_tw1,
                     c->d_tw2, c->d_twLo, c->d_twHi,  c->d_part, c->d_sum, c->d_res, c->d_cr,  c->d_sym,    c->d_cen, c->d_mag,
                     c->d_G, c->d_twL, c->d_Gb, c->d_pow, c->d_W};
@@ -390,6 +399,10 @@ extern "C" int mfb_destroy(mfb_ctx *c) {
         if (p) (void)hipFree(p);
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_back) (void)hipHostFree(c->h_back);
+    if (c->h_X) (void)hipHostFree(c->h_X);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->ev_fft) (void)hipEventDestroy(c->ev_fft);
+    if (c->ev_X) (void)hipEventDestroy(c->ev_X);
     for (auto &v : c->ev)
         for (auto e : v) (void)hipEventDestroy(e);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -952,13 +965,43 @@ static void seg_slots(const mfb_ctx *c, int *full, int *total) {
 }
 
 
+#define MIRROR_MAX_N (1 << 18)
+// d_X is about to be overwritten: the copy of the previous spectrum must have left it
+static int before_fft(mfb_ctx *c) {
+    if (c->mirror_valid) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_X, 0));
+    c->mirror_valid = false;
+    return MFB_OK;
+}
+// d_X holds a new spectrum: start its copy to the host mirror beside whatever the handle's stream does next
+static int after_fft(mfb_ctx *c) {
+    if (!c->mirror) return MFB_OK;
+    HIPCHK(hipEventRecord(c->ev_fft, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_fft, 0));
+    HIPCHK(hipMemcpyAsync(c->h_X, c->d_X, (size_t)c->N * sizeof(cf), hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(hipEventRecord(c->ev_X, c->copy_stream));
+    c->mirror_valid = true;
+    return MFB_OK;
+}
+static int enable_mirror(mfb_ctx *c) {
+    if (c->mirror || c->N > MIRROR_MAX_N) return MFB_OK;
+    if (!c->h_X) HIPCHK(hipHostMalloc((void **)&c->h_X, (size_t)c->N * sizeof(cf), hipHostMallocDefault));
+    if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->ev_fft) HIPCHK(hipEventCreateWithFlags(&c->ev_fft, hipEventDisableTiming));
+    if (!c->ev_X) HIPCHK(hipEventCreateWithFlags(&c->ev_X, hipEventDisableTiming));
+    c->mirror = true;
+    return MFB_OK;
+}
+
 extern "C" int mfb_upload(mfb_ctx *c) {
     if (!c) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c->d_x, c->h_in, (size_t)c->N * sizeof(cf), hipMemcpyHostToDevice, c->stream));
     c->d_in = c->d_x;
-    int rc = forward_fft(c, c->d_in, nullptr, c->d_X);
+    int rc = before_fft(c);
     if (rc) return rc;
+    rc = forward_fft(c, c->d_in, nullptr, c->d_X);
+    if (rc) return rc;
+    if ((rc = after_fft(c))) return rc;
     c->have_input = true;
     c->have_xc = false;
     return MFB_OK;
@@ -978,8 +1021,11 @@ extern "C" int mfb_upload_device(mfb_ctx *c, const void *dev) {
     if (!c || !dev) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     c->d_in = (const cf *)dev;
-    int rc = forward_fft(c, c->d_in, nullptr, c->d_X);
+    int rc = before_fft(c);
     if (rc) return rc;
+    rc = forward_fft(c, c->d_in, nullptr, c->d_X);
+    if (rc) return rc;
+    if ((rc = after_fft(c))) return rc;
     c->have_input = true;
     c->have_xc = false;
     return MFB_OK;
@@ -1179,9 +1225,17 @@ extern "C" int mfb_get_spectrum(mfb_ctx *c, float *host, int start, int count) {
     HIPCHK(hipSetDevice(c->device));
     start = ((start % c->N) + c->N) % c->N;
     const int first = (start + count <= c->N) ? count : c->N - start;
+    if (c->mirror_valid) {            // the spectrum is (or is about to be) on the host already
+        HIPCHK(hipEventSynchronize(c->ev_X));
+        memcpy(host, c->h_X + start, (size_t)first * sizeof(cf));
+        if (first < count) memcpy(host + 2 * (size_t)first, c->h_X, (size_t)(count - first) * sizeof(cf));
+        return MFB_OK;
+    }
     const BackPiece bp[2] = {{host, c->d_X + start, (size_t)first * sizeof(cf)},
                              {host + 2 * (size_t)first, c->d_X, (size_t)(count - first) * sizeof(cf)}};
-    return read_back(c, bp, 2);
+    const int rc = read_back(c, bp, 2);
+    if (rc) return rc;
+    return enable_mirror(c);          // a caller that reads the spectrum once will read it again after every block
 }
 
 extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, float res[3]) {
@@ -1499,6 +1553,7 @@ extern "C" int mfb_xcorr(mfb_ctx *c, const float *a, int Na, const float *b, int
     };
     int rc;
     if ((rc = stage(a, Na))) return rc;
+    if ((rc = before_fft(c))) return rc;                                        // d_X is scratch here
     if ((rc = forward_fft(c, nullptr, c->d_env, c->d_X, 1))) return rc;        // A = fft(a, N)
     HIPCHK(hipStreamSynchronize(c->stream));                                    // d_env is reused
     if ((rc = stage(b, Nb))) return rc;

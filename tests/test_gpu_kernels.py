@@ -231,3 +231,29 @@ def test_pick_randomised_tables_exact():
                 assert abs(float(metric) - float(ometric)) <= 3e-6 * abs(float(ometric)) + 1e-6
         finally:
             bank.close()
+
+
+def test_spectrum_windows_from_the_host_mirror():
+    """The first spectrum read of a handle turns on the host mirror (small blocks): later reads, served from page-locked
+    host memory, must equal the device spectrum of the block uploaded last -- whole, windowed and wrapped."""
+    from pycusdr_amd.mfbank import MFBank
+    log2N = 13
+    N = 1 << log2N
+    rs = np.random.RandomState(9)
+    bank = MFBank(log2N, 4, 2)
+    try:
+        for block in range(4):
+            x = (rs.standard_normal(N) + 1j * rs.standard_normal(N)).astype(np.complex64)
+            bank.upload(x)
+            ref = np.fft.fft(x.astype(np.complex128))
+            full = bank.get_spectrum()                    # block 0: fetched from the device; later: from the mirror
+            assert np.abs(full - ref).max() / np.abs(ref).max() < 2e-6
+            for start, count in ((0, 7), (N - 3, 10), (N // 2 - 5, 11), (-4, 9), (N - 1, 1), (5, 0)):
+                w = bank.get_spectrum(start, count)
+                assert np.array_equal(w, np.take(full, np.arange(start, start + count), mode='wrap'))
+        xd = (rs.standard_normal(N) + 1j * rs.standard_normal(N)).astype(np.complex64)
+        bank.upload(xd)
+        bank.upload(x)                                     # two uploads back to back: the mirror follows the last one
+        assert np.array_equal(bank.get_spectrum(), full)
+    finally:
+        bank.close()
