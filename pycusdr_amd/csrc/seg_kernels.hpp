@@ -55,6 +55,10 @@
 #define MFB_SEG_PREFETCH 1
 #endif
 // issue the first filter's spectrum loads BEFORE the forward transform, so that they land while it runs
+// barrier teams (L = 2048 / 4096): two exchange buffers used alternately -> one workgroup barrier per exchange instead of two
+#ifndef MFB_SEG_PP
+#define MFB_SEG_PP 1
+#endif
 #ifndef MFB_SEG_G0EARLY
 #define MFB_SEG_G0EARLY 1
 #endif
@@ -95,7 +99,9 @@ struct SegCfg {
     static constexpr int TPW = 256 / TEAM;        // teams per workgroup
     static constexpr int WPT = TEAM / 64;         // waves per team
     static constexpr int SYNC = NT <= 64 ? 1 : 0;
-    static constexpr int LDS_PER_TEAM = padlen(L) * CT;
+    static constexpr bool PP = !SYNC && MFB_SEG_PP;
+    static constexpr int HALF = padlen(L) * CT;
+    static constexpr int LDS_PER_TEAM = HALF * (PP ? 2 : 1);
     static constexpr int LDS_ELEMS = LDS_PER_TEAM * TPW;
     static constexpr int STEP_ELEMS = 4 * 16;     // 16 step phasors per wave
     // Doppler search, L = 256: per-wave table of the relative mixing phasors W_N^(s*j), j < L (2 KiB a wave)
@@ -253,7 +259,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
             cf A[16];                             // A[k] = conj(U[g + NT*k])
             {
                 auto keep = [&](int, cf val, auto, auto nu) { A[decltype(nu)::value / NT] = val; };
-                fft_passes<L, 1, 0, true, false, 0, SYNC>(v, mylds, ebuf, g, 0, twr, a.twL, keep);
+                fft_passes<L, 1, 0, true, Cfg::PP, Cfg::HALF, SYNC>(v, mylds, ebuf, g, 0, twr, a.twL, keep);
             }
             if constexpr (MFB_SEG_PREFETCH && !MFB_SEG_G0EARLY) load_g(gk, r0);
 
@@ -298,7 +304,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                             racc[k & 3] = __builtin_elementwise_fma(val, val, racc[k & 3]);
                         }
                     };
-                    fft_passes<L, 1, 0, true, false, 0, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, acc);
+                    fft_passes<L, 1, 0, true, Cfg::PP, Cfg::HALF, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, acc);
                     const cf rsum = (racc[0] + racc[1]) + (racc[2] + racc[3]);
                     float s = rsum.x + rsum.y;
                     if constexpr (!MASKED && !SYNC) s = active ? s : 0.f;
@@ -313,7 +319,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                         // same fp32 order as k_envelope: s = s + fma(re, re, im * im), filters ascending
                         if (in_env) envacc[k] = __fadd_rn(envacc[k], __fmaf_rn(val.x, val.x, __fmul_rn(val.y, val.y)));
                     };
-                    fft_passes<L, 1, 0, true, false, 0, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, put);
+                    fft_passes<L, 1, 0, true, Cfg::PP, Cfg::HALF, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, put);
                 }
             }
             if constexpr (MODE == SEG_STORE) {
