@@ -1,0 +1,32 @@
+"""The bench line kept under profiles/ (written by bench.py on an MI355X at this round's HEAD) carries every key the
+driver's contract names, with consistent numbers.  CPU only: reads the stored JSON."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_stored_bench_line_follows_the_contract():
+    line = open(os.path.join(ROOT, 'profiles', 'r02_bench.json')).read().strip().splitlines()[-1]
+    d = json.loads(line)
+    base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
+    assert base['metric'].startswith(d['metric']) and d['unit'] == 'Msamples/s'      # BASELINE adds "at 1/2/4/8 GPUs"; n_gpus says which
+    for k in ('value', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
+              'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert d['dtype'] == 'f32' and d['data'] == 'synthetic' and 'workload' in d['config'] and 'model' not in d['config']
+    # value = (N - ov) / t
+    assert abs(d['value'] - (2 ** 20 - 2 ** 10) / (d['ms_per_step'] * 1e-3) / 1e6) / d['value'] < 1e-3
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and 0 < r['frac'] < 1
+    assert r['avg_launch_ms'] <= d['ms_per_step']                     # the dominant kernel fits inside a step
+    if r['bound'] == 'valu_fp32':
+        assert abs(r['achieved'] - r['flops_per_launch'] / (r['avg_launch_ms'] * 1e-3) / 1e12) / r['achieved'] < 1e-3
+        assert r['traffic'] < 0.01 * r['twopass_formulation_alg_bytes_per_block']      # no length-N intermediate
+    c = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] in ('port', 'reference') and c['max_rel_diff_vs_gpu'] < c['parity_tolerance'] == 1e-5
