@@ -11,7 +11,6 @@ stays numpy on the host.
 There is no CPU fallback: constructing a Demodulator without libmfbank.so / a GPU raises.
 """
 import logging
-import time
 from enum import Enum
 
 import numpy as np
