@@ -47,7 +47,7 @@ typedef struct mfb_ctx mfb_ctx;
 
 const char *mfb_strerror(int status);
 /* Library/ABI version, bumped whenever a prototype changes. */
-int mfb_abi_version(void);   /* 2: search paths, mfb_xcorr */
+int mfb_abi_version(void);   /* 2: search paths, mfb_xcorr; 3: mfb_set_search_mode, mfb_sync_find_multi */
 
 /* Create a handle on HIP device `device` for blocks of N = 2^log2N samples, `num_dopplers`
  * Doppler bins plus `doppler_offset` leading noise-reference bins (DB:150-159), M matched

@@ -145,7 +145,7 @@ extern "C" const char *mfb_strerror(int s) {
         default: return "unknown status";
     }
 }
-extern "C" int mfb_abi_version(void) { return 2; }
+extern "C" int mfb_abi_version(void) { return 3; }
 
 static void make_twiddles(std::vector<cf> &v, int count, double denom, double stepmul) {
     v.resize(count);
