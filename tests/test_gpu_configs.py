@@ -223,3 +223,47 @@ def test_two_handles_and_concurrent_sync_calls():
     for t in th:
         t.join()
     assert not errors, errors
+
+
+def test_three_channels_in_three_threads_one_device():
+    """The reference's 3-channel receive config (config/benchmark/bench_3_chan_rx_base.json) runs one Demodulator_process
+    per channel; here three runners, each with its own handle, stream and decoder, work concurrently from three threads
+    of ONE process on one device.  Every channel must produce exactly what it produces alone."""
+    import threading
+    from pycusdr_amd import signals as sg
+    from pycusdr_amd.decoder import Decoder
+    from pycusdr_amd.demodulator_process import DemodulatorRunner
+    bs, ov = 15, 1 << 10
+    N = 1 << bs
+    mods = [('GMSK', 'bench_GMSK'), ('FSK', 'bench_FSK'), ('BPSK', 'bench_BPSK')]
+    streams = {}
+    for k, (mod, _) in enumerate(mods):
+        s = sg.awgn(np.concatenate((sg.get_padded_packet(mod)[0], np.zeros(2 * N))), 12.0, rng=np.random.RandomState(40 + k))
+        streams[mod] = s.astype(np.complex64)
+
+    def run_channel(mod, pname, out):
+        try:
+            conf = cfg.bench_config(pname, blockSize=bs, doppCarrierSteps=48)
+            proto = loadProtocol(pname)(conf=conf)
+            run = DemodulatorRunner(conf, proto, 'UHF-H')
+            sig = streams[mod]
+            res, packets = run.run_stream((sig[i:i + 4096] for i in range(0, len(sig), 4096)), decoder=Decoder(conf, proto))
+            run.close()
+            out[mod] = ([(r['doppler'], r['spSymEst'], r['data'].tobytes(), r['trust'].tobytes()) for r in res],
+                        [p.checkPacketData() for p in packets])
+        except BaseException as e:      # noqa: BLE001 -- reported by the assertion below
+            out[mod] = e
+
+    alone, together = {}, {}
+    for mod, pname in mods:
+        run_channel(mod, pname, alone)
+    threads = [threading.Thread(target=run_channel, args=(mod, pname, together)) for mod, pname in mods]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    for mod, _ in mods:
+        assert not isinstance(alone[mod], BaseException), alone[mod]
+        assert not isinstance(together.get(mod), BaseException), together.get(mod)
+        assert together[mod] == alone[mod], mod
+        assert alone[mod][1] == [0], (mod, alone[mod][1])          # one packet, no bit errors
