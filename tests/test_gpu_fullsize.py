@@ -260,3 +260,25 @@ def test_largest_supported_blocks(log2N):
     assert np.abs(ds - ref).max() / ref.max() < 1e-5
     yref = np.fft.ifft(np.roll(X.astype(np.complex128), -int(shifts[1])) * masks[1]) * N
     assert np.abs(xc0 - yref).max() / np.abs(yref).max() < 5e-6
+
+
+def test_c2_scores_against_the_vendor_fft_formulation(c2):
+    """Third implementation: the reference's own formulation -- shift the spectrum, multiply by every filter, batched
+    UNNORMALISED inverse complex64 FFT, |.|^2 / 2^18 row sums (CU:339-373, DB:578-591, CU:421-480) -- evaluated with the
+    vendor FFT (torch.fft on ROCm = rocFFT, the library family of the reference's cuFFT) in fp32 on the same device.
+    16 of the 256 bins at full size; independent of both our kernels and the numpy oracle."""
+    torch = pytest.importorskip('torch')
+    bank = c2['bank']
+    bank.find_carrier()
+    ds = bank.get_scores()[:, 0]
+    dev = torch.device('cuda', 0)
+    X = torch.from_numpy(bank.get_spectrum()).to(dev)
+    H = torch.from_numpy(np.ascontiguousarray(c2['masks'])).to(dev)
+    sel = list(range(0, 256, 17)) + [255]
+    got = []
+    for j in sel:
+        xs = torch.roll(X, -int(c2['shifts'][j]))                      # xs[k] = X[(k + s) mod N]
+        y = torch.fft.ifft(xs[None, :] * H, dim=1, norm='forward')     # 'forward' = no 1/N on the inverse: cuFFT's convention
+        got.append(float((y.real.double() ** 2 + y.imag.double() ** 2).sum() / 2 ** 18))
+    got = np.array(got)
+    assert np.abs(ds[sel] - got).max() / got.max() < 1e-5

@@ -257,3 +257,44 @@ def test_spectrum_windows_from_the_host_mirror():
         assert np.array_equal(bank.get_spectrum(), full)
     finally:
         bank.close()
+
+
+@pytest.mark.parametrize('sum_all', [True, False])
+def test_scores_and_demod_outputs_against_the_vendor_fft(sum_all):
+    """The reference's formulation evaluated with the vendor FFT in fp32 on the device (torch.fft = rocFFT): per-filter
+    row sums and the matched-filter outputs at one shift, against both search paths."""
+    torch = pytest.importorskip('torch')
+    from pycusdr_amd import config as cfg
+    from pycusdr_amd.mfbank import MFBank
+    from pycusdr_amd.protocol import loadProtocol
+    log2N, D = 15, 24
+    N = 1 << log2N
+    rs = np.random.RandomState(3)
+    M, masks = loadProtocol('bench_FSK')(conf=cfg.bench_config('bench_FSK', blockSize=log2N)).get_filter(N, 16, 3)
+    x = (rs.standard_normal(N) + 1j * rs.standard_normal(N)).astype(np.complex64)
+    shifts = rs.randint(0, N, D).astype(np.int32)
+    bank = MFBank(log2N, D, M, sum_all_masks=sum_all)
+    try:
+        bank.set_filters(masks)
+        bank.set_shifts(shifts)
+        bank.upload(x)
+        dev = torch.device('cuda', 0)
+        X = torch.from_numpy(bank.get_spectrum()).to(dev)
+        H = torch.from_numpy(np.ascontiguousarray(masks)).to(dev)
+        ref = np.zeros((D, M))
+        for j in range(D):
+            y = torch.fft.ifft(torch.roll(X, -int(shifts[j]))[None, :] * H, dim=1, norm='forward')
+            ref[j] = ((y.real.double() ** 2 + y.imag.double() ** 2).sum(dim=1) / 2 ** 18).cpu().numpy()
+        want = ref.sum(axis=1) if sum_all else ref
+        for path in ('segment', 'twopass'):
+            bank.set_search_path(path)
+            bank.find_carrier()
+            ds = bank.get_scores()
+            got = ds[:, 0] if sum_all else ds
+            assert np.abs(got - want).max() / want.max() < 1e-5, path
+            bank.demodulate(int(shifts[5]), 5, 50)
+            y = torch.fft.ifft(torch.roll(X, -int(shifts[5]))[None, :] * H, dim=1, norm='forward').cpu().numpy()
+            xc = bank.get_xcorr()
+            assert np.abs(xc - y).max() / np.abs(y).max() < 1e-5, path
+    finally:
+        bank.close()
