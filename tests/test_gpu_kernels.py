@@ -292,9 +292,20 @@ def test_scores_and_demod_outputs_against_the_vendor_fft(sum_all):
             ds = bank.get_scores()
             got = ds[:, 0] if sum_all else ds
             assert np.abs(got - want).max() / want.max() < 1e-5, path
-            bank.demodulate(int(shifts[5]), 5, 50)
-            y = torch.fft.ifft(torch.roll(X, -int(shifts[5]))[None, :] * H, dim=1, norm='forward').cpu().numpy()
+            k_off, k_len = int(N / (1.1 * 16)), int(N / (0.9 * 16)) - int(N / (1.1 * 16))
+            kstar, arg, mag = bank.demodulate(int(shifts[5]), k_off, k_len)
+            yt = torch.fft.ifft(torch.roll(X, -int(shifts[5]))[None, :] * H, dim=1, norm='forward')
+            y = yt.cpu().numpy()
             xc = bank.get_xcorr()
             assert np.abs(xc - y).max() / np.abs(y).max() < 1e-5, path
+            # A10 with the vendor FFT: envelope, its real-input spectrum, windowed argmax, phase
+            env = (yt.real ** 2 + yt.imag ** 2).sum(dim=0)
+            assert np.abs(bank.get_envelope() - env.cpu().numpy()).max() / float(env.max()) < 1e-5
+            P = torch.fft.rfft(env)[k_off:k_off + k_len]
+            p2 = (P.real.double() ** 2 + P.imag.double() ** 2).cpu().numpy()
+            assert int(kstar) == k_off + int(p2.argmax())
+            assert abs(float(mag) - p2.max()) / p2.max() < 1e-4
+            ref_arg = float(torch.atan2(P.imag[int(p2.argmax())], P.real[int(p2.argmax())]))
+            assert abs(np.angle(np.exp(1j * (float(arg) - ref_arg)))) < 1e-3
     finally:
         bank.close()
