@@ -66,37 +66,112 @@ __global__ void __launch_bounds__(256) k_transpose(const cf *Z, cf *out, int N1,
 // findDopplerEst (cuda_kernels.cu:502-597).  The reference scans every column sequentially: a value
 // replaces the smaller of the two kept maxima when it is strictly greater (first come wins ties), and
 // which of the two slots a maximum sits in -- it matters for the fp32 rounding of the weighted index --
-// depends on the whole history.  One wavefront reproduces that scan exactly but skips what cannot change
-// the state: 64 rows are compared against the current threshold at once (ballot); only lanes that beat
-// it are visited, in row order, each visit updating the threshold for the lanes behind it.
+// depends on the whole history.  One wavefront reproduces the outcome of that scan exactly:
+//   * closed form (the usual case).  Without a value that EQUALS the running maximum when it arrives, the scan ends
+//     with the largest value (first occurrence) and the largest of the rest (first occurrence); every new running
+//     maximum ("record") lands in the slot that does not hold the previous one, so the largest value sits in slot
+//     (records - 1) mod 2.  Records, first occurrences and the tie test are prefix-maximum scans over the column,
+//     staged in LDS: a handful of wave operations instead of one dependent step per rising row.
+//   * otherwise (a tie with the running maximum, or a column too long for the staging buffer) the scan itself,
+//     skipping what cannot change the state: 64 rows are compared against the current threshold at once (ballot);
+//     only lanes that beat it are visited, in row order.
 // fp32 evaluation order is pinned with explicit intrinsics (see oracle/mfbank_oracle.py).
+#define PICK_LDS 4096
 __global__ void __launch_bounds__(64) k_pick(const float *in, float *res, int num, int offset, int M, int sum_all) {
     __shared__ float sIdx[64], sVal[64];
+    __shared__ float scol[PICK_LDS];
     const int lane = threadIdx.x;
     const int ncol = sum_all ? 1 : M;
     for (int x = 0; x < ncol; ++x) {
         float mv0 = 0.f, mv1 = 0.f;
         int mi0 = 0, mi1 = 0, cur = 0;
-        for (int r0 = offset; r0 < num + offset; r0 += 64) {
-            const int r = r0 + lane;
-            const bool inside = r < num + offset;
-            const float v = inside ? in[(size_t)r * M + x] : 0.f;
-            unsigned long long todo = ~0ull;
-            while (true) {
-                const float thr = cur ? mv1 : mv0;
-                const unsigned long long hit = __ballot(inside && v > thr) & todo;     // strict '>' (NaN never enters)
-                if (!hit) break;
-                const int l = __builtin_ctzll(hit);
-                const float tmp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));   // l is wave-uniform
-                if (cur) {
-                    mv1 = tmp;
-                    mi1 = r0 + l;
-                } else {
-                    mv0 = tmp;
-                    mi0 = r0 + l;
+        bool closed = false;
+        if (num <= PICK_LDS) {
+            __syncthreads();                              // the previous column's readers are done
+            for (int i = lane; i < num; i += 64) {
+                const float v = in[(size_t)(offset + i) * M + x];
+                scol[i] = (v > 0.f) ? v : 0.f;            // zeros, negatives and NaN never enter the scan (strict '>' against >= 0)
+            }
+            __syncthreads();
+            float carry = 0.f, gmax = 0.f;
+            int records = 0, gidx = 0;
+            bool tie = false;
+            for (int r0 = 0; r0 < num; r0 += 64) {
+                const int i = r0 + lane;
+                const float vv = (i < num) ? scol[i] : 0.f;
+                float pm = vv;                            // inclusive prefix maximum over the lanes
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const float t = __shfl_up(pm, o, 64);
+                    if (lane >= o) pm = fmaxf(pm, t);
                 }
-                cur = (mv0 >= mv1) ? 1 : 0;          // the slot of the smaller value is replaced next
-                todo = (l == 63) ? 0ull : (~0ull << (l + 1));
+                float ex = __shfl_up(pm, 1, 64);          // exclusive: everything before this row
+                ex = lane ? fmaxf(ex, carry) : carry;
+                const unsigned long long rb = __ballot(vv > ex);
+                tie = tie || (__ballot(vv == ex && vv > 0.f) != 0ull);
+                if (rb) {
+                    records += __popcll(rb);
+                    const int l = 63 - __builtin_clzll(rb);           // the chunk's last record = the running maximum so far
+                    gmax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), l));
+                    gidx = r0 + l;
+                }
+                carry = fmaxf(carry, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pm), 63)));
+            }
+            if (!tie) {
+                float best = 0.f;                         // largest of the rest, first occurrence
+                int bidx = 0;
+                for (int i = lane; i < num; i += 64) {
+                    const float vv = (i == gidx) ? 0.f : scol[i];
+                    if (vv > best) {
+                        best = vv;
+                        bidx = i;
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(best, o, 64);
+                    const int oi = __shfl_xor(bidx, o, 64);
+                    if (ov > best || (ov == best && oi < bidx)) {
+                        best = ov;
+                        bidx = oi;
+                    }
+                }
+                if (records > 0) {
+                    const int gi = offset + gidx, bi = best > 0.f ? offset + bidx : 0;
+                    if ((records - 1) & 1) {
+                        mv1 = gmax, mi1 = gi, mv0 = best, mi0 = bi;
+                    } else {
+                        mv0 = gmax, mi0 = gi, mv1 = best, mi1 = bi;
+                    }
+                    cur = (mv0 >= mv1) ? 1 : 0;
+                }
+                closed = true;
+            }
+        }
+        if (!closed) {
+            mv0 = mv1 = 0.f;
+            mi0 = mi1 = cur = 0;
+            for (int r0 = offset; r0 < num + offset; r0 += 64) {
+                const int r = r0 + lane;
+                const bool inside = r < num + offset;
+                const float v = inside ? in[(size_t)r * M + x] : 0.f;
+                unsigned long long todo = ~0ull;
+                while (true) {
+                    const float thr = cur ? mv1 : mv0;
+                    const unsigned long long hit = __ballot(inside && v > thr) & todo;     // strict '>' (NaN never enters)
+                    if (!hit) break;
+                    const int l = __builtin_ctzll(hit);
+                    const float tmp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));   // l is wave-uniform
+                    if (cur) {
+                        mv1 = tmp;
+                        mi1 = r0 + l;
+                    } else {
+                        mv0 = tmp;
+                        mi0 = r0 + l;
+                    }
+                    cur = (mv0 >= mv1) ? 1 : 0;          // the slot of the smaller value is replaced next
+                    todo = (l == 63) ? 0ull : (~0ull << (l + 1));
+                }
             }
         }
         const float numr = __fmaf_rn((float)mi0, mv0, __fmul_rn((float)mi1, mv1));

@@ -233,6 +233,74 @@ def test_pick_randomised_tables_exact():
             bank.close()
 
 
+def test_pick_closed_form_and_scan_agree_with_the_reference_scan():
+    """k_pick's closed form (records / first occurrences) and its sequential fallback against the oracle's restatement
+    of the reference scan, on the shapes that decide which slot a maximum ends up in: ramps, descents, peaks, plateaus,
+    ties with the running maximum early and late, quantised tables full of ties, zeros, negatives, NaN, inf, a single
+    positive value, nothing positive, and columns longer than the staging buffer."""
+    import torch
+    from pycusdr_amd.mfbank import MFBank
+    rs = np.random.RandomState(123)
+
+    def tables():
+        for D in (1, 2, 3, 63, 64, 65, 128, 256, 700, 4096, 4097, 6000):
+            base = rs.rand(D).astype(np.float32) + 0.01
+            yield 'random', base
+            yield 'ramp', np.sort(base)
+            yield 'descent', np.sort(base)[::-1].copy()
+            peak = np.concatenate((np.sort(base[:D // 2]), np.sort(base[D // 2:])[::-1]))
+            yield 'peak', peak
+            q = np.round(base * 7).astype(np.float32)                   # heavy ties, zeros included
+            yield 'quantised', q
+            t = base.copy()
+            if D > 4:
+                t[D // 2] = t[:D // 2].max()                            # equals the running maximum when it arrives
+                yield 'tie-with-running-max', t
+                t2 = base.copy()
+                t2[-1] = t2.max()                                       # a second copy of the global maximum at the end
+                yield 'tie-with-global-max', t2
+                t3 = base.copy()
+                t3[D // 3] = 0.0
+                t3[D // 4] = -1.0
+                t3[D // 5] = np.nan
+                yield 'zero-negative-nan', t3
+                t4 = base.copy()
+                t4[D // 2] = np.inf
+                yield 'inf', t4
+            one = np.zeros(D, np.float32)
+            one[D // 2] = 3.0
+            yield 'single', one
+            yield 'nothing', np.zeros(D, np.float32)
+
+    bank = MFBank(10, 4, 1, sum_all_masks=True)
+    bank3 = MFBank(10, 4, 3, sum_all_masks=False)
+    try:
+        for name, col in tables():
+            for off in (0, 1):
+                D = len(col) - off
+                if D < 1:
+                    continue
+                tab = np.ascontiguousarray(col[:, None])
+                t = torch.from_numpy(tab).cuda()
+                with np.errstate(all='ignore'):
+                    oidx, ometric = orc.find_doppler_est(tab, D, off, True)
+                idx, metric = bank.pick(t.data_ptr(), num=D, offset=off)
+                assert np.array_equal(np.float32(idx), np.float32(oidx), equal_nan=True), (name, len(col), off, idx, oidx)
+                if np.isfinite(ometric):
+                    assert abs(float(metric) - float(ometric)) <= 3e-6 * abs(float(ometric)) + 1e-6, (name, len(col), off)
+        for trial in range(12):                                          # several columns, the mean over filters
+            D = int(rs.randint(2, 5000))
+            tab = (np.round(rs.rand(D, 3) * (50 if trial % 2 else 1e6)) / 7).astype(np.float32)
+            t = torch.from_numpy(tab).cuda()
+            with np.errstate(all='ignore'):
+                oidx, ometric = orc.find_doppler_est(tab, D, 0, False)
+            idx, metric = bank3.pick(t.data_ptr(), num=D, offset=0)
+            assert np.array_equal(np.float32(idx), np.float32(oidx), equal_nan=True), (trial, D)
+    finally:
+        bank.close()
+        bank3.close()
+
+
 def test_spectrum_windows_from_the_host_mirror():
     """The first spectrum read of a handle turns on the host mirror (small blocks): later reads, served from page-locked
     host memory, must equal the device spectrum of the block uploaded last -- whole, windowed and wrapped."""
