@@ -144,6 +144,15 @@ class Demodulator:
                            doppler_offset=self.doppIdxArrayOffset, device=device)
         self.bank.set_filters(masks)
         self.bank.set_shifts(self.doppCyperSymNorm[self._bin_lo:self._bin_hi])
+        # optional search settings next to the reference's "CUDA" block (where it keeps batchSize / streams, DB:171-178):
+        #   "HIP": {"search_path": "auto|segment|twopass", "search_basis": "filters|span", "search_mode": "transforms|energy"}
+        hip_cfg = confGPU.get('HIP', {})
+        if 'search_path' in hip_cfg:
+            self.bank.set_search_path(hip_cfg['search_path'])
+        if 'search_basis' in hip_cfg:
+            self.bank.set_search_basis(hip_cfg['search_basis'])
+        if 'search_mode' in hip_cfg:
+            self.bank.set_search_mode(hip_cfg['search_mode'])
         if shard is not None:
             shard.attach(self.bank, self.num_dopplers, self.num_masks, sum_all=self.SUM_ALL_MASKS_PYTHON)
         self._pick_bin = 0

@@ -120,3 +120,18 @@ def test_demodulator_output_identical_with_energy_search():
         assert a[0] == b[0] and a[1] == b[1] and a[5] == b[5]
         for u, v in zip(a[2:5], b[2:5]):
             assert np.array_equal(u, v)
+
+
+def test_search_settings_from_the_config():
+    """GPU.<set>.HIP carries the optional search settings; what they select is in force after construction."""
+    conf = cfg.bench_config('bench_GMSK', blockSize=14, doppCarrierSteps=16)
+    conf['GPU']['UHF']['HIP'] = {'search_path': 'segment', 'search_basis': 'span', 'search_mode': 'energy'}
+    demod = UHF.Demodulator(conf, loadProtocol('bench_GMSK')(conf=conf), 'UHF-H')
+    try:
+        assert demod.bank.get_search_path()['path'] == 'segment'
+        assert demod.bank.get_search_basis()[0] == 'span' and demod.bank.get_search_mode() == 'energy'
+    finally:
+        demod.close()
+    conf['GPU']['UHF']['HIP'] = {'search_mode': 'fast'}
+    with pytest.raises(KeyError):
+        UHF.Demodulator(conf, loadProtocol('bench_GMSK')(conf=conf), 'UHF-H')
