@@ -467,9 +467,9 @@ static int seg_valid(int l, int T) {
 // three waves per SIMD, phase table in LDS), so it wins whenever at least ~2/3 of a segment is valid; the
 // cost of a valid output is this divided by the segment efficiency V / L.  Checked against the other
 // shipped banks: 80 taps (BPSK) -> 256 (7.7 ms at D = 512 vs 8.9 ms at 1024), 384 taps (CC11xx at 128
-// samples per symbol) -> 4096 (5.9 ms at D = 512 vs 6.1 ms at 2048, 6.7 ms at 1024).
+// samples per symbol) -> 4096 (5.57 ms at D = 512 vs 5.60 ms at 2048, 6.3 ms at 1024).  Figures with 32 workgroups per CU in the grid.
 static double seg_cost(int l, int T) {
-    static const double per_point[13] = {0, 0, 0, 0, 0, 0, 0, 0, 1.37, 2.10, 2.06, 2.80, 2.58};
+    static const double per_point[13] = {0, 0, 0, 0, 0, 0, 0, 0, 1.35, 1.94, 2.02, 2.28, 2.44};
     const int V = seg_valid(l, T);
     if (!V) return 1e30;
     return per_point[l] * (double)(1 << l) / (double)V;
@@ -567,7 +567,7 @@ static int resolve_path(mfb_ctx *c) {
 }
 
 extern "C" int mfb_set_search_path(mfb_ctx *c, int path, int log2L, int wg_per_cu, int filters_per_pass) {
-    if (!c || path < 0 || path > MFB_PATH_SEGMENT || log2L < 0 || wg_per_cu < 0 || wg_per_cu > 16 || filters_per_pass < 0 ||
+    if (!c || path < 0 || path > MFB_PATH_SEGMENT || log2L < 0 || wg_per_cu < 0 || wg_per_cu > 64 || filters_per_pass < 0 ||
         filters_per_pass > SEG_MPB_MAX)
         return MFB_ERR_ARG;
     if (log2L && (log2L < 8 || log2L > 12)) return MFB_ERR_UNSUPPORTED;
@@ -903,10 +903,14 @@ static SegPlan plan_seg(const mfb_ctx *c, int dc, int nfilters, int nslots, int 
     if (mpb > nfilters) mpb = nfilters;
     p.mgroups = (nfilters + mpb - 1) / mpb;
     p.mpb = (nfilters + p.mgroups - 1) / p.mgroups;   // balanced
-    // Workgroups in the grid per CU.  More than are resident at once (3 / 2 per CU) on purpose: the surplus
-    // is dealt out as workgroups retire, which evens out CUs that run at different speeds (measured at C2,
-    // L = 256: 3 per CU 1.85 ms, 6: 1.75, 12: 1.60, 16: 1.60; L = 1024: 2: 2.26, 6: 2.20; L = 4096: 4: 2.75)
-    const int wpc = c->seg_wpc > 0 ? c->seg_wpc : (c->segl <= 8 ? 12 : (c->segl <= 10 ? 6 : 4));
+    // Workgroups in the grid per CU.  Many more than are resident at once (3 / 2 per CU) on purpose: the surplus is
+    // dealt out as workgroups retire, which evens out CUs that run at different speeds -- and devices differ in how
+    // uneven they are.  Measured at C2, L = 256, on a device where it matters: 12 per CU 1.90 ms, 16: 1.71, 24: 1.67,
+    // 32: 1.655, 40: 1.66 (on an even device: 12: 1.64, 16: 1.63); 1024 bins: 12: 6.97, 32: 6.50; BPSK bank, 512 bins:
+    // 16: 7.99, 32: 7.66; L = 512 / 1024: 6: 2.56 / 2.48, 32: 2.21 / 2.16; CC11xx bank, L = 2048 / 4096: 4: 6.2 / 6.0,
+    // 16: 6.07 / 5.77, 32: 5.60 / 5.57, 48: 5.87 / 5.72.  Small blocks are unaffected (the grid never has more teams than
+    // (bin, slot) units).
+    const int wpc = c->seg_wpc > 0 ? c->seg_wpc : 32;
     int wpg = wpc * 256 / p.nsg;                 // workgroups per group: wpc per CU, 256 CUs
     // never more teams than (bin, slot) units in a group
     const long long units = (long long)dc * ((nslots + p.nsg - 1) / p.nsg);

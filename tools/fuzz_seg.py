@@ -53,7 +53,7 @@ for case in range(cases):
                                    err=err, idx=float(idx_), oidx=float(oidx), path=bank.get_search_path(), basis=bank.get_search_basis()))
                 sys.exit(1)
         try:
-            bank.set_search_path('segment', l, int(rs.randint(0, 7)), int(rs.randint(0, 17)))
+            bank.set_search_path('segment', l, int(rs.choice([0, 1, 2, 3, 5, 6, 12, 24, 40, 64])), int(rs.randint(0, 17)))
             tags.append('segment')
         except ValueError:
             tags.append('twopass')                          # e.g. the random taps happened to be too long for this L
