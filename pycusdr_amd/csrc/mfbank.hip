@@ -1588,6 +1588,15 @@ extern "C" int mfb_xcorr(mfb_ctx *c, const float *a, int Na, const float *b, int
     return MFB_OK;
 }
 
+#ifdef MFB_SEG_TRACE
+extern "C" int mfb_debug_read_trace(unsigned long long *out, int nblocks) {
+    if (!out || nblocks < 1 || nblocks > 65536) return MFB_ERR_ARG;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_seg_trace), (size_t)nblocks * 3 * sizeof(unsigned long long)));
+    return MFB_OK;
+}
+#endif
+
 extern "C" int mfb_timer_start(mfb_ctx *c) {
     if (!c) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));

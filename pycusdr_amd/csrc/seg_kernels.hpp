@@ -355,7 +355,26 @@ struct SegWaves {
 #define SEG_KERNEL_ATTRS(L_, PV_) \
     __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SegWaves<L_, PV_>::value, SegWaves<L_, PV_>::value)))
 
+// Variant builds only (-DMFB_SEG_TRACE, tools/xcd_trace.py): start / end time and XCC of every workgroup of the
+// branch-free search kernel, to see how evenly the grid drains over the XCDs.
+#ifdef MFB_SEG_TRACE
+__device__ unsigned long long g_seg_trace[3 * 65536];
+#endif
+
 template <int L, int MODE, int PV>
 __global__ void SEG_KERNEL_ATTRS(L, PV) k_seg(SegArgs a) {
+#ifdef MFB_SEG_TRACE
+    unsigned long long t0 = 0;
+    if (PV >= 0 && MODE == SEG_REDUCE && threadIdx.x == 0) t0 = wall_clock64();
+#endif
     seg_body<L, MODE, PV>(a, (int)blockIdx.x);
+#ifdef MFB_SEG_TRACE
+    if (PV >= 0 && MODE == SEG_REDUCE && threadIdx.x == 0 && blockIdx.x < 65536) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_seg_trace[3 * blockIdx.x] = t0;
+        g_seg_trace[3 * blockIdx.x + 1] = wall_clock64();
+        g_seg_trace[3 * blockIdx.x + 2] = xcc;
+    }
+#endif
 }
