@@ -839,7 +839,7 @@ static int forward_fft(mfb_ctx *c, const cf *src_c, const float *src_r, cf *dst,
 template <int L, int MODE, int PV>
 static int launch_seg_k(mfb_ctx *c, const SegArgs &a, int grid) {
     const size_t lds = SegCfg<L>::lds_bytes(MODE == SEG_REDUCE ? a.mpb : 0);
-    hipLaunchKernelGGL((k_seg<L, MODE, PV>), dim3(grid), dim3(256), lds, c->stream, a);
+    hipLaunchKernelGGL((k_seg<L, MODE, PV>), dim3(grid), dim3(SegCfg<L>::BLOCK), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return MFB_OK;
 }
@@ -885,7 +885,7 @@ static SegGeom seg_geom(const mfb_ctx *c) {
     g.NT = L / 16;
     g.TEAM = g.NT < 64 ? 64 : g.NT;
     g.CT = g.TEAM / g.NT;
-    g.TPW = 256 / g.TEAM;
+    g.TPW = (g.NT <= 64 ? MFB_SEG_BLOCK : 256) / g.TEAM;
     g.WPT = g.TEAM / 64;
     g.wave_sync = g.NT <= 64;
     return g;
@@ -911,7 +911,8 @@ static SegPlan plan_seg(const mfb_ctx *c, int dc, int nfilters, int nslots, int 
     // 16: 6.07 / 5.77, 32: 5.60 / 5.57, 48: 5.87 / 5.72.  Small blocks are unaffected (the grid never has more teams than
     // (bin, slot) units).
     const int wpc = c->seg_wpc > 0 ? c->seg_wpc : 32;
-    int wpg = wpc * 256 / p.nsg;                 // workgroups per group: wpc per CU, 256 CUs
+    // workgroups per group: wpc 256-thread workgroups' worth of teams per CU, 256 CUs
+    int wpg = wpc * 256 / p.nsg * ((256 / g.TEAM) / g.TPW);
     // never more teams than (bin, slot) units in a group
     const long long units = (long long)dc * ((nslots + p.nsg - 1) / p.nsg);
     while (wpg > 1 && (long long)wpg * g.TPW > units) wpg >>= 1;

@@ -59,6 +59,10 @@
 #ifndef MFB_SEG_PP
 #define MFB_SEG_PP 1
 #endif
+// threads per workgroup of the kernels whose teams are single, independent waves (L <= 1024): 64, 128 or 256
+#ifndef MFB_SEG_BLOCK
+#define MFB_SEG_BLOCK 256
+#endif
 #ifndef MFB_SEG_G0EARLY
 #define MFB_SEG_G0EARLY 1
 #endif
@@ -96,20 +100,21 @@ struct SegCfg {
     static constexpr int NT = L / 16;
     static constexpr int TEAM = NT < 64 ? 64 : NT;
     static constexpr int CT = TEAM / NT;          // segments side by side in a team
-    static constexpr int TPW = 256 / TEAM;        // teams per workgroup
+    static constexpr int BLOCK = NT <= 64 ? MFB_SEG_BLOCK : 256;   // threads per workgroup
+    static constexpr int TPW = BLOCK / TEAM;      // teams per workgroup
     static constexpr int WPT = TEAM / 64;         // waves per team
     static constexpr int SYNC = NT <= 64 ? 1 : 0;
     static constexpr bool PP = !SYNC && MFB_SEG_PP;
     static constexpr int HALF = padlen(L) * CT;
     static constexpr int LDS_PER_TEAM = HALF * (PP ? 2 : 1);
     static constexpr int LDS_ELEMS = LDS_PER_TEAM * TPW;
-    static constexpr int STEP_ELEMS = 4 * 16;     // 16 step phasors per wave
+    static constexpr int STEP_ELEMS = (BLOCK / 64) * 16;     // 16 step phasors per wave
     // Doppler search, L = 256: per-wave table of the relative mixing phasors W_N^(s*j), j < L (2 KiB a wave)
     static constexpr bool PHASE_TABLE = L <= 256;
-    static constexpr int PHASE_ELEMS = PHASE_TABLE ? 4 * L : 0;
+    static constexpr int PHASE_ELEMS = PHASE_TABLE ? (BLOCK / 64) * L : 0;
     static constexpr int WAVES = L <= 256 ? MFB_SEG_WAVES_SHORT : MFB_SEG_WAVES_LONG;   // per SIMD = workgroups per CU
     static constexpr size_t lds_bytes(int mpb) {   // mpb = 0: STORE mode (no accumulators, no phase table)
-        return (size_t)(LDS_ELEMS + STEP_ELEMS + (mpb ? PHASE_ELEMS : 0)) * sizeof(cf) + (size_t)mpb * 256 * sizeof(float);
+        return (size_t)(LDS_ELEMS + STEP_ELEMS + (mpb ? PHASE_ELEMS : 0)) * sizeof(cf) + (size_t)mpb * BLOCK * sizeof(float);
     }
 };
 
@@ -203,7 +208,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
             if constexpr (REL) pg = phasor(((unsigned)shift * (unsigned)g) & nmask);
         }
         if constexpr (MODE == SEG_REDUCE) {
-            for (int mi = 0; mi < nm; ++mi) lacc[mi * 256 + tid] = 0.f;
+            for (int mi = 0; mi < nm; ++mi) lacc[mi * Cfg::BLOCK + tid] = 0.f;
         }
         xsync<1>();     // wave-local: every wave fills and reads its own copy
 
@@ -291,7 +296,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                     }
                 }
                 if constexpr (MODE == SEG_REDUCE) {
-                    const float before = lacc[mi * 256 + tid];     // read early: its latency hides behind the transform
+                    const float before = lacc[mi * Cfg::BLOCK + tid];     // read early: its latency hides behind the transform
                     // (sum re^2, sum im^2) in four independent chains: back-to-back dependent packed ops cost a
                     // wait state each (the compiler pads them with s_nop)
                     cf racc[4] = {mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f)};
@@ -308,7 +313,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                     const cf rsum = (racc[0] + racc[1]) + (racc[2] + racc[3]);
                     float s = rsum.x + rsum.y;
                     if constexpr (!MASKED && !SYNC) s = active ? s : 0.f;
-                    lacc[mi * 256 + tid] = before + s;
+                    lacc[mi * Cfg::BLOCK + tid] = before + s;
                 } else {
                     const auto orr = mk_rsrc(a.out + (size_t)rm * a.N, (unsigned)a.N * sizeof(cf));
                     const unsigned o0 = e0 + (unsigned)a.out_off;
@@ -335,7 +340,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
             // registers/LDS -> wavefront -> one float per (bin, filter, wave); fixed order, no atomics
             const int pidx = a.part0 + ((grp * a.ssplit + ssub) * Cfg::WPT) + (lt >> 6);
             for (int mi = 0; mi < nm; ++mi) {
-                const float s = seg_wave_sum(lacc[mi * 256 + tid]);
+                const float s = seg_wave_sum(lacc[mi * Cfg::BLOCK + tid]);
                 if (lane == 0) a.partials[((size_t)(a.part_row0 + jl) * a.MU + (m0 + mi)) * a.parts + pidx] = s * a.scale;
             }
         }
@@ -353,7 +358,7 @@ struct SegWaves {
     static constexpr int value = PV < 0 ? 2 : SegCfg<L>::WAVES;
 };
 #define SEG_KERNEL_ATTRS(L_, PV_) \
-    __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SegWaves<L_, PV_>::value, SegWaves<L_, PV_>::value)))
+    __launch_bounds__(SegCfg<L_>::BLOCK) __attribute__((amdgpu_waves_per_eu(SegWaves<L_, PV_>::value, SegWaves<L_, PV_>::value)))
 
 // Variant builds only (-DMFB_SEG_TRACE, tools/xcd_trace.py): start / end time and XCC of every workgroup of the
 // branch-free search kernel, to see how evenly the grid drains over the XCDs.
