@@ -83,7 +83,7 @@ int mfb_get_tuning(mfb_ctx *ctx, int *doppler_chunk, int *masks_per_block, int *
  *                     reduced -- in registers and LDS, with no length-N intermediate in HBM.
  *   MFB_PATH_TWOPASS  length-N two-pass transforms through an HBM intermediate (any filter).
  * MFB_PATH_AUTO (default) takes the segment path whenever the bank allows it.  log2L = 0 chooses L by
- * a cost model; wg_per_cu / filters_per_pass = 0 keep the defaults.  Requesting MFB_PATH_SEGMENT for a bank
+ * a cost model; wg_per_cu (<= 64; workgroups in the grid per CU, default 32) / filters_per_pass = 0 keep the defaults.  Requesting MFB_PATH_SEGMENT for a bank
  * without short support returns MFB_ERR_UNSUPPORTED and leaves the previous setting in force.
  * (The reference's knobs of this kind are CUDA.batchSize / CUDA.streams, DB:171-178, 301-338.) */
 #define MFB_PATH_AUTO    0

@@ -70,7 +70,8 @@ def test_segment_scores_match_oracle_and_twopass(log2L, sum_all):
         assert np.all(ds[:, 1:] == 0)
 
 
-@pytest.mark.parametrize('log2L,wpc,fpp', [(8, 1, 1), (8, 3, 3), (9, 2, 5), (10, 1, 8), (10, 3, 2), (11, 2, 3), (12, 1, 7), (12, 3, 16)])
+@pytest.mark.parametrize('log2L,wpc,fpp', [(8, 1, 1), (8, 3, 3), (9, 2, 5), (10, 1, 8), (10, 3, 2), (11, 2, 3), (12, 1, 7), (12, 3, 16),
+                                            (8, 64, 2), (9, 48, 0), (12, 64, 4)])
 def test_segment_decompositions_do_not_change_results(log2L, wpc, fpp):
     """Workgroups per CU and filters per pass only regroup the work: scores stay within rounding of the
     default decomposition (the partial sums are regrouped) and the pick stays put."""
@@ -92,6 +93,8 @@ def test_segment_decompositions_do_not_change_results(log2L, wpc, fpp):
         bank.find_carrier()
         ds = bank.get_scores()
         X = bank.get_spectrum()
+        with pytest.raises(ValueError):
+            bank.set_search_path('segment', log2L, 65, fpp)          # at most 64 workgroups per CU in the grid
     finally:
         bank.close()
     ref = orc.doppler_scores(X, masks, shifts, False)
