@@ -18,7 +18,9 @@ bank.set_filters(masks); bank.set_shifts(shifts)
 bank.upload(x)
 X = bank.get_spectrum()
 B_alg = 16.0 * D * M * N + 8.0 * N * (1 + M) + 16.0 * N + 4.0 * D
-configs = [(128, 8, 64, 32), (128, 8, 64, 16), (128, 8, 64, 32), (128, 8, 64, 16), (128, 8, 64, 24), (128, 8, 64, 8), (128, 8, 32, 16), (128, 8, 128, 16)]
+configs = [(128, 8, 64, 32), (128, 8, 64, 64), (128, 8, 64, 128), (128, 8, 32, 32), (128, 8, 16, 32), (128, 8, 32, 64), (128, 8, 64, 32), (128, 8, 16, 64)]
+if len(sys.argv) > 4:
+    configs = [tuple(int(v) for v in c.split(',')) for c in sys.argv[4:]]
 for chunk, mpb, srb, js in configs:
     bank.set_tuning(chunk, mpb, srb, js)
     bank.find_carrier()
