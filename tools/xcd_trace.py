@@ -38,10 +38,12 @@ t0, t1, xcc = buf[used, 0].astype(np.int64), buf[used, 1].astype(np.int64), buf[
 start, end = t0.min(), t1.max()
 span = float(end - start)
 print(f'{used.sum()} workgroups, kernel span {span / 100:.1f} us (100 MHz clock), blockIdx % 8 == XCC for {np.mean((np.nonzero(used)[0] % 8) == xcc) * 100:.1f} % of them')
+idx = np.nonzero(used)[0]
 for k in range(8):
     sel = xcc == k
     if not sel.any():
         continue
+    print(f'XCC {k} runs segment group(s) {sorted(set((idx[sel] % 8).tolist()))}', end=';  ')
     print(f'XCC {k}: {sel.sum():5d} workgroups, first start {(t0[sel].min() - start) / span * 100:5.1f} %, last end {(t1[sel].max() - start) / span * 100:6.2f} % of the span, '
           f'mean workgroup time {np.mean(t1[sel] - t0[sel]) / 100:7.1f} us, busy sum {np.sum(t1[sel] - t0[sel]) / 100 / 1e3:8.2f} ms')
 bank.close()
