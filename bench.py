@@ -113,6 +113,96 @@ def cpu_baseline(masks, shifts, x_block, N, ov, D, budget_bins=None):
     }, scores, single
 
 
+def segment_roofline_core(info, Dl, Mu, launches, kernel_ms_total):
+    """fp32-vector roofline of the segment kernel from its own launch durations (HIP events on the library's stream)."""
+    L, V, Q = 1 << info['log2L'], info['valid_per_segment'], info['segments']
+    fl = seg_flops(Dl, Q, Mu, L, V)
+    launches = max(launches, 1)
+    k_avg_s = kernel_ms_total / launches * 1e-3
+    return {'bound': 'valu_fp32', 'kernel': f'{info.get("kernel", "k_seg")}<{L},REDUCE> ({V} valid outputs of {L}, {Q} segments per bin)',
+            'achieved': round(fl / k_avg_s / 1e12, 2), 'peak': VALU_FP32_PEAK / 1e12, 'unit': 'TFLOP/s',
+            'frac': round(fl / k_avg_s / VALU_FP32_PEAK, 4), 'launches': launches, 'avg_launch_ms': round(k_avg_s * 1e3, 4),
+            'flops_per_launch': fl}
+
+
+def bank_figure(dev, local_rank, protocol, D, log2N, blocks, esz, nblocks, steps=6, warmup=2):
+    """Untimed-region figure of another BASELINE bank on the same device: its own handle, the same step as the headline
+    (forward FFT, search over D bins, pick, 8-byte read-back), HIP-event kernel time, the same flop formula."""
+    import torch
+    from pycusdr_amd import config as cfg
+    from pycusdr_amd.mfbank import MFBank
+    from pycusdr_amd.protocol import loadProtocol
+    N, ov = 1 << log2N, 1 << 10
+    if protocol == 'CC11xx':
+        conf, sps, msz = cfg.cc11xx_config(blockSize=log2N, doppCarrierSteps=D, device=local_rank), 128, 3
+    else:
+        conf, sps, msz = cfg.bench_config(protocol, blockSize=log2N, doppCarrierSteps=D, device=local_rank), 16, (5 if protocol == 'bench_BPSK' else 3)
+    rr, shifts = widen_range_rate(conf, 'UHF-H', N, D)
+    conf['Radios']['rangeRateMax'] = rr
+    proto = loadProtocol(protocol)(conf=conf)
+    t0 = time.perf_counter()
+    M, masks = proto.get_filter(N, sps, msz)
+    t_gen = time.perf_counter() - t0
+    bank = MFBank(log2N, D, M, window_width=7, sum_all_masks=True, device=local_rank)
+    try:
+        t0 = time.perf_counter()
+        bank.set_filters(masks)
+        t_set = time.perf_counter() - t0
+        bank.set_shifts(shifts)
+        info = bank.get_search_path()
+        Mu = bank.get_info()[2]
+
+        def one(i):
+            bank.upload_device(blocks.data_ptr() + (i % nblocks) * esz)
+            return bank.find_carrier()
+        for i in range(1 + warmup):
+            one(i)
+        torch.cuda.synchronize(dev)
+        bank.profile_enable(True)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one(i)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        counts, kms = bank.profile_read()
+        bank.profile_enable(False)
+        out = {'protocol': protocol, 'D': D, 'M': M, 'M_unique': Mu, 'samplesPerSym': sps, 'taps': info['taps'], 'path': info,
+               'steps': steps, 'ms_per_step': round(dt * 1e3, 4), 'msamples': round((N - ov) / dt / 1e6, 2),
+               'filter_generation_s': round(t_gen, 2), 'mfb_set_filters_s': round(t_set, 2),
+               'rangeRateMax_used': rr, 'signal': 'S1 blocks of the headline (throughput only: the stimulus does not match this bank)'}
+        if info['path'] == 'segment':
+            out['roofline'] = segment_roofline_core(info, D, Mu, counts[0], kms[0])
+        return out
+    finally:
+        bank.close()
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, backend):
+    """`python bench.py --gpus N` without a launcher: run the documented launch line as a child process
+    (python -m torch.distributed.run, one fresh rank per GPU) and return its exit code.  With the RCCL backend the
+    node must have N devices -- a smaller box is an error, never a smaller figure."""
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if backend == 'nccl' and have < n:
+        sys.stderr.write(f'bench.py: --gpus {n} needs {n} GPUs, this node has {have} (use --backend gloo to rehearse '
+                         f'{n} ranks on fewer devices)\n')
+        return 2
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write('bench.py: no launcher (WORLD_SIZE unset), starting ' + ' '.join(cmd) + '\n')
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -134,7 +224,21 @@ def main():
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="process-group backend; 'gloo' lets several ranks share ONE GPU (rehearsal of the N>1 path on a 1-GPU box)")
     ap.add_argument('--force-dist', action='store_true', help='run the sharded/RCCL path even with one rank (rehearsal)')
+    ap.add_argument('--no-other-banks', action='store_true',
+                    help='skip the untimed per-bank figures (CC11xx sps 128, BPSK M=32 at D=256; C3 D=1024) in config.other_banks / config.c3')
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        ap.error('--gpus must be >= 1')
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is not None and int(env_world) != args.gpus and not (args.force_dist and args.gpus == 1 and int(env_world) == 1):
+        sys.stderr.write(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks; refusing to print a '
+                         f'{env_world}-rank figure as the {args.gpus}-GPU result\n')
+        sys.exit(2)
+    if args.gpus > 1 and env_world is None:
+        # started without a launcher: start one rank per GPU as FRESH child processes (nothing in this process has
+        # touched the GPU yet -- torch.cuda.device_count() does not initialise it) and leave with their exit code
+        sys.exit(spawn_ranks(args.gpus, args.backend))
 
     import torch
     import __graft_entry__
@@ -150,7 +254,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if G > 1 or world > 1 or args.force_dist:
         import torch.distributed as dist
-        os.environ.setdefault('MASTER_PORT', '29533')
+        if 'MASTER_PORT' not in os.environ:          # --force-dist rehearsal with one rank only
+            os.environ['MASTER_PORT'] = str(free_port())
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -162,7 +267,11 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group('gloo')
-        G = dist.get_world_size()
+        if dist.get_world_size() != G:       # never report a smaller world under the requested --gpus
+            sys.stderr.write(f'bench.py: --gpus {G} but the process group has {dist.get_world_size()} ranks\n')
+            sys.exit(2)
+        if rank == 0:
+            sys.stderr.write(f'bench.py: world_size {dist.get_world_size()} == --gpus {G}, backend {args.backend}\n')
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -173,11 +282,14 @@ def main():
     by_blocks = args.shard == 'blocks'
     D_total = args.bins if by_blocks else args.bins * G
     M_size = 5 if args.protocol == 'bench_BPSK' else 3
-    conf = cfg.bench_config(args.protocol, blockSize=log2N, overlap=10, doppCarrierSteps=D_total, device=local_rank)
+    if args.protocol == 'CC11xx':        # config/CC11xx.json geometry: FSK-2 at 128 samples per symbol (384-tap filters)
+        conf, sps_bank = cfg.cc11xx_config(blockSize=log2N, overlap=10, doppCarrierSteps=D_total, device=local_rank), 128
+    else:
+        conf, sps_bank = cfg.bench_config(args.protocol, blockSize=log2N, overlap=10, doppCarrierSteps=D_total, device=local_rank), 16
     rr, shifts = widen_range_rate(conf, 'UHF-H', N, D_total)
     conf['Radios']['rangeRateMax'] = rr
     proto = loadProtocol(args.protocol)(conf=conf)
-    M, masks = proto.get_filter(N, 16, M_size)
+    M, masks = proto.get_filter(N, sps_bank, M_size)
     lo, hi = (0, D_total) if by_blocks else bin_slice(D_total, rank, G)
 
     bank = MFBank(log2N, hi - lo, M, window_width=7, sum_all_masks=True, device=local_rank)
@@ -247,7 +359,8 @@ def main():
     frac_idx = float(res[0])
     pick_shift = float(np.interp(frac_idx, np.arange(D_total), np.where(shifts > N // 2, shifts - N, shifts)))
     spacing = float(np.median(np.diff(np.sort(shifts))))
-    carrier_ok = abs(pick_shift - N / 4) <= 1.5 * spacing
+    # (only the GMSK bank matches the S1 stimulus; the other banks are timed on it for throughput alone)
+    carrier_ok = abs(pick_shift - N / 4) <= 1.5 * spacing if args.protocol == 'bench_GMSK' else None
 
     # ---- untimed secondary figures -----------------------------------------------------
     extras = {}
@@ -359,6 +472,12 @@ def main():
         extras['sync_correlator'] = {'streams_per_s': round(B / dt, 1), 'B': B, 'bits_per_stream': Lb, 'taps': 64,
                                      'hits_per_stream': int(len(hits[0][0])), 'includes': 'H2D of the bit streams, D2H of the hits'}
 
+    if shard is None and G == 1 and not args.no_extras and not args.no_other_banks:
+        # the other BASELINE-named banks at the same geometry (C5's two filter sets at D = 256) and C3 (D = 1024)
+        extras['other_banks'] = [bank_figure(dev, local_rank, p, args.bins, log2N, blocks, esz, nblocks)
+                                 for p in ('CC11xx', 'bench_BPSK') if p != args.protocol]
+        extras['c3'] = bank_figure(dev, local_rank, args.protocol, 1024, log2N, blocks, esz, nblocks, steps=4, warmup=1)
+
     out = None
     rc = 0
     if rank == 0:
@@ -426,9 +545,13 @@ def main():
             roof = twopass_roofline(Dl, counts, kms, tun, args.steps)
         roof['pipeline'] = {'device_ms_per_block': round(t_block_dev * 1e3, 4),
                             'B_alg_twopass_per_block': b_alg(Dl, Mu, N), 'B_ref_unfused_per_block': b_ref(Dl, M, N)}
-        if G == 1 and log2N == 20 and args.bins == 256:
+        if G == 1 and log2N == 20 and args.bins == 256 and args.protocol == 'bench_GMSK':
             workload = ('C2: single MI355X, D=256 Doppler bins, M=8 GMSK matched filters (bench_GMSK), N=2^20 complex64 chunk, '
                         f'ov=2^10; search path: {pinfo["path"]}'
+                        + (f' (L=2^{pinfo["log2L"]}, {pinfo["taps"]} taps)' if pinfo['path'] == 'segment' else ''))
+        elif G == 1 and not args.force_dist:
+            workload = (f'single MI355X, D={D_total} Doppler bins, M={M} matched filters of {args.protocol} ({sps_bank} samples/symbol), '
+                        f'N=2^{log2N} complex64 chunk, ov=2^10; search path: {pinfo["path"]}'
                         + (f' (L=2^{pinfo["log2L"]}, {pinfo["taps"]} taps)' if pinfo['path'] == 'segment' else ''))
         elif by_blocks:
             workload = (f'block round-robin: every one of {G} GPUs runs the full D={D_total} bank on different time blocks, M={M}, '
@@ -449,7 +572,7 @@ def main():
                 'units': 'samples through a 256-bin bank, summed over ranks',
                 'stream_msamples': round((N - ov) / (elapsed / args.steps) / 1e6, 3) if not by_blocks else round(value, 3),
                 'world_size': G, 'backend': (('nccl (RCCL)' if args.backend == 'nccl' else 'gloo (rehearsal)') if dist is not None else None),
-                'carrier_found': bool(carrier_ok),
+                'carrier_found': carrier_ok if carrier_ok is None else bool(carrier_ok),
             },
             'roofline': roof,
         }
@@ -474,7 +597,7 @@ def main():
                 rc = 1
         else:
             out['cpu_baseline'] = None
-        if not carrier_ok:
+        if carrier_ok is False:
             rc = 1
         print(json.dumps(out), flush=True)
     bank.close()

@@ -174,6 +174,11 @@ int mfb_pick(mfb_ctx *ctx, const void *dev_scores, int num, int offset, float re
  * device vector float32[offset+num] -- the sharded exchange then moves D floats instead of D*M.
  * mfb_pick_column returns MFB_ERR_STATE on a handle created without sum_all_masks. */
 int mfb_export_column_async(mfb_ctx *ctx, void *dev_dst, int row_offset);
+/* Row range of either form: rows [first_row, first_row + nrows) of this handle's doppSum -- whole rows of M floats
+ * (column_only = 0) or column 0 alone (column_only = 1) -- to rows [dst_row, dst_row + nrows) of dev_dst.
+ * Asynchronous.  With a noise-reference bin (doppler_offset > 0; DB:148-159, CU:550-554) a sharded caller moves
+ * its bin slice (first_row = doppler_offset) and the replicated noise row (first_row = 0) separately. */
+int mfb_export_rows_async(mfb_ctx *ctx, void *dev_dst, int dst_row, int first_row, int nrows, int column_only);
 int mfb_pick_column(mfb_ctx *ctx, const void *dev_column, int num, int offset, float res[2]);
 /* mfb_search_async + mfb_pick on the handle's own bins: the device part of __findUHF
  * (DB:567-605). */

@@ -63,6 +63,7 @@ PROTOTYPES = {
     'mfb_export_scores_async': (_i, [_vp, _vp, _i]),
     'mfb_pick': (_i, [_vp, _vp, _i, _i, _fp]),
     'mfb_export_column_async': (_i, [_vp, _vp, _i]),
+    'mfb_export_rows_async': (_i, [_vp, _vp, _i, _i, _i, _i]),
     'mfb_pick_column': (_i, [_vp, _vp, _i, _i, _fp]),
     'mfb_find_carrier': (_i, [_vp, _fp]),
     'mfb_get_scores': (_i, [_vp, _vp]),

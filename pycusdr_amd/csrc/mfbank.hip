@@ -61,6 +61,7 @@ struct mfb_ctx {
     bool chunk_auto;      // chunk still at its default (recomputed when the bank turns out to have duplicates)
     int *d_uniq, *d_rep;  // [MU] bank row of each unique filter; [M] unique index of each filter
     int parts, srb;
+    int num_cus;          // compute units of the handle's device
     hipStream_t own_stream, stream;
     cf *h_in;  // pinned
     // page-locked landing zone of the small read-backs (pick, rate/phase, spectrum windows, symbol decisions): a
@@ -242,7 +243,7 @@ static int attr_p2() {
 }
 template <int L>
 static int attr_seg() {
-    const int b = (int)SegCfg<L>::lds_bytes(SEG_MPB_MAX);
+    const int b = (int)SegCfg<L>::lds_bytes(true);
     HIPCHK(hipFuncSetAttribute((const void *)k_seg<L, SEG_STORE, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
 #define MFB_ATTR_PV(PV_) HIPCHK(hipFuncSetAttribute((const void *)k_seg<L, SEG_REDUCE, PV_>, hipFuncAttributeMaxDynamicSharedMemorySize, b))
     MFB_ATTR_PV(-1);
@@ -340,10 +341,13 @@ extern "C" int mfb_create(mfb_ctx **out, int device, int log2N, int num_dopplers
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(device));
+    int ncu = 0;
+    HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
 
     mfb_ctx *c = new mfb_ctx();
     memset((void *)c, 0, offsetof(mfb_ctx, ev));  // everything before the vectors
     c->device = device;
+    c->num_cus = ncu > 0 ? ncu : 256;
     c->log2N = log2N;
     c->N = 1 << log2N;
     // N = N1 * N2: columns of at most 256 points, rows of at most 8192 (2^22 = 512 x 8192: a 16384-point row would
@@ -572,7 +576,7 @@ extern "C" int mfb_set_search_path(mfb_ctx *c, int path, int log2L, int wg_per_c
         return MFB_ERR_ARG;
     if (log2L && (log2L < 8 || log2L > 12)) return MFB_ERR_UNSUPPORTED;
     HIPCHK(hipSetDevice(c->device));
-    const int old_path = c->path_req, old_l = c->segl_req;
+    const int old_path = c->path_req, old_l = c->segl_req, old_wpc = c->seg_wpc, old_mpb = c->seg_mpb;
     c->path_req = path;
     c->segl_req = log2L;
     c->seg_wpc = wg_per_cu;
@@ -581,6 +585,8 @@ extern "C" int mfb_set_search_path(mfb_ctx *c, int path, int log2L, int wg_per_c
     if (rc) {           // keep the previous, working configuration
         c->path_req = old_path;
         c->segl_req = old_l;
+        c->seg_wpc = old_wpc;
+        c->seg_mpb = old_mpb;
         (void)resolve_path(c);
     }
     return rc;
@@ -712,14 +718,25 @@ static hipEvent_t get_event(mfb_ctx *c) {
         c->ev_pool.pop_back();
         return e;
     }
-    hipEvent_t e;
-    (void)hipEventCreate(&e);
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
+// Profiling marks come in pairs (begin, end); a mark that cannot be created or recorded switches profiling off and drops
+// the marks taken so far, so that mfb_profile_read never pairs events of different launches.
 static void prof_mark(mfb_ctx *c, int which) {
     if (!c->prof) return;
     hipEvent_t e = get_event(c);
-    (void)hipEventRecord(e, c->stream);
+    if (!e || hipEventRecord(e, c->stream) != hipSuccess) {
+        fprintf(stderr, "mfbank: profiling event unavailable, profiling disabled\n");
+        if (e) c->ev_pool.push_back(e);
+        for (auto &v : c->ev) {
+            for (auto q : v) c->ev_pool.push_back(q);
+            v.clear();
+        }
+        c->prof = false;
+        return;
+    }
     c->ev[which].push_back(e);
 }
 
@@ -838,7 +855,7 @@ static int forward_fft(mfb_ctx *c, const cf *src_c, const float *src_r, cf *dst,
 // ---- single-pass overlap-save launches -------------------------------------------------------------
 template <int L, int MODE, int PV>
 static int launch_seg_k(mfb_ctx *c, const SegArgs &a, int grid) {
-    const size_t lds = SegCfg<L>::lds_bytes(MODE == SEG_REDUCE ? a.mpb : 0);
+    const size_t lds = SegCfg<L>::lds_bytes(MODE == SEG_REDUCE);
     hipLaunchKernelGGL((k_seg<L, MODE, PV>), dim3(grid), dim3(SegCfg<L>::BLOCK), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return MFB_OK;
@@ -891,14 +908,14 @@ static SegGeom seg_geom(const mfb_ctx *c) {
     return g;
 }
 struct SegPlan {
-    int nsg, wpg, bsplit, ssplit, mpb, mgroups, parts, grid;
+    int nsg, wpg, bsplit, ssplit, mpb, mgroups, grid;
 };
 static SegPlan plan_seg(const mfb_ctx *c, int dc, int nfilters, int nslots, int mpb_want) {
     const SegGeom g = seg_geom(c);
     SegPlan p;
     p.nsg = nslots >= 64 ? 8 : 1;
-    // L = 256 runs three workgroups per CU only while a workgroup's LDS stays under 53 KiB: 8 filters per pass
-    int mpb = mpb_want > 0 ? mpb_want : (c->segl <= 8 ? 8 : SEG_MPB_MAX);
+    // filters per team pass: all of them when they fit one pass (the forward transform of a segment is then run once)
+    int mpb = mpb_want > 0 ? mpb_want : SEG_MPB_MAX;
     if (mpb > SEG_MPB_MAX) mpb = SEG_MPB_MAX;
     if (mpb > nfilters) mpb = nfilters;
     p.mgroups = (nfilters + mpb - 1) / mpb;
@@ -911,8 +928,10 @@ static SegPlan plan_seg(const mfb_ctx *c, int dc, int nfilters, int nslots, int 
     // 16: 6.07 / 5.77, 32: 5.60 / 5.57, 48: 5.87 / 5.72.  Small blocks are unaffected (the grid never has more teams than
     // (bin, slot) units).
     const int wpc = c->seg_wpc > 0 ? c->seg_wpc : 32;
-    // workgroups per group: wpc 256-thread workgroups' worth of teams per CU, 256 CUs
-    int wpg = wpc * 256 / p.nsg * ((256 / g.TEAM) / g.TPW);
+    // workgroups per group: wpc 256-thread workgroups' worth of teams per CU, over the device's CUs
+    const int teams = wpc * c->num_cus * (256 / g.TEAM);       // teams in the whole grid
+    int wpg = teams / g.TPW / p.nsg;
+    if (wpg < 1) wpg = 1;
     // never more teams than (bin, slot) units in a group
     const long long units = (long long)dc * ((nslots + p.nsg - 1) / p.nsg);
     while (wpg > 1 && (long long)wpg * g.TPW > units) wpg >>= 1;
@@ -935,7 +954,6 @@ static SegPlan plan_seg(const mfb_ctx *c, int dc, int nfilters, int nslots, int 
     }
     p.bsplit = bs;
     p.ssplit = g.wave_sync ? tg / bs : (wpg / bs) * g.TPW;
-    p.parts = p.nsg * p.ssplit * g.WPT;
     p.grid = p.nsg * p.mgroups * p.wpg;
     return p;
 }
@@ -1061,7 +1079,7 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
                            (const int *)c->d_shifts, c->d_part, c->N, c->Dtot, R, parts, (float)c->N / 262144.f);
         HIPCHK(hipGetLastError());
         prof_mark(c, 0);
-        hipLaunchKernelGGL(k_finalize, dim3(c->Dtot), dim3(64), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, R, (const int *)nullptr,
+        hipLaunchKernelGGL(k_finalize, dim3(c->Dtot), dim3(256), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, R, (const int *)nullptr,
                            parts, c->sum_all);
         HIPCHK(hipGetLastError());
         return MFB_OK;
@@ -1076,8 +1094,8 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
         const SegPlan pm = plan_seg(c, c->Dtot, MU, nfull > 0 ? nfull : 1, c->seg_mpb);
         // the tail is a handful of units: spread the filters too (2 per pass) so that it is short
         const SegPlan pt = plan_seg(c, c->Dtot, MU, ntotal - nfull > 0 ? ntotal - nfull : 1, c->seg_mpb > 0 && c->seg_mpb < 2 ? c->seg_mpb : 2);
-        const int parts_main = nfull > 0 ? pm.parts : 0;
-        const int parts = parts_main + (ntotal > nfull ? pt.parts : 0);
+        // one partial per (bin, filter, slot, wave of the team): the index depends on the slot alone (seg_kernels.hpp)
+        const int parts = ntotal * seg_geom(c).WPT;
         int rc = reserve_partials(c, (size_t)c->Dtot * MU * parts);
         if (rc) return rc;
         SegArgs am = seg_base(c, pm), at = seg_base(c, pt);
@@ -1095,10 +1113,8 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
         }
         am.slot0 = 0;
         am.nslots = nfull;
-        am.part0 = 0;
         at.slot0 = nfull;
         at.nslots = ntotal - nfull;
-        at.part0 = parts_main;
         const int pv = c->V / seg_geom(c).NT;
         prof_mark(c, 0);
         // (both roles inside one grid were tried: the merged kernel ran 8-10 % slower than two launches)
@@ -1106,7 +1122,7 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
         if (!rc && ntotal > nfull) rc = launch_seg(c, at, pt.grid, SEG_REDUCE, -1);
         if (rc) return rc;
         prof_mark(c, 0);
-        hipLaunchKernelGGL(k_finalize, dim3(c->Dtot), dim3(64), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, MU,
+        hipLaunchKernelGGL(k_finalize, dim3(c->Dtot), dim3(256), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, MU,
                            span ? (const int *)nullptr : (const int *)c->d_rep, parts, c->sum_all);
         HIPCHK(hipGetLastError());
         return MFB_OK;
@@ -1139,7 +1155,7 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
         prof_mark(c, 1);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_finalize, dim3(c->Dtot), dim3(64), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, MU,
+    hipLaunchKernelGGL(k_finalize, dim3(c->Dtot), dim3(256), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, MU,
                        (const int *)c->d_rep, c->parts, c->sum_all);
     HIPCHK(hipGetLastError());
     return MFB_OK;
@@ -1186,6 +1202,20 @@ extern "C" int mfb_export_column_async(mfb_ctx *c, void *dst, int row_offset) {
     // column 0 of doppSum [Dtot][M] -> dst[row_offset + j]
     HIPCHK(hipMemcpy2DAsync((float *)dst + row_offset, sizeof(float), c->d_sum, (size_t)c->M * sizeof(float), sizeof(float),
                             (size_t)c->Dtot, hipMemcpyDeviceToDevice, c->stream));
+    return MFB_OK;
+}
+
+extern "C" int mfb_export_rows_async(mfb_ctx *c, void *dst, int dst_row, int first_row, int nrows, int column_only) {
+    if (!c || !dst || dst_row < 0 || first_row < 0 || nrows < 0 || first_row + nrows > c->Dtot) return MFB_ERR_ARG;
+    if (!nrows) return MFB_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const float *src = c->d_sum + (size_t)first_row * c->M;
+    if (column_only)
+        HIPCHK(hipMemcpy2DAsync((float *)dst + dst_row, sizeof(float), src, (size_t)c->M * sizeof(float), sizeof(float), (size_t)nrows,
+                                hipMemcpyDeviceToDevice, c->stream));
+    else
+        HIPCHK(hipMemcpyAsync((float *)dst + (size_t)dst_row * c->M, src, (size_t)nrows * c->M * sizeof(float), hipMemcpyDeviceToDevice,
+                              c->stream));
     return MFB_OK;
 }
 

@@ -17,7 +17,8 @@
 // "team" is the set of threads that must synchronise for a transform: one wavefront carrying CT = 64/NT
 // segments side by side for L <= 1024 (no s_barrier anywhere: LDS exchanges are wave-local), or NT
 // threads (2 or 4 waves, workgroup barrier) for L = 2048 / 4096.  Teams never talk to each other: every
-// wave writes its own partial sums, added up in fixed order by k_finalize (bit-reproducible).
+// wave writes one partial sum per slot, added up in fixed order by k_finalize (bit-reproducible, and
+// independent of the grid decomposition: see the store below).
 // The grid is decoded XCD-aware: workgroups with equal blockIdx % nsg share a contiguous range of
 // segments, i.e. one eighth of the block, which stays in that XCD's L2 while every Doppler bin passes
 // over it (placement affects speed only).
@@ -41,7 +42,7 @@
 
 #define SEG_REDUCE 0
 #define SEG_STORE 1
-#define SEG_MPB_MAX 16   // filters per team pass (per-lane accumulators live in LDS)
+#define SEG_MPB_MAX 16   // filters per team pass
 
 // waves per SIMD the register budget is pinned to: 3 for L = 256 (one twiddled pass: 149 VGPRs), 2 for the
 // longer transforms (two twiddled passes: ~210 VGPRs; 3 waves would spill)
@@ -63,6 +64,7 @@
 #ifndef MFB_SEG_BLOCK
 #define MFB_SEG_BLOCK 256
 #endif
+static_assert(MFB_SEG_BLOCK == 64 || MFB_SEG_BLOCK == 128 || MFB_SEG_BLOCK == 256, "MFB_SEG_BLOCK: 64, 128 or 256 threads");
 #ifndef MFB_SEG_G0EARLY
 #define MFB_SEG_G0EARLY 1
 #endif
@@ -91,7 +93,7 @@ struct SegArgs {
     int j0, dc;          // Doppler bins [j0, j0 + dc) of the shift table
     int fixed_shift;
     int out_off;         // STORE: (window start + T_eff - 1) mod N
-    int part_row0, parts, part0;   // REDUCE: row of bin 0, row stride, first column of this launch
+    int part_row0, parts;   // REDUCE: row of bin 0, row stride (= slots of the block x waves per team)
     float scale;         // REDUCE: 1 / 2^18
 };
 
@@ -113,8 +115,8 @@ struct SegCfg {
     static constexpr bool PHASE_TABLE = L <= 256;
     static constexpr int PHASE_ELEMS = PHASE_TABLE ? (BLOCK / 64) * L : 0;
     static constexpr int WAVES = L <= 256 ? MFB_SEG_WAVES_SHORT : MFB_SEG_WAVES_LONG;   // per SIMD = workgroups per CU
-    static constexpr size_t lds_bytes(int mpb) {   // mpb = 0: STORE mode (no accumulators, no phase table)
-        return (size_t)(LDS_ELEMS + STEP_ELEMS + (mpb ? PHASE_ELEMS : 0)) * sizeof(cf) + (size_t)mpb * BLOCK * sizeof(float);
+    static constexpr size_t lds_bytes(bool reduce) {   // STORE mode: no phase table
+        return (size_t)(LDS_ELEMS + STEP_ELEMS + (reduce ? PHASE_ELEMS : 0)) * sizeof(cf);
     }
 };
 
@@ -138,7 +140,6 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
     constexpr bool PTAB = REL && Cfg::PHASE_TABLE;
     cf *lstep = lds + Cfg::LDS_ELEMS;                                         // [4 waves][16]
     cf *lphase = lstep + Cfg::STEP_ELEMS;                                     // [4 waves][L] (PTAB)
-    float *lacc = reinterpret_cast<float *>(lphase + (REL ? Cfg::PHASE_ELEMS : 0));   // [mpb][256]
 
     const int tid = threadIdx.x;
     const int team = __builtin_amdgcn_readfirstlane(tid / TEAM);
@@ -206,9 +207,6 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
             // step phasors W_N^(shift * NT * i), i < 16: the same for every lane, segment and filter of this bin
             if (lane < 16) mystep[lane] = phasor(((unsigned)shift * (unsigned)(NT * lane)) & nmask);
             if constexpr (REL) pg = phasor(((unsigned)shift * (unsigned)g) & nmask);
-        }
-        if constexpr (MODE == SEG_REDUCE) {
-            for (int mi = 0; mi < nm; ++mi) lacc[mi * Cfg::BLOCK + tid] = 0.f;
         }
         xsync<1>();     // wave-local: every wave fills and reads its own copy
 
@@ -296,7 +294,6 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                     }
                 }
                 if constexpr (MODE == SEG_REDUCE) {
-                    const float before = lacc[mi * Cfg::BLOCK + tid];     // read early: its latency hides behind the transform
                     // (sum re^2, sum im^2) in four independent chains: back-to-back dependent packed ops cost a
                     // wait state each (the compiler pads them with s_nop)
                     cf racc[4] = {mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f)};
@@ -311,9 +308,14 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                     };
                     fft_passes<L, 1, 0, true, Cfg::PP, Cfg::HALF, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, acc);
                     const cf rsum = (racc[0] + racc[1]) + (racc[2] + racc[3]);
-                    float s = rsum.x + rsum.y;
-                    if constexpr (!MASKED && !SYNC) s = active ? s : 0.f;
-                    lacc[mi * Cfg::BLOCK + tid] = before + s;
+                    // One partial per (bin, filter, slot, wave of the team), at an index that depends on the slot alone:
+                    // lanes -> wavefront in a fixed butterfly, k_finalize adds the slots in a fixed order.  A score is
+                    // therefore a function of the block, the shift and the filter only -- not of how many bins the
+                    // handle holds, of the grid decomposition or of the tuning: shards of any size reproduce the
+                    // unsharded table bit for bit.
+                    const float s = seg_wave_sum(rsum.x + rsum.y);
+                    if (lane == 0 && active)
+                        a.partials[((size_t)(a.part_row0 + jl) * a.MU + (m0 + mi)) * a.parts + (slot * Cfg::WPT + (lt >> 6))] = s * a.scale;
                 } else {
                     const auto orr = mk_rsrc(a.out + (size_t)rm * a.N, (unsigned)a.N * sizeof(cf));
                     const unsigned o0 = e0 + (unsigned)a.out_off;
@@ -334,14 +336,6 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                     for (int k = 0; k < 16; ++k)
                         if (k * NT < lim) a.env[(o0 + (unsigned)(k * NT)) & nmask] = envacc[k];
                 }
-            }
-        }
-        if constexpr (MODE == SEG_REDUCE) {
-            // registers/LDS -> wavefront -> one float per (bin, filter, wave); fixed order, no atomics
-            const int pidx = a.part0 + ((grp * a.ssplit + ssub) * Cfg::WPT) + (lt >> 6);
-            for (int mi = 0; mi < nm; ++mi) {
-                const float s = seg_wave_sum(lacc[mi * Cfg::BLOCK + tid]);
-                if (lane == 0) a.partials[((size_t)(a.part_row0 + jl) * a.MU + (m0 + mi)) * a.parts + pidx] = s * a.scale;
             }
         }
         xsync<1>();     // the step phasors are rewritten for the next bin

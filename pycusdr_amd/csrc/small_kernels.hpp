@@ -11,36 +11,40 @@
 // ------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------
-// doppSum[j][m] from the per-workgroup partials.  One wavefront per Doppler bin: lane l adds partials
-// l, l+64, ... of a filter, then a fixed butterfly over the 64 lanes -- the order depends on nothing but
-// `parts`, so results are bit-reproducible (no float atomics, unlike cuda_kernels.cu:463,474).
-// SUM_ALL_MASKS: column 0 gets the sum over masks (added in filter order), the other columns stay 0
+// doppSum[j][m] from the partial sums.  One workgroup of four wavefronts per Doppler bin; a wavefront takes the filter
+// rows w, w+4, ...: lane l adds partials l, l+64, ... of the row, then a fixed butterfly over the 64 lanes -- the order
+// depends on nothing but `parts`, so results are bit-reproducible (no float atomics, unlike cuda_kernels.cu:463,474).
+// SUM_ALL_MASKS: column 0 gets the sum over masks (added in filter order by one thread), the other columns stay 0
 // (cuda_kernels.cu:453-464); else per mask (472-475).
 // The partials hold MU <= M rows per bin (filters that are exact copies or exact negatives of an
 // earlier filter are transformed once: |.|^2 is identical bit for bit); rep[m] names filter m's row.
-__global__ void __launch_bounds__(64) k_finalize(const float *partials, float *dsum, int D, int M, int MU, const int *rep, int parts,
-                                                 int sum_all) {
+#define FIN_MAX_ROWS 64
+__global__ void __launch_bounds__(256) k_finalize(const float *partials, float *dsum, int D, int M, int MU, const int *rep, int parts,
+                                                  int sum_all) {
+    __shared__ float srow[FIN_MAX_ROWS];
     const int j = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (j >= D) return;
-    float tot = 0.f;
     const int nrows = rep ? M : MU;       // rep == nullptr: sum every transformed row (span basis, SUM_ALL only)
-    if (!rep && lane == 0)
-        for (int m = 0; m < M; ++m) dsum[j * M + m] = 0.f;
-    for (int m = 0; m < nrows; ++m) {
+    for (int m = wave; m < nrows; m += 4) {
         const float *p = partials + ((size_t)j * MU + (rep ? rep[m] : m)) * parts;
         float s = 0.f;
         for (int q = lane; q < parts; q += 64) s += p[q];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) srow[m] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
         if (sum_all) {
-            tot += s;
-            if (rep && lane == 0) dsum[j * M + m] = 0.f;
-        } else if (lane == 0) {
-            dsum[j * M + m] = s;
+            float tot = 0.f;
+            for (int m = 0; m < nrows; ++m) tot += srow[m];
+            dsum[j * M] = tot;
+            for (int m = 1; m < M; ++m) dsum[j * M + m] = 0.f;
+        } else {
+            for (int m = 0; m < M; ++m) dsum[j * M + m] = srow[m];
         }
     }
-    if (sum_all && lane == 0) dsum[j * M] = tot;
 }
 
 // Z[row][n1][n2] -> out[row][n1 + N1*n2] (natural order), optional conjugation (forward transform).

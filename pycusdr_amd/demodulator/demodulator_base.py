@@ -130,20 +130,22 @@ class Demodulator:
         if self.symbolLUT is not None:
             self.symbolLUT = np.asarray(self.symbolLUT)
 
-        # device side: this rank's slice of the Doppler bins (all of them without sharding)
+        # device side: this rank's slice of the Doppler bins (all of them without sharding).  The noise-reference bin
+        # (doppIdxArrayOffset rows in front of the table, DB:148-159) is searched by every rank: the pick needs its score
+        # (CU:550-554), and one more bin per rank costs less than a second exchange
+        doff = self.doppIdxArrayOffset
         if shard is not None:
-            if self.doppIdxArrayOffset:
-                raise ValueError('the noise-reference bin is not supported together with Doppler-bin sharding')
             self._bin_lo, self._bin_hi = shard.bin_range(self.num_dopplers)
         else:
-            self._bin_lo, self._bin_hi = 0, self.doppIdxArrayLen
+            self._bin_lo, self._bin_hi = 0, self.num_dopplers
         nloc = self._bin_hi - self._bin_lo
-        self.bank = MFBank(confGPU['blockSize'], nloc - self.doppIdxArrayOffset, self.num_masks,
+        self.bank = MFBank(confGPU['blockSize'], nloc, self.num_masks,
                            window_width=self.windowWidth, sum_all_masks=self.SUM_ALL_MASKS_PYTHON,
                            code_search_mask_offset=self.CODE_SEARCH_MASK_OFFSET,
-                           doppler_offset=self.doppIdxArrayOffset, device=device)
+                           doppler_offset=doff, device=device)
         self.bank.set_filters(masks)
-        self.bank.set_shifts(self.doppCyperSymNorm[self._bin_lo:self._bin_hi])
+        self.bank.set_shifts(np.concatenate((self.doppCyperSymNorm[:doff],
+                                             self.doppCyperSymNorm[doff + self._bin_lo:doff + self._bin_hi])))
         # optional search settings next to the reference's "CUDA" block (where it keeps batchSize / streams, DB:171-178):
         #   "HIP": {"search_path": "auto|segment|twopass", "search_basis": "filters|span", "search_mode": "transforms|energy"}
         hip_cfg = confGPU.get('HIP', {})
@@ -154,7 +156,7 @@ class Demodulator:
         if 'search_mode' in hip_cfg:
             self.bank.set_search_mode(hip_cfg['search_mode'])
         if shard is not None:
-            shard.attach(self.bank, self.num_dopplers, self.num_masks, sum_all=self.SUM_ALL_MASKS_PYTHON)
+            shard.attach(self.bank, self.num_dopplers, self.num_masks, sum_all=self.SUM_ALL_MASKS_PYTHON, noise_rows=doff)
         self._pick_bin = 0
 
         # windowed argmax range of the symbol-rate estimate (reference DB:508-512)
@@ -199,8 +201,14 @@ class Demodulator:
             return
         sh = self.shard
         if sh.rank == 0:
-            src = sh.torch.from_numpy(np.ascontiguousarray(samples, dtype=np.complex64).view(np.float32))
-            sh.broadcast_block(self.bank, src.to(sh.device, non_blocking=False) if sh.on_gpu else src)
+            # straight from the library's page-locked input buffer into the shard's block buffer, on the shard's stream
+            # (no temporary device tensor); the pick's read-back synchronises that stream before the caller gets the
+            # buffer back
+            raw = self.bank.input
+            if samples is not raw and not (isinstance(samples, np.ndarray) and samples.ctypes.data == raw.ctypes.data
+                                           and samples.size == raw.size):
+                np.copyto(raw, np.asarray(samples, dtype=np.complex64))
+            sh.broadcast_block(self.bank, sh.torch.from_numpy(raw.view(np.float32)))
         else:
             sh.broadcast_block(self.bank)
 
@@ -321,11 +329,8 @@ class Demodulator:
     def _demodulate(self):
         """Symbols of the uploaded block at the found shift (reference DB:765-859).  Returns
         (bits uint8[], centres uint8[] (mod 256), trust uint8[], spSym)."""
-        if self.shard is not None and self.shard.world > 1 and self.backend == 'UHF' \
-                and self.shard.owner(min(max(self._pick_bin, 0), self.num_dopplers - 1)) != self.shard.rank:
-            # sharded: the demodulation stage (1/D of the work) runs on the rank that owns the picked bin
-            empty = np.empty(0, dtype=np.uint8)
-            return empty, empty, empty, 0.0
+        # (sharded: every rank runs this stage -- each holds the block, the filters and the pick -- so the symbol-overlap
+        # state below and the caller's decoder see one contiguous stream whichever rank owns the picked bin)
         spSym, codeOffset = self.findCodeRateAndPhaseGPU()
         idxSymbol, _, centres, _, _, trustSymbol = self.cudaFindCentres(spSym, codeOffset, Operations.CENTRES_ABS)
         dataBits, symError_t = self.extractBits(centres, idxSymbol)

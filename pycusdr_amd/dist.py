@@ -15,7 +15,9 @@ the filter bank.  Per block:
      protocol) only column 0 of doppSum is populated (reference cuda_kernels.cu:453-464), so only that
      column travels: D floats instead of D*M;
   4. the Doppler pick on the full table on every rank (identical everywhere);
-  5. the demodulation stage (1/D of the work) runs on the rank that owns the picked bin only.
+  5. the demodulation stage (1/D of the work) runs on EVERY rank: each one holds the block, the full filter bank and
+     the pick, so every rank returns the same bits and carries the same block-to-block state (checkSymbolOverlap's
+     windows DB:977-979, the decoder's overlap buffer DEC:89-90) whichever slice the carrier drifts through.
 The exchange is latency-bound (<= 8 KiB), not link-bandwidth-bound.
 """
 import contextlib
@@ -43,15 +45,21 @@ class DopplerShard:
     """Glue between a bank (MFBank, or any object with its device-pointer methods) holding this rank's
     bins and the process group.  Works on CUDA/HIP tensors over RCCL and on CPU tensors over gloo."""
 
-    def __init__(self, rank=None, world=None, group=None, device=None):
+    def __init__(self, rank=None, world=None, group=None, device=None, comm=None):
+        """``comm``: an object with torch.distributed's call surface (get_rank, get_world_size, get_backend, new_group,
+        broadcast, all_gather_into_tensor, all_reduce, ReduceOp); default torch.distributed itself.  A caller that
+        runs several ranks inside one process (rehearsals of many-rank geometries on one device) passes its own."""
         import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
+        if comm is None:
+            import torch.distributed as comm
+        self.torch, self.dist = torch, comm
+        dist = comm
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
+        self.backend = dist.get_backend(group)
         if device is None:
-            device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+            device = torch.device('cuda', torch.cuda.current_device()) if self.backend == 'nccl' else torch.device('cpu')
         self.device = torch.device(device)
         self.on_gpu = self.device.type == 'cuda'
         self.scores = None
@@ -62,7 +70,7 @@ class DopplerShard:
         # block distribution ahead of time: its own stream and its own communicator, so that the broadcast of
         # the next block runs beside the search and the all-reduce of the current one
         self.comm = torch.cuda.Stream(self.device) if self.on_gpu else None
-        self.bcast_group = dist.new_group(backend=dist.get_backend(group)) if (self.world > 1 and group is None) else group
+        self.bcast_group = dist.new_group(backend=self.backend) if (self.world > 1 and group is None) else group
 
     def _on_stream(self, which=None):
         which = self.stream if which is None else which
@@ -71,22 +79,39 @@ class DopplerShard:
     def bin_range(self, num_bins):
         return bin_slice(num_bins, self.rank, self.world)
 
-    def owner(self, bin_index):
-        return bin_owner(self.D, self.world, int(bin_index))
+    def owner(self, table_index):
+        """Rank whose slice holds row ``table_index`` of the exchanged table (noise rows: rank 0)."""
+        b = int(table_index) - getattr(self, 'doff', 0)
+        return 0 if b < 0 else bin_owner(self.D, self.world, b)
 
-    def attach(self, bank, num_bins_total, M, sum_all=False):
+    def attach(self, bank, num_bins_total, M, sum_all=False, noise_rows=0, exchange='auto'):
         """Allocate the exchange buffers and run the bank on the shard's stream so that the collectives
-        are ordered after the search without host synchronisation."""
+        are ordered after the search without host synchronisation.
+
+        ``exchange``: 'allgather' / 'allreduce' force one form of the exchange (default: all-gather whenever the slices
+        are equal).  ``noise_rows``: rows in front of the bin table that every rank computes itself -- the reference's
+        noise-reference bin (DB:148-159; its score divides the metric, CU:550-554).  The table every rank picks on is
+        [noise rows | all D bins]; the noise rows are taken from rank 0 so that it is bit-identical everywhere."""
         torch = self.torch
-        self.D, self.M, self.sum_all = int(num_bins_total), int(M), bool(sum_all)
-        shape = (self.D,) if self.sum_all else (self.D, self.M)
+        self.D, self.M, self.sum_all, self.doff = int(num_bins_total), int(M), bool(sum_all), int(noise_rows)
+        rows = self.doff + self.D
+        shape = (rows,) if self.sum_all else (rows, self.M)
         self.scores = torch.zeros(shape, dtype=torch.float32, device=self.device)
         # equal slices: every rank exports into a slice-sized buffer and the table is all-gathered (no clearing,
         # no additions); uneven slices: all-reduce of the zero-padded table
         # (gloo moves device tensors through host staging and has no all_gather_into_tensor for them: all-reduce there)
-        backend = self.dist.get_backend(self.group)
-        self.even = self.D % self.world == 0 and (backend == 'nccl' or not self.on_gpu)
-        self.local = torch.zeros((self.D // self.world,) + shape[1:], dtype=torch.float32, device=self.device) if self.even else None
+        if exchange not in ('auto', 'allgather', 'allreduce'):
+            raise ValueError(f'exchange must be auto, allgather or allreduce, got {exchange!r}')
+        can_gather = self.D % self.world == 0 and (self.backend != 'gloo' or not self.on_gpu)
+        if exchange == 'allgather' and not can_gather:
+            raise ValueError('all-gather needs equal slices (and, over gloo, CPU tensors)')
+        self.even = can_gather and exchange != 'allreduce'
+        self.nloc = self.D // self.world if self.even else None
+        lrows = self.doff + self.D // self.world
+        self.local = torch.zeros((lrows,) + shape[1:], dtype=torch.float32, device=self.device) if self.even else None
+        # with noise rows the gathered layout is [rank][noise rows | slice]; it is re-packed into the table afterwards
+        self.gathered = (torch.zeros((self.world * lrows,) + shape[1:], dtype=torch.float32, device=self.device)
+                         if self.even and self.doff else None)
         # complex64 blocks, interleaved: two buffers so that one can be filled while the other is searched
         self.blocks = [torch.empty(2 * bank.N, dtype=torch.float32, device=self.device) for _ in range(2)]
         self.block = self.blocks[0]
@@ -98,11 +123,11 @@ class DopplerShard:
             bank.set_stream(self.stream.cuda_stream)
 
     def full_scores(self):
-        """The reduced score table as float32 [D, M] (column 0 only is populated under SUM_ALL_MASKS)."""
+        """The exchanged score table as float32 [noise rows + D, M] (column 0 only is populated under SUM_ALL_MASKS)."""
         s = self.scores.detach().cpu().numpy()
         if not self.sum_all:
             return s
-        out = np.zeros((self.D, self.M), dtype=np.float32)
+        out = np.zeros((self.doff + self.D, self.M), dtype=np.float32)
         out[:, 0] = s
         return out
 
@@ -144,6 +169,9 @@ class DopplerShard:
             bank.upload_device(self.blocks[k].data_ptr())
 
     def search_and_pick(self, bank, row_offset):
+        """Search this rank's bins, exchange, pick.  ``row_offset`` = first bin of this rank's slice (bin_range()[0])."""
+        col = self.sum_all
+        doff = self.doff
         with self._on_stream():
             if not self.even:
                 self.scores.zero_()
@@ -152,18 +180,25 @@ class DopplerShard:
                 ev = self.torch.cuda.Event()
                 ev.record(self.stream)
                 self.free[self.cur] = ev
-            dst, off = (self.local, 0) if self.even else (self.scores, row_offset)
-            if self.sum_all:
-                bank.export_column_async(dst.data_ptr(), off)
-            else:
-                bank.export_scores_async(dst.data_ptr(), off)
             if self.even:
-                self.dist.all_gather_into_tensor(self.scores, self.local, group=self.group)
+                # [noise rows | slice] of every rank, gathered; without noise rows that IS the table
+                bank.export_rows_async(self.local.data_ptr(), 0, 0, doff + self.nloc, column_only=col)
+                if doff:
+                    self.dist.all_gather_into_tensor(self.gathered, self.local, group=self.group)
+                    g = self.gathered.view((self.world, doff + self.nloc) + tuple(self.gathered.shape[1:]))
+                    self.scores[:doff].copy_(g[0, :doff])                                   # rank 0's noise rows
+                    self.scores[doff:].view((self.world, self.nloc) + tuple(self.scores.shape[1:])).copy_(g[:, doff:])
+                else:
+                    self.dist.all_gather_into_tensor(self.scores, self.local, group=self.group)
             else:
-                self.dist.all_reduce(self.scores, op=self.dist.ReduceOp.SUM, group=self.group)
+                nloc = bank.D
+                bank.export_rows_async(self.scores.data_ptr(), doff + row_offset, doff, nloc, column_only=col)
+                if doff and self.rank == 0:
+                    bank.export_rows_async(self.scores.data_ptr(), 0, 0, doff, column_only=col)
+                self.dist.all_reduce(self.scores, op=self.dist.ReduceOp.SUM, group=self.group)     # adds exact zeros
             if self.sum_all:
-                return bank.pick_column(self.scores.data_ptr(), num=self.D, offset=0)
-            return bank.pick(self.scores.data_ptr(), num=self.D, offset=0)
+                return bank.pick_column(self.scores.data_ptr(), num=self.D, offset=doff)
+            return bank.pick(self.scores.data_ptr(), num=self.D, offset=doff)
 
     def step(self, bank, row_offset, block=None, next_block=None, prefetch_next=False):
         """One block of the sharded hot path: (take the prefetched block or broadcast now), start the next block's

@@ -160,6 +160,12 @@ class MFBank:
         _lib.check(self._lib.mfb_export_column_async(self._h, C.c_void_p(int(dev_ptr)), int(row_offset)),
                    'mfb_export_column_async')
 
+    def export_rows_async(self, dev_ptr, dst_row, first_row, nrows, column_only=False):
+        """Rows [first_row, first_row + nrows) of doppSum (whole rows, or column 0 alone) to rows dst_row... of a
+        device array."""
+        _lib.check(self._lib.mfb_export_rows_async(self._h, C.c_void_p(int(dev_ptr)), int(dst_row), int(first_row), int(nrows),
+                                                   int(bool(column_only))), 'mfb_export_rows_async')
+
     def pick_column(self, dev_column, num, offset=0):
         res = (C.c_float * 2)()
         _lib.check(self._lib.mfb_pick_column(self._h, C.c_void_p(int(dev_column)), int(num), int(offset), res), 'mfb_pick_column')

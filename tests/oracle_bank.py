@@ -70,6 +70,12 @@ class OracleBank:
     def export_column_async(self, ptr, row_offset):
         self._view(ptr, row_offset + self.Dtot)[row_offset:] = self.ds[:, 0]
 
+    def export_rows_async(self, ptr, dst_row, first_row, nrows, column_only=False):
+        if column_only:
+            self._view(ptr, dst_row + nrows)[dst_row:] = self.ds[first_row:first_row + nrows, 0]
+        else:
+            self._view(ptr, (dst_row + nrows) * self.M)[dst_row * self.M:] = self.ds[first_row:first_row + nrows].ravel()
+
     def pick(self, ptr=None, num=None, offset=None):
         num = self.D if num is None else num
         offset = self.Doff if offset is None else offset

@@ -98,3 +98,141 @@ def test_sharded_scores_allreduce_world2():
         p.join(timeout=30)
     assert all(ok for _, ok, _ in res)
     assert res[0][2] == res[1][2]
+
+
+def _worker_noise(rank, world, port, q):
+    """Noise-reference bin under sharding (reference DB:148-159, CU:550-554): every rank searches the noise bin beside its
+    slice; the exchanged table [noise | D bins] and the pick equal the single-process ones, even and uneven slices."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    import torch
+    import torch.distributed as dist
+    from oracle import mfbank_oracle as orc
+    from oracle_bank import OracleBank
+    from pycusdr_amd.dist import DopplerShard
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    rs = np.random.RandomState(11)
+    log2N, M = 12, 4
+    N = 1 << log2N
+    x = (rs.standard_normal(N) + 1j * rs.standard_normal(N)).astype(np.complex64)
+    masks = (rs.standard_normal((M, N)) + 1j * rs.standard_normal((M, N))).astype(np.complex64)
+    X = orc.forward_fft(x)
+    ok = True
+    for sum_all, D in ((True, 10), (False, 10), (True, 7), (False, 7)):
+        shifts = rs.randint(0, N, D + 1)                 # row 0 = the noise bin
+        shard = DopplerShard(device=torch.device('cpu'))
+        lo, hi = shard.bin_range(D)
+        bank = OracleBank(log2N, hi - lo, M, sum_all_masks=sum_all, doppler_offset=1)
+        bank.set_filters(masks)
+        bank.set_shifts(np.concatenate((shifts[:1], shifts[1 + lo:1 + hi])))
+        shard.attach(bank, D, M, sum_all=sum_all, noise_rows=1)
+        block = torch.from_numpy(x.view(np.float32).copy()) if rank == 0 else None
+        idx, metric = shard.step(bank, lo, block)
+        single = orc.doppler_scores(X, masks, shifts, sum_all).astype(np.float32)
+        sidx, smetric = orc.find_doppler_est(single, D, 1, sum_all)
+        ok &= bool(np.array_equal(shard.full_scores(), single))
+        ok &= bool(idx == sidx and metric == smetric)
+        ok &= shard.owner(0) == 0 and shard.owner(1) == 0 and shard.owner(D) == world - 1
+    q.put((rank, bool(ok), float(idx)))
+    dist.destroy_process_group()
+
+
+def _spawn(worker, world=2, timeout=100):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=timeout) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    return sorted(res)
+
+
+@pytest.mark.timeout(120)
+def test_noise_reference_bin_under_sharding_world2():
+    res = _spawn(_worker_noise)
+    assert all(ok for _, ok, _ in res) and res[0][2] == res[1][2]
+
+
+def _hopping_stream(N, ov, nblocks, offsets_hz, fs=153600):
+    """The GMSK bench packet, tiled; the carrier sits at fs/4 + offsets_hz[b] during block b's new samples: the picked
+    Doppler bin moves through the bin table from block to block."""
+    from pycusdr_amd import signals as sg
+    sig = sg.s1_stream(nblocks, N, ov, 'GMSK', snr_db=20.0, seed=3).astype(np.complex128)
+    n = np.arange(len(sig))
+    f = np.zeros(len(sig))
+    for b, hz in enumerate(offsets_hz):
+        f[ov + b * (N - ov): ov + (b + 1) * (N - ov)] = hz
+    return (sig * np.exp(2j * np.pi * np.cumsum(f) / fs)).astype(np.complex64), n
+
+
+def _worker_stream(rank, world, port, q):
+    """The sharded streaming loop against the single-process loop on a carrier that drifts from rank 0's bins into rank
+    1's while a packet is on the air: every rank must hand the decoder the same contiguous bit stream, with the same
+    block-to-block alignment state, as the unsharded Demodulator -- and the same packets come out."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    import torch
+    import torch.distributed as dist
+    from oracle import mfbank_oracle as orc
+    from oracle_bank import OracleBank
+    import pycusdr_amd.demodulator.demodulator_base as dbm
+    from pycusdr_amd import config as cfg
+    from pycusdr_amd.decoder import Decoder
+    from pycusdr_amd.demodulator_process import DemodulatorRunner
+    from pycusdr_amd.dist import DopplerShard
+    from pycusdr_amd.protocol import loadProtocol
+    dbm.MFBank = OracleBank
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    bs, ov, D = 13, 1 << 10, 9                     # uneven slices: 5 + 4 bins, and a noise-reference bin in front
+    N = 1 << bs
+    nblocks = 27                                   # the whole bench packet: 10 000 symbols in blocks of 448
+    conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=D)
+    conf['Radios']['Rx']['UHF-H']['noise_measure_offset_Hz'] = 60000
+    p = loadProtocol('bench_GMSK')(conf=conf)
+    sig, _ = _hopping_stream(N, ov, nblocks, np.linspace(-7000, 7000, nblocks))
+    step = N - ov
+    chunks = [sig[ov + i * step: ov + (i + 1) * step] for i in range(nblocks)]
+    shard = DopplerShard(device=torch.device('cpu'))
+    run = DemodulatorRunner(conf, p, 'UHF-H', shard=shard)
+    dec = Decoder({}, p, correlator=orc.sync_correlate)
+    res, packets = run.run([c if rank == 0 else np.zeros(step, np.complex64) for c in chunks], decoder=dec)
+    owners = [shard.owner(run.demod.doppIdxArrayOffset) for _ in range(1)]
+    picks = [float(d['doppler']) for d in res]
+    ok = True
+    if rank == 0:
+        plain = DemodulatorRunner(conf, p, 'UHF-H')
+        ref, ref_packets = plain.run(chunks, decoder=Decoder({}, p, correlator=orc.sync_correlate))
+        for a, b in zip(res, ref):
+            ok &= bool(np.array_equal([a['doppler'], a['doppler_std'], a['SNR']], [b['doppler'], b['doppler_std'], b['SNR']], equal_nan=True))
+            ok &= bool(np.array_equal(a['data'], b['data']) and np.array_equal(a['trust'], b['trust'])) and a['spSymEst'] == b['spSymEst']
+        ok &= bool(np.array_equal(run.demod.poswinP, plain.demod.poswinP) and np.array_equal(run.demod.posSymEnd, plain.demod.posSymEnd))
+        ok &= len(packets) == len(ref_packets) and all(np.array_equal(u.bits if hasattr(u, 'bits') else u.rawData, v.bits if hasattr(v, 'bits') else v.rawData)
+                                                        for u, v in zip(packets, ref_packets))
+    # every rank: the same stream (hash of all bits), and the pick really moved across the slice boundary
+    bits = np.concatenate([d['data'] for d in res])
+    t = torch.tensor([float(bits.sum()), float(len(bits)), float(len(packets))] + picks, dtype=torch.float64)
+    g = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(g, t)
+    ok &= all(bool(torch.equal(g[0], u)) for u in g)
+    hz = np.array(picks)
+    q.put((rank, bool(ok), float(hz.min()), float(hz.max()), len(bits), len(packets)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_stream_is_contiguous_when_the_owner_changes():
+    res = _spawn(_worker_stream, timeout=280)
+    assert all(r[1] for r in res), res
+    assert res[0][2] < -3000 and res[0][3] > 3000          # the carrier crossed from rank 0's bins into rank 1's
+    assert res[0][4] == res[1][4] > 10000 and res[0][5] == res[1][5] == 1      # one packet, on every rank

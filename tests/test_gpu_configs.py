@@ -15,6 +15,7 @@ from oracle import mfbank_oracle as orc
 from pycusdr_amd import config as cfg, signals as sg
 from pycusdr_amd.mfbank import MFBank, sync_correlate, sync_find
 from pycusdr_amd.protocol import loadProtocol
+from ports import free_port
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -105,39 +106,53 @@ def test_c3_1024_bins_gmsk_bank(path):
     assert abs(pick['dopplerIdxlast'] - N // 4) <= np.median(np.diff(np.sort(shifts)))
 
 
+def _run_ranks(n, args, timeout=900):
+    import re
+    child = os.path.join(ROOT, 'tests', 'children', 'dist_child.py')
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), child] + [str(a) for a in args]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = [json.loads(m) for m in re.findall(r'\{[^{}]*\}', r.stdout)]      # the ranks' lines may interleave
+    assert len(res) == n and all(q['ok'] for q in res), (res, r.stderr[-2000:])
+    return res
+
+
 def test_multi_gpu_sharded_pick_equals_unsharded():
     """Sharded search on every visible GPU (one fresh process per rank via torch.distributed.run, RCCL):
-    broadcast of rank 0's block, search, one all-reduce, pick -- equal, bit for bit, to the unsharded search;
-    the demodulation stage runs on the owner rank only."""
+    broadcast of rank 0's block, search, one all-gather / all-reduce, pick -- equal, bit for bit, to the unsharded
+    search; every rank demodulates the same bits.  On an 8-GPU node also BASELINE config C4 itself: 2048 bins, 256
+    per GPU, N = 2^20, and the same with a noise-reference bin."""
     import torch
     n = torch.cuda.device_count()
     if n < 2:
         pytest.skip('needs >= 2 GPUs (the driver runs it on the 8-GPU node)')
-    n = min(n, 4)
-    child = os.path.join(ROOT, 'tests', 'children', 'dist_child.py')
-    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
-           '--master-port', '29577', child, 'nccl']
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
-    assert r.returncode == 0, r.stderr[-3000:]
-    import re
-    res = [json.loads(m) for m in re.findall(r'\{[^{}]*\}', r.stdout)]
-    assert len(res) == n and all(q['ok'] for q in res), (res, r.stderr[-2000:])
+    _run_ranks(min(n, 4), ['nccl'])
+    if n >= 8:
+        assert all(q['even'] for q in _run_ranks(8, ['nccl', 20, 2048]))
+        _run_ranks(8, ['nccl', 20, 2048, 1])
 
 
 def test_two_ranks_sharing_one_gpu_over_gloo():
     """The sharded path with TWO ranks on the GPU box's single device (gloo moves the device tensors): broadcast of
     rank 0's block, search of each rank's bin slice on its own handle, exchange, pick on both ranks -- equal, bit
-    for bit, to the unsharded search; demodulation on the owner only.  Everything but RCCL itself."""
-    child = os.path.join(ROOT, 'tests', 'children', 'dist_child.py')
-    env = dict(os.environ, PYTHONPATH=ROOT)
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
-           '--master-port', '29578', child, 'gloo']
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
-    assert r.returncode == 0, r.stderr[-3000:]
-    import re
-    res = [json.loads(m) for m in re.findall(r'\{[^{}]*\}', r.stdout)]      # the ranks' lines may interleave
-    assert len(res) == 2 and all(q['ok'] for q in res), (res, r.stderr[-2000:])
+    for bit, to the unsharded search; the same bits demodulated on both ranks.  Everything but RCCL itself."""
+    _run_ranks(2, ['gloo'])
+
+
+def test_two_ranks_uneven_slices_and_noise_bin_over_gloo():
+    """World 2, 129 bins (65 + 64: the all-reduce form of the exchange on device tensors) plus the reference's
+    noise-reference bin (DB:148-159), which every rank searches beside its slice and rank 0's copy of which enters the
+    table the pick runs on (CU:550-554)."""
+    res = _run_ranks(2, ['gloo', 16, 129, 1])
+    assert all(q['noise_rows'] == 1 and not q['even'] for q in res)
+
+
+def test_c4_slices_four_gloo_ranks_full_size():
+    """C4's per-rank geometry in four real processes on the one device (the box admits at most six): N = 2^20, 1024 bins,
+    256 per rank, GMSK bank -- sharded pick and table equal the unsharded 1024-bin handle's bit for bit."""
+    _run_ranks(4, ['gloo', 20, 1024])
 
 
 def test_failed_create_frees_everything():
