@@ -243,7 +243,7 @@ static int attr_p2() {
 }
 template <int L>
 static int attr_seg() {
-    const int b = (int)SegCfg<L>::lds_bytes(true);
+    const int b = (int)SegCfg<L>::lds_bytes(SEG_MPB_MAX);
     HIPCHK(hipFuncSetAttribute((const void *)k_seg<L, SEG_STORE, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
 #define MFB_ATTR_PV(PV_) HIPCHK(hipFuncSetAttribute((const void *)k_seg<L, SEG_REDUCE, PV_>, hipFuncAttributeMaxDynamicSharedMemorySize, b))
     MFB_ATTR_PV(-1);
@@ -855,7 +855,7 @@ static int forward_fft(mfb_ctx *c, const cf *src_c, const float *src_r, cf *dst,
 // ---- single-pass overlap-save launches -------------------------------------------------------------
 template <int L, int MODE, int PV>
 static int launch_seg_k(mfb_ctx *c, const SegArgs &a, int grid) {
-    const size_t lds = SegCfg<L>::lds_bytes(MODE == SEG_REDUCE);
+    const size_t lds = SegCfg<L>::lds_bytes(MODE == SEG_REDUCE ? a.mpb : 0);
     hipLaunchKernelGGL((k_seg<L, MODE, PV>), dim3(grid), dim3(SegCfg<L>::BLOCK), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return MFB_OK;
@@ -914,8 +914,8 @@ static SegPlan plan_seg(const mfb_ctx *c, int dc, int nfilters, int nslots, int 
     const SegGeom g = seg_geom(c);
     SegPlan p;
     p.nsg = nslots >= 64 ? 8 : 1;
-    // filters per team pass: all of them when they fit one pass (the forward transform of a segment is then run once)
-    int mpb = mpb_want > 0 ? mpb_want : SEG_MPB_MAX;
+    // L = 256 runs three workgroups per CU only while a workgroup's LDS stays under 53 KiB: 8 filters per pass
+    int mpb = mpb_want > 0 ? mpb_want : (c->segl <= 8 ? 8 : SEG_MPB_MAX);
     if (mpb > SEG_MPB_MAX) mpb = SEG_MPB_MAX;
     if (mpb > nfilters) mpb = nfilters;
     p.mgroups = (nfilters + mpb - 1) / mpb;

@@ -43,6 +43,9 @@
 #define SEG_REDUCE 0
 #define SEG_STORE 1
 #define SEG_MPB_MAX 16   // filters per team pass
+// Per-wave stash of the per-lane |.|^2 sums of a slot, one row per filter of the pass: row stride 68 floats keeps both the
+// row-wise stores and the column-wise reads of the reduction (lane = (filter, j): elements j, j+4, ...) off shared banks.
+#define SEG_ACC_STRIDE 68
 
 // waves per SIMD the register budget is pinned to: 3 for L = 256 (one twiddled pass: 149 VGPRs), 2 for the
 // longer transforms (two twiddled passes: ~210 VGPRs; 3 waves would spill)
@@ -115,16 +118,10 @@ struct SegCfg {
     static constexpr bool PHASE_TABLE = L <= 256;
     static constexpr int PHASE_ELEMS = PHASE_TABLE ? (BLOCK / 64) * L : 0;
     static constexpr int WAVES = L <= 256 ? MFB_SEG_WAVES_SHORT : MFB_SEG_WAVES_LONG;   // per SIMD = workgroups per CU
-    static constexpr size_t lds_bytes(bool reduce) {   // STORE mode: no phase table
-        return (size_t)(LDS_ELEMS + STEP_ELEMS + (reduce ? PHASE_ELEMS : 0)) * sizeof(cf);
+    static constexpr size_t lds_bytes(int mpb) {   // mpb = 0: STORE mode (no phase table, no reduction stash)
+        return (size_t)(LDS_ELEMS + STEP_ELEMS + (mpb ? PHASE_ELEMS : 0)) * sizeof(cf) + (size_t)(BLOCK / 64) * mpb * SEG_ACC_STRIDE * sizeof(float);
     }
 };
-
-DEVI float seg_wave_sum(float x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-    return x;
-}
 
 // PV >= 0: every segment this role touches is complete; valid outputs = register slots k < PV.
 // PV < 0 : per-lane masking (incomplete / padding segments, any V).
@@ -151,6 +148,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
     cf *mylds = lds + team * Cfg::LDS_PER_TEAM + col * padlen(L);
     cf *mystep = lstep + wave * 16;
     [[maybe_unused]] cf *myphase = lphase + wave * L;
+    [[maybe_unused]] float *lacc = reinterpret_cast<float *>(lphase + (REL ? Cfg::PHASE_ELEMS : 0)) + wave * (a.mpb * SEG_ACC_STRIDE);
     int ebuf = 0;
 
     TwRegs<L> twr;
@@ -308,14 +306,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                     };
                     fft_passes<L, 1, 0, true, Cfg::PP, Cfg::HALF, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, acc);
                     const cf rsum = (racc[0] + racc[1]) + (racc[2] + racc[3]);
-                    // One partial per (bin, filter, slot, wave of the team), at an index that depends on the slot alone:
-                    // lanes -> wavefront in a fixed butterfly, k_finalize adds the slots in a fixed order.  A score is
-                    // therefore a function of the block, the shift and the filter only -- not of how many bins the
-                    // handle holds, of the grid decomposition or of the tuning: shards of any size reproduce the
-                    // unsharded table bit for bit.
-                    const float s = seg_wave_sum(rsum.x + rsum.y);
-                    if (lane == 0 && active)
-                        a.partials[((size_t)(a.part_row0 + jl) * a.MU + (m0 + mi)) * a.parts + (slot * Cfg::WPT + (lt >> 6))] = s * a.scale;
+                    lacc[mi * SEG_ACC_STRIDE + lane] = rsum.x + rsum.y;       // reduced over the lanes after the last filter
                 } else {
                     const auto orr = mk_rsrc(a.out + (size_t)rm * a.N, (unsigned)a.N * sizeof(cf));
                     const unsigned o0 = e0 + (unsigned)a.out_off;
@@ -328,6 +319,27 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                     };
                     fft_passes<L, 1, 0, true, Cfg::PP, Cfg::HALF, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, put);
                 }
+            }
+            if constexpr (MODE == SEG_REDUCE) {
+                // One partial per (bin, filter, slot, wave of the team), at an index that depends on the slot alone, summed
+                // over the wave's lanes in ONE fixed order: lane (f, j) = (lane / 4, lane % 4) adds elements j, j+4, ... of
+                // filter f's row as a balanced tree, two quad steps finish.  k_finalize adds the slots in a fixed order.
+                // A score is therefore a function of the block, the shift and the filter only -- not of how many bins the
+                // handle holds, of the grid decomposition or of the tuning: shards of any size reproduce the unsharded
+                // table bit for bit.  (All filters of the pass share the 16 + 2 steps; a butterfly per filter cost 8-10 %.)
+                xsync<1>();
+                const int f = lane >> 2, j = lane & 3;
+                const float *row = lacc + min(f, nm - 1) * SEG_ACC_STRIDE + j;
+                float t[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) t[k] = row[4 * k];
+                float s = (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) +
+                          (((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15])));
+                s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+                s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+                if (j == 0 && f < nm && active)
+                    a.partials[((size_t)(a.part_row0 + jl) * a.MU + (m0 + f)) * a.parts + (slot * Cfg::WPT + (lt >> 6))] = s * a.scale;
+                xsync<1>();     // the rows are rewritten by the next slot
             }
             if constexpr (MODE == SEG_STORE) {
                 if (a.env) {
