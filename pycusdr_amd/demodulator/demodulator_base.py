@@ -329,20 +329,34 @@ class Demodulator:
     def _demodulate(self):
         """Symbols of the uploaded block at the found shift (reference DB:765-859).  Returns
         (bits uint8[], centres uint8[] (mod 256), trust uint8[], spSym)."""
-        # (sharded: every rank runs this stage -- each holds the block, the filters and the pick -- so the symbol-overlap
-        # state below and the caller's decoder see one contiguous stream whichever rank owns the picked bin)
+        # (Doppler-sharded: every rank runs this stage -- each holds the block, the filters and the pick -- so the
+        # symbol-overlap state below and the caller's decoder see one contiguous stream whichever rank owns the picked bin)
+        return self.demodulateHost(self.demodulateDevice())
+
+    def demodulateDevice(self):
+        """The device half of the demodulation (reference DB:776-785, 711-752, 991-1009): matched filters at
+        ``dopplerIdxlast``, symbol rate and phase, per-symbol decisions.  Nothing here depends on earlier blocks, so any
+        process may run it for any block (time-chunk sharding, dist.BlockShard); the result travels as plain arrays."""
         spSym, codeOffset = self.findCodeRateAndPhaseGPU()
         idxSymbol, _, centres, _, _, trustSymbol = self.cudaFindCentres(spSym, codeOffset, Operations.CENTRES_ABS)
+        return {'spSym': spSym, 'symbols': idxSymbol, 'centres': centres, 'trust': trustSymbol,
+                'clipped': np.asarray(self.clippedPeakIPure, dtype=np.int64)}
+
+    def demodulateHost(self, rec):
+        """The sequential half (reference DB:1012-1051, 863-988, 817-859): bit lookup, alignment against the previous
+        block (stateful: ``poswinP``, ``posSymEnd``), clipped-peak tagging, uint8 casts.  Must see the blocks in order."""
+        spSym, idxSymbol, centres, trustSymbol = rec['spSym'], rec['symbols'], rec['centres'], rec['trust']
         dataBits, symError_t = self.extractBits(centres, idxSymbol)
         noError = len(symError_t)
         centresWin, dataBitsWin, trustSymbolWin, _ = self.checkSymbolOverlap(noError, centres, idxSymbol, dataBits, trustSymbol)
 
         # tag symbols next to clipped interference peaks (reference DB:830-837)
-        marks = np.zeros(self.Nfft, dtype=bool)
-        spSymc = int(np.ceil(spSym))
-        for cp in self.clippedPeakIPure:
-            marks[cp - 2 * spSymc:cp + 2 * spSymc + 1] = 1
-        trustSymbolWin[marks[centresWin]] = -2
+        if len(rec['clipped']):
+            marks = np.zeros(self.Nfft, dtype=bool)
+            spSymc = int(np.ceil(spSym))
+            for cp in rec['clipped']:
+                marks[cp - 2 * spSymc:cp + 2 * spSymc + 1] = 1
+            trustSymbolWin[marks[centresWin]] = -2
         return dataBitsWin.astype(np.uint8), centresWin.astype(np.uint8), trustSymbolWin.astype(np.uint8), spSym
 
     def cudaFindCentres(self, spSym, codePhase, operation=Operations.CENTRES_ABS):

@@ -66,30 +66,60 @@ class DemodulatorRunner:
         return self.timeMA
 
     def feed(self, new_samples):
+        return self.feed_host(self.feed_device(new_samples))
+
+    def feed_device(self, new_samples):
+        """Device half of one block (A3..A11): overlap carry, Doppler search, matched filters at the found shift, symbol
+        decisions.  Carries no block-to-block state besides the overlap samples, so with time-chunk sharding
+        (dist.BlockShard) any rank may run it for any block; the returned dict travels to the rank that runs
+        ``feed_host`` in block order."""
         if len(new_samples) != self.samplesPerSlice:
             raise ValueError(f'expected {self.samplesPerSlice} new samples per block, got {len(new_samples)}')
         raw = self.raw
         raw[self.overlap:] = new_samples
         stamp = time.time()
+        part = {'count': self.count, 'timestamp': stamp}
+        part['doppler'], part['doppler_std'], _, part['SNR'] = self.demod.uploadAndFindCarrier(raw)
+        if self.radioBackend == 'UHF':
+            rec = self.demod.demodulateDevice()
+        else:                                   # STX: fixed shift, no search (reference STX.py:21-24)
+            self.demod.dopplerIdxlast = self.demod.doppOffsetIdx
+            rec = self.demod.demodulateDevice()
+        part['rec'] = rec
+        part['time_device'] = time.time() - stamp
+        raw[:self.overlap] = raw[-self.overlap:]      # overlap carry for the next block
+        self.count += 1
+        return part
+
+    def skip_block(self, new_samples):
+        """A block another rank processes: keep the overlap carry and the block counter in step."""
+        if len(new_samples) != self.samplesPerSlice:
+            raise ValueError(f'expected {self.samplesPerSlice} new samples per block, got {len(new_samples)}')
+        self.raw[:self.overlap] = new_samples[-self.overlap:]
+        self.count += 1
+
+    def feed_host(self, part):
+        """Sequential half of one block (A12, A13): bits, alignment against the previous block, trust tagging, and the
+        result dict that goes to the decoder.  Must be called in block order."""
+        t0 = time.time()
+        stamp = part['timestamp']
         # every key of the reference's result dict (DP:259-276), including the two it initialises and never
         # updates ('rangerateEst', 'baudRate_est': its loop writes 'rangerate' and 'baudrate_est' instead, DP:299,303)
-        data = {'workerId': self.workerId, 'count': self.count, 'timestamp': stamp, 'voteGroup': self.voteGroup,
+        data = {'workerId': self.workerId, 'count': part['count'], 'timestamp': stamp, 'voteGroup': self.voteGroup,
                 'doppler': 0, 'doppler_std': 0, 'data': np.array([]), 'trust': np.array([]), 'spSymEst': 0, 'SNR': float(0),
                 'rangerateEst': 0, 'baudRate': self.baudRate, 'baudRate_est': 0, 'sample_rate': self.Fs,
                 'protocol': self.decoderProtocol}
-        data['doppler'], data['doppler_std'], _, data['SNR'] = self.demod.uploadAndFindCarrier(raw)
-        data['data'], centres, data['trust'], data['spSymEst'] = self.demod.demodulate()
+        data['doppler'], data['doppler_std'], data['SNR'] = part['doppler'], part['doppler_std'], part['SNR']
+        data['data'], centres, data['trust'], data['spSymEst'] = self.demod.demodulateHost(part['rec'])
         data['baudrate_est'] = self.Fs / data['spSymEst'] if data['spSymEst'] else 0.0
         # range rate implied by the measured frequency offset (reference computeTxFreqOffset, DP:359-379)
         fc = self.confRadio['frequency_Hz']
         data['rangerate'] = -data['doppler'] / fc * 299792458.0
-        spent = time.time() - stamp
+        spent = part['time_device'] + (time.time() - t0)
         self.computeMATime(spent)
         data['time_ms'] = spent * 1e3
         data['rate_ksps'] = self.samplesPerSlice / spent / 1000
         data['rate_ksps_avg'] = self.samplesPerSlice / self.timeMA / 1000
-        raw[:self.overlap] = raw[-self.overlap:]      # overlap carry for the next block
-        self.count += 1
         return data
 
     def run_stream(self, chunk_source, sink=None, decoder=None, pipelined=False):

@@ -219,3 +219,124 @@ def allreduce_scores_host(local_scores, row_offset, num_bins_total, group=None):
     full[row_offset:row_offset + local_scores.shape[0]] = torch.from_numpy(local_scores)
     dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
     return full.numpy()
+
+
+# ---- time-chunk sharding ---------------------------------------------------------------------------------------------
+class BlockShard:
+    """Blocks dealt round-robin over the ranks (SURVEY 8e "Alternative"; best when one GPU holds the whole bin table):
+    rank r runs the device stages (forward FFT, Doppler search, pick, matched filters at the found shift, symbol
+    decisions: A3..A11) of blocks r, r + G, ...; the ROOT runs the sequential host stages -- bit lookup, alignment
+    against the previous block (reference demodulator_base.py:977-979), the decoder with its overlap buffer (reference
+    decoder.py:89-90) -- strictly in block order on what the owners hand back.  No collective on the data path: one
+    point-to-point message per block (symbol decisions, a few hundred KiB at most), in block order.
+
+    Every rank reads the same sample stream (in the reference any number of processes may subscribe to the SDR's ZeroMQ
+    publisher, pyCuSDR.py:245-251 starts one Demodulator_process per radio on it); a rank copies only the overlap tail of
+    the blocks it does not own.  ``comm``: torch.distributed's call surface (send, recv, isend, get_rank, get_world_size);
+    ``group``: a process group whose backend moves CPU tensors (gloo) -- with an RCCL default group pass
+    ``torch.distributed.new_group(backend='gloo')``.
+    """
+    HEADER = 8          # float64: block index, doppler, doppler_std, SNR, spSym, symbols, clipped samples, device seconds
+
+    def __init__(self, rank=None, world=None, group=None, comm=None, root=0):
+        import torch
+        if comm is None:
+            import torch.distributed as comm
+        self.torch, self.dist, self.group = torch, comm, group
+        self.rank = comm.get_rank(group) if rank is None else int(rank)
+        self.world = comm.get_world_size(group) if world is None else int(world)
+        self.root = int(root)
+        if not 0 <= self.root < self.world:
+            raise ValueError(f'root {root} outside the world of {self.world} ranks')
+        self._inflight = []
+
+    def owner(self, block_index):
+        return int(block_index) % self.world
+
+    # -- wire format: a fixed header, then one byte string (symbols int32 | centres int32 | trust int8 | clipped int64) ----
+    def pack(self, part):
+        rec = part['rec']
+        sym = np.ascontiguousarray(rec['symbols'], dtype=np.int32)
+        cen = np.ascontiguousarray(rec['centres'], dtype=np.int32)
+        tru = np.ascontiguousarray(rec['trust'], dtype=np.int8)
+        clip = np.ascontiguousarray(rec['clipped'], dtype=np.int64)
+        if not (len(sym) == len(cen) == len(tru)):
+            raise ValueError('symbol arrays of unequal length')
+        head = np.array([part['count'], part['doppler'], part['doppler_std'], part['SNR'], rec['spSym'], len(sym), len(clip),
+                         part['time_device']], dtype=np.float64)
+        body = np.concatenate((sym.view(np.uint8), cen.view(np.uint8), tru.view(np.uint8), clip.view(np.uint8)))
+        return head, body
+
+    @staticmethod
+    def unpack(head, body, timestamp):
+        S, C = int(head[5]), int(head[6])
+        sym = body[:4 * S].view(np.int32)
+        cen = body[4 * S:8 * S].view(np.int32)
+        tru = body[8 * S:9 * S].view(np.int8)
+        clip = body[9 * S:9 * S + 8 * C].view(np.int64)
+        return {'count': int(head[0]), 'timestamp': timestamp, 'doppler': float(head[1]), 'doppler_std': float(head[2]),
+                'SNR': float(head[3]), 'time_device': float(head[7]),
+                'rec': {'spSym': float(head[4]), 'symbols': sym, 'centres': cen, 'trust': tru, 'clipped': clip}}
+
+    def send_part(self, part):
+        """Owner -> root, asynchronously; at most two blocks of this rank are in flight."""
+        torch = self.torch
+        head, body = self.pack(part)
+        th, tb = torch.from_numpy(head), torch.from_numpy(body)
+        works = [self.dist.isend(th, self.root, group=self.group)]
+        if len(body):
+            works.append(self.dist.isend(tb, self.root, group=self.group))
+        self._inflight.append((works, th, tb))
+        while len(self._inflight) > 2:
+            self._wait_oldest()
+
+    def _wait_oldest(self):
+        works, _, _ = self._inflight.pop(0)
+        for w in works:
+            w.wait()
+
+    def flush(self):
+        while self._inflight:
+            self._wait_oldest()
+
+    def recv_part(self, src):
+        import time
+        torch = self.torch
+        th = torch.empty(self.HEADER, dtype=torch.float64)
+        self.dist.recv(th, src, group=self.group)
+        head = th.numpy()
+        nbytes = 9 * int(head[5]) + 8 * int(head[6])
+        tb = torch.empty(nbytes, dtype=torch.uint8)
+        if nbytes:
+            self.dist.recv(tb, src, group=self.group)
+        return self.unpack(head, tb.numpy(), time.time())
+
+    # -- the loop ------------------------------------------------------------------------------------------------------
+    def run(self, runner, sample_source, sink=None, decoder=None):
+        """Drive ``runner`` (a DemodulatorRunner on this rank's device) over the stream of new-sample slices.  Returns
+        (results, packets) on the root -- the same as ``DemodulatorRunner.run`` of one process on the whole stream -- and
+        ([], []) elsewhere."""
+        results, packets = [], []
+        for i, chunk in enumerate(sample_source):
+            own = self.owner(i) == self.rank
+            part = None
+            if own:
+                part = runner.feed_device(np.asarray(chunk, dtype=np.complex64))
+            else:
+                runner.skip_block(chunk)
+            if self.rank == self.root:
+                if not own:
+                    part = self.recv_part(self.owner(i))
+                d = runner.feed_host(part)
+                if decoder is not None:
+                    pk, _, nsync = decoder.findFrames(d['data'], 0)
+                    d['numSyncSig'] = nsync
+                    packets.extend(pk)
+                if sink is not None:
+                    sink(d)
+                else:
+                    results.append(d)
+            elif own:
+                self.send_part(part)
+        self.flush()
+        return results, packets

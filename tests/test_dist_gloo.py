@@ -236,3 +236,65 @@ def test_sharded_stream_is_contiguous_when_the_owner_changes():
     assert all(r[1] for r in res), res
     assert res[0][2] < -3000 and res[0][3] > 3000          # the carrier crossed from rank 0's bins into rank 1's
     assert res[0][4] == res[1][4] > 10000 and res[0][5] == res[1][5] == 1      # one packet, on every rank
+
+
+def _worker_blockshard(rank, world, port, q):
+    """Time-chunk sharding: rank r runs the device stages of blocks r, r + G, ...; the root runs the sequential host stages
+    and the decoder in block order.  The bit stream, the alignment state and the packets must equal those of one process
+    running the whole stream."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    import torch.distributed as dist
+    from oracle import mfbank_oracle as orc
+    from oracle_bank import OracleBank
+    import pycusdr_amd.demodulator.demodulator_base as dbm
+    from pycusdr_amd import config as cfg
+    from pycusdr_amd.decoder import Decoder
+    from pycusdr_amd.demodulator_process import DemodulatorRunner
+    from pycusdr_amd.dist import BlockShard
+    from pycusdr_amd.protocol import loadProtocol
+    dbm.MFBank = OracleBank
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    bs, ov, D = 13, 1 << 10, 8
+    N = 1 << bs
+    nblocks = 27
+    conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=D)
+    p = loadProtocol('bench_GMSK')(conf=conf)
+    sig, _ = _hopping_stream(N, ov, nblocks, np.linspace(-3000, 3000, nblocks))
+    step = N - ov
+    chunks = [sig[ov + i * step: ov + (i + 1) * step] for i in range(nblocks)]
+    shard = BlockShard()
+    run = DemodulatorRunner(conf, p, 'UHF-H')
+    run.raw[:ov] = sig[:ov]
+    res, packets = shard.run(run, chunks, decoder=Decoder({}, p, correlator=orc.sync_correlate))
+    ok = True
+    if rank == 0:
+        plain = DemodulatorRunner(conf, p, 'UHF-H')
+        plain.raw[:ov] = sig[:ov]
+        ref, ref_packets = plain.run(chunks, decoder=Decoder({}, p, correlator=orc.sync_correlate))
+        ok &= len(res) == len(ref) == nblocks
+        for a, b in zip(res, ref):
+            ok &= a['count'] == b['count'] and a['numSyncSig'] == b['numSyncSig']
+            ok &= bool(np.array_equal([a['doppler'], a['doppler_std'], a['SNR'], a['spSymEst']],
+                                      [b['doppler'], b['doppler_std'], b['SNR'], b['spSymEst']], equal_nan=True))
+            ok &= bool(np.array_equal(a['data'], b['data']) and np.array_equal(a['trust'], b['trust']))
+        ok &= bool(np.array_equal(run.demod.poswinP, plain.demod.poswinP) and np.array_equal(run.demod.posSymEnd, plain.demod.posSymEnd))
+        ok &= len(packets) == len(ref_packets) == 1 and bool(np.array_equal(packets[0].bits, ref_packets[0].bits))
+        ok &= packets[0].checkPacketData() == ref_packets[0].checkPacketData()
+    else:
+        ok &= res == [] and packets == [] and run.count == nblocks
+    q.put((rank, bool(ok), len(res)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('world', [2, 3])
+def test_block_round_robin_equals_single_process_stream(world):
+    res = _spawn(_worker_blockshard, world=world, timeout=280)
+    assert all(r[1] for r in res), res
+    assert res[0][2] == 27

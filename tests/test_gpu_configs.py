@@ -106,9 +106,9 @@ def test_c3_1024_bins_gmsk_bank(path):
     assert abs(pick['dopplerIdxlast'] - N // 4) <= np.median(np.diff(np.sort(shifts)))
 
 
-def _run_ranks(n, args, timeout=900):
+def _run_ranks(n, args, timeout=900, child='dist_child.py'):
     import re
-    child = os.path.join(ROOT, 'tests', 'children', 'dist_child.py')
+    child = os.path.join(ROOT, 'tests', 'children', child)
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
            '--master-port', str(free_port()), child] + [str(a) for a in args]
@@ -147,6 +147,15 @@ def test_two_ranks_uneven_slices_and_noise_bin_over_gloo():
     table the pick runs on (CU:550-554)."""
     res = _run_ranks(2, ['gloo', 16, 129, 1])
     assert all(q['noise_rows'] == 1 and not q['even'] for q in res)
+
+
+def test_block_round_robin_two_ranks_one_gpu():
+    """Time-chunk sharding (dist.BlockShard) with two ranks on the one device: blocks dealt round-robin, device stages on
+    the owner's handle, host stages and decoder on rank 0 in block order -- the same bit stream, alignment state and packet
+    (zero bit errors) as one process on the whole stream."""
+    res = _run_ranks(2, [15], child='block_child.py')
+    assert res[0]['blocks'] > 6
+    _run_ranks(3, [16], child='block_child.py')
 
 
 def test_c4_slices_four_gloo_ranks_full_size():
