@@ -47,7 +47,8 @@ typedef struct mfb_ctx mfb_ctx;
 
 const char *mfb_strerror(int status);
 /* Library/ABI version, bumped whenever a prototype changes. */
-int mfb_abi_version(void);   /* 2: search paths, mfb_xcorr; 3: mfb_set_search_mode, mfb_sync_find_multi */
+int mfb_abi_version(void);   /* 2: search paths, mfb_xcorr; 3: mfb_set_search_mode, mfb_sync_find_multi; 4: mfb_receive_block,
+                              * mfb_export_rows_async, mfb_sync_find_packed */
 
 /* Create a handle on HIP device `device` for blocks of N = 2^log2N samples, `num_dopplers`
  * Doppler bins plus `doppler_offset` leading noise-reference bins (DB:150-159), M matched
@@ -197,6 +198,43 @@ int mfb_get_spectrum(mfb_ctx *ctx, float *host_c64, int start, int count);
  *   findCodeRateAndPhase (CU:236-320; DB:725-726) over k in [k_offset, k_offset+k_len),
  * then synchronises and returns res = {k*, arg P[k*], |P[k*]|^2} (DB:730). */
 int mfb_demodulate(mfb_ctx *ctx, int shift, int k_offset, int k_len, float res[3]);
+/* One call per block: everything the receive loop does with a block on the device, as one stream of launches and ONE
+ * synchronisation -- uploadToGPU (DB:548-558), __findUHF's search and pick (DB:567-605), its shift interpolation (DB:609-616,
+ * float64, on the device), the spectrum windows computeSNR reads (DB:635-667), the matched filters at that shift, envelope,
+ * R2C, findCodeRateAndPhase (DB:711-730), the float64 rate/phase arithmetic (DB:733-752), the clamp and symbol count of
+ * cudaFindCentres (DB:994-999), findCentres and its three read-backs (DB:996-1006).  Results are bit-identical to the
+ * sequence mfb_upload, mfb_find_carrier, mfb_get_spectrum, mfb_demodulate, mfb_find_centres with the reference's host
+ * arithmetic in between (tests/test_gpu_block.py). */
+enum { MFB_BLOCK_SEARCH = 0, MFB_BLOCK_FIXED_SHIFT = 1 };            /* UHF: Doppler search; STX: shift = IF offset (STX.py:21-24) */
+enum { MFB_INPUT_PINNED = 0, MFB_INPUT_DEVICE = 1, MFB_INPUT_UPLOADED = 2 };
+typedef struct mfb_block_params {
+    int32_t mode;            /* MFB_BLOCK_* */
+    int32_t input;           /* MFB_INPUT_PINNED: H2D of the pinned input buffer first; _DEVICE: N complex64 at device_block;
+                              * _UPLOADED: the block was uploaded by an earlier mfb_upload* call */
+    const void *device_block;
+    int32_t fixed_shift;     /* MFB_BLOCK_FIXED_SHIFT */
+    int32_t k_offset, k_len; /* symbol-rate search window (DB:508-512) */
+    int32_t spsym_min;       /* clamp of cudaFindCentres (DB:994-995) */
+    int32_t op;              /* 0 |.|^2, 1 |re|, 2 |im| (DB:28-31) */
+    int32_t snr_window;      /* computeSNR's windowWidth (DB:618: 5) */
+    int32_t max_symbols;     /* capacity of sym / cen / mag */
+    int32_t band_capacity;   /* complex64 elements per SNR window in bands_c64 [2][band_capacity]; 0 = no windows */
+} mfb_block_params;
+typedef struct mfb_block_result {
+    float pick[2];           /* {index, metric} of findDopplerEst */
+    int32_t pick_valid;      /* 0: NaN index, the block is to be skipped (DB:625-630); shift = 0 was demodulated */
+    int32_t shift;           /* dopplerIdxlast */
+    int32_t low, high;       /* int(index), ceil(index) */
+    double frac;             /* index % 1 */
+    float cr[3];             /* {k*, arg P[k*], |P[k*]|^2} */
+    double spSym, codeOffset;/* DB:733-752 */
+    int32_t count;           /* symbols written to sym / cen / mag */
+    int32_t rate_fallback;   /* k* == 0: spSym = 10 (DB:737-740) */
+    int32_t band_len[2];     /* elements of the signal / noise window; > band_capacity: not delivered, fetch with mfb_get_spectrum */
+} mfb_block_result;
+int mfb_receive_block(mfb_ctx *ctx, const mfb_block_params *params, mfb_block_result *result, int32_t *sym, int32_t *centres,
+                      float *magnitude, float *bands_c64);
+
 /* Symbol centres on the matched-filter outputs left by mfb_demodulate.  Replaces findCentres
  * (CU:78-146) + the three memcpy_dtoh of cudaFindCentres (DB:996-1006).  Writes `count` =
  * int(N/spSym) entries (must be <= capacity) of symbol index, centre sample and fp32 magnitude. */

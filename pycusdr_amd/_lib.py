@@ -34,6 +34,21 @@ _EXC = {
 _vp, _i, _fp = C.c_void_p, C.c_int, C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
 
+
+class BlockParams(C.Structure):
+    """mfb_block_params of include/mfbank.h."""
+    _fields_ = [('mode', C.c_int32), ('input', C.c_int32), ('device_block', C.c_void_p), ('fixed_shift', C.c_int32),
+                ('k_offset', C.c_int32), ('k_len', C.c_int32), ('spsym_min', C.c_int32), ('op', C.c_int32),
+                ('snr_window', C.c_int32), ('max_symbols', C.c_int32), ('band_capacity', C.c_int32)]
+
+
+class BlockResult(C.Structure):
+    """mfb_block_result of include/mfbank.h."""
+    _fields_ = [('pick', C.c_float * 2), ('pick_valid', C.c_int32), ('shift', C.c_int32), ('low', C.c_int32), ('high', C.c_int32),
+                ('frac', C.c_double), ('cr', C.c_float * 3), ('spSym', C.c_double), ('codeOffset', C.c_double),
+                ('count', C.c_int32), ('rate_fallback', C.c_int32), ('band_len', C.c_int32 * 2)]
+
+
 # name -> (restype, argtypes); exactly the prototypes of include/mfbank.h
 PROTOTYPES = {
     'mfb_strerror': (C.c_char_p, [_i]),
@@ -64,6 +79,7 @@ PROTOTYPES = {
     'mfb_pick': (_i, [_vp, _vp, _i, _i, _fp]),
     'mfb_export_column_async': (_i, [_vp, _vp, _i]),
     'mfb_export_rows_async': (_i, [_vp, _vp, _i, _i, _i, _i]),
+    'mfb_receive_block': (_i, [_vp, C.POINTER(BlockParams), C.POINTER(BlockResult), _vp, _vp, _vp, _vp]),
     'mfb_pick_column': (_i, [_vp, _vp, _i, _i, _fp]),
     'mfb_find_carrier': (_i, [_vp, _fp]),
     'mfb_get_scores': (_i, [_vp, _vp]),

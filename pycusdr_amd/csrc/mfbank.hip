@@ -104,6 +104,9 @@ struct mfb_ctx {
     int gb_l;                 // segment length d_Gb was built for
     int search_mode;          // MFB_SEARCH_*: transforms (default) or the opt-in spectral-energy shortcut
     float *d_pow, *d_W;       // |X|^2 [N]; filter energy [R][N] (R = 1 under SUM_ALL_MASKS, else M)
+    BlockScalars *d_scal;     // mfb_receive_block: scalars computed between the stages
+    cf *d_bands;              // ... and the two spectrum windows of computeSNR, [2][band_cap]
+    int band_cap;
     bool W_valid;
     std::vector<hipEvent_t> ev[2];
     std::vector<hipEvent_t> ev_pool;
@@ -146,7 +149,7 @@ extern "C" const char *mfb_strerror(int s) {
         default: return "unknown status";
     }
 }
-extern "C" int mfb_abi_version(void) { return 3; }
+extern "C" int mfb_abi_version(void) { return 4; }
 
 static void make_twiddles(std::vector<cf> &v, int count, double denom, double stepmul) {
     v.resize(count);
@@ -292,7 +295,8 @@ static int create_impl(mfb_ctx *c) {
     const size_t nb = (size_t)c->N * sizeof(cf);
     HIPCHK(hipHostMalloc((void **)&c->h_in, nb, hipHostMallocDefault));
     memset(c->h_in, 0, nb);
-    c->back_cap = (size_t)3 * (c->N / 2) * sizeof(int) + 64;      // three arrays of at most N/2 symbol decisions
+    // three arrays of at most N/2 symbol decisions, the block scalars and the two SNR windows of mfb_receive_block
+    c->back_cap = (size_t)3 * (c->N / 2) * sizeof(int) + ((size_t)256 << 10);
     if (c->back_cap < ((size_t)64 << 10)) c->back_cap = (size_t)64 << 10;
     HIPCHK(hipHostMalloc((void **)&c->h_back, c->back_cap, hipHostMallocDefault));
     HIPCHK(dev_alloc((void **)&c->d_x, nb));
@@ -398,7 +402,7 @@ extern "C" int mfb_destroy(mfb_ctx *c) {
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     void *bufs[] = {c->d_uniq, c->d_rep, c->d_x,  c->d_X,    c->d_masks, c->d_Z,   c->d_xc,  c->d_P,   c->d_env, c->d_shifts, c->d_tw1,
                     c->d_tw2, c->d_twLo, c->d_twHi,  c->d_part, c->d_sum, c->d_res, c->d_cr,  c->d_sym,    c->d_cen, c->d_mag,
-                    c->d_G, c->d_twL, c->d_Gb, c->d_pow, c->d_W};
+                    c->d_G, c->d_twL, c->d_Gb, c->d_pow, c->d_W, c->d_scal, c->d_bands};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (c->h_in) (void)hipHostFree(c->h_in);
@@ -1273,12 +1277,9 @@ extern "C" int mfb_get_spectrum(mfb_ctx *c, float *host, int start, int count) {
     return enable_mirror(c);          // a caller that reads the spectrum once will read it again after every block
 }
 
-extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, float res[3]) {
-    if (!c || !res) return MFB_ERR_ARG;
-    if (!c->have_filters || !c->have_input) return MFB_ERR_STATE;
-    if (k_offset < 0 || k_len < 0 || k_offset + k_len > c->N) return MFB_ERR_ARG;
-    HIPCHK(hipSetDevice(c->device));
-    shift = ((shift % c->N) + c->N) % c->N;
+// A9 + A10 enqueued on the handle's stream: matched filters at one shift (a value, or -- shift_dev != nullptr -- an int the
+// device has just computed), envelope, its spectrum, windowed argmax into d_cr.  No synchronisation.
+static int demod_enqueue(mfb_ctx *c, int shift, const int *shift_dev, int k_offset, int k_len) {
     // A9: matched filters at one shift -> xc[M][N] natural order
     int rc;
     if (c->path == MFB_PATH_SEGMENT) {
@@ -1301,6 +1302,8 @@ extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, fl
         sa.dc = 1;
         sa.slot0 = 0;
         sa.nslots = ntotal;
+        sa.shifts = shift_dev;
+        sa.j0 = 0;
         sa.fixed_shift = shift;
         sa.out_off = (c->win_start + c->T - 1) & (c->N - 1);
         rc = launch_seg(c, sa, p.grid, SEG_STORE, -1);
@@ -1308,7 +1311,8 @@ extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, fl
     } else {
         P1Args a = p1_base(c);
         a.X = c->d_X;
-        a.shifts = nullptr;
+        a.shifts = shift_dev;
+        a.j0 = 0;
         a.fixed_shift = shift;
         a.dc = 1;
         const int mgroups = (c->M + c->mpb - 1) / c->mpb;
@@ -1333,9 +1337,125 @@ extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, fl
     if (rc) return rc;
     hipLaunchKernelGGL(k_code_rate, dim3(1), dim3(1024), 0, c->stream, c->d_P, c->d_cr, k_offset, k_len);
     HIPCHK(hipGetLastError());
+    return MFB_OK;
+}
+
+extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, float res[3]) {
+    if (!c || !res) return MFB_ERR_ARG;
+    if (!c->have_filters || !c->have_input) return MFB_ERR_STATE;
+    if (k_offset < 0 || k_len < 0 || k_offset + k_len > c->N) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    shift = ((shift % c->N) + c->N) % c->N;
+    int rc = demod_enqueue(c, shift, nullptr, k_offset, k_len);
+    if (rc) return rc;
     const BackPiece bp = {res, c->d_cr, 3 * sizeof(float)};
     if ((rc = read_back(c, &bp, 1))) return rc;
     c->have_xc = true;
+    return MFB_OK;
+}
+
+// ---- one call per block --------------------------------------------------------------------------------------------
+// Everything the receive loop does with one block on the device (reference demodulator_base.py:548-632 and 711-1009), as ONE
+// stream of launches and ONE synchronisation: [H2D of the pinned input buffer,] forward FFT, Doppler search, pick, shift
+// interpolation (k_block_pick), the two spectrum windows of computeSNR, matched filters at that shift, envelope, its
+// spectrum, rate/phase argmax, the float64 arithmetic behind it (k_block_rate), symbol centres -- then one packed read-back.
+extern "C" int mfb_receive_block(mfb_ctx *c, const mfb_block_params *p, mfb_block_result *r, int32_t *sym, int32_t *cen, float *mag,
+                                 float *bands_c64) {
+    if (!c || !p || !r || !sym || !cen || !mag) return MFB_ERR_ARG;
+    if (!c->have_filters || (p->mode == MFB_BLOCK_SEARCH && !c->have_shifts)) return MFB_ERR_STATE;
+    if (p->mode != MFB_BLOCK_SEARCH && p->mode != MFB_BLOCK_FIXED_SHIFT) return MFB_ERR_ARG;
+    if (p->k_offset < 0 || p->k_len < 0 || p->k_offset + p->k_len > c->N || p->spsym_min < 2 || p->op < 0 || p->op > 2 ||
+        p->max_symbols < 1 || p->snr_window < 0 || p->band_capacity < 0 || (p->band_capacity > 0 && !bands_c64))
+        return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if (!c->d_scal) HIPCHK(dev_alloc((void **)&c->d_scal, sizeof(BlockScalars)));
+    const int bcap = p->band_capacity;
+    if (bcap > c->band_cap) {
+        if (c->d_bands) HIPCHK(hipFree(c->d_bands));
+        c->d_bands = nullptr;
+        c->band_cap = 0;
+        HIPCHK(dev_alloc((void **)&c->d_bands, (size_t)2 * bcap * sizeof(cf)));
+        c->band_cap = bcap;
+    }
+    // input
+    if (p->input == MFB_INPUT_PINNED) {
+        HIPCHK(hipMemcpyAsync(c->d_x, c->h_in, (size_t)c->N * sizeof(cf), hipMemcpyHostToDevice, c->stream));
+        c->d_in = c->d_x;
+    } else if (p->input == MFB_INPUT_DEVICE) {
+        if (!p->device_block) return MFB_ERR_ARG;
+        c->d_in = (const cf *)p->device_block;
+    } else if (p->input != MFB_INPUT_UPLOADED || !c->have_input) {
+        return p->input == MFB_INPUT_UPLOADED ? MFB_ERR_STATE : MFB_ERR_ARG;
+    }
+    if (p->input != MFB_INPUT_UPLOADED) {
+        if ((rc = before_fft(c))) return rc;
+        if ((rc = forward_fft(c, c->d_in, nullptr, c->d_X))) return rc;
+        if ((rc = after_fft(c))) return rc;
+        c->have_input = true;
+        c->have_xc = false;
+    }
+    HIPCHK(hipMemsetAsync(c->d_scal, 0, sizeof(BlockScalars), c->stream));
+    const int *shift_dev = nullptr;
+    int shift = 0;
+    if (p->mode == MFB_BLOCK_SEARCH) {
+        if ((rc = mfb_search_async(c))) return rc;
+        hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, c->stream, (const float *)c->d_sum, c->d_res, c->D, c->Doff, c->M, c->sum_all);
+        hipLaunchKernelGGL(k_block_pick, dim3(1), dim3(1), 0, c->stream, (const float *)c->d_res, (const int *)c->d_shifts, c->Dtot, c->N,
+                           p->snr_window, c->d_scal);
+        HIPCHK(hipGetLastError());
+        if (bcap > 0) {
+            hipLaunchKernelGGL(k_block_bands, dim3((bcap + 255) / 256 < 64 ? (bcap + 255) / 256 : 64, 2), dim3(256), 0, c->stream,
+                               (const cf *)c->d_X, (const BlockScalars *)c->d_scal, c->d_bands, bcap);
+            HIPCHK(hipGetLastError());
+        }
+        shift_dev = &c->d_scal->shift;
+    } else {
+        shift = ((p->fixed_shift % c->N) + c->N) % c->N;
+    }
+    if ((rc = demod_enqueue(c, shift, shift_dev, p->k_offset, p->k_len))) return rc;
+    const int capacity = p->max_symbols < c->cap ? p->max_symbols : c->cap;
+    hipLaunchKernelGGL(k_block_rate, dim3(1), dim3(1), 0, c->stream, (const float *)c->d_cr, c->N, p->spsym_min, capacity, c->d_scal);
+    // every symbol the rate window admits (k* < k_offset + k_len  =>  count <= k_offset + k_len), bounded by the capacity;
+    // the k* == 0 fallback (spSym = 10, DB:737-740) may need more: then a second read-back below
+    int nthreads = p->k_offset + p->k_len + 1;
+    if (nthreads > capacity) nthreads = capacity;
+    const int fallback_threads = capacity < c->N / 10 + 1 ? capacity : c->N / 10 + 1;
+    const int launch_threads = nthreads > fallback_threads ? nthreads : fallback_threads;
+    hipLaunchKernelGGL(k_centres_block, dim3((launch_threads + 255) / 256), dim3(256), 0, c->stream, c->d_sym, c->d_cen, c->d_mag,
+                       (const cf *)c->d_xc, (const BlockScalars *)c->d_scal, c->N, c->M, c->W, p->op, capacity);
+    HIPCHK(hipGetLastError());
+    BlockScalars hs;
+    const BackPiece bp[5] = {{&hs, c->d_scal, sizeof(BlockScalars)},
+                             {sym, c->d_sym, (size_t)nthreads * sizeof(int)},
+                             {cen, c->d_cen, (size_t)nthreads * sizeof(int)},
+                             {mag, c->d_mag, (size_t)nthreads * sizeof(float)},
+                             {bands_c64, c->d_bands, p->mode == MFB_BLOCK_SEARCH ? (size_t)2 * bcap * sizeof(cf) : 0}};
+    if ((rc = read_back(c, bp, 5))) return rc;
+    c->have_xc = true;
+    if (hs.count > nthreads) {      // rate fallback: fetch the rest
+        const int more = hs.count - nthreads;
+        const BackPiece bq[3] = {{sym + nthreads, c->d_sym + nthreads, (size_t)more * sizeof(int)},
+                                 {cen + nthreads, c->d_cen + nthreads, (size_t)more * sizeof(int)},
+                                 {mag + nthreads, c->d_mag + nthreads, (size_t)more * sizeof(float)}};
+        if ((rc = read_back(c, bq, 3))) return rc;
+    }
+    r->pick[0] = hs.pick[0];
+    r->pick[1] = hs.pick[1];
+    r->pick_valid = hs.pick_valid;
+    r->shift = p->mode == MFB_BLOCK_SEARCH ? hs.shift : shift;
+    r->low = hs.low;
+    r->high = hs.high;
+    r->frac = hs.frac;
+    r->cr[0] = hs.cr[0];
+    r->cr[1] = hs.cr[1];
+    r->cr[2] = hs.cr[2];
+    r->spSym = hs.spSym;
+    r->codeOffset = hs.codeOffset;
+    r->count = hs.count;
+    r->rate_fallback = hs.rate_fallback;
+    r->band_len[0] = hs.band_len[0];
+    r->band_len[1] = hs.band_len[1];
     return MFB_OK;
 }
 

@@ -272,9 +272,8 @@ __global__ void k_code_rate(const cf *P, float *out, int offset, int len) {
 }
 
 // findCentres (cuda_kernels.cu:78-146); thread = symbol index.
-__global__ void k_centres(int *outSym, int *outIdx, float *mag, const cf *sig, float spSym, float offset,
-                          int lenSig, int M, int W, int op, int capacity) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+DEVI void centres_body(int *outSym, int *outIdx, float *mag, const cf *sig, float spSym, float offset, int lenSig, int M, int W, int op,
+                       int capacity, const int x) {
     if (x >= capacity) return;
     const float half = (float)(W / 2);  // WINDOW_WIDTH/2 is an integer division (demodulator_base.py:407)
     const float base = __fmaf_rn((float)x, spSym, -half);
@@ -310,4 +309,124 @@ __global__ void k_centres(int *outSym, int *outIdx, float *mag, const cf *sig, f
         outIdx[x] = INT32_MIN;
         mag[x] = 0.f;
     }
+}
+__global__ void k_centres(int *outSym, int *outIdx, float *mag, const cf *sig, float spSym, float offset,
+                          int lenSig, int M, int W, int op, int capacity) {
+    centres_body(outSym, outIdx, mag, sig, spSym, offset, lenSig, M, W, op, capacity, (int)(blockIdx.x * blockDim.x + threadIdx.x));
+}
+
+// ---- one-call block path (mfb_receive_block): the scalar host arithmetic of the receive loop, on the device ----------
+// The reference reads the pick back, interpolates the shift on the host in float64 (DB:609-620), launches the matched
+// filters, reads the rate/phase triple back, derives samples per symbol and code phase on the host in float64
+// (DB:733-752) and launches findCentres -- two round trips in the middle of a block.  Here the same float64 arithmetic,
+// operation for operation (explicit round-to-nearest intrinsics: no contraction), runs in two single-thread kernels
+// between the stages, so that a block is ONE stream of launches and one read-back.
+struct BlockScalars {
+    double frac, spSym, codeOffset;
+    float pick[2];         // {index, metric} of findDopplerEst
+    float cr[3];           // {k*, arg P[k*], |P[k*]|^2}
+    float spSymF, offsetF; // what findCentres gets (DB:999: float32 casts)
+    int shift;             // dopplerIdxlast
+    int low, high;         // int(idx), ceil(idx)
+    int pick_valid;        // 0: NaN index -> block skipped (DB:625-630), shift = 0
+    int count;             // int(N / max(spSym, spsym_min))
+    int rate_fallback;     // k* == 0 -> spSym = 10 (DB:737-740)
+    int band[2][2][2];     // SNR windows (DB:635-667): [signal | noise][piece][start, length] in the spectrum
+    int band_len[2];
+};
+
+// Python's slice(a, b).indices(N) for step 1; has_a / has_b = 0 stand for None
+DEVI void slice_indices(int has_a, int a, int has_b, int b, int N, int *start, int *len) {
+    int s = has_a ? (a < 0 ? (a + N < 0 ? 0 : a + N) : (a > N ? N : a)) : 0;
+    int e = has_b ? (b < 0 ? (b + N < 0 ? 0 : b + N) : (b > N ? N : b)) : N;
+    *start = s;
+    *len = e > s ? e - s : 0;
+}
+
+// after k_pick: shift interpolation (DB:609-616) and the spectrum windows computeSNR reads (DB:635-667)
+__global__ void k_block_pick(const float *res, const int *shifts, int Dtot, int N, int w, BlockScalars *out) {
+    if (threadIdx.x || blockIdx.x) return;
+    const float idx = res[0];
+    out->pick[0] = idx;
+    out->pick[1] = res[1];
+    out->band_len[0] = out->band_len[1] = 0;
+    for (int q = 0; q < 8; ++q) (&out->band[0][0][0])[q] = 0;
+    // int(NaN) raises in the reference (ValueError -> block skipped); +-inf cannot come out of findDopplerEst
+    if (!(idx == idx) || idx < 0.f || idx > (float)(Dtot - 1)) {
+        out->pick_valid = 0;
+        out->shift = 0;
+        out->low = out->high = 0;
+        out->frac = 0.0;
+        return;
+    }
+    const int low = (int)idx;                    // int() truncates
+    const int high = (int)ceilf(idx);
+    const double frac = (double)idx - floor((double)idx);      // float(idx) % 1 for idx >= 0: exact
+    const int s_lo = shifts[low], s_hi = shifts[high];
+    const double pos = __dadd_rn((double)s_lo, __dmul_rn((double)(s_hi - s_lo), frac));
+    out->pick_valid = 1;
+    out->low = low;
+    out->high = high;
+    out->frac = frac;
+    out->shift = (int)rint(pos);                 // np.round: half to even
+    const int half = N / 2;
+    const int lo = s_lo, hi = s_hi;
+    const int nlo = (lo + half) % N, nhi = (hi + half) % N;
+    const int ab[2][2] = {{lo, hi}, {nlo, nhi}};
+    for (int b = 0; b < 2; ++b) {
+        const int a = ab[b][0], e = ab[b][1];
+        int (*piece)[2] = out->band[b];
+        if (a > e) {         // the band wraps around 0 Hz: X[a-w:] then X[:e+w]
+            slice_indices(1, a - w, 0, 0, N, &piece[0][0], &piece[0][1]);
+            slice_indices(0, 0, 1, e + w, N, &piece[1][0], &piece[1][1]);
+        } else {
+            slice_indices(1, a - w, 1, e + w, N, &piece[0][0], &piece[0][1]);
+            piece[1][0] = piece[1][1] = 0;
+        }
+        out->band_len[b] = piece[0][1] + piece[1][1];
+    }
+}
+
+// the two SNR windows, piece after piece, into dst[band][cap] (longer bands are flagged by band_len > cap on the host)
+__global__ void k_block_bands(const cf *X, const BlockScalars *sc, cf *dst, int cap) {
+    const int b = blockIdx.y;
+    const int n0 = sc->band[b][0][1], n = n0 + sc->band[b][1][1];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n && i < cap; i += gridDim.x * blockDim.x)
+        dst[(size_t)b * cap + i] = i < n0 ? X[sc->band[b][0][0] + i] : X[sc->band[b][1][0] + (i - n0)];
+}
+
+// after k_code_rate: samples per symbol and code phase (DB:733-752), the clamp and the symbol count of cudaFindCentres
+// (DB:994-999), in float64 exactly as the host wrote them
+__global__ void k_block_rate(const float *cr, int N, int spsym_min, int capacity, BlockScalars *out) {
+    if (threadIdx.x || blockIdx.x) return;
+    out->cr[0] = cr[0];
+    out->cr[1] = cr[1];
+    out->cr[2] = cr[2];
+    const double k = (double)cr[0];
+    double spSym;
+    if (k == 0.0) {
+        spSym = 10.0;
+        out->rate_fallback = 1;
+    } else {
+        spSym = __ddiv_rn((double)N, k);
+        out->rate_fallback = 0;
+    }
+    // codeOffset = -arg / pi * spSym / 2, left to right
+    double off = __ddiv_rn(__dmul_rn(__ddiv_rn(-(double)cr[1], 3.141592653589793), spSym), 2.0);
+    if (off < 0.0) off = __dadd_rn(off, __dadd_rn(spSym, -1.0));
+    out->spSym = spSym;
+    out->codeOffset = off;
+    double sp = spSym;
+    if (sp < (double)spsym_min) sp = (double)spsym_min;
+    out->spSymF = (float)sp;
+    out->offsetF = (float)off;
+    int count = (int)__ddiv_rn((double)N, sp);
+    if (count > capacity) count = capacity;
+    out->count = count;
+}
+
+// findCentres with its two float arguments taken from the block scalars
+__global__ void k_centres_block(int *outSym, int *outIdx, float *mag, const cf *sig, const BlockScalars *sc, int lenSig, int M, int W,
+                                int op, int capacity) {
+    centres_body(outSym, outIdx, mag, sig, sc->spSymF, sc->offsetF, lenSig, M, W, op, capacity, (int)(blockIdx.x * blockDim.x + threadIdx.x));
 }

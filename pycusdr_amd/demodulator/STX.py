@@ -15,7 +15,11 @@ class Demodulator(_HostDriver):
         forward-FFT the block.  The first, second and fourth results are the constants the
         reference returns in place of a Doppler estimate."""
         self._thresholdInput(samples)
-        self.uploadToGPU(samples)
+        if self._one_call:
+            self.dopplerIdxlast = self.doppOffsetIdx
+            self._receive_block(samples, fixed_shift=int(self.doppOffsetIdx))
+        else:
+            self.uploadToGPU(samples)
         no_estimate = 0
         return no_estimate, no_estimate, self.clippedPeakIPure, no_estimate
 

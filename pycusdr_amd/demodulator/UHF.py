@@ -10,10 +10,12 @@ from .demodulator_base import Demodulator as _HostDriver
 class Demodulator(_HostDriver):
     backend = 'UHF'
 
-    def uploadAndFindCarrier(self, samples):
+    def uploadAndFindCarrier(self, samples, device_ptr=None):
         """Forward FFT of the block on the GPU, then the Doppler search.
         Returns (frequency offset in Hz, search metric, indices of clipped samples, SNR in dB)."""
-        self.uploadToGPU(samples)
+        if self._one_call:
+            return self._estimate_from_block(self._receive_block(samples, device_ptr=device_ptr))
+        self.uploadToGPU(samples, device_ptr=device_ptr)
         estimate = self._findUHF(samples)
         return estimate
 

@@ -158,6 +158,11 @@ class Demodulator:
         if shard is not None:
             shard.attach(self.bank, self.num_dopplers, self.num_masks, sum_all=self.SUM_ALL_MASKS_PYTHON, noise_rows=doff)
         self._pick_bin = 0
+        # one library call (one synchronisation) per block -- mfb_receive_block -- unless the Doppler bins are sharded over
+        # ranks (the exchange sits between search and pick) or the config asks for the stage-by-stage calls:
+        #   "HIP": {"one_call": false}
+        self._one_call = bool(hip_cfg.get('one_call', True)) and shard is None and hasattr(self.bank, 'receive_block')
+        self._pending = None
 
         # windowed argmax range of the symbol-rate estimate (reference DB:508-512)
         self.symsTolLow = 0.9 * spsym
@@ -193,9 +198,15 @@ class Demodulator:
         return self.bank.input
 
     # ---- input ---------------------------------------------------------------------------------
-    def uploadToGPU(self, samples):
+    def uploadToGPU(self, samples, device_ptr=None):
         """H2D copy + forward FFT (reference DB:548-558).  Sharded: rank 0 owns the IQ stream; its block is
-        broadcast to every rank (``samples`` is ignored on the other ranks and may be None)."""
+        broadcast to every rank (``samples`` is ignored on the other ranks and may be None).  ``device_ptr``: the block
+        already sits in device memory (N complex64 samples): no copy."""
+        if device_ptr is not None:
+            if self.shard is not None:
+                raise ValueError('device-resident blocks are not supported together with Doppler-bin sharding')
+            self.bank.upload_device(device_ptr)
+            return
         if self.shard is None:
             self.bank.upload(samples)
             return
@@ -244,6 +255,42 @@ class Demodulator:
         self.uploadToGPU(samples)
         return self._findUHF(samples)
 
+    # ---- one call per block ----------------------------------------------------------------------
+    def _receive_block(self, samples, device_ptr=None, fixed_shift=None):
+        """Everything the device does with this block in one library call; the result waits in ``_pending`` for
+        ``demodulateDevice``."""
+        if device_ptr is not None:
+            source = 'device'
+        else:
+            raw = self.bank.input
+            if samples is not raw and not (isinstance(samples, np.ndarray) and samples.ctypes.data == raw.ctypes.data
+                                           and samples.size == raw.size):
+                np.copyto(raw, np.asarray(samples, dtype=np.complex64))
+            source = 'pinned'
+        self._pending = self.bank.receive_block(self.codeRateAndPhaseOffsetHigh,
+                                                self.codeRateAndPhaseOffsetLow - self.codeRateAndPhaseOffsetHigh, self.spsymMin,
+                                                op=Operations.CENTRES_ABS.value, snr_window=5, fixed_shift=fixed_shift,
+                                                source=source, device_ptr=device_ptr)
+        return self._pending
+
+    def _estimate_from_block(self, blk):
+        """The host half of __findUHF (reference DB:604-632) on what mfb_receive_block returned: Hz interpolation, SNR,
+        the tuple the caller gets.  The shift interpolation itself ran on the device, same float64 operations."""
+        best = blk['pick']
+        if not blk['pick_valid']:       # NaN index (all-zero block): skip the block (reference DB:625-630)
+            log.error('Error occurred during find_UHF -- skipping block. Message: cannot convert float NaN to integer')
+            self.dopplerIdxlast = 0
+            return 0., 0., self.clippedPeakIPure, 0.
+        lowIdx, highIdx, frac = blk['low'], blk['high'], blk['frac']
+        self._pick_bin = lowIdx
+        lowVal, highVal = self.doppHzLUT[lowIdx], self.doppHzLUT[highIdx]
+        bestDopplerScaled = lowVal + (highVal - lowVal) * frac
+        self.dopplerIdxlast = np.int32(blk['shift'])
+        SNR = self.computeSNR(lowIdx, highIdx, 5, bands=blk['bands'])
+        freqOffset = bestDopplerScaled - self.centreFreqOffset
+        sdev_Hz = float(best[1]) / self.Nfft * self.sampleRate
+        return freqOffset, sdev_Hz, self.clippedPeakIPure, SNR
+
     # ---- Doppler search ------------------------------------------------------------------------
     def _device_search(self):
         """Device part of the search: [index, metric] as float32."""
@@ -284,8 +331,12 @@ class Demodulator:
             return np.empty(0, dtype=np.complex64)
         return self.bank.get_spectrum(start, stop - start)
 
-    def computeSNR(self, doppMatchLow, doppMatchHigh, windowWidth):
-        """Signal band vs the band half a spectrum away (reference DB:635-667)."""
+    def computeSNR(self, doppMatchLow, doppMatchHigh, windowWidth, bands=None):
+        """Signal band vs the band half a spectrum away (reference DB:635-667).  ``bands``: the two spectrum windows, if
+        the block call delivered them (the same elements, in the same order, as the slices below)."""
+        if bands is not None:
+            with np.errstate(divide='ignore', invalid='ignore'):
+                return 20 * np.log10(np.mean(np.abs(bands[0])) / np.mean(np.abs(bands[1])) - 1)
         lo = int(self.doppCyperSymNorm[doppMatchLow])
         hi = int(self.doppCyperSymNorm[doppMatchHigh])
         nlo = (lo + int(self.Nfft // 2)) % self.Nfft
@@ -337,8 +388,19 @@ class Demodulator:
         """The device half of the demodulation (reference DB:776-785, 711-752, 991-1009): matched filters at
         ``dopplerIdxlast``, symbol rate and phase, per-symbol decisions.  Nothing here depends on earlier blocks, so any
         process may run it for any block (time-chunk sharding, dist.BlockShard); the result travels as plain arrays."""
-        spSym, codeOffset = self.findCodeRateAndPhaseGPU()
-        idxSymbol, _, centres, _, _, trustSymbol = self.cudaFindCentres(spSym, codeOffset, Operations.CENTRES_ABS)
+        blk, self._pending = self._pending, None
+        if blk is not None and blk['shift'] == int(self.dopplerIdxlast):
+            # the block call already ran this stage at the shift it found (same kernels, same float64 arithmetic)
+            if blk['rate_fallback']:
+                log.error('Code rate result 0 should not happen but happened -- fixing it to 10')
+            self._codeRateResult = np.array(blk['cr'], dtype=np.float32)
+            self.magnitudes = blk['magnitudes']
+            spSym = blk['spSym']
+            idxSymbol, centres = blk['symbols'], blk['centres']
+            trustSymbol = self.magnitudes.view(TRUSTTYPE)[:len(idxSymbol)].copy()
+        else:
+            spSym, codeOffset = self.findCodeRateAndPhaseGPU()
+            idxSymbol, _, centres, _, _, trustSymbol = self.cudaFindCentres(spSym, codeOffset, Operations.CENTRES_ABS)
         return {'spSym': spSym, 'symbols': idxSymbol, 'centres': centres, 'trust': trustSymbol,
                 'clipped': np.asarray(self.clippedPeakIPure, dtype=np.int64)}
 

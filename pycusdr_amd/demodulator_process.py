@@ -68,15 +68,31 @@ class DemodulatorRunner:
     def feed(self, new_samples):
         return self.feed_host(self.feed_device(new_samples))
 
-    def feed_device(self, new_samples):
+    def feed_resident(self, device_ptr):
+        """``feed_device`` for a whole block (N complex64 samples, overlap included) that already sits in device memory
+        at ``device_ptr``: no host copy, no overlap carry."""
+        stamp = time.time()
+        part = {'count': self.count, 'timestamp': stamp}
+        part['doppler'], part['doppler_std'], _, part['SNR'] = self.demod.uploadAndFindCarrier(None, device_ptr=device_ptr)
+        if self.radioBackend != 'UHF':
+            self.demod.dopplerIdxlast = self.demod.doppOffsetIdx
+        part['rec'] = self.demod.demodulateDevice()
+        part['time_device'] = time.time() - stamp
+        self.count += 1
+        return part
+
+    def feed_device(self, new_samples=None):
         """Device half of one block (A3..A11): overlap carry, Doppler search, matched filters at the found shift, symbol
         decisions.  Carries no block-to-block state besides the overlap samples, so with time-chunk sharding
         (dist.BlockShard) any rank may run it for any block; the returned dict travels to the rank that runs
-        ``feed_host`` in block order."""
-        if len(new_samples) != self.samplesPerSlice:
-            raise ValueError(f'expected {self.samplesPerSlice} new samples per block, got {len(new_samples)}')
+        ``feed_host`` in block order.  ``new_samples`` None: the block has been assembled in ``self.raw`` already and
+        the assembler carries the overlap (run_stream)."""
         raw = self.raw
-        raw[self.overlap:] = new_samples
+        in_place = new_samples is None
+        if not in_place:
+            if len(new_samples) != self.samplesPerSlice:
+                raise ValueError(f'expected {self.samplesPerSlice} new samples per block, got {len(new_samples)}')
+            raw[self.overlap:] = new_samples
         stamp = time.time()
         part = {'count': self.count, 'timestamp': stamp}
         part['doppler'], part['doppler_std'], _, part['SNR'] = self.demod.uploadAndFindCarrier(raw)
@@ -87,7 +103,8 @@ class DemodulatorRunner:
             rec = self.demod.demodulateDevice()
         part['rec'] = rec
         part['time_device'] = time.time() - stamp
-        raw[:self.overlap] = raw[-self.overlap:]      # overlap carry for the next block
+        if not in_place:
+            raw[:self.overlap] = raw[-self.overlap:]      # overlap carry for the next block
         self.count += 1
         return part
 
@@ -124,18 +141,23 @@ class DemodulatorRunner:
 
     def run_stream(self, chunk_source, sink=None, decoder=None, pipelined=False):
         """The reference's loop shape (DP:284-338): chunks of ANY size (GNU Radio ~4096 samples, the BER bench
-        2^14) go through a SigFIFO that hands out blocks of blockSize - overlap new samples; ends when the
-        chunk source is exhausted."""
-        from .sigFIFO import SigFIFO
-        fifo = SigFIFO(chunk_source, self.samplesPerSlice)
+        2^14); ends when the chunk source is exhausted.  Sequential form: every chunk is copied once, straight into the
+        page-locked input buffer behind the carried overlap (sigFIFO.BlockAssembler), and each completed block is processed
+        in place.  Pipelined form: the stages run in threads, so blocks travel as copies through a SigFIFO."""
+        if pipelined:
+            from .sigFIFO import SigFIFO
+            fifo = SigFIFO(chunk_source, self.samplesPerSlice)
 
-        def blocks():
-            while True:
-                try:
-                    yield fifo.getBlock()
-                except TimeoutError:
-                    return
-        return self.run(blocks(), sink=sink, decoder=decoder, pipelined=pipelined)
+            def blocks():
+                while True:
+                    try:
+                        yield fifo.getBlock()
+                    except TimeoutError:
+                        return
+            return self.run(blocks(), sink=sink, decoder=decoder, pipelined=True)
+        from .sigFIFO import BlockAssembler
+        asm = BlockAssembler(self.raw, self.overlap)
+        return self.run((None for chunk in chunk_source for _ in asm.push(chunk)), sink=sink, decoder=decoder)
 
     def run(self, sample_source, sink=None, decoder=None, pipelined=False):
         """Drive the loop over an iterable of new-sample slices.  With a ``decoder`` every block's
@@ -164,8 +186,8 @@ class DemodulatorRunner:
                          d['time_ms'], self.timeMA * 1e3, d['rate_ksps'], d['rate_ksps_avg'])
 
         if not pipelined:
-            for chunk in sample_source:
-                d = self.feed(np.asarray(chunk, dtype=np.complex64))
+            for chunk in sample_source:       # None: the block sits in self.raw already (run_stream)
+                d = self.feed(None if chunk is None else np.asarray(chunk, dtype=np.complex64))
                 decode(d)
                 report(d)
             return results, packets

@@ -312,18 +312,21 @@ class BlockShard:
         return self.unpack(head, tb.numpy(), time.time())
 
     # -- the loop ------------------------------------------------------------------------------------------------------
-    def run(self, runner, sample_source, sink=None, decoder=None):
+    def run(self, runner, sample_source, sink=None, decoder=None, feed=None, skip=None):
         """Drive ``runner`` (a DemodulatorRunner on this rank's device) over the stream of new-sample slices.  Returns
         (results, packets) on the root -- the same as ``DemodulatorRunner.run`` of one process on the whole stream -- and
-        ([], []) elsewhere."""
+        ([], []) elsewhere.  ``feed(item) -> part`` / ``skip(item)`` replace ``runner.feed_device`` / ``runner.skip_block``
+        for sources that do not yield host sample slices (bench.py: blocks already resident in device memory)."""
         results, packets = [], []
+        feed = feed or (lambda c: runner.feed_device(np.asarray(c, dtype=np.complex64)))
+        skip = skip or runner.skip_block
         for i, chunk in enumerate(sample_source):
             own = self.owner(i) == self.rank
             part = None
             if own:
-                part = runner.feed_device(np.asarray(chunk, dtype=np.complex64))
+                part = feed(chunk)
             else:
-                runner.skip_block(chunk)
+                skip(chunk)
             if self.rank == self.root:
                 if not own:
                     part = self.recv_part(self.owner(i))

@@ -202,6 +202,37 @@ class MFBank:
                                               _ptr(sym), _ptr(cen), _ptr(mag)), 'mfb_find_centres')
         return sym, cen, mag
 
+    BAND_CAPACITY = 8192       # complex64 elements per SNR window delivered with the block (longer ones: get_spectrum)
+
+    def receive_block(self, k_offset, k_len, spsym_min, op=0, snr_window=5, fixed_shift=None, source='pinned', device_ptr=None):
+        """The whole device side of one block in ONE library call with one synchronisation (mfb_receive_block): upload
+        (``source``: 'pinned' = the library's input buffer, 'device' = ``device_ptr``, 'uploaded' = an earlier upload),
+        Doppler search + pick + shift interpolation (or ``fixed_shift`` for the STX back end), the spectrum windows of
+        computeSNR, matched filters, rate/phase, symbol centres.  Returns a dict of plain numbers and numpy arrays."""
+        P, R = _lib.BlockParams(), _lib.BlockResult()
+        P.mode = 0 if fixed_shift is None else 1
+        P.input = {'pinned': 0, 'device': 1, 'uploaded': 2}[source]
+        P.device_block = C.c_void_p(int(device_ptr)) if device_ptr else None
+        P.fixed_shift = 0 if fixed_shift is None else int(fixed_shift)
+        P.k_offset, P.k_len, P.spsym_min, P.op, P.snr_window = int(k_offset), int(k_len), int(spsym_min), int(op), int(snr_window)
+        cap = self.N // 2
+        if getattr(self, '_blk', None) is None:
+            self._blk = (np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty(cap, np.float32),
+                         np.empty((2, self.BAND_CAPACITY), np.complex64))
+        sym, cen, mag, bands = self._blk
+        P.max_symbols, P.band_capacity = cap, (self.BAND_CAPACITY if fixed_shift is None else 0)
+        _lib.check(self._lib.mfb_receive_block(self._h, C.byref(P), C.byref(R), _ptr(sym), _ptr(cen), _ptr(mag), _ptr(bands)),
+                   'mfb_receive_block')
+        n = R.count
+        out = {'pick': (np.float32(R.pick[0]), np.float32(R.pick[1])), 'pick_valid': bool(R.pick_valid), 'shift': int(R.shift),
+               'low': int(R.low), 'high': int(R.high), 'frac': float(R.frac),
+               'cr': (np.float32(R.cr[0]), np.float32(R.cr[1]), np.float32(R.cr[2])), 'spSym': float(R.spSym),
+               'codeOffset': float(R.codeOffset), 'rate_fallback': bool(R.rate_fallback),
+               'symbols': sym[:n].copy(), 'centres': cen[:n].copy(), 'magnitudes': mag[:n].copy(), 'bands': None}
+        if fixed_shift is None and R.band_len[0] <= self.BAND_CAPACITY and R.band_len[1] <= self.BAND_CAPACITY:
+            out['bands'] = (bands[0, :R.band_len[0]].copy(), bands[1, :R.band_len[1]].copy())
+        return out
+
     def get_xcorr(self):
         out = np.empty((self.M, self.N), dtype=np.complex64)
         _lib.check(self._lib.mfb_get_xcorr(self._h, _ptr(out)), 'mfb_get_xcorr')

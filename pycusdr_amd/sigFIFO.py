@@ -1,14 +1,23 @@
 """Fixed-size blocks out of arbitrary-size chunks: the buffer half of the reference's sigFIFO.py.
 
-``RingBuffer`` keeps the reference's semantics (sigFIFO.py:13-103, pinned by fixture G14): ``insert`` appends
-a chunk, ``popBlock(n)`` returns ``n`` samples or an empty list while fewer are buffered (:70-75).  One
-deliberate difference: a chunk that would overflow the buffer flushes it first and is then stored, which is
-what the reference's docstring and log message say (:44-54); the reference's code stores with the end index
-it computed before the flush and raises ValueError instead (recorded in G14, not reproduced).  ``SigFIFO.getBlock`` (sigFIFO.py:147-181) keeps
-feeding chunks into the ring until a block can be popped.  The reference receives the chunks from a ZeroMQ SUB
-socket (GNU Radio sends ~4096 samples at a time, the BER bench 2^14, examples/benchmark/bench_modem.py:32);
-transport is out of scope here, so the chunks come from any iterator and the end of the iterator plays the role
-of the cleared ``runStatus`` flag (``TimeoutError('Terminated')``, sigFIFO.py:167-169).
+Three pieces:
+
+* ``BlockAssembler`` -- what the streaming loop uses.  Chunks of any size are copied ONCE, straight into the block buffer
+  the device reads from (the library's page-locked input buffer) behind the overlap carried over from the previous block;
+  there is no intermediate ring.  (The reference copies every sample three times: ZeroMQ frame -> ring buffer -> popped
+  block -> page-locked buffer, sigFIFO.py:147-181 + demodulator_process.py:287.)
+* ``RingBuffer`` -- the reference's standalone class (sigFIFO.py:13-103) for callers that use it directly: same contract
+  (``insert`` appends a chunk and returns the fill level, ``popBlock(n)`` returns ``n`` samples or ``[]`` while fewer are
+  buffered, ``flush``) and the same observable state (``headIdx``, ``tailIdx``, ``currentBufSize``; pinned by fixture G14),
+  kept here as two running counters over a circular store.  One deliberate difference: a chunk that would overflow the
+  buffer flushes it first and is then stored, which is what the reference's docstring and log message say (:44-54); the
+  reference's code stores with the end index it computed before the flush and raises ValueError instead (recorded in G14,
+  not reproduced).  A single chunk larger than the whole buffer cannot be stored and raises ValueError.
+* ``SigFIFO.getBlock`` (sigFIFO.py:147-181) keeps feeding chunks into a ring until a block can be popped; chunks larger
+  than the ring go in piece by piece.  The reference receives the chunks from a ZeroMQ SUB socket (GNU Radio sends ~4096
+  samples at a time, the BER bench 2^14, examples/benchmark/bench_modem.py:32); transport is out of scope here, so the
+  chunks come from any iterator and the end of the iterator plays the role of the cleared ``runStatus`` flag
+  (``TimeoutError('Terminated')``, sigFIFO.py:167-169).
 """
 import logging
 
@@ -17,64 +26,99 @@ import numpy as np
 log = logging.getLogger('pycusdr_amd.sigFIFO')
 
 
+class BlockAssembler:
+    """Blocks assembled in place.  ``buffer``: the N-sample block buffer (overlap included); ``push(chunk)`` yields the
+    buffer every time it is complete -- the consumer must be done with it before it asks for the next one -- and carries the
+    last ``overlap`` samples to the front afterwards."""
+
+    def __init__(self, buffer, overlap):
+        if not 0 <= overlap < len(buffer):
+            raise IndexError('overlap must be shorter than the block')
+        self.buf, self.ov = buffer, int(overlap)
+        self.fill = self.ov              # the first block starts behind whatever the caller left in buffer[:overlap]
+        self.blocks = 0
+
+    def push(self, chunk):
+        chunk = np.asarray(chunk)
+        n, pos, size = len(chunk), 0, len(self.buf)
+        while pos < n:
+            take = min(n - pos, size - self.fill)
+            self.buf[self.fill:self.fill + take] = chunk[pos:pos + take]
+            self.fill += take
+            pos += take
+            if self.fill == size:
+                self.blocks += 1
+                yield self.buf
+                self.buf[:self.ov] = self.buf[size - self.ov:]
+                self.fill = self.ov
+
+
 class RingBuffer:
     def __init__(self, outLen, bufLen=None, dtype=np.complex64):
         self.outLen = outLen
         if bufLen is None:
-            self.bufLen = 10 * outLen
-        else:
-            if bufLen < outLen:
-                raise IndexError('bufLen < outLen', 'Buffer size too small for expected output size')
-            self.bufLen = bufLen
+            bufLen = 10 * outLen
+        elif bufLen < outLen:
+            raise IndexError('bufLen < outLen', 'Buffer size too small for expected output size')
+        self.bufLen = bufLen
         self.dtype = dtype
         self.buf = np.empty(self.bufLen, dtype=self.dtype)
-        self.headIdx = 0
-        self.tailIdx = 0
-        self.currentBufSize = 0
+        self._written = 0          # samples stored / consumed since the last flush
+        self._read = 0
+
+    # the reference's observable state, derived from the two counters
+    @property
+    def currentBufSize(self):
+        return self._written - self._read
+
+    @property
+    def headIdx(self):            # one past the last stored sample, in [1, bufLen] once anything was stored
+        return (self._written - 1) % self.bufLen + 1 if self._written else 0
+
+    @property
+    def tailIdx(self):
+        return self._read % self.bufLen
+
+    def _spans(self, counter, n):
+        """The one or two contiguous pieces of the store that hold positions counter ... counter + n - 1."""
+        start = counter % self.bufLen
+        first = min(n, self.bufLen - start)
+        return (start, first), (0, n - first)
 
     def insert(self, data):
         """Append a chunk; returns the number of buffered samples."""
         data = np.asarray(data)
         if data.dtype != self.dtype:
-            log.error('wrong datatype. Expected %s', self.dtype)
+            log.error('chunk of %s handed to a %s buffer: converting', data.dtype, np.dtype(self.dtype))
             data = data.astype(self.dtype)
         n = len(data)
+        if n > self.bufLen:
+            raise ValueError(f'chunk of {n} samples cannot be stored in a buffer of {self.bufLen}')
         if self.currentBufSize + n > self.bufLen:
-            log.error('buffer full: Flush')
+            log.error('chunk of %d samples does not fit beside the %d buffered ones: buffer flushed', n, self.currentBufSize)
             self.flush()
-        end = self.headIdx + n
-        if end > self.bufLen:
-            first = self.bufLen - self.headIdx
-            self.buf[self.headIdx:] = data[:first]
-            self.headIdx = n - first
-            self.buf[:self.headIdx] = data[first:]
-        else:
-            self.buf[self.headIdx:end] = data
-            self.headIdx = end
-        self.currentBufSize += n
+        (a, na), (b, nb) = self._spans(self._written, n)
+        self.buf[a:a + na] = data[:na]
+        if nb:
+            self.buf[b:b + nb] = data[na:]
+        self._written += n
         return self.currentBufSize
 
     def popBlock(self, noSamples):
         """``noSamples`` samples from the tail, or [] while fewer are buffered."""
         if self.currentBufSize < noSamples:
             return []
-        end = self.tailIdx + noSamples
-        if end > self.bufLen:
-            first = self.bufLen - self.tailIdx
-            data = np.empty(noSamples, dtype=self.dtype)
-            data[:first] = self.buf[-first:]
-            self.tailIdx = noSamples - first
-            data[first:] = self.buf[:self.tailIdx]
+        (a, na), (b, nb) = self._spans(self._read, noSamples)
+        if nb:
+            out = np.concatenate((self.buf[a:a + na], self.buf[b:b + nb]))
         else:
-            data = self.buf[self.tailIdx:end]         # a view, as in the reference: consume it before the next insert
-            self.tailIdx = 0 if end == self.bufLen else end
-        self.currentBufSize -= noSamples
-        return data
+            out = self.buf[a:a + na]        # a view, as in the reference: consume it before the next insert
+        self._read += noSamples
+        return out
 
     def flush(self):
-        self.headIdx = 0
-        self.tailIdx = 0
-        self.currentBufSize = 0
+        self._written = 0
+        self._read = 0
 
 
 class SigFIFO:
@@ -85,14 +129,22 @@ class SigFIFO:
         self.dtype = dtype
         self.source = iter(source)
         self.buf = RingBuffer(self.blockSize, bufLen=self.blockSize * 2, dtype=dtype)     # sigFIFO.py:141
+        self._rest = None          # the part of an oversized chunk that has not gone in yet
 
     def getBlock(self):
         data = self.buf.popBlock(self.blockSize)
         while len(data) == 0:
-            try:
-                chunk = next(self.source)
-            except StopIteration:
-                raise TimeoutError('Terminated') from None
-            self.buf.insert(np.asarray(chunk))
+            if self._rest is None:
+                try:
+                    self._rest = np.asarray(next(self.source))
+                except StopIteration:
+                    raise TimeoutError('Terminated') from None
+            room = self.buf.bufLen - self.buf.currentBufSize
+            if len(self._rest) <= room or (room == 0 and len(self._rest) <= self.buf.bufLen):
+                # fits -- or fits after the flush the ring does when it is full, as the reference intends
+                piece, self._rest = self._rest, None
+            else:
+                piece, self._rest = self._rest[:room], self._rest[room:]
+            self.buf.insert(piece)
             data = self.buf.popBlock(self.blockSize)
         return data

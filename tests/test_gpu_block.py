@@ -1,0 +1,128 @@
+"""mfb_receive_block -- one library call, one synchronisation per block -- against the stage-by-stage calls with the
+reference's host arithmetic in between (mfb_upload, mfb_find_carrier, mfb_get_spectrum, mfb_demodulate,
+mfb_find_centres): every number the caller sees must be identical, bit for bit.  Both paths run the same kernels; what moved
+is the float64 scalar arithmetic of DB:609-616 and DB:733-752 (now two single-thread kernels) and the read-backs."""
+import copy
+
+import numpy as np
+import pytest
+
+from pycusdr_amd import config as cfg, signals as sg
+from pycusdr_amd.demodulator import STX, UHF
+from pycusdr_amd.demodulator_process import DemodulatorRunner
+from pycusdr_amd.protocol import loadProtocol
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(conf, pname, backend=UHF):
+    p = loadProtocol(pname)(conf=conf)
+    one = backend.Demodulator(conf, p, 'UHF-H')
+    stage_conf = copy.deepcopy(conf)
+    stage_conf['GPU']['UHF'].setdefault('HIP', {})['one_call'] = False
+    stages = backend.Demodulator(stage_conf, p, 'UHF-H')
+    assert one._one_call and not stages._one_call
+    return one, stages
+
+
+def _same(a, b):
+    return bool(np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True))
+
+
+@pytest.mark.parametrize('mod,pname,bs,D', [('GMSK', 'bench_GMSK', 15, 64), ('FSK', 'bench_FSK', 16, 33), ('GFSK', 'bench_GFSK', 14, 16),
+                                            ('BPSK', 'bench_BPSK', 16, 40), ('GMSK', 'bench_GMSK', 18, 256)])
+def test_one_call_equals_stage_by_stage(mod, pname, bs, D):
+    N, ov = 1 << bs, 1 << 10
+    conf = cfg.bench_config(pname, blockSize=bs, doppCarrierSteps=D)
+    one, stages = _pair(conf, pname)
+    sig = sg.s1_stream(5, N, ov, mod, snr_db=9.0, seed=11)
+    sig[2 * (N - ov) + ov: 3 * (N - ov) + ov] = 0         # an all-zero stretch: NaN index, block skipped (DB:625-630)
+    try:
+        for b in range(5):
+            x = sig[b * (N - ov): b * (N - ov) + N]
+            raw = one.get_signalBufferHostPointer()        # the caller's usual way: fill the page-locked buffer in place
+            raw[:] = x
+            ra = one.uploadAndFindCarrier(raw)
+            rb = stages.uploadAndFindCarrier(x.copy())
+            assert _same([ra[0], ra[1], ra[3]], [rb[0], rb[1], rb[3]]), (b, ra, rb)
+            assert int(one.dopplerIdxlast) == int(stages.dopplerIdxlast)
+            assert np.array_equal(one.bank.get_scores(), stages.bank.get_scores())
+            da, db = one.demodulate(), stages.demodulate()
+            assert all(_same(u, v) for u, v in zip(da[:3], db[:3])) and _same(da[3], db[3]), b
+            assert _same(one._codeRateResult, stages._codeRateResult) and _same(one.magnitudes[:len(stages.magnitudes)], stages.magnitudes)
+            assert _same(one.poswinP, stages.poswinP) and _same(one.posSymEnd, stages.posSymEnd)
+    finally:
+        one.close()
+        stages.close()
+
+
+def test_one_call_with_noise_bin_wrapped_band_and_long_filters():
+    """CC11xx geometry (IF offset 148.32 kHz, 128 samples per symbol, 384-tap filters: L = 4096 segments) with the
+    noise-reference bin in front of the table (DB:148-159): the metric divides by its score (CU:550-554)."""
+    from pycusdr_amd.protocol.CC11xx import frame_bits
+    bs, sps = 17, 128
+    N = 1 << bs
+    conf = cfg.cc11xx_config(blockSize=bs, doppCarrierSteps=48, samplesPerSym=sps)
+    conf['Radios']['Rx']['UHF-H']['noise_measure_offset_Hz'] = 300000
+    one, stages = _pair(conf, 'CC11xx')
+    rs = np.random.RandomState(4)
+    fs = 7416 * sps
+    bits = np.concatenate([frame_bits(rs.randint(0, 256, 60).astype(np.uint8), preamble=(0xAA,) * 10) for _ in range(4)])
+    sig = sg.modulateFSK(bits, sps)[:3 * N]
+    sig = sg.awgn(sig * np.exp(2j * np.pi * 148320 / fs * np.arange(len(sig))), 12.0, rng=np.random.RandomState(2)).astype(np.complex64)
+    try:
+        assert one.doppIdxArrayOffset == 1
+        for b in range(2):
+            x = sig[b * (N - 1024): b * (N - 1024) + N]
+            ra, rb = one.uploadAndFindCarrier(x.copy()), stages.uploadAndFindCarrier(x.copy())
+            assert _same([ra[0], ra[1], ra[3]], [rb[0], rb[1], rb[3]])
+            da, db = one.demodulate(), stages.demodulate()
+            assert all(_same(u, v) for u, v in zip(da, db)) and len(da[0]) > 900
+    finally:
+        one.close()
+        stages.close()
+
+
+def test_one_call_stx_fixed_shift_and_clipping():
+    bs = 15
+    N = 1 << bs
+    conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=8)
+    conf['GPU']['UHF']['peakThresholdScale'] = 4.5
+    one, stages = _pair(conf, 'bench_GMSK', backend=STX)
+    x = sg.s1_stream(2, N, 1 << 10, 'GMSK', snr_db=15.0, seed=2)[20000:20000 + N].copy()
+    x[5000] *= 300
+    x[5040] *= 200
+    try:
+        xa, xb = x.copy(), x.copy()
+        assert one.uploadAndFindCarrier(xa)[:2] == stages.uploadAndFindCarrier(xb)[:2] == (0, 0)
+        assert np.array_equal(xa, xb) and len(one.clippedPeakIPure) >= 2
+        da, db = one.demodulate(), stages.demodulate()
+        assert all(_same(u, v) for u, v in zip(da, db)) and (da[2] == 254).any()       # trust -2 next to the clipped peaks
+    finally:
+        one.close()
+        stages.close()
+
+
+def test_runner_stream_in_place_assembly_equals_ring_buffer_path():
+    """run_stream assembles blocks directly in the page-locked input buffer from chunks of any size (one copy per sample):
+    the same result dicts as feeding whole slices."""
+    bs, ov = 15, 1 << 10
+    N = 1 << bs
+    conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=32)
+    p = loadProtocol('bench_GMSK')(conf=conf)
+    sig = sg.s1_stream(6, N, ov, 'GMSK', snr_db=10.0, seed=5)[ov:]
+    step = N - ov
+    a, b = DemodulatorRunner(conf, p, 'UHF-H'), DemodulatorRunner(conf, p, 'UHF-H')
+    try:
+        ra, _ = a.run([sig[i * step:(i + 1) * step] for i in range(6)])
+        for chunk in (4096, 16384, 1000, 3 * step + 17):
+            b2 = DemodulatorRunner(conf, p, 'UHF-H')
+            rb, _ = b2.run_stream((sig[i:i + chunk] for i in range(0, 6 * step, chunk)))
+            b2.close()
+            assert len(rb) == 6
+            for u, v in zip(ra, rb):
+                assert u['count'] == v['count'] and _same(u['data'], v['data']) and _same(u['trust'], v['trust'])
+                assert _same([u['doppler'], u['SNR'], u['spSymEst']], [v['doppler'], v['SNR'], v['spSymEst']])
+    finally:
+        a.close()
+        b.close()

@@ -154,3 +154,33 @@ def test_sigfifo_blocks_from_arbitrary_chunks():
             while True:
                 got.append(np.array(fifo.getBlock()))
         assert len(got) == len(x) // 15360 and np.array_equal(np.concatenate(got), x[:len(got) * 15360])
+
+
+def test_oversized_chunks_and_block_assembler():
+    """Chunks larger than the ring (2 blocks) go through SigFIFO piece by piece; the ring itself refuses what it cannot hold
+    (the reference raises ValueError there too); BlockAssembler builds the same blocks in place with the overlap carried."""
+    from pycusdr_amd.sigFIFO import BlockAssembler, RingBuffer, SigFIFO
+    rs = np.random.RandomState(8)
+    x = (rs.standard_normal(200000) + 1j * rs.standard_normal(200000)).astype(np.complex64)
+    for chunk in (65536, 31745, 30720, 100000):
+        fifo = SigFIFO((x[i:i + chunk] for i in range(0, len(x), chunk)), 15360)
+        got = []
+        with pytest.raises(TimeoutError):
+            while True:
+                got.append(np.array(fifo.getBlock()))
+        assert len(got) == len(x) // 15360 and np.array_equal(np.concatenate(got), x[:len(got) * 15360])
+    with pytest.raises(ValueError):
+        RingBuffer(100, bufLen=200).insert(np.zeros(201, np.complex64))
+    N, ov = 4096, 256
+    for chunk in (1000, 4096, 3840, 9001, 17):
+        buf = np.zeros(N, np.complex64)
+        buf[:ov] = x[:ov]
+        asm = BlockAssembler(buf, ov)
+        nb = 0
+        for i in range(ov, 60000, chunk):
+            for blk in asm.push(x[i:min(i + chunk, 60000)]):
+                assert blk is buf and np.array_equal(blk, x[nb * (N - ov): nb * (N - ov) + N])
+                nb += 1
+        assert nb == asm.blocks == (60000 - ov) // (N - ov)
+    with pytest.raises(IndexError):
+        BlockAssembler(np.zeros(8, np.complex64), 8)
