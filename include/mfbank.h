@@ -206,10 +206,10 @@ int mfb_demodulate(mfb_ctx *ctx, int shift, int k_offset, int k_len, float res[3
  * sequence mfb_upload, mfb_find_carrier, mfb_get_spectrum, mfb_demodulate, mfb_find_centres with the reference's host
  * arithmetic in between (tests/test_gpu_block.py). */
 enum { MFB_BLOCK_SEARCH = 0, MFB_BLOCK_FIXED_SHIFT = 1 };            /* UHF: Doppler search; STX: shift = IF offset (STX.py:21-24) */
-enum { MFB_INPUT_PINNED = 0, MFB_INPUT_DEVICE = 1, MFB_INPUT_UPLOADED = 2 };
+enum { MFB_INPUT_PINNED = 0, MFB_INPUT_DEVICE = 1, MFB_INPUT_UPLOADED = 2, MFB_INPUT_PINNED2 = 3 };
 typedef struct mfb_block_params {
     int32_t mode;            /* MFB_BLOCK_* */
-    int32_t input;           /* MFB_INPUT_PINNED: H2D of the pinned input buffer first; _DEVICE: N complex64 at device_block;
+    int32_t input;           /* MFB_INPUT_PINNED(2): H2D of the (second) pinned input buffer first; _DEVICE: N complex64 at device_block;
                               * _UPLOADED: the block was uploaded by an earlier mfb_upload* call */
     const void *device_block;
     int32_t fixed_shift;     /* MFB_BLOCK_FIXED_SHIFT */
@@ -234,6 +234,15 @@ typedef struct mfb_block_result {
 } mfb_block_result;
 int mfb_receive_block(mfb_ctx *ctx, const mfb_block_params *params, mfb_block_result *result, int32_t *sym, int32_t *centres,
                       float *magnitude, float *bands_c64);
+/* The same in two halves, so that the caller's sequential host stages of block i-1 (and the assembly of block i+1 in the
+ * other input buffer) run while the device works on block i: _begin enqueues everything including the read-back into
+ * page-locked staging and returns at once; _end waits for that block and hands its results out.  Two blocks may be in
+ * flight (slot 0 / 1); they execute in the order they were begun.  mfb_input_buffer2 is the second page-locked input
+ * buffer (MFB_INPUT_PINNED2).  The reference has no counterpart: its loop is strictly one block at a time (DP:284-338). */
+int mfb_receive_block_begin(mfb_ctx *ctx, const mfb_block_params *params, int slot);
+int mfb_receive_block_end(mfb_ctx *ctx, int slot, mfb_block_result *result, int32_t *sym, int32_t *centres, float *magnitude,
+                          float *bands_c64);
+int mfb_input_buffer2(mfb_ctx *ctx, float **host_c64);
 
 /* Symbol centres on the matched-filter outputs left by mfb_demodulate.  Replaces findCentres
  * (CU:78-146) + the three memcpy_dtoh of cudaFindCentres (DB:996-1006).  Writes `count` =

@@ -80,6 +80,9 @@ PROTOTYPES = {
     'mfb_export_column_async': (_i, [_vp, _vp, _i]),
     'mfb_export_rows_async': (_i, [_vp, _vp, _i, _i, _i, _i]),
     'mfb_receive_block': (_i, [_vp, C.POINTER(BlockParams), C.POINTER(BlockResult), _vp, _vp, _vp, _vp]),
+    'mfb_receive_block_begin': (_i, [_vp, C.POINTER(BlockParams), _i]),
+    'mfb_receive_block_end': (_i, [_vp, _i, C.POINTER(BlockResult), _vp, _vp, _vp, _vp]),
+    'mfb_input_buffer2': (_i, [_vp, C.POINTER(_fp)]),
     'mfb_pick_column': (_i, [_vp, _vp, _i, _i, _fp]),
     'mfb_find_carrier': (_i, [_vp, _fp]),
     'mfb_get_scores': (_i, [_vp, _vp]),

@@ -52,6 +52,13 @@
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+struct BlockFlight {      // one block between mfb_receive_block_begin and _end
+    bool active;
+    int mode, nthreads, bcap, shift;
+    size_t off[5];
+    unsigned long long seq;
+};
+
 struct mfb_ctx {
     int device;
     int log2N, N, N1, N2, l1, l2, lo;
@@ -104,6 +111,12 @@ struct mfb_ctx {
     int gb_l;                 // segment length d_Gb was built for
     int search_mode;          // MFB_SEARCH_*: transforms (default) or the opt-in spectral-energy shortcut
     float *d_pow, *d_W;       // |X|^2 [N]; filter energy [R][N] (R = 1 under SUM_ALL_MASKS, else M)
+    cf *h_in2;                // second page-locked input buffer (blocks in flight alternate between the two)
+    uint8_t *h_blk[2];        // page-locked staging of the two block flights
+    size_t blk_cap[2];
+    hipEvent_t ev_blk[2];
+    BlockFlight flight[2];
+    unsigned long long blk_seq;
     BlockScalars *d_scal;     // mfb_receive_block: scalars computed between the stages
     cf *d_bands;              // ... and the two spectrum windows of computeSNR, [2][band_cap]
     int band_cap;
@@ -120,6 +133,8 @@ struct mfb_ctx {
             return (e_ == hipErrorOutOfMemory) ? MFB_ERR_ALLOC : MFB_ERR_HIP;               \
         }                                                                                    \
     } while (0)
+
+static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // Device allocations of a handle go through dev_alloc so that a test can make the n-th one fail
 // (mfb_debug_fail_alloc): the only way to exercise the free-on-error path of mfb_create without driving
@@ -406,6 +421,11 @@ extern "C" int mfb_destroy(mfb_ctx *c) {
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (c->h_in) (void)hipHostFree(c->h_in);
+    if (c->h_in2) (void)hipHostFree(c->h_in2);
+    for (int i = 0; i < 2; ++i) {
+        if (c->h_blk[i]) (void)hipHostFree(c->h_blk[i]);
+        if (c->ev_blk[i]) (void)hipEventDestroy(c->ev_blk[i]);
+    }
     if (c->h_back) (void)hipHostFree(c->h_back);
     if (c->h_X) (void)hipHostFree(c->h_X);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -1359,28 +1379,46 @@ extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, fl
 // stream of launches and ONE synchronisation: [H2D of the pinned input buffer,] forward FFT, Doppler search, pick, shift
 // interpolation (k_block_pick), the two spectrum windows of computeSNR, matched filters at that shift, envelope, its
 // spectrum, rate/phase argmax, the float64 arithmetic behind it (k_block_rate), symbol centres -- then one packed read-back.
-extern "C" int mfb_receive_block(mfb_ctx *c, const mfb_block_params *p, mfb_block_result *r, int32_t *sym, int32_t *cen, float *mag,
-                                 float *bands_c64) {
-    if (!c || !p || !r || !sym || !cen || !mag) return MFB_ERR_ARG;
+// Enqueue: everything up to and including the device-to-host copies into the flight's page-locked staging; no wait.
+static int block_begin(mfb_ctx *c, const mfb_block_params *p, int slot) {
+    if (!c || !p || slot < 0 || slot > 1) return MFB_ERR_ARG;
     if (!c->have_filters || (p->mode == MFB_BLOCK_SEARCH && !c->have_shifts)) return MFB_ERR_STATE;
     if (p->mode != MFB_BLOCK_SEARCH && p->mode != MFB_BLOCK_FIXED_SHIFT) return MFB_ERR_ARG;
     if (p->k_offset < 0 || p->k_len < 0 || p->k_offset + p->k_len > c->N || p->spsym_min < 2 || p->op < 0 || p->op > 2 ||
-        p->max_symbols < 1 || p->snr_window < 0 || p->band_capacity < 0 || (p->band_capacity > 0 && !bands_c64))
+        p->max_symbols < 1 || p->snr_window < 0 || p->band_capacity < 0)
         return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
+    BlockFlight &f = c->flight[slot];
+    if (f.active) return MFB_ERR_STATE;          // its results have not been collected
     int rc;
     if (!c->d_scal) HIPCHK(dev_alloc((void **)&c->d_scal, sizeof(BlockScalars)));
     const int bcap = p->band_capacity;
     if (bcap > c->band_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));
         if (c->d_bands) HIPCHK(hipFree(c->d_bands));
         c->d_bands = nullptr;
         c->band_cap = 0;
         HIPCHK(dev_alloc((void **)&c->d_bands, (size_t)2 * bcap * sizeof(cf)));
         c->band_cap = bcap;
     }
+    const int capacity = p->max_symbols < c->cap ? p->max_symbols : c->cap;
+    // every symbol the rate window admits (k* < k_offset + k_len  =>  count <= k_offset + k_len), bounded by the capacity
+    int nthreads = p->k_offset + p->k_len + 1;
+    if (nthreads > capacity) nthreads = capacity;
+    const size_t need = align16(sizeof(BlockScalars)) + 3 * align16((size_t)nthreads * sizeof(int)) + align16((size_t)2 * bcap * sizeof(cf));
+    if (need > c->blk_cap[slot]) {
+        if (c->h_blk[slot]) HIPCHK(hipHostFree(c->h_blk[slot]));
+        c->h_blk[slot] = nullptr;
+        c->blk_cap[slot] = 0;
+        HIPCHK(hipHostMalloc((void **)&c->h_blk[slot], need, hipHostMallocDefault));
+        c->blk_cap[slot] = need;
+    }
+    if (!c->ev_blk[slot]) HIPCHK(hipEventCreateWithFlags(&c->ev_blk[slot], hipEventDisableTiming));
     // input
-    if (p->input == MFB_INPUT_PINNED) {
-        HIPCHK(hipMemcpyAsync(c->d_x, c->h_in, (size_t)c->N * sizeof(cf), hipMemcpyHostToDevice, c->stream));
+    if (p->input == MFB_INPUT_PINNED || p->input == MFB_INPUT_PINNED2) {
+        const cf *src = p->input == MFB_INPUT_PINNED ? c->h_in : c->h_in2;
+        if (!src) return MFB_ERR_STATE;
+        HIPCHK(hipMemcpyAsync(c->d_x, src, (size_t)c->N * sizeof(cf), hipMemcpyHostToDevice, c->stream));
         c->d_in = c->d_x;
     } else if (p->input == MFB_INPUT_DEVICE) {
         if (!p->device_block) return MFB_ERR_ARG;
@@ -1414,36 +1452,70 @@ extern "C" int mfb_receive_block(mfb_ctx *c, const mfb_block_params *p, mfb_bloc
         shift = ((p->fixed_shift % c->N) + c->N) % c->N;
     }
     if ((rc = demod_enqueue(c, shift, shift_dev, p->k_offset, p->k_len))) return rc;
-    const int capacity = p->max_symbols < c->cap ? p->max_symbols : c->cap;
     hipLaunchKernelGGL(k_block_rate, dim3(1), dim3(1), 0, c->stream, (const float *)c->d_cr, c->N, p->spsym_min, capacity, c->d_scal);
-    // every symbol the rate window admits (k* < k_offset + k_len  =>  count <= k_offset + k_len), bounded by the capacity;
-    // the k* == 0 fallback (spSym = 10, DB:737-740) may need more: then a second read-back below
-    int nthreads = p->k_offset + p->k_len + 1;
-    if (nthreads > capacity) nthreads = capacity;
+    // the k* == 0 fallback (spSym = 10, DB:737-740; unreachable while the rate window starts above bin 0) may need more threads
     const int fallback_threads = capacity < c->N / 10 + 1 ? capacity : c->N / 10 + 1;
     const int launch_threads = nthreads > fallback_threads ? nthreads : fallback_threads;
     hipLaunchKernelGGL(k_centres_block, dim3((launch_threads + 255) / 256), dim3(256), 0, c->stream, c->d_sym, c->d_cen, c->d_mag,
                        (const cf *)c->d_xc, (const BlockScalars *)c->d_scal, c->N, c->M, c->W, p->op, capacity);
     HIPCHK(hipGetLastError());
-    BlockScalars hs;
-    const BackPiece bp[5] = {{&hs, c->d_scal, sizeof(BlockScalars)},
-                             {sym, c->d_sym, (size_t)nthreads * sizeof(int)},
-                             {cen, c->d_cen, (size_t)nthreads * sizeof(int)},
-                             {mag, c->d_mag, (size_t)nthreads * sizeof(float)},
-                             {bands_c64, c->d_bands, p->mode == MFB_BLOCK_SEARCH ? (size_t)2 * bcap * sizeof(cf) : 0}};
-    if ((rc = read_back(c, bp, 5))) return rc;
+    // one packed read-back into this flight's staging
+    uint8_t *h = c->h_blk[slot];
+    size_t off = 0;
+    const void *src[5] = {c->d_scal, c->d_sym, c->d_cen, c->d_mag, c->d_bands};
+    const size_t len[5] = {sizeof(BlockScalars), (size_t)nthreads * sizeof(int), (size_t)nthreads * sizeof(int), (size_t)nthreads * sizeof(float),
+                           p->mode == MFB_BLOCK_SEARCH ? (size_t)2 * bcap * sizeof(cf) : 0};
+    for (int i = 0; i < 5; ++i) {
+        f.off[i] = off;
+        if (len[i]) HIPCHK(hipMemcpyAsync(h + off, src[i], len[i], hipMemcpyDeviceToHost, c->stream));
+        off += align16(len[i]);
+    }
+    HIPCHK(hipEventRecord(c->ev_blk[slot], c->stream));
+    f.active = true;
+    f.mode = p->mode;
+    f.nthreads = nthreads;
+    f.bcap = bcap;
+    f.shift = shift;
+    f.seq = ++c->blk_seq;
     c->have_xc = true;
-    if (hs.count > nthreads) {      // rate fallback: fetch the rest
-        const int more = hs.count - nthreads;
-        const BackPiece bq[3] = {{sym + nthreads, c->d_sym + nthreads, (size_t)more * sizeof(int)},
-                                 {cen + nthreads, c->d_cen + nthreads, (size_t)more * sizeof(int)},
-                                 {mag + nthreads, c->d_mag + nthreads, (size_t)more * sizeof(float)}};
-        if ((rc = read_back(c, bq, 3))) return rc;
+    return MFB_OK;
+}
+
+// Collect: wait for the flight's event, hand the results out.
+static int block_end(mfb_ctx *c, int slot, mfb_block_result *r, int32_t *sym, int32_t *cen, float *mag, float *bands_c64) {
+    if (!c || slot < 0 || slot > 1 || !r || !sym || !cen || !mag) return MFB_ERR_ARG;
+    BlockFlight &f = c->flight[slot];
+    if (!f.active) return MFB_ERR_STATE;
+    if (f.bcap > 0 && f.mode == MFB_BLOCK_SEARCH && !bands_c64) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventSynchronize(c->ev_blk[slot]));
+    f.active = false;
+    const uint8_t *h = c->h_blk[slot];
+    BlockScalars hs;
+    memcpy(&hs, h + f.off[0], sizeof(hs));
+    int n = hs.count;
+    if (n > f.nthreads) {            // rate fallback: the rest is still on the device -- unless a later block has overwritten it
+        if (c->blk_seq != f.seq) return MFB_ERR_UNSUPPORTED;
+        const int more = n - f.nthreads;
+        const BackPiece bq[3] = {{sym + f.nthreads, c->d_sym + f.nthreads, (size_t)more * sizeof(int)},
+                                 {cen + f.nthreads, c->d_cen + f.nthreads, (size_t)more * sizeof(int)},
+                                 {mag + f.nthreads, c->d_mag + f.nthreads, (size_t)more * sizeof(float)}};
+        const int rc = read_back(c, bq, 3);
+        if (rc) return rc;
+        n = f.nthreads;
+    }
+    memcpy(sym, h + f.off[1], (size_t)n * sizeof(int));
+    memcpy(cen, h + f.off[2], (size_t)n * sizeof(int));
+    memcpy(mag, h + f.off[3], (size_t)n * sizeof(float));
+    if (f.mode == MFB_BLOCK_SEARCH && f.bcap > 0) {
+        const int l0 = hs.band_len[0] < f.bcap ? hs.band_len[0] : f.bcap, l1 = hs.band_len[1] < f.bcap ? hs.band_len[1] : f.bcap;
+        memcpy(bands_c64, h + f.off[4], (size_t)l0 * sizeof(cf));
+        memcpy(bands_c64 + (size_t)2 * f.bcap, h + f.off[4] + (size_t)f.bcap * sizeof(cf), (size_t)l1 * sizeof(cf));
     }
     r->pick[0] = hs.pick[0];
     r->pick[1] = hs.pick[1];
     r->pick_valid = hs.pick_valid;
-    r->shift = p->mode == MFB_BLOCK_SEARCH ? hs.shift : shift;
+    r->shift = f.mode == MFB_BLOCK_SEARCH ? hs.shift : f.shift;
     r->low = hs.low;
     r->high = hs.high;
     r->frac = hs.frac;
@@ -1456,6 +1528,30 @@ extern "C" int mfb_receive_block(mfb_ctx *c, const mfb_block_params *p, mfb_bloc
     r->rate_fallback = hs.rate_fallback;
     r->band_len[0] = hs.band_len[0];
     r->band_len[1] = hs.band_len[1];
+    return MFB_OK;
+}
+
+extern "C" int mfb_receive_block_begin(mfb_ctx *c, const mfb_block_params *p, int slot) { return block_begin(c, p, slot); }
+extern "C" int mfb_receive_block_end(mfb_ctx *c, int slot, mfb_block_result *r, int32_t *sym, int32_t *cen, float *mag, float *bands_c64) {
+    return block_end(c, slot, r, sym, cen, mag, bands_c64);
+}
+extern "C" int mfb_receive_block(mfb_ctx *c, const mfb_block_params *p, mfb_block_result *r, int32_t *sym, int32_t *cen, float *mag,
+                                 float *bands_c64) {
+    if (!c || !p || !r || !sym || !cen || !mag || (p->band_capacity > 0 && p->mode == MFB_BLOCK_SEARCH && !bands_c64)) return MFB_ERR_ARG;
+    if (c->flight[0].active) return MFB_ERR_STATE;
+    const int rc = block_begin(c, p, 0);
+    if (rc) return rc;
+    return block_end(c, 0, r, sym, cen, mag, bands_c64);
+}
+
+extern "C" int mfb_input_buffer2(mfb_ctx *c, float **p) {
+    if (!c || !p) return MFB_ERR_ARG;
+    if (!c->h_in2) {
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipHostMalloc((void **)&c->h_in2, (size_t)c->N * sizeof(cf), hipHostMallocDefault));
+        memset(c->h_in2, 0, (size_t)c->N * sizeof(cf));
+    }
+    *p = (float *)c->h_in2;
     return MFB_OK;
 }
 
@@ -1590,7 +1686,6 @@ extern "C" int mfb_sync_correlate(int device, const uint8_t *bits, int B, int L,
     return MFB_OK;
 }
 
-static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // K templates against the same B bit streams; template t: T[t] taps at tmpls + sum(T[0..t)), threshold thr[t];
 // its results sit at counts + t*B, hit_idx / hit_score + t*B*max_hits.

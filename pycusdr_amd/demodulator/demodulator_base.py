@@ -273,6 +273,23 @@ class Demodulator:
                                                 source=source, device_ptr=device_ptr)
         return self._pending
 
+    def beginBlock(self, slot, source='pinned', fixed_shift=None):
+        """Enqueue the whole device side of the block assembled in input buffer ``source`` ('pinned' / 'pinned2') and
+        return at once; ``endBlock(slot)`` collects it.  Lets the caller run the sequential host stages of the previous
+        block (and assemble the next one in the other buffer) while the device works -- the blocks themselves still
+        execute, and are collected, strictly in order."""
+        self.bank.begin_block(slot, self.codeRateAndPhaseOffsetHigh, self.codeRateAndPhaseOffsetLow - self.codeRateAndPhaseOffsetHigh,
+                              self.spsymMin, op=Operations.CENTRES_ABS.value, snr_window=5, fixed_shift=fixed_shift, source=source)
+
+    def endBlock(self, slot):
+        """(freqOffset_Hz, metric, clippedPeakIdx, SNR_dB) of the block begun in ``slot`` -- what ``uploadAndFindCarrier``
+        returns -- with its symbol decisions waiting for ``demodulateDevice``."""
+        self._pending = self.bank.end_block(slot)
+        if self.backend == 'UHF':
+            return self._estimate_from_block(self._pending)
+        self.dopplerIdxlast = self.doppOffsetIdx
+        return 0, 0, self.clippedPeakIPure, 0
+
     def _estimate_from_block(self, blk):
         """The host half of __findUHF (reference DB:604-632) on what mfb_receive_block returned: Hz interpolation, SNR,
         the tuple the caller gets.  The shift interpolation itself ran on the device, same float64 operations."""

@@ -139,11 +139,12 @@ class DemodulatorRunner:
         data['rate_ksps_avg'] = self.samplesPerSlice / self.timeMA / 1000
         return data
 
-    def run_stream(self, chunk_source, sink=None, decoder=None, pipelined=False):
+    def run_stream(self, chunk_source, sink=None, decoder=None, pipelined=False, overlapped=True):
         """The reference's loop shape (DP:284-338): chunks of ANY size (GNU Radio ~4096 samples, the BER bench
         2^14); ends when the chunk source is exhausted.  Sequential form: every chunk is copied once, straight into the
         page-locked input buffer behind the carried overlap (sigFIFO.BlockAssembler), and each completed block is processed
-        in place.  Pipelined form: the stages run in threads, so blocks travel as copies through a SigFIFO."""
+        in place; by default the device side of block i also overlaps the host stages of block i-1 (``overlapped``).
+        Pipelined form: the stages run in threads, so blocks travel as copies through a SigFIFO."""
         if pipelined:
             from .sigFIFO import SigFIFO
             fifo = SigFIFO(chunk_source, self.samplesPerSlice)
@@ -156,8 +157,50 @@ class DemodulatorRunner:
                         return
             return self.run(blocks(), sink=sink, decoder=decoder, pipelined=True)
         from .sigFIFO import BlockAssembler
-        asm = BlockAssembler(self.raw, self.overlap)
-        return self.run((None for chunk in chunk_source for _ in asm.push(chunk)), sink=sink, decoder=decoder)
+        if not (overlapped and self.radioBackend == 'UHF' and getattr(self.demod, '_one_call', False)):
+            asm = BlockAssembler(self.raw, self.overlap)
+            return self.run((None for chunk in chunk_source for _ in asm.push(chunk)), sink=sink, decoder=decoder)
+        # Overlapped form: block i is on the device while this thread runs the sequential host stages and the decoder of
+        # block i-1 and assembles block i+1 in the other page-locked buffer.  Same calls in the same order on the same data
+        # as the plain loop, so the same results; only the waiting moves.
+        bufs = (self.raw, self.demod.bank.input2)
+        bufs[1][:self.overlap] = 0
+        names = ('pinned', 'pinned2')
+        asm = BlockAssembler(bufs[0], self.overlap)
+        results, packets = [], []
+        flying = None                    # (slot, count, timestamp)
+
+        def collect(fl):
+            slot, count, stamp = fl
+            part = {'count': count, 'timestamp': stamp}
+            part['doppler'], part['doppler_std'], _, part['SNR'] = self.demod.endBlock(slot)
+            part['rec'] = self.demod.demodulateDevice()
+            part['time_device'] = time.time() - stamp
+            d = self.feed_host(part)
+            if decoder is not None:
+                pk, _, nsync = decoder.findFrames(d['data'], 0)
+                d['numSyncSig'] = nsync
+                packets.extend(pk)
+            if sink is not None:
+                sink(d)
+            else:
+                results.append(d)
+
+        cur = 0
+        for chunk in chunk_source:
+            for _ in asm.push(chunk):
+                self.demod.beginBlock(cur, source=names[cur])
+                started = (cur, self.count, time.time())
+                self.count += 1
+                cur = 1 - cur
+                asm.retarget(bufs[cur])
+                if flying is not None:
+                    collect(flying)
+                flying = started
+        if flying is not None:
+            collect(flying)
+        self.raw = bufs[cur]             # where the next block would be assembled
+        return results, packets
 
     def run(self, sample_source, sink=None, decoder=None, pipelined=False):
         """Drive the loop over an iterable of new-sample slices.  With a ``decoder`` every block's

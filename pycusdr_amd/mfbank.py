@@ -38,6 +38,7 @@ class MFBank:
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:
             self.input = None
+            self._input2 = None
             self._lib.mfb_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -204,34 +205,73 @@ class MFBank:
 
     BAND_CAPACITY = 8192       # complex64 elements per SNR window delivered with the block (longer ones: get_spectrum)
 
-    def receive_block(self, k_offset, k_len, spsym_min, op=0, snr_window=5, fixed_shift=None, source='pinned', device_ptr=None):
-        """The whole device side of one block in ONE library call with one synchronisation (mfb_receive_block): upload
-        (``source``: 'pinned' = the library's input buffer, 'device' = ``device_ptr``, 'uploaded' = an earlier upload),
-        Doppler search + pick + shift interpolation (or ``fixed_shift`` for the STX back end), the spectrum windows of
-        computeSNR, matched filters, rate/phase, symbol centres.  Returns a dict of plain numbers and numpy arrays."""
-        P, R = _lib.BlockParams(), _lib.BlockResult()
+    SOURCES = {'pinned': 0, 'device': 1, 'uploaded': 2, 'pinned2': 3}
+
+    def _block_params(self, k_offset, k_len, spsym_min, op, snr_window, fixed_shift, source, device_ptr):
+        P = _lib.BlockParams()
         P.mode = 0 if fixed_shift is None else 1
-        P.input = {'pinned': 0, 'device': 1, 'uploaded': 2}[source]
+        P.input = self.SOURCES[source]
         P.device_block = C.c_void_p(int(device_ptr)) if device_ptr else None
         P.fixed_shift = 0 if fixed_shift is None else int(fixed_shift)
         P.k_offset, P.k_len, P.spsym_min, P.op, P.snr_window = int(k_offset), int(k_len), int(spsym_min), int(op), int(snr_window)
-        cap = self.N // 2
+        P.max_symbols, P.band_capacity = self.N // 2, (self.BAND_CAPACITY if fixed_shift is None else 0)
+        return P
+
+    def _block_arrays(self):
         if getattr(self, '_blk', None) is None:
+            cap = self.N // 2
             self._blk = (np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty(cap, np.float32),
                          np.empty((2, self.BAND_CAPACITY), np.complex64))
-        sym, cen, mag, bands = self._blk
-        P.max_symbols, P.band_capacity = cap, (self.BAND_CAPACITY if fixed_shift is None else 0)
-        _lib.check(self._lib.mfb_receive_block(self._h, C.byref(P), C.byref(R), _ptr(sym), _ptr(cen), _ptr(mag), _ptr(bands)),
-                   'mfb_receive_block')
+        return self._blk
+
+    def _block_result(self, R, searched):
+        sym, cen, mag, bands = self._block_arrays()
         n = R.count
         out = {'pick': (np.float32(R.pick[0]), np.float32(R.pick[1])), 'pick_valid': bool(R.pick_valid), 'shift': int(R.shift),
                'low': int(R.low), 'high': int(R.high), 'frac': float(R.frac),
                'cr': (np.float32(R.cr[0]), np.float32(R.cr[1]), np.float32(R.cr[2])), 'spSym': float(R.spSym),
                'codeOffset': float(R.codeOffset), 'rate_fallback': bool(R.rate_fallback),
                'symbols': sym[:n].copy(), 'centres': cen[:n].copy(), 'magnitudes': mag[:n].copy(), 'bands': None}
-        if fixed_shift is None and R.band_len[0] <= self.BAND_CAPACITY and R.band_len[1] <= self.BAND_CAPACITY:
+        if searched and R.band_len[0] <= self.BAND_CAPACITY and R.band_len[1] <= self.BAND_CAPACITY:
             out['bands'] = (bands[0, :R.band_len[0]].copy(), bands[1, :R.band_len[1]].copy())
         return out
+
+    def receive_block(self, k_offset, k_len, spsym_min, op=0, snr_window=5, fixed_shift=None, source='pinned', device_ptr=None):
+        """The whole device side of one block in ONE library call with one synchronisation (mfb_receive_block): upload
+        (``source``: 'pinned' = the library's input buffer, 'device' = ``device_ptr``, 'uploaded' = an earlier upload),
+        Doppler search + pick + shift interpolation (or ``fixed_shift`` for the STX back end), the spectrum windows of
+        computeSNR, matched filters, rate/phase, symbol centres.  Returns a dict of plain numbers and numpy arrays."""
+        P, R = self._block_params(k_offset, k_len, spsym_min, op, snr_window, fixed_shift, source, device_ptr), _lib.BlockResult()
+        sym, cen, mag, bands = self._block_arrays()
+        _lib.check(self._lib.mfb_receive_block(self._h, C.byref(P), C.byref(R), _ptr(sym), _ptr(cen), _ptr(mag), _ptr(bands)),
+                   'mfb_receive_block')
+        return self._block_result(R, fixed_shift is None)
+
+    @property
+    def input2(self):
+        """The second page-locked input buffer: while the device works on the block in one buffer, the caller assembles
+        the next block in the other (``begin_block(..., source='pinned2')``)."""
+        if getattr(self, '_input2', None) is None:
+            buf = C.POINTER(C.c_float)()
+            _lib.check(self._lib.mfb_input_buffer2(self._h, C.byref(buf)), 'mfb_input_buffer2')
+            self._input2 = np.ctypeslib.as_array(buf, shape=(2 * self.N,)).view(np.complex64)
+        return self._input2
+
+    def begin_block(self, slot, k_offset, k_len, spsym_min, op=0, snr_window=5, fixed_shift=None, source='pinned', device_ptr=None):
+        """First half of ``receive_block``: enqueue everything (read-back included) and return at once.  Up to two blocks
+        (``slot`` 0 / 1) may be in flight."""
+        P = self._block_params(k_offset, k_len, spsym_min, op, snr_window, fixed_shift, source, device_ptr)
+        _lib.check(self._lib.mfb_receive_block_begin(self._h, C.byref(P), int(slot)), 'mfb_receive_block_begin')
+        self._searched = getattr(self, '_searched', {})
+        self._searched[int(slot)] = fixed_shift is None
+
+    def end_block(self, slot):
+        """Second half: wait for the block begun in ``slot`` and return its results (same dict as ``receive_block``)."""
+        R = _lib.BlockResult()
+        sym, cen, mag, bands = self._block_arrays()
+        _lib.check(self._lib.mfb_receive_block_end(self._h, int(slot), C.byref(R), _ptr(sym), _ptr(cen), _ptr(mag), _ptr(bands)),
+                   'mfb_receive_block_end')
+        return self._block_result(R, self._searched.get(int(slot), True))
 
     def get_xcorr(self):
         out = np.empty((self.M, self.N), dtype=np.complex64)

@@ -48,9 +48,20 @@ class BlockAssembler:
             pos += take
             if self.fill == size:
                 self.blocks += 1
+                self._moved = False
                 yield self.buf
-                self.buf[:self.ov] = self.buf[size - self.ov:]
-                self.fill = self.ov
+                if not self._moved:          # (a consumer that called retarget() has carried the overlap already)
+                    self.buf[:self.ov] = self.buf[size - self.ov:]
+                    self.fill = self.ov
+
+    def retarget(self, other):
+        """Continue in another buffer of the same length (called by the consumer while it holds a completed block): the
+        overlap is carried over into ``other`` and the completed buffer is left untouched -- e.g. for a copy engine that is
+        still reading it."""
+        if len(other) != len(self.buf):
+            raise IndexError('block buffers of unequal length')
+        other[:self.ov] = self.buf[len(self.buf) - self.ov:]
+        self.buf, self.fill, self._moved = other, self.ov, True
 
 
 class RingBuffer:

@@ -104,8 +104,9 @@ def test_one_call_stx_fixed_shift_and_clipping():
 
 
 def test_runner_stream_in_place_assembly_equals_ring_buffer_path():
-    """run_stream assembles blocks directly in the page-locked input buffer from chunks of any size (one copy per sample):
-    the same result dicts as feeding whole slices."""
+    """run_stream assembles blocks directly in the page-locked input buffers from chunks of any size (one copy per sample)
+    and, by default, keeps block i on the device while the host stages of block i-1 run (mfb_receive_block_begin / _end):
+    the same result dicts as feeding whole slices one at a time."""
     bs, ov = 15, 1 << 10
     N = 1 << bs
     conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=32)
@@ -115,9 +116,9 @@ def test_runner_stream_in_place_assembly_equals_ring_buffer_path():
     a, b = DemodulatorRunner(conf, p, 'UHF-H'), DemodulatorRunner(conf, p, 'UHF-H')
     try:
         ra, _ = a.run([sig[i * step:(i + 1) * step] for i in range(6)])
-        for chunk in (4096, 16384, 1000, 3 * step + 17):
+        for chunk, overlapped in ((4096, True), (16384, True), (1000, False), (3 * step + 17, True), (16384, False)):
             b2 = DemodulatorRunner(conf, p, 'UHF-H')
-            rb, _ = b2.run_stream((sig[i:i + chunk] for i in range(0, 6 * step, chunk)))
+            rb, _ = b2.run_stream((sig[i:i + chunk] for i in range(0, 6 * step, chunk)), overlapped=overlapped)
             b2.close()
             assert len(rb) == 6
             for u, v in zip(ra, rb):
