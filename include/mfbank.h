@@ -281,6 +281,19 @@ int mfb_sync_find_multi(int device, const uint8_t *bits, int B, int L, const int
                         const int *thresholds, int ntmpl, int max_hits, int32_t *hit_idx, int32_t *hit_score,
                         int32_t *counts);
 
+/* The same search on PACKED bit streams -- 8 bits per byte in numpy.packbits layout (stream bit i = bit 7 - i%8 of byte
+ * i/8), row b at packed + b*row_bytes -- for taps in {-1, 0, +1}: the correlation is popcount(W & P) - popcount(W & Q) on
+ * 64-bit windows (exact), an eighth of the bytes cross the host link, and only the hits come back, as ONE flat list: stream
+ * b's hits (ascending position) start at sum(counts[0..b)).  total_hits may exceed max_total: the lists then hold the
+ * first max_total hits, call again with more room.  device_ms (optional): kernel time between the copies, from HIP
+ * events.  Returns MFB_ERR_UNSUPPORTED for other tap values.  Replaces np.convolve + np.where of DEC:96-113 for batches.
+ * mfb_sync_pinned_buffer: a page-locked buffer of at least `bytes` owned by the library (per device) that a caller may
+ * produce its packed streams into, so that their copy to the device is a plain asynchronous DMA. */
+int mfb_sync_find_packed(int device, const uint8_t *packed_bits, int B, int L, int row_bytes, const int8_t *tmpl, int T,
+                         int threshold, int max_total, int32_t *hit_idx, int32_t *hit_score, int32_t *counts,
+                         int32_t *total_hits, float *device_ms);
+int mfb_sync_pinned_buffer(int device, size_t bytes, void **host);
+
 /* Bit-stream alignment cross-correlation of the soft combiner:
  *   out = ifft( fft(a, N) * conj(fft(b, N)) ),  N = the handle's block length,
  * a, b real float32 sequences truncated / zero-padded to N as np.fft.fft(a, N) does; out complex64 [N].

@@ -1781,6 +1781,94 @@ extern "C" int mfb_sync_find_multi(int device, const uint8_t *bits, int B, int L
     return sync_find_impl(device, bits, B, L, tmpls, T, thresholds, ntmpl, max_hits, hit_idx, hit_score, counts);
 }
 
+// ---- packed sync correlation (sync_kernels.hpp, second half) -------------------------------------------------------------
+// One page-locked buffer per device, grown on demand: callers that produce their packed bit streams straight into it
+// (mfb_sync_pinned_buffer) get a true asynchronous host-to-device copy; any other host pointer works too (the runtime stages it).
+static std::mutex g_pin_mu;
+static uint8_t *g_pin[SYNC_MAX_DEVICES];
+static size_t g_pin_cap[SYNC_MAX_DEVICES];
+
+extern "C" int mfb_sync_pinned_buffer(int device, size_t bytes, void **host) {
+    if (!host || bytes < 1) return MFB_ERR_ARG;
+    int rc = sync_device_ok(device);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    if (g_pin_cap[device] < bytes) {
+        if (g_pin[device]) HIPCHK(hipHostFree(g_pin[device]));
+        g_pin[device] = nullptr;
+        g_pin_cap[device] = 0;
+        HIPCHK(hipHostMalloc((void **)&g_pin[device], bytes, hipHostMallocDefault));
+        g_pin_cap[device] = bytes;
+    }
+    *host = g_pin[device];
+    return MFB_OK;
+}
+
+extern "C" int mfb_sync_find_packed(int device, const uint8_t *packed, int B, int L, int row_bytes, const int8_t *tmpl, int T,
+                                    int threshold, int max_total, int32_t *hit_idx, int32_t *hit_score, int32_t *counts,
+                                    int32_t *total_hits, float *device_ms) {
+    if (!packed || !tmpl || !hit_idx || !hit_score || !counts || !total_hits || B < 1 || L < 1 || T < 1 || T > 64 * SYNCP_MAXK ||
+        max_total < 1 || row_bytes < (L + 7) / 8)
+        return MFB_ERR_ARG;
+    const int K = (T + 63) / 64;
+    std::vector<unsigned long long> masks(2 * (size_t)K, 0ull);
+    for (int t = 0; t < T; ++t) {
+        if (tmpl[t] == 1) masks[t / 64] |= 1ull << (t % 64);
+        else if (tmpl[t] == -1) masks[K + t / 64] |= 1ull << (t % 64);
+        else if (tmpl[t] != 0) return MFB_ERR_UNSUPPORTED;       // the packed form takes taps in {-1, 0, +1} only
+    }
+    int rc = sync_device_ok(device);
+    if (rc) return rc;
+    WsLease lease{device, ws_acquire(device)};
+    if (!lease.w) return MFB_ERR_HIP;
+    SyncWs &w = *lease.w;
+    const int nseg = (L + T - 1 + SYNCP_SEG - 1) / SYNCP_SEG;
+    const size_t nbytes = (size_t)B * row_bytes;
+    if ((rc = ws_reserve(&w.bits, &w.cap_bits, nbytes))) return rc;
+    if ((rc = ws_reserve(&w.tmpl, &w.cap_tmpl, masks.size() * sizeof(unsigned long long)))) return rc;
+    if ((rc = ws_reserve(&w.seg, &w.cap_seg, ((size_t)2 * B * nseg + 2 * (size_t)B + 1) * sizeof(int)))) return rc;
+    if ((rc = ws_reserve(&w.hits, &w.cap_hits, (size_t)2 * max_total * sizeof(int32_t)))) return rc;
+    int *segcnt = w.seg, *segoff = segcnt + (size_t)B * nseg, *d_counts = segoff + (size_t)B * nseg, *d_streamoff = d_counts + B;
+    int32_t *d_idx = w.hits, *d_sc = w.hits + max_total;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (device_ms) {
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+    }
+    HIPCHK(hipMemcpyAsync(w.bits, packed, nbytes, hipMemcpyHostToDevice, w.stream));
+    HIPCHK(hipMemcpyAsync(w.tmpl, masks.data(), masks.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, w.stream));
+    if (e0) HIPCHK(hipEventRecord(e0, w.stream));
+    const unsigned long long *d_masks = (const unsigned long long *)w.tmpl;
+    hipLaunchKernelGGL((k_sync_packed<false>), dim3(nseg, B), dim3(SYNCP_THREADS), 0, w.stream, (const uint8_t *)w.bits, row_bytes, L, T, K,
+                       d_masks, threshold, nseg, segcnt, (const int *)nullptr, (const int *)nullptr, max_total, (int32_t *)nullptr,
+                       (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_sync_scan, dim3((B + 63) / 64), dim3(64), 0, w.stream, (const int *)segcnt, segoff, d_counts, B, nseg);
+    hipLaunchKernelGGL(k_sync_stream_scan, dim3(1), dim3(256), 0, w.stream, (const int *)d_counts, d_streamoff, B);
+    hipLaunchKernelGGL((k_sync_packed<true>), dim3(nseg, B), dim3(SYNCP_THREADS), 0, w.stream, (const uint8_t *)w.bits, row_bytes, L, T, K,
+                       d_masks, threshold, nseg, segcnt, (const int *)segoff, (const int *)d_streamoff, max_total, d_idx, d_sc);
+    HIPCHK(hipGetLastError());
+    if (e1) HIPCHK(hipEventRecord(e1, w.stream));
+    // counts and the grand total first, then exactly the hits
+    std::vector<int> hc((size_t)2 * B + 1);
+    HIPCHK(hipMemcpyAsync(hc.data(), d_counts, hc.size() * sizeof(int), hipMemcpyDeviceToHost, w.stream));
+    HIPCHK(hipStreamSynchronize(w.stream));
+    memcpy(counts, hc.data(), (size_t)B * sizeof(int));
+    const int total = hc[(size_t)2 * B];
+    *total_hits = total;
+    const int n = total < max_total ? total : max_total;
+    if (n > 0) {
+        HIPCHK(hipMemcpyAsync(hit_idx, d_idx, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, w.stream));
+        HIPCHK(hipMemcpyAsync(hit_score, d_sc, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, w.stream));
+        HIPCHK(hipStreamSynchronize(w.stream));
+    }
+    if (device_ms) {
+        HIPCHK(hipEventElapsedTime(device_ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    return MFB_OK;
+}
+
 // ---- N4: bit-stream alignment cross-correlation (reference lib/customXCorr.py:5-18) -----------------
 // out = ifft( fft(a, N) * conj(fft(b, N)) ) with N the handle's block length: a and b are real
 // sequences, truncated or zero-padded to N exactly as np.fft.fft(a, N) does.  Built from the handle's

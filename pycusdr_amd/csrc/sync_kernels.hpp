@@ -104,3 +104,130 @@ __global__ void k_sync_scan(const int *segcnt, int *segoff, int *counts, int B, 
     }
     counts[b] = run;
 }
+
+// ---- packed form: 8 bits per byte (np.packbits layout: stream bit i is bit 7 - i%8 of byte i/8) ------------------------
+// score[i] = sum_t tmpl[t] * bits[i - t] with taps in {-1, 0, +1} is  popcount(W & P) - popcount(W & Q)  on the window
+// W (bit j = bits[i - j]) and the masks P / Q of the +1 / -1 taps: exact, 64 taps per pair of popcounts instead of 64
+// multiply-adds.  A thread owns one 64-bit word of the stream (big-endian: oldest bit on top) and walks over its 64 output
+// positions, so hits come out in ascending position order per thread; the same three-step scheme as above (count per
+// segment, scan, recompute and write) keeps them ordered without atomics.  Results are a FLAT list over all streams
+// (stream b's hits start at the exclusive scan of the stream totals): only hits travel back to the host.
+#define SYNCP_THREADS 256
+#define SYNCP_SEG (SYNCP_THREADS * 64)      // output positions per workgroup
+#define SYNCP_MAXK 64                        // 64-bit words per template: T <= 4096
+
+template <bool WRITE>
+__global__ void __launch_bounds__(SYNCP_THREADS) k_sync_packed(const uint8_t *packed, int row_bytes, int L, int T, int K,
+                                                              const unsigned long long *masks /* P[K] | Q[K] */, int thr, int nseg,
+                                                              int *segcnt, const int *segoff, const int *streamoff, int max_total,
+                                                              int32_t *hit_idx, int32_t *hit_score) {
+    __shared__ unsigned long long sw[SYNCP_THREADS + SYNCP_MAXK + 1];    // stream words q0 - K - 1 ... q0 + 255, big-endian
+    __shared__ unsigned long long sp[2 * SYNCP_MAXK];
+    __shared__ int wsum[SYNCP_THREADS / 64];
+    const int b = blockIdx.y, seg = blockIdx.x, tid = threadIdx.x;
+    const long long q0 = (long long)seg * SYNCP_THREADS;                 // first stream word of this segment
+    const uint8_t *row = packed + (size_t)b * row_bytes;
+    const int nwords = SYNCP_THREADS + K + 1;
+    for (int w = tid; w < nwords; w += SYNCP_THREADS) {
+        const long long q = q0 - K - 1 + w;                              // stream word index (bits 64q ... 64q + 63)
+        unsigned long long v = 0;
+        if (q >= 0) {
+            const long long byte0 = q * 8;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long by = byte0 + u;
+                const unsigned long long x = by < row_bytes ? row[by] : 0;
+                v = (v << 8) | x;
+            }
+            // bits past the end of the stream (padding of the last byte, or garbage the caller left there) do not exist
+            const long long first = q * 64;
+            if (first + 64 > L) v = first >= L ? 0ull : (v & (~0ull << (64 - (L - first))));
+        }
+        sw[w] = v;
+    }
+    for (int w = tid; w < 2 * K; w += SYNCP_THREADS) sp[w] = masks[w];
+    __syncthreads();
+    const int outLen = L + T - 1;
+    const long long i0 = (q0 + tid) * 64;                                // first output position of this thread
+    int cnt = 0;
+    int pos = 0;
+    if constexpr (WRITE) pos = 0;
+    // pass 1 (both modes): count; WRITE recomputes below once the offsets are known
+    auto score_at = [&](int r) {
+        // window word k, bit j = bits[i - 64k - j], i = i0 + r: (Z[q-k-1] << (r+1)) | (Z[q-k] >> (63-r))
+        int s = 0;
+        const int base = K + 1 + tid;                                    // sw index of word q = q0 + tid
+        for (int k = 0; k < K; ++k) {
+            const unsigned long long hi = sw[base - k - 1], lo = sw[base - k];
+            const unsigned long long W = (r == 63) ? lo : ((hi << (r + 1)) | (lo >> (63 - r)));
+            s += __popcll(W & sp[k]) - __popcll(W & sp[K + k]);
+        }
+        return s;
+    };
+    for (int r = 0; r < 64; ++r) {
+        const long long i = i0 + r;
+        if (i < outLen && score_at(r) >= thr) ++cnt;
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if ((tid & 63) >= o) incl += v;
+    }
+    const int wid = tid >> 6;
+    if ((tid & 63) == 63) wsum[wid] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < wid; ++w) wbase += wsum[w];
+    if constexpr (!WRITE) {
+        if (tid == SYNCP_THREADS - 1) segcnt[(size_t)b * nseg + seg] = wbase + incl;
+    } else {
+        pos = streamoff[b] + segoff[(size_t)b * nseg + seg] + wbase + incl - cnt;
+        if (cnt) {
+            for (int r = 0; r < 64; ++r) {
+                const long long i = i0 + r;
+                if (i >= outLen) break;
+                const int s = score_at(r);
+                if (s >= thr) {
+                    if (pos < max_total) {
+                        hit_idx[pos] = (int32_t)i;
+                        hit_score[pos] = s;
+                    }
+                    ++pos;
+                }
+            }
+        }
+    }
+}
+
+// exclusive scan of the stream totals (one workgroup; B is a few thousand at most): streamoff[b], total in streamoff[B]
+__global__ void __launch_bounds__(256) k_sync_stream_scan(const int *counts, int *streamoff, int B) {
+    __shared__ int part[256];
+    const int tid = threadIdx.x;
+    const int per = (B + 255) / 256;
+    int s = 0;
+    for (int k = 0; k < per; ++k) {
+        const int b = tid * per + k;
+        if (b < B) s += counts[b];
+    }
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int t = 0; t < 256; ++t) {
+            const int v = part[t];
+            part[t] = run;
+            run += v;
+        }
+        streamoff[B] = run;
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int k = 0; k < per; ++k) {
+        const int b = tid * per + k;
+        if (b < B) {
+            streamoff[b] = run;
+            run += counts[b];
+        }
+    }
+}

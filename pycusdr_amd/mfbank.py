@@ -380,6 +380,52 @@ def sync_find(bits, template, threshold, max_hits=1024, device=0):
     return out[0] if single else out
 
 
+def sync_pinned_buffer(nbytes, device=0):
+    """uint8 view of the library's page-locked staging buffer of this device (at least ``nbytes``): packed bit streams
+    produced straight into it reach the device by plain asynchronous DMA.  One buffer per device: a later, larger request
+    replaces it."""
+    lib = _lib.load()
+    p = C.c_void_p()
+    _lib.check(lib.mfb_sync_pinned_buffer(int(device), C.c_size_t(int(nbytes)), C.byref(p)), 'mfb_sync_pinned_buffer')
+    return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(int(nbytes),))
+
+
+def sync_find_packed(packed, L, template, threshold, max_total=None, device=0, timing=False):
+    """``sync_find`` on PACKED bit streams: ``packed`` uint8 [B, row_bytes] (or [row_bytes]) in ``np.packbits`` layout, ``L``
+    valid bits per stream, taps in {-1, 0, +1}.  XOR/AND + popcount on 64-bit windows on the GPU, exact; only the hits come
+    back.  Returns a list of (idx int32[], score int32[]) per stream (one pair for a 1-D input); with ``timing`` also the
+    kernel time in ms."""
+    lib = _lib.load()
+    pk = np.asarray(packed)
+    single = pk.ndim == 1
+    pk = pk.reshape(1, -1) if single else pk
+    if pk.dtype != np.uint8 or not pk.flags.c_contiguous:
+        pk = np.ascontiguousarray(pk, dtype=np.uint8)
+    B, row_bytes = pk.shape
+    t = np.asarray(template)
+    ti = np.ascontiguousarray(t, dtype=np.int8)
+    if not np.array_equal(ti, t):
+        raise ValueError('template must hold small integers (int8)')
+    thr = int(np.ceil(threshold))
+    max_total = int(max_total) if max_total else max(4096, 64 * B)
+    while True:
+        idx = np.empty(max_total, dtype=np.int32)
+        sc = np.empty(max_total, dtype=np.int32)
+        cnt = np.empty(B, dtype=np.int32)
+        total = C.c_int32()
+        ms = C.c_float()
+        _lib.check(lib.mfb_sync_find_packed(int(device), _ptr(pk), B, int(L), row_bytes, _ptr(ti), ti.size, thr, max_total,
+                                            _ptr(idx), _ptr(sc), _ptr(cnt), C.byref(total), C.byref(ms) if timing else None),
+                   'mfb_sync_find_packed')
+        if total.value <= max_total:
+            break
+        max_total = int(total.value)
+    off = np.concatenate(([0], np.cumsum(cnt)))
+    out = [(idx[off[b]:off[b + 1]].copy(), sc[off[b]:off[b + 1]].copy()) for b in range(B)]
+    res = out[0] if single else out
+    return (res, ms.value) if timing else res
+
+
 def sync_find_multi(bits, templates, thresholds, max_hits=256, device=0):
     """``sync_find`` for several templates against the same bit stream(s) in ONE library call (one host-device
     round trip): the decoder's header-mask and sync-flag searches of a block (reference decoder.py:96-113).

@@ -120,3 +120,44 @@ def test_custom_xcorr_on_hip_matches_reference(goldens, tag):
     assert np.abs(r2 - f2).max() / np.abs(f2).max() < 1e-5
     with pytest.raises(ValueError):
         customXCorr(a, b, N=5000)
+
+
+@pytest.mark.parametrize('L,T,B', [(67584, 64, 5), (1000, 64, 3), (4097, 128, 2), (777, 16, 4), (20001, 100, 2), (63, 64, 1), (130, 200, 2)])
+def test_sync_find_packed_equals_convolve(L, T, B):
+    """Packed sync correlation (np.packbits layout, XOR/AND + popcount on 64-bit windows): positions and scores equal
+    np.where(np.convolve(bits, template) >= threshold), stream by stream, for any length, tap count (zeros included) and
+    with garbage in the padding bits of the last byte."""
+    from pycusdr_amd.mfbank import sync_find_packed, sync_pinned_buffer
+    rs = np.random.RandomState(L + T)
+    bits = rs.randint(0, 2, (B, L)).astype(np.uint8)
+    tmpl = rs.choice([-1, 1], T).astype(np.int8)
+    if T > 20:
+        tmpl[rs.randint(0, T, 3)] = 0
+    header = ((tmpl[::-1] + 1) // 2).astype(np.uint8)
+    for pos in range(5, L - T, max(T + 30, L // 7)):
+        bits[:, pos:pos + T] = header
+        bits[0, pos + 3] ^= 1
+    packed = np.packbits(bits, axis=1)
+    if L % 8:
+        packed[:, -1] |= (1 << (8 - L % 8)) - 1                      # padding bits set: they are not part of the stream
+    thr = int((tmpl == 1).sum()) - 3
+    got = sync_find_packed(packed, L, tmpl, thr)
+    for b in range(B):
+        sc = np.convolve(bits[b].astype(np.int64), tmpl.astype(np.int64))
+        idx = np.where(sc >= thr)[0]
+        assert np.array_equal(got[b][0], idx) and np.array_equal(got[b][1], sc[idx]), (b, len(idx), len(got[b][0]))
+    assert sum(len(g[0]) for g in got) > 0 or L < T
+    # a low threshold (many hits, more than the first guess of room), rows wider than needed, the page-locked staging
+    thr2 = -2
+    stage = sync_pinned_buffer(B * (packed.shape[1] + 5))
+    wide = stage[:B * (packed.shape[1] + 5)].reshape(B, packed.shape[1] + 5)
+    wide[:] = 255
+    wide[:, :packed.shape[1]] = packed
+    got2, ms = sync_find_packed(wide, L, tmpl, thr2, max_total=16, timing=True)
+    for b in range(B):
+        sc = np.convolve(bits[b].astype(np.int64), tmpl.astype(np.int64))
+        idx = np.where(sc >= thr2)[0]
+        assert np.array_equal(got2[b][0], idx) and np.array_equal(got2[b][1], sc[idx])
+    assert ms >= 0.0
+    with pytest.raises(ValueError):
+        sync_find_packed(packed, L, np.array([2, 1, -1], np.int8), 1)      # taps outside {-1, 0, +1}
