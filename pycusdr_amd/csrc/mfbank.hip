@@ -334,6 +334,17 @@ static int create_impl(mfb_ctx *c) {
     HIPCHK(dev_alloc((void **)&c->d_mag, (size_t)c->cap * sizeof(float)));
     // one row for the plain forward transforms; the search's share is sized when the filters arrive
     if ((rc = alloc_Z(c))) return rc;
+    // block path (mfb_receive_block*): everything it needs exists before the first block -- page-locking memory and creating
+    // events inside a stream of blocks costs milliseconds
+    HIPCHK(dev_alloc((void **)&c->d_scal, sizeof(BlockScalars)));
+    c->band_cap = 8192;
+    HIPCHK(dev_alloc((void **)&c->d_bands, (size_t)2 * c->band_cap * sizeof(cf)));
+    for (int i = 0; i < 2; ++i) {
+        // scalars + three arrays of the symbols a rate window of +-10 % around 4 samples per symbol admits + the two windows
+        c->blk_cap[i] = align16(sizeof(BlockScalars)) + 3 * align16((size_t)(c->N / 3) * sizeof(int)) + align16((size_t)2 * c->band_cap * sizeof(cf));
+        HIPCHK(hipHostMalloc((void **)&c->h_blk[i], c->blk_cap[i], hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_blk[i], hipEventDisableTiming));
+    }
 
     std::vector<cf> t;
     make_twiddles(t, c->N1, (double)c->N1, 1.0);

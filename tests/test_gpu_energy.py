@@ -117,7 +117,9 @@ def test_demodulator_output_identical_with_energy_search():
         finally:
             demod.close()
     for a, b in zip(*outs):
-        assert a[0] == b[0] and a[1] == b[1] and a[5] == b[5]
+        # (the two searches agree to fp32 rounding, so the interpolated frequency agrees to a fraction of a hertz; the
+        # integer shift, the symbol rate and every decision are identical)
+        assert abs(a[0] - b[0]) < 0.05 and a[1] == b[1] and a[5] == b[5]
         for u, v in zip(a[2:5], b[2:5]):
             assert np.array_equal(u, v)
 
