@@ -54,7 +54,7 @@
 // ------------------------------------------------------------------------------------------------
 struct BlockFlight {      // one block between mfb_receive_block_begin and _end
     bool active;
-    int mode, nthreads, bcap, shift;
+    int mode, nthreads, bcap, shift, op;
     size_t off[5];
     unsigned long long seq;
 };
@@ -117,8 +117,8 @@ struct mfb_ctx {
     hipEvent_t ev_blk[2];
     BlockFlight flight[2];
     unsigned long long blk_seq;
-    BlockScalars *d_scal;     // mfb_receive_block: scalars computed between the stages
-    cf *d_bands;              // ... and the two spectrum windows of computeSNR, [2][band_cap]
+    uint8_t *d_blkout;        // mfb_receive_block: the block's result record (scalars | SNR windows | symbols), one copy to the host
+    BlockScalars *d_scal;     // = d_blkout
     int band_cap;
     bool W_valid;
     std::vector<hipEvent_t> ev[2];
@@ -237,6 +237,24 @@ static int reserve_partials(mfb_ctx *c, size_t floats) {
     return MFB_OK;
 }
 
+// Device-side result record of a block: [BlockScalars, 256 B][bands 2 x bcap complex64][sym][cen][mag] (nthreads each),
+// contiguous so that ONE copy brings it to the host.
+#define BLK_HEAD 256
+static size_t blkout_bytes(int bcap, int nthreads) {
+    return BLK_HEAD + align16((size_t)2 * bcap * sizeof(cf)) + 3 * align16((size_t)nthreads * sizeof(int));
+}
+static int blkout_reserve(mfb_ctx *c, int bcap) {
+    if (c->d_blkout && bcap <= c->band_cap) return MFB_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->d_blkout) HIPCHK(hipFree(c->d_blkout));
+    c->d_blkout = nullptr;
+    c->band_cap = 0;
+    HIPCHK(dev_alloc((void **)&c->d_blkout, blkout_bytes(bcap, c->cap)));
+    c->band_cap = bcap;
+    c->d_scal = (BlockScalars *)c->d_blkout;
+    return MFB_OK;
+}
+
 // ---- per-device kernel attributes ------------------------------------------------------------------
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): it is set for every
 // instantiation that can need more than 48 KiB whenever a handle is created, on that handle's device.
@@ -336,12 +354,10 @@ static int create_impl(mfb_ctx *c) {
     if ((rc = alloc_Z(c))) return rc;
     // block path (mfb_receive_block*): everything it needs exists before the first block -- page-locking memory and creating
     // events inside a stream of blocks costs milliseconds
-    HIPCHK(dev_alloc((void **)&c->d_scal, sizeof(BlockScalars)));
-    c->band_cap = 8192;
-    HIPCHK(dev_alloc((void **)&c->d_bands, (size_t)2 * c->band_cap * sizeof(cf)));
+    if ((rc = blkout_reserve(c, 1024))) return rc;
     for (int i = 0; i < 2; ++i) {
         // scalars + three arrays of the symbols a rate window of +-10 % around 4 samples per symbol admits + the two windows
-        c->blk_cap[i] = align16(sizeof(BlockScalars)) + 3 * align16((size_t)(c->N / 3) * sizeof(int)) + align16((size_t)2 * c->band_cap * sizeof(cf));
+        c->blk_cap[i] = blkout_bytes(c->band_cap, c->N / 3);
         HIPCHK(hipHostMalloc((void **)&c->h_blk[i], c->blk_cap[i], hipHostMallocDefault));
         HIPCHK(hipEventCreateWithFlags(&c->ev_blk[i], hipEventDisableTiming));
     }
@@ -428,7 +444,7 @@ extern "C" int mfb_destroy(mfb_ctx *c) {
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     void *bufs[] = {c->d_uniq, c->d_rep, c->d_x,  c->d_X,    c->d_masks, c->d_Z,   c->d_xc,  c->d_P,   c->d_env, c->d_shifts, c->d_tw1,
                     c->d_tw2, c->d_twLo, c->d_twHi,  c->d_part, c->d_sum, c->d_res, c->d_cr,  c->d_sym,    c->d_cen, c->d_mag,
-                    c->d_G, c->d_twL, c->d_Gb, c->d_pow, c->d_W, c->d_scal, c->d_bands};
+                    c->d_G, c->d_twL, c->d_Gb, c->d_pow, c->d_W, c->d_blkout};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (c->h_in) (void)hipHostFree(c->h_in);
@@ -1310,7 +1326,8 @@ extern "C" int mfb_get_spectrum(mfb_ctx *c, float *host, int start, int count) {
 
 // A9 + A10 enqueued on the handle's stream: matched filters at one shift (a value, or -- shift_dev != nullptr -- an int the
 // device has just computed), envelope, its spectrum, windowed argmax into d_cr.  No synchronisation.
-static int demod_enqueue(mfb_ctx *c, int shift, const int *shift_dev, int k_offset, int k_len) {
+static int demod_enqueue(mfb_ctx *c, int shift, const int *shift_dev, int k_offset, int k_len, int spsym_min = 0, int capacity = 0,
+                         BlockScalars *scal = nullptr) {
     // A9: matched filters at one shift -> xc[M][N] natural order
     int rc;
     if (c->path == MFB_PATH_SEGMENT) {
@@ -1366,7 +1383,10 @@ static int demod_enqueue(mfb_ctx *c, int shift, const int *shift_dev, int k_offs
     }
     rc = forward_fft(c, nullptr, c->d_env, c->d_P);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_code_rate, dim3(1), dim3(1024), 0, c->stream, c->d_P, c->d_cr, k_offset, k_len);
+    if (scal)
+        hipLaunchKernelGGL(k_code_rate_block, dim3(1), dim3(1024), 0, c->stream, c->d_P, c->d_cr, k_offset, k_len, c->N, spsym_min, capacity, scal);
+    else
+        hipLaunchKernelGGL(k_code_rate, dim3(1), dim3(1024), 0, c->stream, c->d_P, c->d_cr, k_offset, k_len);
     HIPCHK(hipGetLastError());
     return MFB_OK;
 }
@@ -1390,7 +1410,7 @@ extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, fl
 // stream of launches and ONE synchronisation: [H2D of the pinned input buffer,] forward FFT, Doppler search, pick, shift
 // interpolation (k_block_pick), the two spectrum windows of computeSNR, matched filters at that shift, envelope, its
 // spectrum, rate/phase argmax, the float64 arithmetic behind it (k_block_rate), symbol centres -- then one packed read-back.
-// Enqueue: everything up to and including the device-to-host copies into the flight's page-locked staging; no wait.
+// Enqueue: everything up to and including the ONE device-to-host copy into the flight's page-locked staging; no wait.
 static int block_begin(mfb_ctx *c, const mfb_block_params *p, int slot) {
     if (!c || !p || slot < 0 || slot > 1) return MFB_ERR_ARG;
     if (!c->have_filters || (p->mode == MFB_BLOCK_SEARCH && !c->have_shifts)) return MFB_ERR_STATE;
@@ -1402,21 +1422,13 @@ static int block_begin(mfb_ctx *c, const mfb_block_params *p, int slot) {
     BlockFlight &f = c->flight[slot];
     if (f.active) return MFB_ERR_STATE;          // its results have not been collected
     int rc;
-    if (!c->d_scal) HIPCHK(dev_alloc((void **)&c->d_scal, sizeof(BlockScalars)));
-    const int bcap = p->band_capacity;
-    if (bcap > c->band_cap) {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if (c->d_bands) HIPCHK(hipFree(c->d_bands));
-        c->d_bands = nullptr;
-        c->band_cap = 0;
-        HIPCHK(dev_alloc((void **)&c->d_bands, (size_t)2 * bcap * sizeof(cf)));
-        c->band_cap = bcap;
-    }
+    const int bcap = p->mode == MFB_BLOCK_SEARCH ? p->band_capacity : 0;
+    if ((rc = blkout_reserve(c, bcap > c->band_cap ? bcap : c->band_cap))) return rc;
     const int capacity = p->max_symbols < c->cap ? p->max_symbols : c->cap;
     // every symbol the rate window admits (k* < k_offset + k_len  =>  count <= k_offset + k_len), bounded by the capacity
     int nthreads = p->k_offset + p->k_len + 1;
     if (nthreads > capacity) nthreads = capacity;
-    const size_t need = align16(sizeof(BlockScalars)) + 3 * align16((size_t)nthreads * sizeof(int)) + align16((size_t)2 * bcap * sizeof(cf));
+    const size_t need = blkout_bytes(bcap, nthreads);
     if (need > c->blk_cap[slot]) {
         if (c->h_blk[slot]) HIPCHK(hipHostFree(c->h_blk[slot]));
         c->h_blk[slot] = nullptr;
@@ -1444,50 +1456,48 @@ static int block_begin(mfb_ctx *c, const mfb_block_params *p, int slot) {
         c->have_input = true;
         c->have_xc = false;
     }
-    HIPCHK(hipMemsetAsync(c->d_scal, 0, sizeof(BlockScalars), c->stream));
+    uint8_t *d = c->d_blkout;
+    cf *d_bands = (cf *)(d + BLK_HEAD);
+    int *d_sym = (int *)(d + BLK_HEAD + align16((size_t)2 * bcap * sizeof(cf)));
+    int *d_cen = (int *)((uint8_t *)d_sym + align16((size_t)nthreads * sizeof(int)));
+    float *d_mag = (float *)((uint8_t *)d_cen + align16((size_t)nthreads * sizeof(int)));
     const int *shift_dev = nullptr;
     int shift = 0;
     if (p->mode == MFB_BLOCK_SEARCH) {
         if ((rc = mfb_search_async(c))) return rc;
-        hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, c->stream, (const float *)c->d_sum, c->d_res, c->D, c->Doff, c->M, c->sum_all);
-        hipLaunchKernelGGL(k_block_pick, dim3(1), dim3(1), 0, c->stream, (const float *)c->d_res, (const int *)c->d_shifts, c->Dtot, c->N,
-                           p->snr_window, c->d_scal);
+        hipLaunchKernelGGL(k_pick_block, dim3(1), dim3(64), 0, c->stream, (const float *)c->d_sum, c->d_res, c->D, c->Doff, c->M, c->sum_all,
+                           (const int *)c->d_shifts, c->Dtot, c->N, p->snr_window, (const cf *)c->d_X, c->d_scal, d_bands, bcap);
         HIPCHK(hipGetLastError());
-        if (bcap > 0) {
-            hipLaunchKernelGGL(k_block_bands, dim3((bcap + 255) / 256 < 64 ? (bcap + 255) / 256 : 64, 2), dim3(256), 0, c->stream,
-                               (const cf *)c->d_X, (const BlockScalars *)c->d_scal, c->d_bands, bcap);
-            HIPCHK(hipGetLastError());
-        }
         shift_dev = &c->d_scal->shift;
     } else {
+        hipLaunchKernelGGL(k_block_clear, dim3(1), dim3(1), 0, c->stream, c->d_scal);
+        HIPCHK(hipGetLastError());
         shift = ((p->fixed_shift % c->N) + c->N) % c->N;
     }
-    if ((rc = demod_enqueue(c, shift, shift_dev, p->k_offset, p->k_len))) return rc;
-    hipLaunchKernelGGL(k_block_rate, dim3(1), dim3(1), 0, c->stream, (const float *)c->d_cr, c->N, p->spsym_min, capacity, c->d_scal);
+    if ((rc = demod_enqueue(c, shift, shift_dev, p->k_offset, p->k_len, p->spsym_min, capacity, c->d_scal))) return rc;
     // the k* == 0 fallback (spSym = 10, DB:737-740; unreachable while the rate window starts above bin 0) may need more threads
     const int fallback_threads = capacity < c->N / 10 + 1 ? capacity : c->N / 10 + 1;
-    const int launch_threads = nthreads > fallback_threads ? nthreads : fallback_threads;
-    hipLaunchKernelGGL(k_centres_block, dim3((launch_threads + 255) / 256), dim3(256), 0, c->stream, c->d_sym, c->d_cen, c->d_mag,
-                       (const cf *)c->d_xc, (const BlockScalars *)c->d_scal, c->N, c->M, c->W, p->op, capacity);
+    // (entries past nthreads are not part of the record: the kernel's capacity bounds what it writes)
+    const int launch_threads = nthreads;
+    (void)fallback_threads;
+    hipLaunchKernelGGL(k_centres_block, dim3((launch_threads + 255) / 256), dim3(256), 0, c->stream, d_sym, d_cen, d_mag,
+                       (const cf *)c->d_xc, (const BlockScalars *)c->d_scal, c->N, c->M, c->W, p->op, nthreads);
     HIPCHK(hipGetLastError());
-    // one packed read-back into this flight's staging
-    uint8_t *h = c->h_blk[slot];
-    size_t off = 0;
-    const void *src[5] = {c->d_scal, c->d_sym, c->d_cen, c->d_mag, c->d_bands};
-    const size_t len[5] = {sizeof(BlockScalars), (size_t)nthreads * sizeof(int), (size_t)nthreads * sizeof(int), (size_t)nthreads * sizeof(float),
-                           p->mode == MFB_BLOCK_SEARCH ? (size_t)2 * bcap * sizeof(cf) : 0};
-    for (int i = 0; i < 5; ++i) {
-        f.off[i] = off;
-        if (len[i]) HIPCHK(hipMemcpyAsync(h + off, src[i], len[i], hipMemcpyDeviceToHost, c->stream));
-        off += align16(len[i]);
-    }
+    // one read-back into this flight's staging
+    HIPCHK(hipMemcpyAsync(c->h_blk[slot], d, need, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipEventRecord(c->ev_blk[slot], c->stream));
+    f.off[0] = 0;
+    f.off[4] = BLK_HEAD;
+    f.off[1] = (size_t)((uint8_t *)d_sym - d);
+    f.off[2] = (size_t)((uint8_t *)d_cen - d);
+    f.off[3] = (size_t)((uint8_t *)d_mag - d);
     f.active = true;
     f.mode = p->mode;
     f.nthreads = nthreads;
     f.bcap = bcap;
     f.shift = shift;
     f.seq = ++c->blk_seq;
+    f.op = p->op;
     c->have_xc = true;
     return MFB_OK;
 }
@@ -1505,8 +1515,15 @@ static int block_end(mfb_ctx *c, int slot, mfb_block_result *r, int32_t *sym, in
     BlockScalars hs;
     memcpy(&hs, h + f.off[0], sizeof(hs));
     int n = hs.count;
-    if (n > f.nthreads) {            // rate fallback: the rest is still on the device -- unless a later block has overwritten it
+    if (n > f.nthreads) {
+        // rate fallback (k* == 0 -> spSym = 10, DB:737-740; unreachable while the rate window starts above bin 0): the
+        // record holds the symbols the window admits; the rest is computed now, if the matched-filter outputs are still
+        // this block's
         if (c->blk_seq != f.seq) return MFB_ERR_UNSUPPORTED;
+        const int nb = (n + 255) / 256;
+        hipLaunchKernelGGL(k_centres, dim3(nb), dim3(256), 0, c->stream, c->d_sym, c->d_cen, c->d_mag, (const cf *)c->d_xc, hs.spSymF,
+                           hs.offsetF, c->N, c->M, c->W, f.op, c->cap);
+        HIPCHK(hipGetLastError());
         const int more = n - f.nthreads;
         const BackPiece bq[3] = {{sym + f.nthreads, c->d_sym + f.nthreads, (size_t)more * sizeof(int)},
                                  {cen + f.nthreads, c->d_cen + f.nthreads, (size_t)more * sizeof(int)},
@@ -1751,6 +1768,20 @@ static int sync_find_impl(int device, const uint8_t *bits, int B, int L, const i
     }
     int *segcnt = w.seg, *segoff = w.seg + (size_t)B * nseg;
     size_t toff = 0;
+    if ((long long)B * nseg * K <= 64) {
+        // the decoder's case: everything in one launch (k_sync_small)
+        SyncSmallArgs sa;
+        size_t o = 0;
+        for (int t = 0; t < K; ++t) {
+            sa.T[t] = T[t];
+            sa.thr[t] = thr[t];
+            sa.toff[t] = (int)o;
+            o += (size_t)T[t];
+        }
+        const size_t lds = (size_t)Tmax + SYNC_SEG + Tmax - 1;
+        hipLaunchKernelGGL(k_sync_small, dim3(K, B), dim3(256), lds, w.stream, d_bits, d_tmpl, sa, B, L, max_hits, d_counts, d_idx, d_sc);
+        HIPCHK(hipGetLastError());
+    } else
     for (int t = 0; t < K; ++t) {
         const int Tt = T[t];
         const int ns = (L + Tt - 1 + SYNC_SEG - 1) / SYNC_SEG;

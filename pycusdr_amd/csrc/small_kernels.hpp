@@ -81,9 +81,7 @@ __global__ void __launch_bounds__(256) k_transpose(const cf *Z, cf *out, int N1,
 //     only lanes that beat it are visited, in row order.
 // fp32 evaluation order is pinned with explicit intrinsics (see oracle/mfbank_oracle.py).
 #define PICK_LDS 4096
-__global__ void __launch_bounds__(64) k_pick(const float *in, float *res, int num, int offset, int M, int sum_all) {
-    __shared__ float sIdx[64], sVal[64];
-    __shared__ float scol[PICK_LDS];
+DEVI void pick_body(const float *in, float *res, int num, int offset, int M, int sum_all, float *sIdx, float *sVal, float *scol) {
     const int lane = threadIdx.x;
     const int ncol = sum_all ? 1 : M;
     for (int x = 0; x < ncol; ++x) {
@@ -220,6 +218,11 @@ __global__ void __launch_bounds__(64) k_pick(const float *in, float *res, int nu
         res[1] = 10.f * log10f(__fdiv_rn(sVal[0], (float)M));
     }
 }
+__global__ void __launch_bounds__(64) k_pick(const float *in, float *res, int num, int offset, int M, int sum_all) {
+    __shared__ float sIdx[64], sVal[64];
+    __shared__ float scol[PICK_LDS];
+    pick_body(in, res, num, offset, M, sum_all, sIdx, sVal, scol);
+}
 
 // |z|^2 the way nvcc contracts in.x*in.x+in.y*in.y (cuda_kernels.cu:1022-1026): fma(x,x,y*y)
 DEVI float abs2c(cf z) { return __fmaf_rn(z.x, z.x, __fmul_rn(z.y, z.y)); }
@@ -235,9 +238,7 @@ __global__ void k_envelope(const cf *xc, float *env, int N, int M, int off) {
 
 // findCodeRateAndPhase (cuda_kernels.cu:236-320): argmax |P[k]|^2 over [offset, offset+len);
 // ties resolve to the lowest k (deterministic).  out = {k, atan2(im,re), |P|^2}
-__global__ void k_code_rate(const cf *P, float *out, int offset, int len) {
-    __shared__ float sv[1024];
-    __shared__ int si[1024];
+DEVI void code_rate_body(const cf *P, float *out, int offset, int len, float *sv, int *si) {
     const int tid = threadIdx.x;
     float best = -1.f;
     int bi = 0x7fffffff;
@@ -270,7 +271,11 @@ __global__ void k_code_rate(const cf *P, float *out, int offset, int len) {
         out[2] = sv[0];
     }
 }
-
+__global__ void k_code_rate(const cf *P, float *out, int offset, int len) {
+    __shared__ float sv[1024];
+    __shared__ int si[1024];
+    code_rate_body(P, out, offset, len, sv, si);
+}
 // findCentres (cuda_kernels.cu:78-146); thread = symbol index.
 DEVI void centres_body(int *outSym, int *outIdx, float *mag, const cf *sig, float spSym, float offset, int lenSig, int M, int W, int op,
                        int capacity, const int x) {
@@ -343,9 +348,8 @@ DEVI void slice_indices(int has_a, int a, int has_b, int b, int N, int *start, i
     *len = e > s ? e - s : 0;
 }
 
-// after k_pick: shift interpolation (DB:609-616) and the spectrum windows computeSNR reads (DB:635-667)
-__global__ void k_block_pick(const float *res, const int *shifts, int Dtot, int N, int w, BlockScalars *out) {
-    if (threadIdx.x || blockIdx.x) return;
+// shift interpolation (DB:609-616) and the spectrum windows computeSNR reads (DB:635-667); one thread
+DEVI void block_pick_body(const float *res, const int *shifts, int Dtot, int N, int w, BlockScalars *out) {
     const float idx = res[0];
     out->pick[0] = idx;
     out->pick[1] = res[1];
@@ -387,18 +391,43 @@ __global__ void k_block_pick(const float *res, const int *shifts, int Dtot, int 
     }
 }
 
-// the two SNR windows, piece after piece, into dst[band][cap] (longer bands are flagged by band_len > cap on the host)
-__global__ void k_block_bands(const cf *X, const BlockScalars *sc, cf *dst, int cap) {
-    const int b = blockIdx.y;
-    const int n0 = sc->band[b][0][1], n = n0 + sc->band[b][1][1];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n && i < cap; i += gridDim.x * blockDim.x)
-        dst[(size_t)b * cap + i] = i < n0 ? X[sc->band[b][0][0] + i] : X[sc->band[b][1][0] + (i - n0)];
+// Block path, search mode: findDopplerEst, then (one thread) the shift interpolation, then (all 64 threads) the two SNR
+// windows copied piece after piece into bands[band][cap] -- one launch instead of three; longer bands are flagged by
+// band_len > cap on the host.
+__global__ void __launch_bounds__(64) k_pick_block(const float *in, float *res, int num, int offset, int M, int sum_all, const int *shifts,
+                                                   int Dtot, int N, int w, const cf *X, BlockScalars *out, cf *bands, int cap) {
+    __shared__ float sIdx[64], sVal[64];
+    __shared__ float scol[PICK_LDS];
+    pick_body(in, res, num, offset, M, sum_all, sIdx, sVal, scol);
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out->rate_fallback = 0;
+        out->count = 0;
+        block_pick_body(res, shifts, Dtot, N, w, out);
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int b = 0; b < 2; ++b) {
+        const int n0 = out->band[b][0][1], n = n0 + out->band[b][1][1];
+        for (int i = threadIdx.x; i < n && i < cap; i += 64)
+            bands[(size_t)b * cap + i] = i < n0 ? X[out->band[b][0][0] + i] : X[out->band[b][1][0] + (i - n0)];
+    }
+}
+// Block path, fixed shift (STX): no pick -- the scalars of the search are cleared
+__global__ void k_block_clear(BlockScalars *out) {
+    if (threadIdx.x || blockIdx.x) return;
+    out->pick[0] = out->pick[1] = 0.f;
+    out->pick_valid = 0;
+    out->shift = out->low = out->high = 0;
+    out->frac = 0.0;
+    out->band_len[0] = out->band_len[1] = 0;
+    for (int q = 0; q < 8; ++q) (&out->band[0][0][0])[q] = 0;
 }
 
-// after k_code_rate: samples per symbol and code phase (DB:733-752), the clamp and the symbol count of cudaFindCentres
-// (DB:994-999), in float64 exactly as the host wrote them
-__global__ void k_block_rate(const float *cr, int N, int spsym_min, int capacity, BlockScalars *out) {
-    if (threadIdx.x || blockIdx.x) return;
+// samples per symbol and code phase (DB:733-752), the clamp and the symbol count of cudaFindCentres (DB:994-999), in
+// float64 exactly as the host wrote them; one thread
+DEVI void block_rate_body(const float *cr, int N, int spsym_min, int capacity, BlockScalars *out) {
     out->cr[0] = cr[0];
     out->cr[1] = cr[1];
     out->cr[2] = cr[2];
@@ -430,3 +459,15 @@ __global__ void k_centres_block(int *outSym, int *outIdx, float *mag, const cf *
                                 int op, int capacity) {
     centres_body(outSym, outIdx, mag, sig, sc->spSymF, sc->offsetF, lenSig, M, W, op, capacity, (int)(blockIdx.x * blockDim.x + threadIdx.x));
 }
+
+// Block path: the same, and thread 0 goes on to the float64 rate/phase arithmetic (one launch instead of two)
+__global__ void k_code_rate_block(const cf *P, float *out, int offset, int len, int N, int spsym_min, int capacity, BlockScalars *sc) {
+    __shared__ float sv[1024];
+    __shared__ int si[1024];
+    code_rate_body(P, out, offset, len, sv, si);
+    if (threadIdx.x == 0) {
+        __threadfence_block();
+        block_rate_body(out, N, spsym_min, capacity, sc);
+    }
+}
+

@@ -231,3 +231,74 @@ __global__ void __launch_bounds__(256) k_sync_stream_scan(const int *counts, int
         }
     }
 }
+
+// ---- small inputs (the decoder's call: one block's bit stream, a couple of templates) ------------------------------------
+// ONE launch for all templates and streams: workgroup (template, stream) walks over the stream's segments in order, so a
+// running offset keeps the hits ordered without the count / scan / write passes -- at this size the three passes per
+// template were six dependent launches of a few microseconds of work each.
+struct SyncSmallArgs {
+    int T[16], thr[16], toff[16];
+};
+__global__ void __launch_bounds__(256) k_sync_small(const uint8_t *bits, const int8_t *tmpls, SyncSmallArgs a, int B, int L, int max_hits,
+                                                    int32_t *counts, int32_t *hit_idx, int32_t *hit_score) {
+    extern __shared__ __attribute__((aligned(16))) int8_t sm[];
+    __shared__ int wsum[4];
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int T = a.T[t], thr = a.thr[t];
+    int8_t *st = sm;      // T taps
+    int8_t *sb = sm + T;  // SYNC_SEG + T - 1 bits
+    for (int q = threadIdx.x; q < T; q += 256) st[q] = tmpls[a.toff[t] + q];
+    const uint8_t *row = bits + (size_t)b * L;
+    const int outLen = L + T - 1;
+    const int nseg = (outLen + SYNC_SEG - 1) / SYNC_SEG;
+    int32_t *oi = hit_idx + ((size_t)t * B + b) * max_hits, *os = hit_score + ((size_t)t * B + b) * max_hits;
+    int run = 0;
+    for (int seg = 0; seg < nseg; ++seg) {
+        const int i0 = seg * SYNC_SEG;
+        __syncthreads();                                  // the previous segment's readers are done
+        for (int q = threadIdx.x; q < SYNC_SEG + T - 1; q += 256) {
+            const int src = i0 - (T - 1) + q;
+            sb[q] = (src >= 0 && src < L) ? (int8_t)row[src] : (int8_t)0;
+        }
+        __syncthreads();
+        int sc[4];
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int li = threadIdx.x * 4 + u;
+            int acc = 0;
+            const int8_t *p = sb + li + T - 1;
+            for (int q = 0; q < T; ++q) acc += (int)st[q] * (int)p[-q];
+            sc[u] = acc;
+            cnt += (i0 + li < outLen && acc >= thr) ? 1 : 0;
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if ((threadIdx.x & 63) >= o) incl += v;
+        }
+        const int wid = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 63) wsum[wid] = incl;
+        __syncthreads();
+        int wbase = 0, total = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wid) wbase += wsum[w];
+            total += wsum[w];
+        }
+        int pos = run + wbase + incl - cnt;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int li = threadIdx.x * 4 + u;
+            if (i0 + li < outLen && sc[u] >= thr) {
+                if (pos < max_hits) {
+                    oi[pos] = i0 + li;
+                    os[pos] = sc[u];
+                }
+                ++pos;
+            }
+        }
+        run += total;
+    }
+    if (threadIdx.x == 0) counts[(size_t)t * B + b] = run;
+}

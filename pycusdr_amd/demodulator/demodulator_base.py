@@ -163,6 +163,12 @@ class Demodulator:
         #   "HIP": {"one_call": false}
         self._one_call = bool(hip_cfg.get('one_call', True)) and shard is None and hasattr(self.bank, 'receive_block')
         self._pending = None
+        if self._one_call:
+            # room for the two spectrum windows computeSNR reads (DB:635-667): the widest gap between neighbouring bins + margins
+            sh = self.doppCyperSymNorm.astype(np.int64)
+            gap = int(np.abs(np.diff(sh)).max()) if len(sh) > 1 else 0
+            gap = min(gap, self.Nfft - gap) + 2 * 5 + 2
+            self.bank.BAND_CAPACITY = int(min(1 << 16, max(256, 1 << int(np.ceil(np.log2(gap))))))
 
         # windowed argmax range of the symbol-rate estimate (reference DB:508-512)
         self.symsTolLow = 0.9 * spsym

@@ -203,7 +203,8 @@ class MFBank:
                                               _ptr(sym), _ptr(cen), _ptr(mag)), 'mfb_find_centres')
         return sym, cen, mag
 
-    BAND_CAPACITY = 8192       # complex64 elements per SNR window delivered with the block (longer ones: get_spectrum)
+    BAND_CAPACITY = 1024       # complex64 elements per SNR window delivered with the block (longer ones: get_spectrum);
+                               # an instance may set its own before the first block (Demodulator: from the bin spacing)
 
     SOURCES = {'pinned': 0, 'device': 1, 'uploaded': 2, 'pinned2': 3}
 
