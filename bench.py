@@ -456,6 +456,14 @@ def main():
             bank.find_centres(np.float32(spS), np.float32(cOff), 0, int(N / spS))
         torch.cuda.synchronize(dev)
         extras['find_carrier_plus_demodulate_ms'] = round((time.perf_counter() - t1) / reps * 1e3, 4)
+        # the same stages (plus the shift interpolation, the SNR windows and the rate arithmetic) as ONE library call with one
+        # synchronisation: mfb_receive_block on the block resident in HBM
+        bank.receive_block(k_off, k_len, 8, source='device', device_ptr=blocks.data_ptr())
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for i in range(reps):
+            bank.receive_block(k_off, k_len, 8, source='device', device_ptr=blocks.data_ptr() + block_index(i) * esz)
+        extras['receive_block_one_call_ms'] = round((time.perf_counter() - t1) / reps * 1e3, 4)
         # S2: pure-throughput signal (unit-variance white noise, RandomState(0)), same step
         s2 = sg.s2_noise(4, N)
         if s2 is not None:

@@ -1655,7 +1655,10 @@ static SyncWs *ws_acquire(int device) {
         }
     }
     SyncWs *w = new SyncWs();
-    if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) {
+    // highest priority: the decoder's small searches run while the demodulator's stream has the next block's kernels queued
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&w->stream, hipStreamNonBlocking, hi) != hipSuccess) {
         delete w;
         return nullptr;
     }

@@ -58,6 +58,7 @@ class Decoder:
         # correlator returns the full np.convolve-style score array and is thresholded on the host
         self.correlate = correlator if correlator is not None else (lambda b, t: _hip_correlator(b, t, device=self.device))
         self._finder = _hip_finder if correlator is None else None
+        self._multi = None
         self.preprocessor = protocol.decoderPreprocessor
         self.postprocessor = protocol.decoderPostprocessor
         self.mask = protocol.get_mask()
@@ -93,10 +94,13 @@ class Decoder:
         self.bitsOverlapBuf = rawBits_DS[-self.numBitsOverlap:]
 
         if self._finder is not None:
-            # both searches of the block in one library call (one host-device round trip)
-            (idxCand, candScore), (syncSigStartIdx, _) = _hip_finder_multi(
-                rawBits_DS, (self.mask, self.syncSig), (p.numOnesHeader - p.headerTol, p.numOnesSyncSig - p.syncSigTol),
-                device=self.device)
+            # both searches of the block in one library call (one host-device round trip); templates and thresholds are
+            # handed over once (they are read here, after get_mask / get_syncFlag have set the protocol's counts)
+            if self._multi is None:
+                from .mfbank import SyncFinder
+                self._multi = SyncFinder((self.mask, self.syncSig),
+                                         (p.numOnesHeader - p.headerTol, p.numOnesSyncSig - p.syncSigTol), device=self.device)
+            (idxCand, candScore), (syncSigStartIdx, _) = self._multi.find(rawBits_DS)
         else:
             idxCand, candScore = self.hits(rawBits_DS, self.mask, p.numOnesHeader - p.headerTol)
             syncSigStartIdx, _ = self.hits(rawBits_DS, self.syncSig, p.numOnesSyncSig - p.syncSigTol)

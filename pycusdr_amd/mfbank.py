@@ -470,6 +470,50 @@ def sync_find_multi(bits, templates, thresholds, max_hits=256, device=0):
     return out
 
 
+class SyncFinder:
+    """``sync_find_multi`` for a caller that searches the SAME templates block after block (the decoder): templates,
+    thresholds and result buffers are prepared once, a call costs one library call.  ``find(bits)`` takes a 1-D 0/1 stream
+    (uint8 is used as it is; other dtypes are converted without re-validation: the decoder's bits come from the
+    demodulator's LUT) and returns one (idx, score) pair per template."""
+
+    def __init__(self, templates, thresholds, max_hits=256, device=0):
+        self._lib = _lib.load()
+        tis = []
+        for t in templates:
+            t = np.asarray(t)
+            ti = np.ascontiguousarray(t, dtype=np.int8)
+            if not np.array_equal(ti, t):
+                raise ValueError('template must hold small integers (int8)')
+            tis.append(ti)
+        if len(tis) != len(thresholds):
+            raise ValueError('one threshold per template')
+        self.K = len(tis)
+        self.packed = np.concatenate(tis)
+        self.T = np.array([t.size for t in tis], dtype=np.int32)
+        self.thr = np.array([int(np.ceil(x)) for x in thresholds], dtype=np.int32)
+        self.device = int(device)
+        self._alloc(int(max_hits))
+
+    def _alloc(self, max_hits):
+        self.max_hits = max_hits
+        self.idx = np.empty((self.K, 1, max_hits), dtype=np.int32)
+        self.sc = np.empty((self.K, 1, max_hits), dtype=np.int32)
+        self.cnt = np.empty((self.K, 1), dtype=np.int32)
+        self._args = (_ptr(self.packed), _ptr(self.T), _ptr(self.thr), self.K)
+        self._outs = (_ptr(self.idx), _ptr(self.sc), _ptr(self.cnt))
+
+    def find(self, bits):
+        b = bits if (isinstance(bits, np.ndarray) and bits.dtype == np.uint8 and bits.flags.c_contiguous) else \
+            np.ascontiguousarray(bits, dtype=np.uint8)
+        while True:
+            _lib.check(self._lib.mfb_sync_find_multi(self.device, _ptr(b), 1, b.size, *self._args, self.max_hits, *self._outs),
+                       'mfb_sync_find_multi')
+            if self.cnt.max() <= self.max_hits:
+                break
+            self._alloc(int(self.cnt.max()))
+        return [(self.idx[k, 0, :self.cnt[k, 0]].copy(), self.sc[k, 0, :self.cnt[k, 0]].copy()) for k in range(self.K)]
+
+
 def sync_correlate(bits, template, device=0):
     """Batched full convolution of 0/1 bit streams with an integer template on the GPU
     (reference decoder.py:96,112 does this with np.convolve).  ``bits`` uint8 [L] or [B, L];
