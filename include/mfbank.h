@@ -281,6 +281,18 @@ int mfb_sync_find_multi(int device, const uint8_t *bits, int B, int L, const int
                         const int *thresholds, int ntmpl, int max_hits, int32_t *hit_idx, int32_t *hit_score,
                         int32_t *counts);
 
+/* A decoder's own sync finder: the templates and thresholds it searches in every block's bit stream (header mask and sync flag,
+ * DEC:96-113) stay on the device with a stream (highest priority), page-locked staging and result buffers of the finder's own.
+ * _begin copies the stream in, enqueues the search and returns at once; _end waits and hands out, per template t,
+ * counts[t] and the first min(counts[t], max_hits) positions / scores at hit_idx + t*max_hits (ascending).  One search in
+ * flight per finder.  The reference computes both correlations with np.convolve on the host, synchronously. */
+typedef struct mfb_syncfinder mfb_syncfinder;
+int mfb_syncfinder_create(mfb_syncfinder **out, int device, const int8_t *tmpls, const int *T, const int *thresholds, int ntmpl,
+                          int max_bits, int max_hits);
+int mfb_syncfinder_destroy(mfb_syncfinder *finder);
+int mfb_syncfinder_begin(mfb_syncfinder *finder, const uint8_t *bits, int L);
+int mfb_syncfinder_end(mfb_syncfinder *finder, int32_t *counts, int32_t *hit_idx, int32_t *hit_score);
+
 /* The same search on PACKED bit streams -- 8 bits per byte in numpy.packbits layout (stream bit i = bit 7 - i%8 of byte
  * i/8), row b at packed + b*row_bytes -- for taps in {-1, 0, +1}: the correlation is popcount(W & P) - popcount(W & Q) on
  * 64-bit windows (exact), an eighth of the bytes cross the host link, and only the hits come back, as ONE flat list: stream

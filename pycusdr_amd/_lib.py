@@ -94,6 +94,10 @@ PROTOTYPES = {
     'mfb_sync_correlate': (_i, [_i, _vp, _i, _i, _vp, _i, _vp]),
     'mfb_sync_find': (_i, [_i, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'mfb_sync_find_multi': (_i, [_i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    'mfb_syncfinder_create': (_i, [C.POINTER(_vp), _i, _vp, _vp, _vp, _i, _i, _i]),
+    'mfb_syncfinder_destroy': (_i, [_vp]),
+    'mfb_syncfinder_begin': (_i, [_vp, _vp, _i]),
+    'mfb_syncfinder_end': (_i, [_vp, _vp, _vp, _vp]),
     'mfb_sync_find_packed': (_i, [_i, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     'mfb_sync_pinned_buffer': (_i, [_i, C.c_size_t, C.POINTER(_vp)]),
     'mfb_xcorr': (_i, [_vp, _vp, _i, _vp, _i, _vp]),

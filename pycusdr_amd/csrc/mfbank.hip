@@ -1826,6 +1826,172 @@ extern "C" int mfb_sync_find_multi(int device, const uint8_t *bits, int B, int L
     return sync_find_impl(device, bits, B, L, tmpls, T, thresholds, ntmpl, max_hits, hit_idx, hit_score, counts);
 }
 
+// ---- a decoder's own sync finder -------------------------------------------------------------------------------------------
+// The decoder searches the SAME templates in every block's bit stream (DEC:96-113).  A finder object keeps them on the
+// device together with a stream, page-locked staging and result buffers of its own, and splits the search into begin
+// (copy in, enqueue, return) and end (wait, copy out): the caller overlaps the round trip with its other work.
+struct mfb_syncfinder {
+    int device, K, max_hits, Tmax;
+    std::vector<int> T, thr;
+    hipStream_t stream;
+    hipEvent_t done;
+    int8_t *d_tmpl;
+    uint8_t *d_bits, *h_bits;
+    int cap_bits;
+    int32_t *d_res, *h_res;        // counts[K] | idx[K][max_hits] | score[K][max_hits]
+    int *d_seg;                    // segcnt | segoff of the multi-pass form (long streams)
+    size_t cap_seg;
+    SyncSmallArgs sa;
+    bool busy;
+};
+
+static int sf_reserve_bits(mfb_syncfinder *f, int L) {
+    if (L <= f->cap_bits) return MFB_OK;
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (f->d_bits) HIPCHK(hipFree(f->d_bits));
+    if (f->h_bits) HIPCHK(hipHostFree(f->h_bits));
+    f->d_bits = f->h_bits = nullptr;
+    f->cap_bits = 0;
+    const int cap = L + L / 2 + 1024;
+    HIPCHK(hipMalloc((void **)&f->d_bits, (size_t)cap));
+    HIPCHK(hipHostMalloc((void **)&f->h_bits, (size_t)cap, hipHostMallocDefault));
+    f->cap_bits = cap;
+    return MFB_OK;
+}
+
+extern "C" int mfb_syncfinder_destroy(mfb_syncfinder *f) {
+    if (!f) return MFB_ERR_ARG;
+    (void)hipSetDevice(f->device);
+    if (f->stream) (void)hipStreamSynchronize(f->stream);
+    if (f->d_tmpl) (void)hipFree(f->d_tmpl);
+    if (f->d_bits) (void)hipFree(f->d_bits);
+    if (f->h_bits) (void)hipHostFree(f->h_bits);
+    if (f->d_res) (void)hipFree(f->d_res);
+    if (f->h_res) (void)hipHostFree(f->h_res);
+    if (f->d_seg) (void)hipFree(f->d_seg);
+    if (f->done) (void)hipEventDestroy(f->done);
+    if (f->stream) (void)hipStreamDestroy(f->stream);
+    delete f;
+    return MFB_OK;
+}
+
+static int sf_create_impl(mfb_syncfinder *f, const int8_t *tmpls, int max_bits) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    HIPCHK(hipStreamCreateWithPriority(&f->stream, hipStreamNonBlocking, hi));
+    HIPCHK(hipEventCreateWithFlags(&f->done, hipEventDisableTiming));
+    size_t taps = 0;
+    for (int t = 0; t < f->K; ++t) {
+        f->sa.T[t] = f->T[t];
+        f->sa.thr[t] = f->thr[t];
+        f->sa.toff[t] = (int)taps;
+        taps += (size_t)f->T[t];
+    }
+    HIPCHK(hipMalloc((void **)&f->d_tmpl, taps));
+    HIPCHK(hipMemcpy(f->d_tmpl, tmpls, taps, hipMemcpyHostToDevice));
+    const size_t res_bytes = (size_t)f->K * (1 + 2 * (size_t)f->max_hits) * sizeof(int32_t);
+    HIPCHK(hipMalloc((void **)&f->d_res, res_bytes));
+    HIPCHK(hipHostMalloc((void **)&f->h_res, res_bytes, hipHostMallocDefault));
+    return sf_reserve_bits(f, max_bits);
+}
+
+extern "C" int mfb_syncfinder_create(mfb_syncfinder **out, int device, const int8_t *tmpls, const int *T, const int *thresholds, int ntmpl,
+                                     int max_bits, int max_hits) {
+    if (!out) return MFB_ERR_ARG;
+    *out = nullptr;
+    if (!tmpls || !T || !thresholds || ntmpl < 1 || ntmpl > 16 || max_bits < 1 || max_hits < 1) return MFB_ERR_ARG;
+    for (int t = 0; t < ntmpl; ++t)
+        if (T[t] < 1 || T[t] > 4096) return MFB_ERR_ARG;
+    int rc = sync_device_ok(device);
+    if (rc) return rc;
+    mfb_syncfinder *f = new mfb_syncfinder();
+    f->device = device;
+    f->K = ntmpl;
+    f->max_hits = max_hits;
+    f->T.assign(T, T + ntmpl);
+    f->thr.assign(thresholds, thresholds + ntmpl);
+    f->Tmax = 0;
+    for (int t = 0; t < ntmpl; ++t) f->Tmax = T[t] > f->Tmax ? T[t] : f->Tmax;
+    f->stream = nullptr;
+    f->done = nullptr;
+    f->d_tmpl = nullptr;
+    f->d_bits = f->h_bits = nullptr;
+    f->cap_bits = 0;
+    f->d_res = f->h_res = nullptr;
+    f->d_seg = nullptr;
+    f->cap_seg = 0;
+    f->busy = false;
+    rc = sf_create_impl(f, tmpls, max_bits);
+    if (rc) {
+        (void)mfb_syncfinder_destroy(f);
+        return rc;
+    }
+    *out = f;
+    return MFB_OK;
+}
+
+extern "C" int mfb_syncfinder_begin(mfb_syncfinder *f, const uint8_t *bits, int L) {
+    if (!f || !bits || L < 1) return MFB_ERR_ARG;
+    if (f->busy) return MFB_ERR_STATE;
+    HIPCHK(hipSetDevice(f->device));
+    int rc = sf_reserve_bits(f, L);
+    if (rc) return rc;
+    memcpy(f->h_bits, bits, (size_t)L);
+    HIPCHK(hipMemcpyAsync(f->d_bits, f->h_bits, (size_t)L, hipMemcpyHostToDevice, f->stream));
+    const int K = f->K, mh = f->max_hits;
+    int32_t *d_counts = f->d_res, *d_idx = f->d_res + K, *d_sc = d_idx + (size_t)K * mh;
+    const int nseg = (L + f->Tmax - 1 + SYNC_SEG - 1) / SYNC_SEG;
+    if (nseg <= 16) {
+        const size_t lds = (size_t)f->Tmax + SYNC_SEG + f->Tmax - 1;
+        hipLaunchKernelGGL(k_sync_small, dim3(K, 1), dim3(256), lds, f->stream, (const uint8_t *)f->d_bits, (const int8_t *)f->d_tmpl, f->sa, 1,
+                           L, mh, d_counts, d_idx, d_sc);
+    } else {
+        const size_t need = (size_t)2 * nseg * sizeof(int);
+        if (f->cap_seg < need) {
+            HIPCHK(hipStreamSynchronize(f->stream));
+            if (f->d_seg) HIPCHK(hipFree(f->d_seg));
+            f->d_seg = nullptr;
+            f->cap_seg = 0;
+            HIPCHK(hipMalloc((void **)&f->d_seg, need));
+            f->cap_seg = need;
+        }
+        int *segcnt = f->d_seg, *segoff = f->d_seg + nseg;
+        for (int t = 0; t < K; ++t) {
+            const int Tt = f->T[t];
+            const int ns = (L + Tt - 1 + SYNC_SEG - 1) / SYNC_SEG;
+            const size_t lds = (size_t)Tt + SYNC_SEG + Tt - 1;
+            const int8_t *tp = f->d_tmpl + f->sa.toff[t];
+            hipLaunchKernelGGL((k_sync_find<false>), dim3(ns, 1), dim3(256), lds, f->stream, (const uint8_t *)f->d_bits, tp, L, Tt, f->thr[t], ns,
+                               segcnt, (const int *)nullptr, mh, (int32_t *)nullptr, (int32_t *)nullptr);
+            hipLaunchKernelGGL(k_sync_scan, dim3(1), dim3(64), 0, f->stream, (const int *)segcnt, segoff, d_counts + t, 1, ns);
+            hipLaunchKernelGGL((k_sync_find<true>), dim3(ns, 1), dim3(256), lds, f->stream, (const uint8_t *)f->d_bits, tp, L, Tt, f->thr[t], ns,
+                               segcnt, (const int *)segoff, mh, d_idx + (size_t)t * mh, d_sc + (size_t)t * mh);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(f->h_res, f->d_res, (size_t)K * (1 + 2 * (size_t)mh) * sizeof(int32_t), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipEventRecord(f->done, f->stream));
+    f->busy = true;
+    return MFB_OK;
+}
+
+extern "C" int mfb_syncfinder_end(mfb_syncfinder *f, int32_t *counts, int32_t *hit_idx, int32_t *hit_score) {
+    if (!f || !counts || !hit_idx || !hit_score) return MFB_ERR_ARG;
+    if (!f->busy) return MFB_ERR_STATE;
+    HIPCHK(hipSetDevice(f->device));
+    HIPCHK(hipEventSynchronize(f->done));
+    f->busy = false;
+    const int K = f->K, mh = f->max_hits;
+    const int32_t *r = f->h_res;
+    memcpy(counts, r, (size_t)K * sizeof(int32_t));
+    for (int t = 0; t < K; ++t) {
+        const int n = r[t] < mh ? r[t] : mh;
+        memcpy(hit_idx + (size_t)t * mh, r + K + (size_t)t * mh, (size_t)n * sizeof(int32_t));
+        memcpy(hit_score + (size_t)t * mh, r + K + (size_t)K * mh + (size_t)t * mh, (size_t)n * sizeof(int32_t));
+    }
+    return MFB_OK;
+}
+
 // ---- packed sync correlation (sync_kernels.hpp, second half) -------------------------------------------------------------
 // One page-locked buffer per device, grown on demand: callers that produce their packed bit streams straight into it
 // (mfb_sync_pinned_buffer) get a true asynchronous host-to-device copy; any other host pointer works too (the runtime stages it).

@@ -59,6 +59,7 @@ class Decoder:
         self.correlate = correlator if correlator is not None else (lambda b, t: _hip_correlator(b, t, device=self.device))
         self._finder = _hip_finder if correlator is None else None
         self._multi = None
+        self._flight = None
         self.preprocessor = protocol.decoderPreprocessor
         self.postprocessor = protocol.decoderPostprocessor
         self.mask = protocol.get_mask()
@@ -88,22 +89,38 @@ class Decoder:
         return idx, score[idx]
 
     def findFrames(self, bits_raw, frameStartIdx, debugMode=False):
+        self.findFrames_begin(bits_raw, frameStartIdx)
+        return self.findFrames_end()
+
+    def findFrames_begin(self, bits_raw, frameStartIdx):
+        """First half of ``findFrames``: preprocessing, the overlap stitch, and the two searches handed to the device.
+        Returns at once; ``findFrames_end`` collects the hits and runs the packet state machine.  A caller may do other
+        work in between (the streaming loop assembles and launches the next block), but must call _end before the next
+        _begin: the state machine of block i decides what block i + 1 is stitched to (DEC:254-263)."""
         p = self.protocol
         bits_less_raw = self.preprocessor(bits_raw)
         rawBits_DS = np.concatenate((self.bitsOverlapBuf, bits_less_raw))
         self.bitsOverlapBuf = rawBits_DS[-self.numBitsOverlap:]
-
+        hits = None
         if self._finder is not None:
-            # both searches of the block in one library call (one host-device round trip); templates and thresholds are
-            # handed over once (they are read here, after get_mask / get_syncFlag have set the protocol's counts)
+            # both searches of the block in one device round trip; templates and thresholds are handed over once (they are
+            # read here, after get_mask / get_syncFlag have set the protocol's counts)
             if self._multi is None:
                 from .mfbank import SyncFinder
                 self._multi = SyncFinder((self.mask, self.syncSig),
                                          (p.numOnesHeader - p.headerTol, p.numOnesSyncSig - p.syncSigTol), device=self.device)
-            (idxCand, candScore), (syncSigStartIdx, _) = self._multi.find(rawBits_DS)
+            self._multi.begin(rawBits_DS)
         else:
-            idxCand, candScore = self.hits(rawBits_DS, self.mask, p.numOnesHeader - p.headerTol)
-            syncSigStartIdx, _ = self.hits(rawBits_DS, self.syncSig, p.numOnesSyncSig - p.syncSigTol)
+            hits = (self.hits(rawBits_DS, self.mask, p.numOnesHeader - p.headerTol),
+                    self.hits(rawBits_DS, self.syncSig, p.numOnesSyncSig - p.syncSigTol))
+        self._flight = (rawBits_DS, bits_less_raw, frameStartIdx, hits)
+
+    def findFrames_end(self):
+        rawBits_DS, bits_less_raw, frameStartIdx, hits = self._flight
+        self._flight = None
+        if hits is None:
+            hits = self._multi.end()
+        (idxCand, candScore), (syncSigStartIdx, _) = hits
         packetIdx = idxCand - len(self.mask) + 1          # the peak sits on the template's last bit
         numSyncSig = len(syncSigStartIdx)
 

@@ -170,6 +170,23 @@ class DemodulatorRunner:
         results, packets = [], []
         flying = None                    # (slot, count, timestamp)
 
+        searching = []                   # the result dict whose bits the decoder is searching right now
+        split = decoder is not None and hasattr(decoder, 'findFrames_begin')
+
+        def deliver(d):
+            if sink is not None:
+                sink(d)
+            else:
+                results.append(d)
+
+        def finish_search():
+            if searching:
+                d = searching.pop()
+                pk, _, nsync = decoder.findFrames_end()
+                d['numSyncSig'] = nsync
+                packets.extend(pk)
+                deliver(d)
+
         def collect(fl):
             slot, count, stamp = fl
             part = {'count': count, 'timestamp': stamp}
@@ -177,14 +194,18 @@ class DemodulatorRunner:
             part['rec'] = self.demod.demodulateDevice()
             part['time_device'] = time.time() - stamp
             d = self.feed_host(part)
+            if split:
+                # the decoder's searches of this block run on the device while this thread goes on; their hits are
+                # collected, and the packet state machine run, right before the next block's bits go in
+                finish_search()
+                decoder.findFrames_begin(d['data'], 0)
+                searching.append(d)
+                return
             if decoder is not None:
                 pk, _, nsync = decoder.findFrames(d['data'], 0)
                 d['numSyncSig'] = nsync
                 packets.extend(pk)
-            if sink is not None:
-                sink(d)
-            else:
-                results.append(d)
+            deliver(d)
 
         cur = 0
         for chunk in chunk_source:
@@ -199,6 +220,7 @@ class DemodulatorRunner:
                 flying = started
         if flying is not None:
             collect(flying)
+        finish_search()
         self.raw = bufs[cur]             # where the next block would be assembled
         return results, packets
 

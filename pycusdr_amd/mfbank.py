@@ -471,12 +471,13 @@ def sync_find_multi(bits, templates, thresholds, max_hits=256, device=0):
 
 
 class SyncFinder:
-    """``sync_find_multi`` for a caller that searches the SAME templates block after block (the decoder): templates,
-    thresholds and result buffers are prepared once, a call costs one library call.  ``find(bits)`` takes a 1-D 0/1 stream
-    (uint8 is used as it is; other dtypes are converted without re-validation: the decoder's bits come from the
-    demodulator's LUT) and returns one (idx, score) pair per template."""
+    """The decoder's sync search as an object (mfb_syncfinder_*): the templates it searches block after block (header mask,
+    sync flag) and their thresholds are handed to the library once and stay on the device; ``begin(bits)`` copies a 1-D
+    0/1 stream in and returns at once, ``end()`` waits and returns one (idx, score) pair per template; ``find`` does
+    both.  uint8 streams are used as they are; other dtypes are converted without re-validation (the decoder's bits come
+    from the demodulator's LUT)."""
 
-    def __init__(self, templates, thresholds, max_hits=256, device=0):
+    def __init__(self, templates, thresholds, max_hits=256, max_bits=1 << 16, device=0):
         self._lib = _lib.load()
         tis = []
         for t in templates:
@@ -488,30 +489,53 @@ class SyncFinder:
         if len(tis) != len(thresholds):
             raise ValueError('one threshold per template')
         self.K = len(tis)
-        self.packed = np.concatenate(tis)
-        self.T = np.array([t.size for t in tis], dtype=np.int32)
-        self.thr = np.array([int(np.ceil(x)) for x in thresholds], dtype=np.int32)
-        self.device = int(device)
-        self._alloc(int(max_hits))
+        self._templates = np.concatenate(tis)
+        self._T = np.array([t.size for t in tis], dtype=np.int32)
+        self._thr = np.array([int(np.ceil(x)) for x in thresholds], dtype=np.int32)
+        self.device, self.max_bits = int(device), int(max_bits)
+        self._h = C.c_void_p()
+        self._pending = None
+        self._create(int(max_hits))
 
-    def _alloc(self, max_hits):
+    def _create(self, max_hits):
+        self.close()
         self.max_hits = max_hits
-        self.idx = np.empty((self.K, 1, max_hits), dtype=np.int32)
-        self.sc = np.empty((self.K, 1, max_hits), dtype=np.int32)
-        self.cnt = np.empty((self.K, 1), dtype=np.int32)
-        self._args = (_ptr(self.packed), _ptr(self.T), _ptr(self.thr), self.K)
-        self._outs = (_ptr(self.idx), _ptr(self.sc), _ptr(self.cnt))
+        _lib.check(self._lib.mfb_syncfinder_create(C.byref(self._h), self.device, _ptr(self._templates), _ptr(self._T), _ptr(self._thr),
+                                                   self.K, self.max_bits, max_hits), 'mfb_syncfinder_create')
+        self._idx = np.empty((self.K, max_hits), dtype=np.int32)
+        self._sc = np.empty((self.K, max_hits), dtype=np.int32)
+        self._cnt = np.empty(self.K, dtype=np.int32)
+        self._outs = (_ptr(self._cnt), _ptr(self._idx), _ptr(self._sc))
 
-    def find(self, bits):
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self._lib.mfb_syncfinder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def begin(self, bits):
         b = bits if (isinstance(bits, np.ndarray) and bits.dtype == np.uint8 and bits.flags.c_contiguous) else \
             np.ascontiguousarray(bits, dtype=np.uint8)
-        while True:
-            _lib.check(self._lib.mfb_sync_find_multi(self.device, _ptr(b), 1, b.size, *self._args, self.max_hits, *self._outs),
-                       'mfb_sync_find_multi')
-            if self.cnt.max() <= self.max_hits:
-                break
-            self._alloc(int(self.cnt.max()))
-        return [(self.idx[k, 0, :self.cnt[k, 0]].copy(), self.sc[k, 0, :self.cnt[k, 0]].copy()) for k in range(self.K)]
+        _lib.check(self._lib.mfb_syncfinder_begin(self._h, _ptr(b), b.size), 'mfb_syncfinder_begin')
+        self._pending = b
+
+    def end(self):
+        _lib.check(self._lib.mfb_syncfinder_end(self._h, *self._outs), 'mfb_syncfinder_end')
+        bits, self._pending = self._pending, None
+        if self._cnt.max() > self.max_hits:         # more hits than room: once more with enough of it
+            self._create(int(self._cnt.max()))
+            self.begin(bits)
+            return self.end()
+        return [(self._idx[k, :self._cnt[k]].copy(), self._sc[k, :self._cnt[k]].copy()) for k in range(self.K)]
+
+    def find(self, bits):
+        self.begin(bits)
+        return self.end()
 
 
 def sync_correlate(bits, template, device=0):
