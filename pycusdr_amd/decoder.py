@@ -92,6 +92,16 @@ class Decoder:
         self.findFrames_begin(bits_raw, frameStartIdx)
         return self.findFrames_end()
 
+    def prepare(self):
+        """Create the device-side finder now (page-locked staging, stream, templates on the device) instead of inside the
+        first block of a stream.  No-op with an injected correlator."""
+        if self._finder is not None and self._multi is None:
+            from .mfbank import SyncFinder
+            p = self.protocol
+            self._multi = SyncFinder((self.mask, self.syncSig),
+                                     (p.numOnesHeader - p.headerTol, p.numOnesSyncSig - p.syncSigTol), device=self.device)
+            self._multi.find(np.zeros(max(len(self.mask), len(self.syncSig)) + 8, dtype=np.uint8))     # code objects loaded
+
     def findFrames_begin(self, bits_raw, frameStartIdx):
         """First half of ``findFrames``: preprocessing, the overlap stitch, and the two searches handed to the device.
         Returns at once; ``findFrames_end`` collects the hits and runs the packet state machine.  A caller may do other
@@ -105,10 +115,7 @@ class Decoder:
         if self._finder is not None:
             # both searches of the block in one device round trip; templates and thresholds are handed over once (they are
             # read here, after get_mask / get_syncFlag have set the protocol's counts)
-            if self._multi is None:
-                from .mfbank import SyncFinder
-                self._multi = SyncFinder((self.mask, self.syncSig),
-                                         (p.numOnesHeader - p.headerTol, p.numOnesSyncSig - p.syncSigTol), device=self.device)
+            self.prepare()
             self._multi.begin(rawBits_DS)
         else:
             hits = (self.hits(rawBits_DS, self.mask, p.numOnesHeader - p.headerTol),

@@ -172,6 +172,8 @@ class DemodulatorRunner:
 
         searching = []                   # the result dict whose bits the decoder is searching right now
         split = decoder is not None and hasattr(decoder, 'findFrames_begin')
+        if split and hasattr(decoder, 'prepare'):
+            decoder.prepare()
 
         def deliver(d):
             if sink is not None:
