@@ -226,24 +226,52 @@ DEVI void bfly(cf (&v)[16]) {
 // bin being transformed).  TwRegs keeps them in registers across the work loop of a kernel
 // (HOIST) -- or, for the very large transforms whose register budget is 128, reloads them from
 // the table each time.
-template <int L>
+// LTW: only the first twiddled pass is kept in registers; the later ones (whose factors depend on the lane's position
+// inside a group of L/256 lanes only) are read from a small table in LDS (broadcast reads), which frees 30 VGPRs per pass --
+// what the barrier-team kernels need to run three waves per SIMD.
+template <int L, bool LTW = false>
 struct TwRegs {
     static constexpr int l = ilog2c(L);
     static constexpr int NTW = npass(l) - 1;  // twiddled passes
-    cf r[NTW > 0 ? NTW : 1][16];
+    static constexpr int NREG = LTW ? (NTW > 1 ? 1 : NTW) : NTW;      // of them in registers
+    static constexpr bool LDS_TW = LTW;
+    static constexpr int LSTRIDE = L / 256;   // lanes with distinct factors in pass 1 (L >= 512)
+    static constexpr int LDS_ELEMS = LTW && NTW > 1 ? (NTW - 1) * 15 * (L / 256) : 0;
+    cf r[NREG > 0 ? NREG : 1][16];
+    const cf *ltab;                           // [pass - 1][p - 1][t]
 };
 
-template <int L, int S = 0>
-DEVI void load_twiddles(TwRegs<L> &tw, const cf *__restrict__ table, const int g) {
+template <int L, bool LTW, int S = 0>
+DEVI void load_twiddles(TwRegs<L, LTW> &tw, const cf *__restrict__ table, const int g) {
     constexpr int l = ilog2c(L);
-    if constexpr (S < npass(l) - 1) {
+    if constexpr (S < TwRegs<L, LTW>::NREG) {
         constexpr int Lcur = L >> (4 * S);
         constexpr int Lnext = Lcur / 16;
         constexpr int PC = L / Lcur;
         const int t = g % Lnext;  // NB == 1 for radix-16 passes: beta == g
         sfor<1, 16>([&](auto p) { tw.r[S][decltype(p)::value] = table[(t * decltype(p)::value) * PC]; });
-        load_twiddles<L, S + 1>(tw, table, g);
+        load_twiddles<L, LTW, S + 1>(tw, table, g);
     }
+}
+template <int L>
+DEVI void load_twiddles(TwRegs<L, false> &tw, const cf *__restrict__ table, const int g) {
+    load_twiddles<L, false, 0>(tw, table, g);
+}
+// the LDS part of an LTW set: `nthreads` threads fill ltab (the caller synchronises before the first transform)
+template <int L>
+DEVI void fill_lds_twiddles(cf *ltab, const cf *__restrict__ table, const int tid, const int nthreads) {
+    using TW = TwRegs<L, true>;
+    constexpr int l = ilog2c(L);
+    for (int e = tid; e < TW::LDS_ELEMS; e += nthreads) {
+        const int per = 15 * TW::LSTRIDE;
+        const int S = 1 + e / per, rem = e % per;
+        const int pp = 1 + rem / TW::LSTRIDE, t = rem % TW::LSTRIDE;
+        const int Lcur = L >> (4 * S);
+        const int Lnext = Lcur / 16 > 0 ? Lcur / 16 : 1;
+        const int PC = L / Lcur;
+        ltab[e] = table[((t % Lnext) * pp) * PC];
+    }
+    (void)l;
 }
 
 // Exchange synchronisation.  SYNC 0: the FFT group spans several wavefronts -> workgroup barrier.
@@ -270,8 +298,8 @@ DEVI void xsync() {
 // g    : thread index inside the FFT group, 0 <= g < L/16 ;  col: column inside the tile
 // store(n, value, slot, nu): natural output index n = nu + g; slot (register slot id) and nu are
 //        compile-time constants (std::integral_constant)
-template <int L, int T, int S, bool HOIST, bool PP, int HALF, int SYNC = 0, class Store>
-DEVI void fft_passes(cf (&v)[16], cf *lds, int &ebuf, const int g, const int col, const TwRegs<L> &twr,
+template <int L, int T, int S, bool HOIST, bool PP, int HALF, int SYNC = 0, class TW, class Store>
+DEVI void fft_passes(cf (&v)[16], cf *lds, int &ebuf, const int g, const int col, const TW &twr,
                      const cf *__restrict__ table, Store &store) {
     constexpr int l = ilog2c(L);
     constexpr int NP = npass(l);
@@ -308,7 +336,9 @@ DEVI void fft_passes(cf (&v)[16], cf *lds, int &ebuf, const int g, const int col
                 constexpr int pp = decltype(p)::value;
                 cf val = v[rev(R, pp)];
                 if constexpr (pp > 0) {
-                    if constexpr (HOIST) val = cmul(val, twr.r[S][pp]);
+                    if constexpr (HOIST && TW::LDS_TW && S >= TW::NREG)
+                        val = cmul(val, twr.ltab[((S - 1) * 15 + (pp - 1)) * TW::LSTRIDE + t % TW::LSTRIDE]);
+                    else if constexpr (HOIST) val = cmul(val, twr.r[S][pp]);
                     else val = cmul(val, table[(t * pp) * PC]);
                 }
                 buf[padi((pp * PC + prefix) * Lnext + t) * T + col] = val;

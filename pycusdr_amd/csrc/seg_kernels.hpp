@@ -52,8 +52,11 @@
 #ifndef MFB_SEG_WAVES_SHORT
 #define MFB_SEG_WAVES_SHORT 3
 #endif
+#ifndef MFB_SEG_WAVES_MID
+#define MFB_SEG_WAVES_MID 2      // wave-local transforms of 512 / 1024 points
+#endif
 #ifndef MFB_SEG_WAVES_LONG
-#define MFB_SEG_WAVES_LONG 2
+#define MFB_SEG_WAVES_LONG 2     // barrier teams: 2048 / 4096 points
 #endif
 #ifndef MFB_SEG_PREFETCH
 #define MFB_SEG_PREFETCH 1
@@ -109,7 +112,16 @@ struct SegCfg {
     static constexpr int TPW = BLOCK / TEAM;      // teams per workgroup
     static constexpr int WPT = TEAM / 64;         // waves per team
     static constexpr int SYNC = NT <= 64 ? 1 : 0;
-    static constexpr bool PP = !SYNC && MFB_SEG_PP;
+    // Barrier teams (L = 2048 / 4096) at THREE waves per SIMD: measured on the CC11xx bank (384 taps, L = 4096), two waves
+    // leave the vector pipe 57 % busy and the LDS pipe 38 % -- neither is saturated, the two waves of a SIMD simply cannot
+    // cover each other's exchange latency (alternating exchange buffers, i.e. half the barriers, changes nothing).  A third
+    // wave needs <= 168 VGPRs: the second twiddle set moves to LDS (fft_core.hpp, LTW), the spectrum prefetch registers go
+    // (a third wave hides those loads instead), and one exchange buffer per team instead of two keeps three teams in LDS.
+    static constexpr bool LONG3 = !SYNC && MFB_SEG_WAVES_LONG >= 3;
+    static constexpr bool PP = !SYNC && MFB_SEG_PP && !LONG3;
+    static constexpr bool PREFETCH = MFB_SEG_PREFETCH && !LONG3;
+    static constexpr bool LTW = LONG3;
+    static constexpr int LTW_ELEMS = TwRegs<L, LTW>::LDS_ELEMS;
     static constexpr int HALF = padlen(L) * CT;
     static constexpr int LDS_PER_TEAM = HALF * (PP ? 2 : 1);
     static constexpr int LDS_ELEMS = LDS_PER_TEAM * TPW;
@@ -117,9 +129,10 @@ struct SegCfg {
     // Doppler search, L = 256: per-wave table of the relative mixing phasors W_N^(s*j), j < L (2 KiB a wave)
     static constexpr bool PHASE_TABLE = L <= 256;
     static constexpr int PHASE_ELEMS = PHASE_TABLE ? (BLOCK / 64) * L : 0;
-    static constexpr int WAVES = L <= 256 ? MFB_SEG_WAVES_SHORT : MFB_SEG_WAVES_LONG;   // per SIMD = workgroups per CU
+    static constexpr int WAVES = L <= 256 ? MFB_SEG_WAVES_SHORT : (SYNC ? MFB_SEG_WAVES_MID : MFB_SEG_WAVES_LONG);   // per SIMD
     static constexpr size_t lds_bytes(int mpb) {   // mpb = 0: STORE mode (no phase table, no reduction stash)
-        return (size_t)(LDS_ELEMS + STEP_ELEMS + (mpb ? PHASE_ELEMS : 0)) * sizeof(cf) + (size_t)(BLOCK / 64) * mpb * SEG_ACC_STRIDE * sizeof(float);
+        return (size_t)(LDS_ELEMS + STEP_ELEMS + LTW_ELEMS + (mpb ? PHASE_ELEMS : 0)) * sizeof(cf) +
+               (size_t)(BLOCK / 64) * mpb * SEG_ACC_STRIDE * sizeof(float);
     }
 };
 
@@ -136,7 +149,8 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
     constexpr bool REL = MODE == SEG_REDUCE;                  // phase relative to the segment start suffices
     constexpr bool PTAB = REL && Cfg::PHASE_TABLE;
     cf *lstep = lds + Cfg::LDS_ELEMS;                                         // [4 waves][16]
-    cf *lphase = lstep + Cfg::STEP_ELEMS;                                     // [4 waves][L] (PTAB)
+    cf *ltw = lstep + Cfg::STEP_ELEMS;                                        // LTW: twiddles of the later passes
+    cf *lphase = ltw + Cfg::LTW_ELEMS;                                        // [4 waves][L] (PTAB)
 
     const int tid = threadIdx.x;
     const int team = __builtin_amdgcn_readfirstlane(tid / TEAM);
@@ -151,8 +165,13 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
     [[maybe_unused]] float *lacc = reinterpret_cast<float *>(lphase + (REL ? Cfg::PHASE_ELEMS : 0)) + wave * (a.mpb * SEG_ACC_STRIDE);
     int ebuf = 0;
 
-    TwRegs<L> twr;
-    load_twiddles<L>(twr, a.twL, g);
+    TwRegs<L, Cfg::LTW> twr;
+    load_twiddles<L, Cfg::LTW>(twr, a.twL, g);
+    twr.ltab = ltw;
+    if constexpr (Cfg::LTW) {
+        fill_lds_twiddles<L>(ltw, a.twL, tid, Cfg::BLOCK);
+        __syncthreads();
+    }
 
     // ---- which Doppler bins and which slots this team owns -----------------------------------
     int grp, mg, bstream, ssub;
@@ -256,13 +275,13 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                 }
             }
             const int r0 = a.rows ? a.rows[m0] : m0;
-            if constexpr (MFB_SEG_PREFETCH && MFB_SEG_G0EARLY) load_g(gk, r0);    // lands while the forward transform runs
+            if constexpr (Cfg::PREFETCH && MFB_SEG_G0EARLY) load_g(gk, r0);    // lands while the forward transform runs
             cf A[16];                             // A[k] = conj(U[g + NT*k])
             {
                 auto keep = [&](int, cf val, auto, auto nu) { A[decltype(nu)::value / NT] = val; };
                 fft_passes<L, 1, 0, true, Cfg::PP, Cfg::HALF, SYNC>(v, mylds, ebuf, g, 0, twr, a.twL, keep);
             }
-            if constexpr (MFB_SEG_PREFETCH && !MFB_SEG_G0EARLY) load_g(gk, r0);
+            if constexpr (Cfg::PREFETCH && !MFB_SEG_G0EARLY) load_g(gk, r0);
 
             // ---- per filter: multiply by the segment spectrum, inverse transform, reduce or store ----
             [[maybe_unused]] int lim = 0;
@@ -278,7 +297,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
             for (int mi = 0; mi < nm; ++mi) {
                 const int rm = a.rows ? a.rows[m0 + mi] : (m0 + mi);
                 cf w[16];
-                if constexpr (MFB_SEG_PREFETCH) {
+                if constexpr (Cfg::PREFETCH) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) w[i] = cmul_cj(A[i], gk[i]);    // conj(A) * G = U * G
                     if (mi + 1 < nm) load_g(gk, a.rows ? a.rows[m0 + mi + 1] : (m0 + mi + 1));
