@@ -556,11 +556,12 @@ def main():
         reps, dts, dev_ms = 5, [], []
         for _ in range(reps):
             t1 = time.perf_counter()
-            hits, kms_sync = sync_find_packed(stage, Lb, tmpl, thr, device=local_rank, timing=True)
+            (hcnt, hidx, hsc), kms_sync = sync_find_packed(stage, Lb, tmpl, thr, device=local_rank, timing=True, flat=True)
             dts.append(time.perf_counter() - t1)
             dev_ms.append(kms_sync)
         dt, kdev = float(np.median(dts)), float(np.median(dev_ms))
-        nh = int(sum(len(h[0]) for h in hits))
+        nh = int(hcnt.sum())
+        hits = [(hidx[:hcnt[0]], hsc[:hcnt[0]])]
         bytes_in, bytes_out = B * row_bytes, nh * 8 + B * 4
         ref0 = np.convolve(bits[0].astype(np.int64), tmpl.astype(np.int64))
         extras['sync_correlator'] = {

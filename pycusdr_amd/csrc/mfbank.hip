@@ -59,6 +59,14 @@ struct BlockFlight {      // one block between mfb_receive_block_begin and _end
     unsigned long long seq;
 };
 
+struct BlockGraph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    mfb_block_params params;
+    unsigned long long epoch;
+    bool seen, failed;
+};
+
 struct mfb_ctx {
     int device;
     int log2N, N, N1, N2, l1, l2, lo;
@@ -117,6 +125,8 @@ struct mfb_ctx {
     hipEvent_t ev_blk[2];
     BlockFlight flight[2];
     unsigned long long blk_seq;
+    BlockGraph bgraph[2][2];  // [input buffer][slot]: the block's launches as a HIP graph
+    unsigned long long epoch; // bumped by every change that invalidates them
     uint8_t *d_blkout;        // mfb_receive_block: the block's result record (scalars | SNR windows | symbols), one copy to the host
     BlockScalars *d_scal;     // = d_blkout
     int band_cap;
@@ -437,6 +447,7 @@ extern "C" int mfb_create(mfb_ctx **out, int device, int log2N, int num_dopplers
     return MFB_OK;
 }
 
+static void graph_drop(BlockGraph &g);
 extern "C" int mfb_destroy(mfb_ctx *c) {
     if (!c) return MFB_ERR_ARG;
     (void)hipSetDevice(c->device);
@@ -449,6 +460,8 @@ extern "C" int mfb_destroy(mfb_ctx *c) {
         if (p) (void)hipFree(p);
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_in2) (void)hipHostFree(c->h_in2);
+    for (auto &row : c->bgraph)
+        for (auto &g : row) graph_drop(g);
     for (int i = 0; i < 2; ++i) {
         if (c->h_blk[i]) (void)hipHostFree(c->h_blk[i]);
         if (c->ev_blk[i]) (void)hipEventDestroy(c->ev_blk[i]);
@@ -474,11 +487,13 @@ extern "C" int mfb_set_stream(mfb_ctx *c, void *s) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->stream = s ? (hipStream_t)s : c->own_stream;
+    ++c->epoch;
     return MFB_OK;
 }
 
 extern "C" int mfb_set_tuning(mfb_ctx *c, int chunk, int mpb, int rows_per_block, int jsplit) {
     if (!c || chunk < 0 || mpb < 0 || rows_per_block < 0 || jsplit < 0) return MFB_ERR_ARG;
+    ++c->epoch;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (rows_per_block > 0) set_rows_per_block(c, rows_per_block);
@@ -546,6 +561,7 @@ static int choose_segl(const mfb_ctx *c, int T) {
 
 // settle path and segment length from the request and the analysed bank; (re)build G and W_L
 static int resolve_path(mfb_ctx *c) {
+    ++c->epoch;               // whatever changes here changes the launches of a block
     if (!c->have_filters || !c->bank) return MFB_OK;
     const int T = c->bank->T;
     int l = 0;
@@ -734,6 +750,7 @@ extern "C" int mfb_set_filters(mfb_ctx *c, const float *masks, int M, int N) {
     c->have_filters = true;
     c->have_xc = false;
     c->W_valid = false;
+    ++c->epoch;
     c->segl = 0;    // force G to be rebuilt for the new bank
     c->gb_l = 0;
     int rc = resolve_path(c);
@@ -753,6 +770,7 @@ extern "C" int mfb_set_shifts(mfb_ctx *c, const int32_t *shifts, int count) {
     HIPCHK(hipMemcpyAsync(c->d_shifts, shifts, (size_t)count * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->have_shifts = true;
+    ++c->epoch;
     return MFB_OK;
 }
 
@@ -763,6 +781,7 @@ extern "C" int mfb_input_buffer(mfb_ctx *c, float **p) {
 }
 
 // ---- launch helpers ------------------------------------------------------------------------------
+static int fin_threads(int rows) { return 64 * (rows < 1 ? 1 : (rows > 16 ? 16 : rows)); }   // k_finalize: one wave per row
 static hipEvent_t get_event(mfb_ctx *c) {
     if (!c->ev_pool.empty()) {
         hipEvent_t e = c->ev_pool.back();
@@ -1130,7 +1149,7 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
                            (const int *)c->d_shifts, c->d_part, c->N, c->Dtot, R, parts, (float)c->N / 262144.f);
         HIPCHK(hipGetLastError());
         prof_mark(c, 0);
-        hipLaunchKernelGGL(k_finalize, dim3(c->Dtot), dim3(256), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, R, (const int *)nullptr,
+        hipLaunchKernelGGL(k_finalize, dim3(c->Dtot), dim3(fin_threads(R)), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, R, (const int *)nullptr,
                            parts, c->sum_all);
         HIPCHK(hipGetLastError());
         return MFB_OK;
@@ -1173,7 +1192,7 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
         if (!rc && ntotal > nfull) rc = launch_seg(c, at, pt.grid, SEG_REDUCE, -1);
         if (rc) return rc;
         prof_mark(c, 0);
-        hipLaunchKernelGGL(k_finalize, dim3(c->Dtot), dim3(256), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, MU,
+        hipLaunchKernelGGL(k_finalize, dim3(c->Dtot), dim3(fin_threads(MU)), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, MU,
                            span ? (const int *)nullptr : (const int *)c->d_rep, parts, c->sum_all);
         HIPCHK(hipGetLastError());
         return MFB_OK;
@@ -1206,7 +1225,7 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
         prof_mark(c, 1);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_finalize, dim3(c->Dtot), dim3(256), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, MU,
+    hipLaunchKernelGGL(k_finalize, dim3(c->Dtot), dim3(fin_threads(MU)), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, MU,
                        (const int *)c->d_rep, c->parts, c->sum_all);
     HIPCHK(hipGetLastError());
     return MFB_OK;
@@ -1410,34 +1429,9 @@ extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, fl
 // stream of launches and ONE synchronisation: [H2D of the pinned input buffer,] forward FFT, Doppler search, pick, shift
 // interpolation (k_block_pick), the two spectrum windows of computeSNR, matched filters at that shift, envelope, its
 // spectrum, rate/phase argmax, the float64 arithmetic behind it (k_block_rate), symbol centres -- then one packed read-back.
-// Enqueue: everything up to and including the ONE device-to-host copy into the flight's page-locked staging; no wait.
-static int block_begin(mfb_ctx *c, const mfb_block_params *p, int slot) {
-    if (!c || !p || slot < 0 || slot > 1) return MFB_ERR_ARG;
-    if (!c->have_filters || (p->mode == MFB_BLOCK_SEARCH && !c->have_shifts)) return MFB_ERR_STATE;
-    if (p->mode != MFB_BLOCK_SEARCH && p->mode != MFB_BLOCK_FIXED_SHIFT) return MFB_ERR_ARG;
-    if (p->k_offset < 0 || p->k_len < 0 || p->k_offset + p->k_len > c->N || p->spsym_min < 2 || p->op < 0 || p->op > 2 ||
-        p->max_symbols < 1 || p->snr_window < 0 || p->band_capacity < 0)
-        return MFB_ERR_ARG;
-    HIPCHK(hipSetDevice(c->device));
-    BlockFlight &f = c->flight[slot];
-    if (f.active) return MFB_ERR_STATE;          // its results have not been collected
+// The launches of one block, from the input copy to the ONE device-to-host copy of the result record.
+static int block_enqueue(mfb_ctx *c, const mfb_block_params *p, int slot, int nthreads, int bcap, int capacity, int *shift_out) {
     int rc;
-    const int bcap = p->mode == MFB_BLOCK_SEARCH ? p->band_capacity : 0;
-    if ((rc = blkout_reserve(c, bcap > c->band_cap ? bcap : c->band_cap))) return rc;
-    const int capacity = p->max_symbols < c->cap ? p->max_symbols : c->cap;
-    // every symbol the rate window admits (k* < k_offset + k_len  =>  count <= k_offset + k_len), bounded by the capacity
-    int nthreads = p->k_offset + p->k_len + 1;
-    if (nthreads > capacity) nthreads = capacity;
-    const size_t need = blkout_bytes(bcap, nthreads);
-    if (need > c->blk_cap[slot]) {
-        if (c->h_blk[slot]) HIPCHK(hipHostFree(c->h_blk[slot]));
-        c->h_blk[slot] = nullptr;
-        c->blk_cap[slot] = 0;
-        HIPCHK(hipHostMalloc((void **)&c->h_blk[slot], need, hipHostMallocDefault));
-        c->blk_cap[slot] = need;
-    }
-    if (!c->ev_blk[slot]) HIPCHK(hipEventCreateWithFlags(&c->ev_blk[slot], hipEventDisableTiming));
-    // input
     if (p->input == MFB_INPUT_PINNED || p->input == MFB_INPUT_PINNED2) {
         const cf *src = p->input == MFB_INPUT_PINNED ? c->h_in : c->h_in2;
         if (!src) return MFB_ERR_STATE;
@@ -1475,22 +1469,120 @@ static int block_begin(mfb_ctx *c, const mfb_block_params *p, int slot) {
         shift = ((p->fixed_shift % c->N) + c->N) % c->N;
     }
     if ((rc = demod_enqueue(c, shift, shift_dev, p->k_offset, p->k_len, p->spsym_min, capacity, c->d_scal))) return rc;
-    // the k* == 0 fallback (spSym = 10, DB:737-740; unreachable while the rate window starts above bin 0) may need more threads
-    const int fallback_threads = capacity < c->N / 10 + 1 ? capacity : c->N / 10 + 1;
-    // (entries past nthreads are not part of the record: the kernel's capacity bounds what it writes)
-    const int launch_threads = nthreads;
-    (void)fallback_threads;
-    hipLaunchKernelGGL(k_centres_block, dim3((launch_threads + 255) / 256), dim3(256), 0, c->stream, d_sym, d_cen, d_mag,
-                       (const cf *)c->d_xc, (const BlockScalars *)c->d_scal, c->N, c->M, c->W, p->op, nthreads);
+    // (entries past nthreads are not part of the record: the kernel's capacity bounds what it writes; the k* == 0 fallback --
+    // spSym = 10, DB:737-740, unreachable while the rate window starts above bin 0 -- is completed in block_end)
+    hipLaunchKernelGGL(k_centres_block, dim3((nthreads + 255) / 256), dim3(256), 0, c->stream, d_sym, d_cen, d_mag, (const cf *)c->d_xc,
+                       (const BlockScalars *)c->d_scal, c->N, c->M, c->W, p->op, nthreads);
     HIPCHK(hipGetLastError());
-    // one read-back into this flight's staging
-    HIPCHK(hipMemcpyAsync(c->h_blk[slot], d, need, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_blk[slot], d, blkout_bytes(bcap, nthreads), hipMemcpyDeviceToHost, c->stream));
+    *shift_out = shift;
+    return MFB_OK;
+}
+
+// A block whose input is one of the handle's two page-locked buffers is the same sequence of launches with the same
+// arguments every time (the shift the matched filters run at is read from device memory): the second such block is captured
+// into a HIP graph, later ones replay it -- one call into the runtime per block instead of a dozen launches, which is what the
+// host side of a stream of small blocks was spending its time on.  Any change of filters, shifts, search settings or stream
+// drops the graphs (c->epoch).  MFB_NO_GRAPH=1 in the environment keeps every block on plain launches.
+static bool graphs_allowed() {
+    static const int off = getenv("MFB_NO_GRAPH") ? atoi(getenv("MFB_NO_GRAPH")) : 0;
+    return !off;
+}
+static void graph_drop(BlockGraph &g) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+    g.exec = nullptr;
+    g.graph = nullptr;
+    g.seen = false;
+}
+static bool same_params(const mfb_block_params &a, const mfb_block_params &b) {
+    return a.mode == b.mode && a.input == b.input && a.fixed_shift == b.fixed_shift && a.k_offset == b.k_offset && a.k_len == b.k_len &&
+           a.spsym_min == b.spsym_min && a.op == b.op && a.snr_window == b.snr_window && a.max_symbols == b.max_symbols &&
+           a.band_capacity == b.band_capacity;
+}
+
+// Enqueue: everything up to and including the ONE device-to-host copy into the flight's page-locked staging; no wait.
+static int block_begin(mfb_ctx *c, const mfb_block_params *p, int slot) {
+    if (!c || !p || slot < 0 || slot > 1) return MFB_ERR_ARG;
+    if (!c->have_filters || (p->mode == MFB_BLOCK_SEARCH && !c->have_shifts)) return MFB_ERR_STATE;
+    if (p->mode != MFB_BLOCK_SEARCH && p->mode != MFB_BLOCK_FIXED_SHIFT) return MFB_ERR_ARG;
+    if (p->k_offset < 0 || p->k_len < 0 || p->k_offset + p->k_len > c->N || p->spsym_min < 2 || p->op < 0 || p->op > 2 ||
+        p->max_symbols < 1 || p->snr_window < 0 || p->band_capacity < 0)
+        return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    BlockFlight &f = c->flight[slot];
+    if (f.active) return MFB_ERR_STATE;          // its results have not been collected
+    int rc;
+    const int bcap = p->mode == MFB_BLOCK_SEARCH ? p->band_capacity : 0;
+    if ((rc = blkout_reserve(c, bcap > c->band_cap ? bcap : c->band_cap))) return rc;
+    const int capacity = p->max_symbols < c->cap ? p->max_symbols : c->cap;
+    // every symbol the rate window admits (k* < k_offset + k_len  =>  count <= k_offset + k_len), bounded by the capacity
+    int nthreads = p->k_offset + p->k_len + 1;
+    if (nthreads > capacity) nthreads = capacity;
+    const size_t need = blkout_bytes(bcap, nthreads);
+    if (need > c->blk_cap[slot]) {
+        for (auto &row : c->bgraph) graph_drop(row[slot]);          // the staging address is baked into the graphs
+        if (c->h_blk[slot]) HIPCHK(hipHostFree(c->h_blk[slot]));
+        c->h_blk[slot] = nullptr;
+        c->blk_cap[slot] = 0;
+        HIPCHK(hipHostMalloc((void **)&c->h_blk[slot], need, hipHostMallocDefault));
+        c->blk_cap[slot] = need;
+    }
+    if (!c->ev_blk[slot]) HIPCHK(hipEventCreateWithFlags(&c->ev_blk[slot], hipEventDisableTiming));
+    int shift = p->mode == MFB_BLOCK_FIXED_SHIFT ? ((p->fixed_shift % c->N) + c->N) % c->N : 0;
+    const bool pinned_in = p->input == MFB_INPUT_PINNED || p->input == MFB_INPUT_PINNED2;
+    bool done = false;
+    if (pinned_in && graphs_allowed() && !c->prof && !c->mirror && (p->input == MFB_INPUT_PINNED || c->h_in2)) {
+        BlockGraph &g = c->bgraph[p->input == MFB_INPUT_PINNED ? 0 : 1][slot];
+        if (g.epoch != c->epoch || !same_params(g.params, *p)) {
+            graph_drop(g);
+            g.epoch = c->epoch;
+            g.params = *p;
+        }
+        if (g.exec) {
+            HIPCHK(hipGraphLaunch(g.exec, c->stream));
+            c->d_in = c->d_x;
+            c->have_input = true;
+            done = true;
+        } else if (g.seen) {
+            // second block with these settings: record it (the first one went out as plain launches, so every workspace
+            // it needs exists already -- nothing is allocated inside the capture)
+            HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+            rc = block_enqueue(c, p, slot, nthreads, bcap, capacity, &shift);
+            hipGraph_t graph = nullptr;
+            const hipError_t ce = hipStreamEndCapture(c->stream, &graph);
+            if (rc || ce != hipSuccess || !graph) {
+                if (graph) (void)hipGraphDestroy(graph);
+                (void)hipGetLastError();
+                if (rc) return rc;
+                g.seen = false;                       // capture not possible here: stay on plain launches
+                g.failed = true;
+            } else {
+                hipGraphExec_t exec = nullptr;
+                if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess && exec) {
+                    g.graph = graph;
+                    g.exec = exec;
+                    HIPCHK(hipGraphLaunch(g.exec, c->stream));
+                    done = true;
+                } else {
+                    (void)hipGraphDestroy(graph);
+                    (void)hipGetLastError();
+                    g.seen = false;
+                    g.failed = true;
+                }
+            }
+        } else if (!g.failed) {
+            g.seen = true;
+        }
+    }
+    if (!done && (rc = block_enqueue(c, p, slot, nthreads, bcap, capacity, &shift))) return rc;
     HIPCHK(hipEventRecord(c->ev_blk[slot], c->stream));
+    const size_t sym_off = BLK_HEAD + align16((size_t)2 * bcap * sizeof(cf)), arr = align16((size_t)nthreads * sizeof(int));
     f.off[0] = 0;
     f.off[4] = BLK_HEAD;
-    f.off[1] = (size_t)((uint8_t *)d_sym - d);
-    f.off[2] = (size_t)((uint8_t *)d_cen - d);
-    f.off[3] = (size_t)((uint8_t *)d_mag - d);
+    f.off[1] = sym_off;
+    f.off[2] = sym_off + arr;
+    f.off[3] = sym_off + 2 * arr;
     f.active = true;
     f.mode = p->mode;
     f.nthreads = nthreads;

@@ -11,38 +11,47 @@
 // ------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------
-// doppSum[j][m] from the partial sums.  One workgroup of four wavefronts per Doppler bin; a wavefront takes the filter
-// rows w, w+4, ...: lane l adds partials l, l+64, ... of the row, then a fixed butterfly over the 64 lanes -- the order
-// depends on nothing but `parts`, so results are bit-reproducible (no float atomics, unlike cuda_kernels.cu:463,474).
+// doppSum[j][m] from the partial sums.  One workgroup per Doppler bin, one wavefront per transformed filter row (up to
+// 16 at a time): lane l adds partials l, l+64, ... of the row in four interleaved chains, then a fixed butterfly over the
+// 64 lanes -- the order depends on nothing but `parts`, so results are bit-reproducible (no float atomics, unlike
+// cuda_kernels.cu:463,474).
 // SUM_ALL_MASKS: column 0 gets the sum over masks (added in filter order by one thread), the other columns stay 0
 // (cuda_kernels.cu:453-464); else per mask (472-475).
 // The partials hold MU <= M rows per bin (filters that are exact copies or exact negatives of an
 // earlier filter are transformed once: |.|^2 is identical bit for bit); rep[m] names filter m's row.
 #define FIN_MAX_ROWS 64
-__global__ void __launch_bounds__(256) k_finalize(const float *partials, float *dsum, int D, int M, int MU, const int *rep, int parts,
-                                                  int sum_all) {
+__global__ void __launch_bounds__(1024) k_finalize(const float *partials, float *dsum, int D, int M, int MU, const int *rep, int parts,
+                                                   int sum_all) {
     __shared__ float srow[FIN_MAX_ROWS];
     const int j = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     if (j >= D) return;
-    const int nrows = rep ? M : MU;       // rep == nullptr: sum every transformed row (span basis, SUM_ALL only)
-    for (int m = wave; m < nrows; m += 4) {
-        const float *p = partials + ((size_t)j * MU + (rep ? rep[m] : m)) * parts;
-        float s = 0.f;
-        for (int q = lane; q < parts; q += 64) s += p[q];
+    for (int u = wave; u < MU; u += nw) {
+        const float *p = partials + ((size_t)j * MU + u) * parts;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int q = lane;
+        for (; q + 192 < parts; q += 256) {
+            a0 += p[q];
+            a1 += p[q + 64];
+            a2 += p[q + 128];
+            a3 += p[q + 192];
+        }
+        for (; q < parts; q += 64) a0 += p[q];
+        float s = (a0 + a1) + (a2 + a3);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (lane == 0) srow[m] = s;
+        if (lane == 0) srow[u] = s;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        const int nrows = rep ? M : MU;       // rep == nullptr: sum every transformed row (span basis, SUM_ALL only)
         if (sum_all) {
             float tot = 0.f;
-            for (int m = 0; m < nrows; ++m) tot += srow[m];
+            for (int m = 0; m < nrows; ++m) tot += srow[rep ? rep[m] : m];
             dsum[j * M] = tot;
             for (int m = 1; m < M; ++m) dsum[j * M + m] = 0.f;
         } else {
-            for (int m = 0; m < M; ++m) dsum[j * M + m] = srow[m];
+            for (int m = 0; m < M; ++m) dsum[j * M + m] = srow[rep ? rep[m] : m];
         }
     }
 }

@@ -127,17 +127,22 @@ __global__ void __launch_bounds__(SYNCP_THREADS) k_sync_packed(const uint8_t *pa
     const int b = blockIdx.y, seg = blockIdx.x, tid = threadIdx.x;
     const long long q0 = (long long)seg * SYNCP_THREADS;                 // first stream word of this segment
     const uint8_t *row = packed + (size_t)b * row_bytes;
+    const bool aligned = (reinterpret_cast<unsigned long long>(row) & 7ull) == 0;
     const int nwords = SYNCP_THREADS + K + 1;
     for (int w = tid; w < nwords; w += SYNCP_THREADS) {
         const long long q = q0 - K - 1 + w;                              // stream word index (bits 64q ... 64q + 63)
         unsigned long long v = 0;
         if (q >= 0) {
             const long long byte0 = q * 8;
+            if (aligned && byte0 + 8 <= row_bytes) {          // one 8-byte load, byte-swapped: the oldest bit on top
+                v = __builtin_bswap64(*reinterpret_cast<const unsigned long long *>(row + byte0));
+            } else {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const long long by = byte0 + u;
-                const unsigned long long x = by < row_bytes ? row[by] : 0;
-                v = (v << 8) | x;
+                for (int u = 0; u < 8; ++u) {
+                    const long long by = byte0 + u;
+                    const unsigned long long x = by < row_bytes ? row[by] : 0;
+                    v = (v << 8) | x;
+                }
             }
             // bits past the end of the stream (padding of the last byte, or garbage the caller left there) do not exist
             const long long first = q * 64;

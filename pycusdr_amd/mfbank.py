@@ -391,11 +391,11 @@ def sync_pinned_buffer(nbytes, device=0):
     return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(int(nbytes),))
 
 
-def sync_find_packed(packed, L, template, threshold, max_total=None, device=0, timing=False):
+def sync_find_packed(packed, L, template, threshold, max_total=None, device=0, timing=False, flat=False):
     """``sync_find`` on PACKED bit streams: ``packed`` uint8 [B, row_bytes] (or [row_bytes]) in ``np.packbits`` layout, ``L``
     valid bits per stream, taps in {-1, 0, +1}.  XOR/AND + popcount on 64-bit windows on the GPU, exact; only the hits come
-    back.  Returns a list of (idx int32[], score int32[]) per stream (one pair for a 1-D input); with ``timing`` also the
-    kernel time in ms."""
+    back.  Returns a list of (idx int32[], score int32[]) per stream (one pair for a 1-D input) -- or, with ``flat``, the
+    library's own (counts[B], idx[total], score[total]) --; with ``timing`` also the kernel time in ms."""
     lib = _lib.load()
     pk = np.asarray(packed)
     single = pk.ndim == 1
@@ -421,6 +421,9 @@ def sync_find_packed(packed, L, template, threshold, max_total=None, device=0, t
         if total.value <= max_total:
             break
         max_total = int(total.value)
+    if flat:            # (counts per stream, positions, scores) as the library delivers them: stream b's hits start at
+        res = (cnt, idx[:total.value], sc[:total.value])       # sum(counts[:b]); no per-stream Python objects
+        return (res, ms.value) if timing else res
     off = np.concatenate(([0], np.cumsum(cnt)))
     out = [(idx[off[b]:off[b + 1]].copy(), sc[off[b]:off[b + 1]].copy()) for b in range(B)]
     res = out[0] if single else out

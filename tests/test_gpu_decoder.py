@@ -159,5 +159,8 @@ def test_sync_find_packed_equals_convolve(L, T, B):
         idx = np.where(sc >= thr2)[0]
         assert np.array_equal(got2[b][0], idx) and np.array_equal(got2[b][1], sc[idx])
     assert ms >= 0.0
+    cnt, fidx, fsc = sync_find_packed(wide, L, tmpl, thr2, flat=True)          # the library's own flat form
+    assert np.array_equal(cnt, [len(g[0]) for g in got2])
+    assert np.array_equal(fidx, np.concatenate([g[0] for g in got2])) and np.array_equal(fsc, np.concatenate([g[1] for g in got2]))
     with pytest.raises(ValueError):
         sync_find_packed(packed, L, np.array([2, 1, -1], np.int8), 1)      # taps outside {-1, 0, +1}
