@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_stored_bench_line_follows_the_contract():
-    line = open(os.path.join(ROOT, 'profiles', 'r02_bench.json')).read().strip().splitlines()[-1]
+    line = open(os.path.join(ROOT, 'profiles', 'r03_bench.json')).read().strip().splitlines()[-1]
     d = json.loads(line)
     base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
     assert base['metric'].startswith(d['metric']) and d['unit'] == 'Msamples/s'      # BASELINE adds "at 1/2/4/8 GPUs"; n_gpus says which
@@ -30,3 +30,10 @@ def test_stored_bench_line_follows_the_contract():
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert k in c, k
     assert c['kind'] in ('port', 'reference') and c['max_rel_diff_vs_gpu'] < c['parity_tolerance'] == 1e-5
+    # the other BASELINE-named banks and C3, each with a roofline of its own; the packed sync correlator with its device time
+    banks = {b['protocol']: b for b in d['config']['other_banks']}
+    assert set(banks) == {'CC11xx', 'bench_BPSK'} and d['config']['c3']['D'] == 1024
+    for b in list(banks.values()) + [d['config']['c3']]:
+        assert b['path']['path'] == 'segment' and 0 < b['roofline']['frac'] < 1 and b['ms_per_step'] > b['roofline']['avg_launch_ms']
+    sc = d['config']['sync_correlator']
+    assert sc['exact_vs_np_convolve_stream0'] and sc['device_ms'] < sc['call_ms'] and 0 < sc['pcie_frac_of_63GBps'] < 1
