@@ -132,6 +132,7 @@ def test_multi_gpu_sharded_pick_equals_unsharded():
     if n >= 8:
         assert all(q['even'] for q in _run_ranks(8, ['nccl', 20, 2048]))
         _run_ranks(8, ['nccl', 20, 2048, 1])
+        _run_ranks(8, ['nccl', 20, 512], child='c5_dist_child.py')        # C5: two instances, 512 bins each, 8 GPUs
 
 
 def test_two_ranks_sharing_one_gpu_over_gloo():
@@ -156,6 +157,13 @@ def test_block_round_robin_two_ranks_one_gpu():
     res = _run_ranks(2, [15], child='block_child.py')
     assert res[0]['blocks'] > 6
     _run_ranks(3, [16], child='block_child.py')
+
+
+def test_c5_two_sharded_instances_per_rank():
+    """C5's multi-GPU shape on one device: two ranks, each holding BOTH demodulator instances (CC11xx FSK-2, M=8, 384-tap
+    filters; BPSK, M=32) with the instance's bins sharded over the ranks on a communicator of its own; the two streams
+    alternate.  Per instance: sharded table and pick equal the unsharded handle's, every rank demodulates the same bits."""
+    _run_ranks(2, ['gloo', 17, 64], child='c5_dist_child.py')
 
 
 def test_c4_slices_four_gloo_ranks_full_size():
