@@ -298,3 +298,23 @@ def test_block_round_robin_equals_single_process_stream(world):
     res = _spawn(_worker_blockshard, world=world, timeout=280)
     assert all(r[1] for r in res), res
     assert res[0][2] == 27
+
+
+def test_block_shard_wire_format_round_trip():
+    """What an owner sends to the root: every array comes back with its dtype and values (INT32_MIN markers included)."""
+    from pycusdr_amd.dist import BlockShard
+    rs = np.random.RandomState(3)
+    S = 777
+    rec = {'spSym': 15.987654321, 'symbols': rs.randint(-2 ** 31, 8, S).astype(np.int32), 'centres': rs.randint(0, 1 << 20, S).astype(np.int32),
+           'trust': rs.randint(-128, 128, S).astype(np.int8), 'clipped': rs.randint(0, 1 << 20, 5).astype(np.int64)}
+    part = {'count': 41, 'timestamp': 0.0, 'doppler': -123.456, 'doppler_std': 7.5, 'SNR': float('nan'), 'time_device': 1e-3, 'rec': rec}
+    sh = BlockShard.__new__(BlockShard)
+    head, body = BlockShard.pack(sh, part)
+    assert head.dtype == np.float64 and len(head) == BlockShard.HEADER and body.dtype == np.uint8 and len(body) == 9 * S + 8 * 5
+    back = BlockShard.unpack(head, body, 1.0)
+    assert back['count'] == 41 and back['doppler'] == -123.456 and np.isnan(back['SNR']) and back['rec']['spSym'] == rec['spSym']
+    for k in ('symbols', 'centres', 'trust', 'clipped'):
+        assert back['rec'][k].dtype == rec[k].dtype and np.array_equal(back['rec'][k], rec[k]), k
+    empty = dict(part, rec=dict(rec, symbols=rec['symbols'][:0], centres=rec['centres'][:0], trust=rec['trust'][:0], clipped=rec['clipped'][:0]))
+    h2, b2 = BlockShard.pack(sh, empty)
+    assert len(b2) == 0 and len(BlockShard.unpack(h2, b2, 0.0)['rec']['symbols']) == 0

@@ -127,3 +127,73 @@ def test_runner_stream_in_place_assembly_equals_ring_buffer_path():
     finally:
         a.close()
         b.close()
+
+
+def test_block_graph_follows_changes_of_shifts_filters_and_tuning():
+    """The block path replays its launches from a HIP graph after the second block with unchanged settings; the graph must
+    be dropped whenever what it captured changes: a new shift table, a new filter bank, other search settings.  After
+    every change the one-call results must again equal the stage-by-stage calls (which never use a graph)."""
+    bs = 15
+    N, ov = 1 << bs, 1 << 10
+    conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=32)
+    one, stages = _pair(conf, 'bench_GMSK')
+    sig = sg.s1_stream(12, N, ov, 'GMSK', snr_db=10.0, seed=21)
+
+    def both(b):
+        x = sig[b * (N - ov): b * (N - ov) + N]
+        raw = one.get_signalBufferHostPointer()
+        raw[:] = x
+        ra, rb = one.uploadAndFindCarrier(raw), stages.uploadAndFindCarrier(x.copy())
+        da, db = one.demodulate(), stages.demodulate()
+        assert _same([ra[0], ra[1], ra[3]], [rb[0], rb[1], rb[3]]) and int(one.dopplerIdxlast) == int(stages.dopplerIdxlast), b
+        assert all(_same(u, v) for u, v in zip(da, db)), b
+        return int(one.dopplerIdxlast)
+    try:
+        first = [both(b) for b in range(4)]                       # blocks 0-1 plain launches, 2-3 from the graph
+        shifted = (one.doppCyperSymNorm + 37) % N                 # a different bin table: the carrier lands elsewhere in it
+        for d in (one, stages):
+            d.doppCyperSymNorm = shifted.astype(np.int32)
+            d.bank.set_shifts(d.doppCyperSymNorm)
+        second = [both(b) for b in range(4, 8)]
+        assert all(abs(v - N // 4) < 160 for v in first + second)        # within a bin spacing of the carrier either way
+        for d in (one, stages):                                   # other search settings: longer segments, other grid
+            d.bank.set_search_path('segment', 9, 8, 4)
+        [both(b) for b in range(8, 10)]
+        p2 = loadProtocol('bench_FSK')(conf=conf)                 # another filter bank on the same handles
+        _, masks = p2.get_filter(N, 16, 3)
+        for d in (one, stages):
+            d.bank.set_filters(masks)
+        [both(b) for b in range(10, 12)]
+    finally:
+        one.close()
+        stages.close()
+
+
+def test_block_calls_refuse_misuse():
+    from pycusdr_amd._lib import MFBankError
+    from pycusdr_amd.mfbank import MFBank
+    bank = MFBank(12, 4, 2)
+    try:
+        with pytest.raises(MFBankError):
+            bank.receive_block(100, 50, 8)                        # no filters, no shifts yet
+        rs = np.random.RandomState(0)
+        bank.set_filters((rs.standard_normal((2, 4096)) + 1j * rs.standard_normal((2, 4096))).astype(np.complex64))
+        bank.set_shifts([1, 2, 3, 4])
+        bank.input[:] = (rs.standard_normal(4096) + 1j * rs.standard_normal(4096)).astype(np.complex64)
+        with pytest.raises(ValueError):
+            bank.receive_block(4000, 200, 8)                      # rate window past the end of the spectrum
+        with pytest.raises(ValueError):
+            bank.receive_block(100, 50, 1)                        # spsym_min below 2
+        with pytest.raises(MFBankError):
+            bank.end_block(0)                                     # nothing in flight
+        bank.begin_block(0, 200, 100, 8)
+        with pytest.raises(MFBankError):
+            bank.begin_block(0, 200, 100, 8)                      # slot busy
+        bank.input2[:] = 0                                        # an all-zero block in the second buffer: NaN index
+        bank.begin_block(1, 200, 100, 8, source='pinned2')
+        a = bank.end_block(0)
+        b = bank.end_block(1)
+        assert a['pick_valid'] and len(a['symbols']) == len(a['centres']) == len(a['magnitudes']) > 0
+        assert not b['pick_valid'] and b['shift'] == 0            # the block is to be skipped (DB:625-630)
+    finally:
+        bank.close()

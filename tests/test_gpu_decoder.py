@@ -164,3 +164,29 @@ def test_sync_find_packed_equals_convolve(L, T, B):
     assert np.array_equal(fidx, np.concatenate([g[0] for g in got2])) and np.array_equal(fsc, np.concatenate([g[1] for g in got2]))
     with pytest.raises(ValueError):
         sync_find_packed(packed, L, np.array([2, 1, -1], np.int8), 1)      # taps outside {-1, 0, +1}
+
+
+def test_sync_finder_object_begin_end_and_growth():
+    """The decoder's finder object: templates resident, begin / end, more hits than room (the finder is rebuilt with enough
+    of it), streams longer than its first allocation, long streams (multi-pass form) -- always np.convolve's hits."""
+    from pycusdr_amd.mfbank import SyncFinder
+    rs = np.random.RandomState(9)
+    t1 = rs.choice([-1, 1], 64).astype(np.int8)
+    t2 = rs.choice([-1, 1], 16).astype(np.int8)
+    thr = (int((t1 == 1).sum()) - 6, 3)                      # the second threshold is low: thousands of hits
+    f = SyncFinder((t1, t2), thr, max_hits=4, max_bits=256)
+    try:
+        for L in (100, 2300, 70000, 300):
+            bits = rs.randint(0, 2, L).astype(np.uint8)
+            hdr = ((t1[::-1] + 1) // 2).astype(np.uint8)
+            if L > 200:
+                bits[50:114] = hdr
+            f.begin(bits.astype(np.float64))                  # the decoder hands over float bits
+            got = f.end()
+            for (idx, sc), t, th in zip(got, (t1, t2), thr):
+                ref = np.convolve(bits.astype(np.int64), t.astype(np.int64))
+                want = np.where(ref >= th)[0]
+                assert np.array_equal(idx, want) and np.array_equal(sc, ref[want]), (L, len(want), len(idx))
+        assert f.max_hits > 4
+    finally:
+        f.close()
