@@ -2131,8 +2131,10 @@ extern "C" int mfb_sync_find_packed(int device, const uint8_t *packed, int B, in
     if ((rc = ws_reserve(&w.tmpl, &w.cap_tmpl, masks.size() * sizeof(unsigned long long)))) return rc;
     if ((rc = ws_reserve(&w.seg, &w.cap_seg, ((size_t)2 * B * nseg + 2 * (size_t)B + 1) * sizeof(int)))) return rc;
     if ((rc = ws_reserve(&w.hits, &w.cap_hits, (size_t)2 * max_total * sizeof(int32_t)))) return rc;
+    if ((rc = ws_reserve(&w.d_stage, &w.cap_dstage, (size_t)B * nseg * SYNCP_THREADS))) return rc;       // hits per thread, one byte
     int *segcnt = w.seg, *segoff = segcnt + (size_t)B * nseg, *d_counts = segoff + (size_t)B * nseg, *d_streamoff = d_counts + B;
     int32_t *d_idx = w.hits, *d_sc = w.hits + max_total;
+    uint8_t *d_tcnt = w.d_stage;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (device_ms) {
         HIPCHK(hipEventCreate(&e0));
@@ -2142,13 +2144,18 @@ extern "C" int mfb_sync_find_packed(int device, const uint8_t *packed, int B, in
     HIPCHK(hipMemcpyAsync(w.tmpl, masks.data(), masks.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, w.stream));
     if (e0) HIPCHK(hipEventRecord(e0, w.stream));
     const unsigned long long *d_masks = (const unsigned long long *)w.tmpl;
-    hipLaunchKernelGGL((k_sync_packed<false>), dim3(nseg, B), dim3(SYNCP_THREADS), 0, w.stream, (const uint8_t *)w.bits, row_bytes, L, T, K,
-                       d_masks, threshold, nseg, segcnt, (const int *)nullptr, (const int *)nullptr, max_total, (int32_t *)nullptr,
-                       (int32_t *)nullptr);
+#define SYNCP_LAUNCH(WRITE_, KT_)                                                                                                        \
+    hipLaunchKernelGGL((k_sync_packed<WRITE_, KT_>), dim3(nseg, B), dim3(SYNCP_THREADS), 0, w.stream, (const uint8_t *)w.bits, row_bytes, L, T, \
+                       K, d_masks, threshold, nseg, segcnt, d_tcnt, (const int *)segoff, (const int *)d_streamoff, max_total, d_idx, d_sc)
+    if (K == 1) SYNCP_LAUNCH(false, 1);
+    else if (K == 2) SYNCP_LAUNCH(false, 2);
+    else SYNCP_LAUNCH(false, 0);
     hipLaunchKernelGGL(k_sync_scan, dim3((B + 63) / 64), dim3(64), 0, w.stream, (const int *)segcnt, segoff, d_counts, B, nseg);
     hipLaunchKernelGGL(k_sync_stream_scan, dim3(1), dim3(256), 0, w.stream, (const int *)d_counts, d_streamoff, B);
-    hipLaunchKernelGGL((k_sync_packed<true>), dim3(nseg, B), dim3(SYNCP_THREADS), 0, w.stream, (const uint8_t *)w.bits, row_bytes, L, T, K,
-                       d_masks, threshold, nseg, segcnt, (const int *)segoff, (const int *)d_streamoff, max_total, d_idx, d_sc);
+    if (K == 1) SYNCP_LAUNCH(true, 1);
+    else if (K == 2) SYNCP_LAUNCH(true, 2);
+    else SYNCP_LAUNCH(true, 0);
+#undef SYNCP_LAUNCH
     HIPCHK(hipGetLastError());
     if (e1) HIPCHK(hipEventRecord(e1, w.stream));
     // counts and the grand total first, then exactly the hits

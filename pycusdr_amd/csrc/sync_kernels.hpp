@@ -116,16 +116,27 @@ __global__ void k_sync_scan(const int *segcnt, int *segoff, int *counts, int B, 
 #define SYNCP_SEG (SYNCP_THREADS * 64)      // output positions per workgroup
 #define SYNCP_MAXK 64                        // 64-bit words per template: T <= 4096
 
-template <bool WRITE>
+// KT: words per template when small (1 or 2: the window slides in registers, one shift per position), 0 = any K <= SYNCP_MAXK
+// (the window words are rebuilt from the staged stream words at every position).
+// Pass 1 (WRITE = false) sweeps the positions once, leaves the number of hits of every thread in `tcnt` (one byte) and of every
+// segment in `segcnt`; pass 2 scans those and only threads that own a hit sweep again to write it: hits are sparse, so the
+// whole search costs about one sweep.
+template <bool WRITE, int KT>
 __global__ void __launch_bounds__(SYNCP_THREADS) k_sync_packed(const uint8_t *packed, int row_bytes, int L, int T, int K,
                                                               const unsigned long long *masks /* P[K] | Q[K] */, int thr, int nseg,
-                                                              int *segcnt, const int *segoff, const int *streamoff, int max_total,
-                                                              int32_t *hit_idx, int32_t *hit_score) {
+                                                              int *segcnt, uint8_t *tcnt, const int *segoff, const int *streamoff,
+                                                              int max_total, int32_t *hit_idx, int32_t *hit_score) {
     __shared__ unsigned long long sw[SYNCP_THREADS + SYNCP_MAXK + 1];    // stream words q0 - K - 1 ... q0 + 255, big-endian
     __shared__ unsigned long long sp[2 * SYNCP_MAXK];
     __shared__ int wsum[SYNCP_THREADS / 64];
     const int b = blockIdx.y, seg = blockIdx.x, tid = threadIdx.x;
     const long long q0 = (long long)seg * SYNCP_THREADS;                 // first stream word of this segment
+    const size_t tslot = ((size_t)b * nseg + seg) * SYNCP_THREADS + tid;
+    int cnt = 0;
+    if constexpr (WRITE) {
+        cnt = tcnt[tslot];
+        if (__syncthreads_or(cnt) == 0) return;                          // no hit in this segment: nothing to stage
+    }
     const uint8_t *row = packed + (size_t)b * row_bytes;
     const bool aligned = (reinterpret_cast<unsigned long long>(row) & 7ull) == 0;
     const int nwords = SYNCP_THREADS + K + 1;
@@ -154,54 +165,71 @@ __global__ void __launch_bounds__(SYNCP_THREADS) k_sync_packed(const uint8_t *pa
     __syncthreads();
     const int outLen = L + T - 1;
     const long long i0 = (q0 + tid) * 64;                                // first output position of this thread
-    int cnt = 0;
+    const int base = K + 1 + tid;                                        // sw index of word q = q0 + tid
     int pos = 0;
-    if constexpr (WRITE) pos = 0;
-    // pass 1 (both modes): count; WRITE recomputes below once the offsets are known
-    auto score_at = [&](int r) {
-        // window word k, bit j = bits[i - 64k - j], i = i0 + r: (Z[q-k-1] << (r+1)) | (Z[q-k] >> (63-r))
-        int s = 0;
-        const int base = K + 1 + tid;                                    // sw index of word q = q0 + tid
-        for (int k = 0; k < K; ++k) {
-            const unsigned long long hi = sw[base - k - 1], lo = sw[base - k];
-            const unsigned long long W = (r == 63) ? lo : ((hi << (r + 1)) | (lo >> (63 - r)));
-            s += __popcll(W & sp[k]) - __popcll(W & sp[K + k]);
-        }
-        return s;
-    };
-    for (int r = 0; r < 64; ++r) {
-        const long long i = i0 + r;
-        if (i < outLen && score_at(r) >= thr) ++cnt;
-    }
-    int incl = cnt;
+    if constexpr (WRITE) {
+        int incl = cnt;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o, 64);
-        if ((tid & 63) >= o) incl += v;
-    }
-    const int wid = tid >> 6;
-    if ((tid & 63) == 63) wsum[wid] = incl;
-    __syncthreads();
-    int wbase = 0;
-    for (int w = 0; w < wid; ++w) wbase += wsum[w];
-    if constexpr (!WRITE) {
-        if (tid == SYNCP_THREADS - 1) segcnt[(size_t)b * nseg + seg] = wbase + incl;
-    } else {
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if ((tid & 63) >= o) incl += v;
+        }
+        const int wid = tid >> 6;
+        if ((tid & 63) == 63) wsum[wid] = incl;
+        __syncthreads();
+        int wbase = 0;
+        for (int w = 0; w < wid; ++w) wbase += wsum[w];
         pos = streamoff[b] + segoff[(size_t)b * nseg + seg] + wbase + incl - cnt;
-        if (cnt) {
-            for (int r = 0; r < 64; ++r) {
-                const long long i = i0 + r;
-                if (i >= outLen) break;
-                const int s = score_at(r);
-                if (s >= thr) {
-                    if (pos < max_total) {
-                        hit_idx[pos] = (int32_t)i;
-                        hit_score[pos] = s;
-                    }
-                    ++pos;
+        if (cnt == 0) return;
+        cnt = 0;
+    }
+    auto visit = [&](int r, int s) {
+        const long long i = i0 + r;
+        if (i < outLen && s >= thr) {
+            if constexpr (WRITE) {
+                if (pos < max_total) {
+                    hit_idx[pos] = (int32_t)i;
+                    hit_score[pos] = s;
                 }
+                ++pos;
+            } else {
+                ++cnt;
             }
         }
+    };
+    if constexpr (KT == 1 || KT == 2) {
+        // window word k, bit j = bits[i - 64k - j]; from position i to i + 1 every word shifts up by one and takes the next
+        // older word's top bit -- word 0 takes the new stream bit
+        const unsigned long long cur = sw[base];
+        unsigned long long W0 = sw[base - 1], W1 = KT == 2 ? sw[base - 2] : 0ull;       // the windows of position i0 - 1
+        const unsigned long long P0 = sp[0], Q0 = sp[K], P1 = KT == 2 ? sp[1] : 0ull, Q1 = KT == 2 ? sp[K + 1] : 0ull;
+        for (int r = 0; r < 64; ++r) {
+            if constexpr (KT == 2) W1 = (W1 << 1) | (W0 >> 63);
+            W0 = (W0 << 1) | ((cur >> (63 - r)) & 1ull);
+            int s = __popcll(W0 & P0) - __popcll(W0 & Q0);
+            if constexpr (KT == 2) s += __popcll(W1 & P1) - __popcll(W1 & Q1);
+            visit(r, s);
+        }
+    } else {
+        for (int r = 0; r < 64; ++r) {
+            // (Z[q-k-1] << (r+1)) | (Z[q-k] >> (63-r))
+            int s = 0;
+            for (int k = 0; k < K; ++k) {
+                const unsigned long long hi = sw[base - k - 1], lo = sw[base - k];
+                const unsigned long long W = (r == 63) ? lo : ((hi << (r + 1)) | (lo >> (63 - r)));
+                s += __popcll(W & sp[k]) - __popcll(W & sp[K + k]);
+            }
+            visit(r, s);
+        }
+    }
+    if constexpr (!WRITE) {
+        tcnt[tslot] = (uint8_t)cnt;
+        int incl = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) incl += __shfl_xor(incl, o, 64);
+        if ((tid & 63) == 0) wsum[tid >> 6] = incl;
+        __syncthreads();
+        if (tid == 0) segcnt[(size_t)b * nseg + seg] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
 }
 
