@@ -7,8 +7,10 @@
  * A 2-FSK stream (16 samples per symbol, tones at -/+ half a cycle per symbol around a carrier near fs/4) is
  * received with a two-filter bank (one symbol-long tone each, stored as conj(FFT(template, N)) like the
  * reference's protocol plug-ins do, protocol/FSK2_base.py:17-46): Doppler search over 33 bins, pick,
- * matched filtering at the picked shift, symbol rate and phase, symbol decisions.  The program checks the
- * carrier bin, the symbol rate and the bits it sent, and exits non-zero on any mismatch.
+ * matched filtering at the picked shift, symbol rate and phase, symbol decisions -- first with one call per stage and the
+ * reference's host arithmetic in between, then with mfb_receive_block (one call for the whole block).  The program checks
+ * the carrier bin, the symbol rate, the bits it sent and that the two forms agree bit for bit; it exits non-zero on any
+ * mismatch.
  */
 #define _GNU_SOURCE
 #include <math.h>
@@ -118,12 +120,39 @@ int main(void) {
         ++compared;
     }
     printf("%d symbol decisions compared, %d errors\n", compared, errors);
+
+    /* The same block once more through the ONE-call form: forward FFT, search, pick, shift interpolation, matched filters,
+     * rate/phase arithmetic and symbol decisions as one stream of launches with one synchronisation.  Every number must
+     * equal what the five calls above produced (the float64 host arithmetic of DB:609-616 and DB:733-752 runs on the
+     * device in the same operations; np.round there, lround here: the interpolated shift is not a tie). */
+    mfb_block_params bp;
+    mfb_block_result br;
+    memset(&bp, 0, sizeof(bp));
+    bp.mode = MFB_BLOCK_SEARCH;
+    bp.input = MFB_INPUT_PINNED;
+    bp.k_offset = k_off;
+    bp.k_len = k_len;
+    bp.spsym_min = SPS / 2;
+    bp.op = MFB_CENTRES_ABS;
+    bp.snr_window = 5;
+    bp.max_symbols = N / 2;
+    bp.band_capacity = 256;
+    int32_t *sym2 = (int32_t *)malloc(sizeof(int32_t) * (N / 2)), *cen2 = (int32_t *)malloc(sizeof(int32_t) * (N / 2));
+    float *mag2 = (float *)malloc(sizeof(float) * (N / 2)), *bands = (float *)malloc(sizeof(float) * 2 * 2 * 256);
+    CHECK(mfb_receive_block(h, &bp, &br, sym2, cen2, mag2, bands));
+    int same = br.pick_valid && br.pick[0] == pick[0] && br.pick[1] == pick[1] && br.shift == shift && br.cr[0] == cr[0] &&
+               br.cr[1] == cr[1] && br.spSym == spSym && br.codeOffset == offset && br.count == count;
+    for (int i = 0; same && i < count; ++i) same = sym2[i] == sym[i] && cen2[i] == cen[i] && mag2[i] == mag[i];
+    printf("one call: shift %d, samples per symbol %.4f, %d symbols, SNR windows of %d and %d bins: %s\n", br.shift, br.spSym, br.count,
+           br.band_len[0], br.band_len[1], same ? "identical to the stage-by-stage calls" : "DIFFERENT");
+    free(sym2); free(cen2); free(mag2); free(bands);
     CHECK(mfb_destroy(h));
 
     int bad = 0;
     if (abs(shift - carrier) > 2) bad |= 1;
     if (fabs(spSym - SPS) > 0.05) bad |= 2;
     if (compared < nsym - 8 || errors != 0) bad |= 4;
+    if (!same) bad |= 8;
     free(masks); free(bits); free(sym); free(cen); free(mag);
     if (bad) {
         fprintf(stderr, "FAILED (%d)\n", bad);

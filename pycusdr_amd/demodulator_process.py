@@ -108,6 +108,40 @@ class DemodulatorRunner:
         self.count += 1
         return part
 
+    def feed_device_begin(self, new_samples):
+        """``feed_device`` in two halves: enqueue the block's device work and return at once (``feed_device_end`` collects it).
+        One block in flight per runner.  Falls back to the synchronous call where the one-call block path is not in use (STX,
+        Doppler-sharded handles, ``"one_call": false``)."""
+        if len(new_samples) != self.samplesPerSlice:
+            raise ValueError(f'expected {self.samplesPerSlice} new samples per block, got {len(new_samples)}')
+        if not (self.radioBackend == 'UHF' and getattr(self.demod, '_one_call', False)):
+            self._flight = ('done', self.feed_device(new_samples))
+            return
+        if getattr(self, '_bufs', None) is None:
+            self._bufs = [self.raw, self.demod.bank.input2]
+            self._cur = 0 if self.raw is self._bufs[0] else 1
+        cur = self._cur
+        raw = self._bufs[cur]
+        raw[self.overlap:] = new_samples
+        stamp = time.time()
+        self.demod.beginBlock(cur, source=('pinned', 'pinned2')[cur])
+        other = self._bufs[1 - cur]
+        other[:self.overlap] = raw[-self.overlap:]      # overlap carry: the next block is assembled in the other buffer
+        self._cur, self.raw = 1 - cur, other
+        self._flight = ('flying', cur, self.count, stamp)
+        self.count += 1
+
+    def feed_device_end(self):
+        fl, self._flight = self._flight, None
+        if fl[0] == 'done':
+            return fl[1]
+        _, slot, count, stamp = fl
+        part = {'count': count, 'timestamp': stamp}
+        part['doppler'], part['doppler_std'], _, part['SNR'] = self.demod.endBlock(slot)
+        part['rec'] = self.demod.demodulateDevice()
+        part['time_device'] = time.time() - stamp
+        return part
+
     def skip_block(self, new_samples):
         """A block another rank processes: keep the overlap carry and the block counter in step."""
         if len(new_samples) != self.samplesPerSlice:

@@ -316,30 +316,51 @@ class BlockShard:
         """Drive ``runner`` (a DemodulatorRunner on this rank's device) over the stream of new-sample slices.  Returns
         (results, packets) on the root -- the same as ``DemodulatorRunner.run`` of one process on the whole stream -- and
         ([], []) elsewhere.  ``feed(item) -> part`` / ``skip(item)`` replace ``runner.feed_device`` / ``runner.skip_block``
-        for sources that do not yield host sample slices (bench.py: blocks already resident in device memory)."""
+        for sources that do not yield host sample slices (bench.py: blocks already resident in device memory).
+
+        The root runs the host stages ``world - 1`` blocks behind the stream: its own block is enqueued on its device
+        (``feed_device_begin``) and collected only when the host stages of the blocks before it -- which the other ranks
+        computed meanwhile -- are done, so its device and its host work overlap."""
         results, packets = [], []
+        own_async = feed is None and hasattr(runner, 'feed_device_begin')
         feed = feed or (lambda c: runner.feed_device(np.asarray(c, dtype=np.complex64)))
         skip = skip or runner.skip_block
+        is_root = self.rank == self.root
+        backlog = []                     # root: blocks whose host stages are still to run, oldest first: (index, part or None)
+
+        def finish(entry):
+            i, part = entry
+            if part is None:
+                part = runner.feed_device_end() if self.owner(i) == self.rank else self.recv_part(self.owner(i))
+            d = runner.feed_host(part)
+            if decoder is not None:
+                pk, _, nsync = decoder.findFrames(d['data'], 0)
+                d['numSyncSig'] = nsync
+                packets.extend(pk)
+            if sink is not None:
+                sink(d)
+            else:
+                results.append(d)
+
         for i, chunk in enumerate(sample_source):
             own = self.owner(i) == self.rank
             part = None
-            if own:
+            if own and is_root and own_async:
+                # nothing of this runner may be in flight: the previous own block is world blocks back, its host stage has run
+                while any(self.owner(j) == self.rank for j, q in backlog if q is None):
+                    finish(backlog.pop(0))
+                runner.feed_device_begin(np.asarray(chunk, dtype=np.complex64))
+            elif own:
                 part = feed(chunk)
             else:
                 skip(chunk)
-            if self.rank == self.root:
-                if not own:
-                    part = self.recv_part(self.owner(i))
-                d = runner.feed_host(part)
-                if decoder is not None:
-                    pk, _, nsync = decoder.findFrames(d['data'], 0)
-                    d['numSyncSig'] = nsync
-                    packets.extend(pk)
-                if sink is not None:
-                    sink(d)
-                else:
-                    results.append(d)
+            if is_root:
+                backlog.append((i, part))
+                while len(backlog) > max(self.world - 1, 0) if own_async else backlog:
+                    finish(backlog.pop(0))
             elif own:
                 self.send_part(part)
+        while backlog:
+            finish(backlog.pop(0))
         self.flush()
         return results, packets

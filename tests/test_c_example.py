@@ -34,4 +34,4 @@ def test_c_host_program_receives_a_block(tmp_path):
     exe = _compile(tmp_path / 'receive_block')
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.strip().endswith('ok') and '0 errors' in r.stdout
+    assert r.stdout.strip().endswith('ok') and '0 errors' in r.stdout and 'identical to the stage-by-stage calls' in r.stdout
