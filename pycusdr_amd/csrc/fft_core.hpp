@@ -361,3 +361,77 @@ DEVI void fft_passes(cf (&v)[16], cf *lds, int &ebuf, const int g, const int col
         fft_passes<L, T, S + 1, HOIST, PP, HALF, SYNC>(v, lds, ebuf, g, col, twr, table, store);
     }
 }
+
+// Two transforms of the same team in lock-step, one exchange buffer each (lds, lds + HALF).  Transform B's butterflies sit
+// between A's exchange stores and loads, and after an exchange both sets of loads are in flight together while A's next
+// butterflies already run: a wave covers its own exchange latency instead of relying on the other wave of its SIMD.
+// Barriers: one before a level's stores (every wave is done reading both buffers), one between stores and loads: two per
+// level for two transforms, what alternating buffers give a single transform.  The caller must put a barrier in front of
+// whatever uses the buffers next.
+template <int L, int T, int S, bool HOIST, int HALF, int SYNC, class TW, class StoreA, class StoreB>
+DEVI void fft_passes2(cf (&va)[16], cf (&vb)[16], cf *lds, const int g, const int col, const TW &twr, const cf *__restrict__ table,
+                      StoreA &sa, StoreB &sb) {
+    constexpr int l = ilog2c(L);
+    constexpr int NP = npass(l);
+    constexpr int R = radix_of(l, S);
+    constexpr int Lcur = L >> (4 * S);
+    constexpr int Lnext = Lcur / R;
+    constexpr int PC = L / Lcur;
+    constexpr int NT = L / 16;
+    constexpr int NB = 16 / R;
+
+    sfor<0, NB>([&](auto u) { bfly<R, decltype(u)::value * R>(va); });
+    if constexpr (S == NP - 1) {
+        sfor<0, NB>([&](auto u) { bfly<R, decltype(u)::value * R>(vb); });
+        auto emit = [&](cf (&v)[16], auto &store) {
+            sfor<0, NB>([&](auto u) {
+                sfor<0, R>([&](auto p) {
+                    constexpr int slot = decltype(u)::value * R + decltype(p)::value;
+                    constexpr int nu = decltype(p)::value * PC + NT * decltype(u)::value;
+                    store(nu + g, v[decltype(u)::value * R + rev(R, decltype(p)::value)], std::integral_constant<int, slot>{},
+                          std::integral_constant<int, nu>{});
+                });
+            });
+        };
+        emit(va, sa);
+        emit(vb, sb);
+    } else {
+        static_assert(R == 16 && NB == 1, "only radix-16 passes are followed by another pass");
+        const int prefix = g / Lnext;
+        const int t = g % Lnext;
+        auto put = [&](cf (&v)[16], cf *buf) {
+            sfor<0, R>([&](auto p) {
+                constexpr int pp = decltype(p)::value;
+                cf val = v[rev(R, pp)];
+                if constexpr (pp > 0) {
+                    if constexpr (HOIST && TW::LDS_TW && S >= TW::NREG)
+                        val = cmul(val, twr.ltab[((S - 1) * 15 + (pp - 1)) * TW::LSTRIDE + t % TW::LSTRIDE]);
+                    else if constexpr (HOIST) val = cmul(val, twr.r[S][pp]);
+                    else val = cmul(val, table[(t * pp) * PC]);
+                }
+                buf[padi((pp * PC + prefix) * Lnext + t) * T + col] = val;
+            });
+        };
+        constexpr int R2 = radix_of(l, S + 1);
+        constexpr int Lnn = Lnext / R2;
+        constexpr int NB2 = 16 / R2;
+        auto get = [&](cf (&v)[16], const cf *buf) {
+            sfor<0, NB2>([&](auto u) {
+                const int beta = g + NT * decltype(u)::value;
+                const int pre2 = beta / Lnn;
+                const int t2 = beta % Lnn;
+                sfor<0, R2>([&](auto i) {
+                    v[decltype(u)::value * R2 + decltype(i)::value] = buf[padi(pre2 * Lnext + t2 + Lnn * decltype(i)::value) * T + col];
+                });
+            });
+        };
+        xsync<SYNC>();                   // nobody still reads either buffer
+        put(va, lds);
+        bfly<R, 0>(vb);
+        put(vb, lds + HALF);
+        xsync<SYNC>();
+        get(va, lds);
+        get(vb, lds + HALF);
+        fft_passes2<L, T, S + 1, HOIST, HALF, SYNC>(va, vb, lds, g, col, twr, table, sa, sb);
+    }
+}

@@ -67,6 +67,12 @@
 #define MFB_SEG_PP 1
 #endif
 // threads per workgroup of the kernels whose teams are single, independent waves (L <= 1024): 64, 128 or 256
+// Barrier teams: two filters of a segment through their inverse transforms in lock-step (fft_passes2), so that a wave has one
+// transform's butterflies to run while the other's exchange is in flight.  Measured on the CC11xx bank: 3.48-3.50 ms against
+// 3.40-3.43 (L = 4096), 3.33 against 3.29 (L = 2048): the kernel does not wait for its own exchanges either.  Off.
+#ifndef MFB_SEG_DUAL
+#define MFB_SEG_DUAL 0
+#endif
 #ifndef MFB_SEG_BLOCK
 #define MFB_SEG_BLOCK 256
 #endif
@@ -118,12 +124,17 @@ struct SegCfg {
     // wave needs <= 168 VGPRs: the second twiddle set moves to LDS (fft_core.hpp, LTW), the spectrum prefetch registers go
     // (a third wave hides those loads instead), and one exchange buffer per team instead of two keeps three teams in LDS.
     static constexpr bool LONG3 = !SYNC && MFB_SEG_WAVES_LONG >= 3;
-    static constexpr bool PP = !SYNC && MFB_SEG_PP && !LONG3;
-    static constexpr bool PREFETCH = MFB_SEG_PREFETCH && !LONG3;
+    // Barrier teams, Doppler search: two filters of a segment go through their inverse transforms in lock-step
+    // (fft_passes2), each with an exchange buffer of its own, so that a wave has butterflies of one to run while the
+    // exchange of the other is in flight.
+    static constexpr bool DUAL = !SYNC && MFB_SEG_DUAL && !LONG3;
+    static constexpr bool PP = !SYNC && MFB_SEG_PP && !LONG3 && !DUAL;
+    static constexpr bool TWO_BUFFERS = PP || DUAL;
+    static constexpr bool PREFETCH = MFB_SEG_PREFETCH && !LONG3 && !DUAL;
     static constexpr bool LTW = LONG3;
     static constexpr int LTW_ELEMS = TwRegs<L, LTW>::LDS_ELEMS;
     static constexpr int HALF = padlen(L) * CT;
-    static constexpr int LDS_PER_TEAM = HALF * (PP ? 2 : 1);
+    static constexpr int LDS_PER_TEAM = HALF * (TWO_BUFFERS ? 2 : 1);
     static constexpr int LDS_ELEMS = LDS_PER_TEAM * TPW;
     static constexpr int STEP_ELEMS = (BLOCK / 64) * 16;     // 16 step phasors per wave
     // Doppler search, L = 256: per-wave table of the relative mixing phasors W_N^(s*j), j < L (2 KiB a wave)
@@ -279,6 +290,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
             cf A[16];                             // A[k] = conj(U[g + NT*k])
             {
                 auto keep = [&](int, cf val, auto, auto nu) { A[decltype(nu)::value / NT] = val; };
+                if constexpr (Cfg::DUAL) xsync<SYNC>();        // the previous slot's last pair may still be read by other waves
                 fft_passes<L, 1, 0, true, Cfg::PP, Cfg::HALF, SYNC>(v, mylds, ebuf, g, 0, twr, a.twL, keep);
             }
             if constexpr (Cfg::PREFETCH && !MFB_SEG_G0EARLY) load_g(gk, r0);
@@ -294,7 +306,51 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) envacc[k] = 0.f;
             }
-            for (int mi = 0; mi < nm; ++mi) {
+            int mi_first = 0;
+            if constexpr (Cfg::DUAL && MODE == SEG_REDUCE) {
+                for (; mi_first + 1 < nm; mi_first += 2) {
+                    const int rA = a.rows ? a.rows[m0 + mi_first] : (m0 + mi_first);
+                    const int rB = a.rows ? a.rows[m0 + mi_first + 1] : (m0 + mi_first + 1);
+                    cf wA[16], wB[16];
+#pragma unroll
+                    for (int ii = 0; ii < 8; ++ii) {
+                        cf g0, g1, h0, h1;
+                        buf_load_cf2(gr, vo_g2, rA * (L * (int)sizeof(cf)) + ii * so_g2, g0, g1);
+                        buf_load_cf2(gr, vo_g2, rB * (L * (int)sizeof(cf)) + ii * so_g2, h0, h1);
+                        wA[2 * ii] = cmul_cj(A[2 * ii], g0);
+                        wA[2 * ii + 1] = cmul_cj(A[2 * ii + 1], g1);
+                        wB[2 * ii] = cmul_cj(A[2 * ii], h0);
+                        wB[2 * ii + 1] = cmul_cj(A[2 * ii + 1], h1);
+                    }
+                    cf raccA[4] = {mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f)};
+                    cf raccB[4] = {mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f)};
+                    auto accA = [&](int, cf val, auto, auto nu) {
+                        constexpr int k = decltype(nu)::value / NT;
+                        if constexpr (MASKED) {
+                            const float wgt = (k * NT < lim) ? 1.f : 0.f;
+                            raccA[k & 3] = __builtin_elementwise_fma(val * wgt, val, raccA[k & 3]);
+                        } else if constexpr (k < PV) {
+                            raccA[k & 3] = __builtin_elementwise_fma(val, val, raccA[k & 3]);
+                        }
+                    };
+                    auto accB = [&](int, cf val, auto, auto nu) {
+                        constexpr int k = decltype(nu)::value / NT;
+                        if constexpr (MASKED) {
+                            const float wgt = (k * NT < lim) ? 1.f : 0.f;
+                            raccB[k & 3] = __builtin_elementwise_fma(val * wgt, val, raccB[k & 3]);
+                        } else if constexpr (k < PV) {
+                            raccB[k & 3] = __builtin_elementwise_fma(val, val, raccB[k & 3]);
+                        }
+                    };
+                    fft_passes2<L, 1, 0, true, Cfg::HALF, SYNC>(wA, wB, mylds, g, 0, twr, a.twL, accA, accB);
+                    const cf sA = (raccA[0] + raccA[1]) + (raccA[2] + raccA[3]);
+                    const cf sB = (raccB[0] + raccB[1]) + (raccB[2] + raccB[3]);
+                    lacc[mi_first * SEG_ACC_STRIDE + lane] = sA.x + sA.y;
+                    lacc[(mi_first + 1) * SEG_ACC_STRIDE + lane] = sB.x + sB.y;
+                }
+                if (mi_first < nm) xsync<SYNC>();          // an odd filter follows on the first buffer
+            }
+            for (int mi = mi_first; mi < nm; ++mi) {
                 const int rm = a.rows ? a.rows[m0 + mi] : (m0 + mi);
                 cf w[16];
                 if constexpr (Cfg::PREFETCH) {
