@@ -1767,18 +1767,7 @@ struct SyncWs {
     // through page-locked staging -- every separate copy of pageable memory costs a round trip of its own
     uint8_t *h_stage = nullptr, *d_stage = nullptr;
     size_t cap_hstage = 0, cap_dstage = 0;
-    // packed batches: the streams arrive in chunks on a copy stream while the chunk before is being searched
-    hipStream_t copy = nullptr;
-    std::vector<hipEvent_t> ev;        // [chunk]: landed | search begins | search ends
 };
-static int ws_events(SyncWs &w, size_t n) {
-    while (w.ev.size() < n) {
-        hipEvent_t e = nullptr;
-        HIPCHK(hipEventCreate(&e));
-        w.ev.push_back(e);
-    }
-    return MFB_OK;
-}
 #define SYNC_STAGE_MAX ((size_t)1 << 20)
 #define SYNC_MAX_DEVICES 64
 static std::mutex g_sync_mu;
@@ -2183,45 +2172,29 @@ extern "C" int mfb_sync_find_packed(int device, const uint8_t *packed, int B, in
     int *segcnt = w.seg, *segoff = segcnt + (size_t)B * nseg, *d_counts = segoff + (size_t)B * nseg, *d_streamoff = d_counts + B;
     int32_t *d_idx = w.hits, *d_sc = w.hits + max_total;
     uint8_t *d_tcnt = w.d_stage;
-    // The batch goes over the host link in a few chunks on a copy stream; the search of a chunk (pass 1: count) starts when it
-    // has landed, while the next chunk is still travelling.  Scan and pass 2 (which revisits only segments with hits) follow.
-    if (!w.copy) HIPCHK(hipStreamCreateWithFlags(&w.copy, hipStreamNonBlocking));
-    int nchunk = (int)(nbytes >> 20);
-    nchunk = nchunk < 1 ? 1 : (nchunk > 8 ? 8 : nchunk);
-    if (nchunk > B) nchunk = B;
-    if ((rc = ws_events(w, (size_t)3 * nchunk + 2))) return rc;
-    hipEvent_t *ev = w.ev.data();
-    HIPCHK(hipMemcpyAsync(w.tmpl, masks.data(), masks.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, w.stream));
-    HIPCHK(hipEventRecord(ev[3 * nchunk], w.stream));
-    HIPCHK(hipStreamWaitEvent(w.copy, ev[3 * nchunk], 0));      // the copy stream starts after whatever used the buffers before
-    const unsigned long long *d_masks = (const unsigned long long *)w.tmpl;
-#define SYNCP_LAUNCH(WRITE_, KT_, B0_, NB_)                                                                                              \
-    hipLaunchKernelGGL((k_sync_packed<WRITE_, KT_>), dim3(nseg, NB_), dim3(SYNCP_THREADS), 0, w.stream,                                   \
-                       (const uint8_t *)w.bits + (size_t)(B0_)*row_bytes, row_bytes, L, T, K, d_masks, threshold, nseg,                  \
-                       segcnt + (size_t)(B0_)*nseg, d_tcnt + (size_t)(B0_)*nseg * SYNCP_THREADS, (const int *)segoff + (size_t)(B0_)*nseg, \
-                       (const int *)d_streamoff + (B0_), max_total, d_idx, d_sc)
-    for (int c = 0; c < nchunk; ++c) {
-        const int b0 = (int)((long long)B * c / nchunk), b1 = (int)((long long)B * (c + 1) / nchunk);
-        HIPCHK(hipMemcpyAsync(w.bits + (size_t)b0 * row_bytes, packed + (size_t)b0 * row_bytes, (size_t)(b1 - b0) * row_bytes,
-                              hipMemcpyHostToDevice, w.copy));
-        HIPCHK(hipEventRecord(ev[3 * c], w.copy));
-        HIPCHK(hipStreamWaitEvent(w.stream, ev[3 * c], 0));
-        HIPCHK(hipEventRecord(ev[3 * c + 1], w.stream));
-        if (K == 1) SYNCP_LAUNCH(false, 1, b0, b1 - b0);
-        else if (K == 2) SYNCP_LAUNCH(false, 2, b0, b1 - b0);
-        else SYNCP_LAUNCH(false, 0, b0, b1 - b0);
-        HIPCHK(hipEventRecord(ev[3 * c + 2], w.stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (device_ms) {
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
     }
-    hipEvent_t e0 = ev[3 * nchunk], e1 = ev[3 * nchunk + 1];
-    HIPCHK(hipEventRecord(e0, w.stream));
+    HIPCHK(hipMemcpyAsync(w.bits, packed, nbytes, hipMemcpyHostToDevice, w.stream));
+    HIPCHK(hipMemcpyAsync(w.tmpl, masks.data(), masks.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, w.stream));
+    if (e0) HIPCHK(hipEventRecord(e0, w.stream));
+    const unsigned long long *d_masks = (const unsigned long long *)w.tmpl;
+#define SYNCP_LAUNCH(WRITE_, KT_)                                                                                                        \
+    hipLaunchKernelGGL((k_sync_packed<WRITE_, KT_>), dim3(nseg, B), dim3(SYNCP_THREADS), 0, w.stream, (const uint8_t *)w.bits, row_bytes, L, T, \
+                       K, d_masks, threshold, nseg, segcnt, d_tcnt, (const int *)segoff, (const int *)d_streamoff, max_total, d_idx, d_sc)
+    if (K == 1) SYNCP_LAUNCH(false, 1);
+    else if (K == 2) SYNCP_LAUNCH(false, 2);
+    else SYNCP_LAUNCH(false, 0);
     hipLaunchKernelGGL(k_sync_scan, dim3((B + 63) / 64), dim3(64), 0, w.stream, (const int *)segcnt, segoff, d_counts, B, nseg);
     hipLaunchKernelGGL(k_sync_stream_scan, dim3(1), dim3(256), 0, w.stream, (const int *)d_counts, d_streamoff, B);
-    if (K == 1) SYNCP_LAUNCH(true, 1, 0, B);
-    else if (K == 2) SYNCP_LAUNCH(true, 2, 0, B);
-    else SYNCP_LAUNCH(true, 0, 0, B);
+    if (K == 1) SYNCP_LAUNCH(true, 1);
+    else if (K == 2) SYNCP_LAUNCH(true, 2);
+    else SYNCP_LAUNCH(true, 0);
 #undef SYNCP_LAUNCH
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(e1, w.stream));
+    if (e1) HIPCHK(hipEventRecord(e1, w.stream));
     // counts and the grand total first, then exactly the hits
     std::vector<int> hc((size_t)2 * B + 1);
     HIPCHK(hipMemcpyAsync(hc.data(), d_counts, hc.size() * sizeof(int), hipMemcpyDeviceToHost, w.stream));
@@ -2235,14 +2208,10 @@ extern "C" int mfb_sync_find_packed(int device, const uint8_t *packed, int B, in
         HIPCHK(hipMemcpyAsync(hit_score, d_sc, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, w.stream));
         HIPCHK(hipStreamSynchronize(w.stream));
     }
-    if (device_ms) {          // kernel time: the pass-1 launches of all chunks + scan and pass 2
-        float tot = 0.f, ms = 0.f;
-        for (int c = 0; c < nchunk; ++c) {
-            HIPCHK(hipEventElapsedTime(&ms, ev[3 * c + 1], ev[3 * c + 2]));
-            tot += ms;
-        }
-        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-        *device_ms = tot + ms;
+    if (device_ms) {
+        HIPCHK(hipEventElapsedTime(device_ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
     }
     return MFB_OK;
 }
