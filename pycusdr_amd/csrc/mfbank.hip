@@ -1573,6 +1573,7 @@ static int block_begin(mfb_ctx *c, const mfb_block_params *p, int slot) {
             graph_drop(g);
             g.epoch = c->epoch;
             g.params = *p;
+            g.failed = false;
         }
         if (g.exec) {
             HIPCHK(hipGraphLaunch(g.exec, c->stream));

@@ -244,20 +244,37 @@ class DemodulatorRunner:
             deliver(d)
 
         cur = 0
-        for chunk in chunk_source:
-            for _ in asm.push(chunk):
-                self.demod.beginBlock(cur, source=names[cur])
-                started = (cur, self.count, time.time())
-                self.count += 1
-                cur = 1 - cur
-                asm.retarget(bufs[cur])
-                if flying is not None:
-                    collect(flying)
-                flying = started
-        if flying is not None:
-            collect(flying)
-        finish_search()
-        self.raw = bufs[cur]             # where the next block would be assembled
+        try:
+            for chunk in chunk_source:
+                for _ in asm.push(chunk):
+                    self.demod.beginBlock(cur, source=names[cur])
+                    started = (cur, self.count, time.time())
+                    self.count += 1
+                    cur = 1 - cur
+                    asm.retarget(bufs[cur])
+                    if flying is not None:
+                        fl, flying = flying, None
+                        collect(fl)
+                    flying = started
+            if flying is not None:
+                fl, flying = flying, None
+                collect(fl)
+            finish_search()
+        except BaseException:
+            # leave nothing in flight behind a failure: the handle and the decoder must be usable for the next call
+            for slot in (0, 1):
+                try:
+                    self.demod.bank.end_block(slot)
+                except Exception:       # noqa: BLE001 -- nothing was in flight in this slot
+                    pass
+            if searching:
+                try:
+                    decoder.findFrames_end()
+                except Exception:       # noqa: BLE001
+                    pass
+            raise
+        finally:
+            self.raw = bufs[cur]         # where the next block would be assembled
         return results, packets
 
     def run(self, sample_source, sink=None, decoder=None, pipelined=False):
