@@ -168,8 +168,10 @@ class DopplerShard:
                 self.stream.wait_event(self.ready[k])
             bank.upload_device(self.blocks[k].data_ptr())
 
-    def search_and_pick(self, bank, row_offset):
-        """Search this rank's bins, exchange, pick.  ``row_offset`` = first bin of this rank's slice (bin_range()[0])."""
+    def search_and_pick(self, bank, row_offset, after_search=None):
+        """Search this rank's bins, exchange, pick.  ``row_offset`` = first bin of this rank's slice (bin_range()[0]).
+        ``after_search()`` runs on the host right after the search has been enqueued (the device is busy from then on):
+        the place to start distributing the next block."""
         col = self.sum_all
         doff = self.doff
         with self._on_stream():
@@ -180,6 +182,9 @@ class DopplerShard:
                 ev = self.torch.cuda.Event()
                 ev.record(self.stream)
                 self.free[self.cur] = ev
+        if after_search is not None:
+            after_search()
+        with self._on_stream():
             if self.even:
                 # [noise rows | slice] of every rank, gathered; without noise rows that IS the table
                 bank.export_rows_async(self.local.data_ptr(), 0, 0, doff + self.nloc, column_only=col)
@@ -204,9 +209,8 @@ class DopplerShard:
         """One block of the sharded hot path: (take the prefetched block or broadcast now), start the next block's
         broadcast if the caller knows it, search, exchange, pick."""
         self.broadcast_block(bank, block)
-        if prefetch_next:
-            self.prefetch(next_block)
-        return self.search_and_pick(bank, row_offset)
+        # the search goes out first; the next block's broadcast is started while it runs
+        return self.search_and_pick(bank, row_offset, after_search=(lambda: self.prefetch(next_block)) if prefetch_next else None)
 
 
 def allreduce_scores_host(local_scores, row_offset, num_bins_total, group=None):
