@@ -57,6 +57,15 @@ def doppler_bin_table(confRadio, rangeRateMax, Nfft):
     return grid, grid * spsym * baud, shifts, int(stx_idx)
 
 
+def _first_true(mask):
+    """Index of the first True -- ``np.where(mask)[0][0]`` (reference DB:880-881) without building the index array; like it,
+    IndexError when there is none."""
+    i = int(np.argmax(mask)) if len(mask) else 0
+    if not len(mask) or not mask[i]:
+        raise IndexError('index 0 is out of bounds for axis 0 with size 0')
+    return i
+
+
 class Demodulator:
     """One receive channel: Doppler search + symbol demodulation of N-sample blocks."""
     backend = None
@@ -129,6 +138,13 @@ class Demodulator:
             raise
         if self.symbolLUT is not None:
             self.symbolLUT = np.asarray(self.symbolLUT)
+        # a bit LUT of plain 0/1 values (every shipped protocol that has one) also as bytes: the lookup of a block's
+        # symbols then yields the uint8 bits the caller gets anyway, without a float64 detour (same values)
+        self._bitLUT_u8 = None
+        if self.bitLUT is not None:
+            lut = np.asarray(self.bitLUT)
+            if lut.ndim == 1 and np.all((lut == 0) | (lut == 1)):
+                self._bitLUT_u8 = lut.astype(np.uint8)
 
         # device side: this rank's slice of the Doppler bins (all of them without sharding).  The noise-reference bin
         # (doppIdxArrayOffset rows in front of the table, DB:148-159) is searched by every rank: the pick needs its score
@@ -431,7 +447,10 @@ class Demodulator:
         """The sequential half (reference DB:1012-1051, 863-988, 817-859): bit lookup, alignment against the previous
         block (stateful: ``poswinP``, ``posSymEnd``), clipped-peak tagging, uint8 casts.  Must see the blocks in order."""
         spSym, idxSymbol, centres, trustSymbol = rec['spSym'], rec['symbols'], rec['centres'], rec['trust']
-        dataBits, symError_t = self.extractBits(centres, idxSymbol)
+        if self._bitLUT_u8 is not None:
+            dataBits, symError_t = self._bitLUT_u8[idxSymbol], []
+        else:
+            dataBits, symError_t = self.extractBits(centres, idxSymbol)
         noError = len(symError_t)
         centresWin, dataBitsWin, trustSymbolWin, _ = self.checkSymbolOverlap(noError, centres, idxSymbol, dataBits, trustSymbol)
 
@@ -483,8 +502,8 @@ class Demodulator:
         """Keep the symbols whose centre lies in [ov/2, N-ov/2] and repair a +-1 symbol slip against
         the previous block (reference DB:863-988).  Stateful: ``poswinP`` (symbols after this
         block's window) and ``posSymEnd`` (last offset+1 kept symbols)."""
-        start = np.where(centres >= self.sigOverlapWin)[0][0]
-        end = np.where(centres > (self.Nfft - self.sigOverlapWin))[0][0]
+        start = _first_true(centres >= self.sigOverlapWin)
+        end = _first_true(centres > (self.Nfft - self.sigOverlapWin))
         win = dataBits[start:end]
         pre = dataBits[:start]
         o = self.overlapOffset
