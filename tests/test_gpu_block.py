@@ -197,3 +197,33 @@ def test_block_calls_refuse_misuse():
         assert not b['pick_valid'] and b['shift'] == 0            # the block is to be skipped (DB:625-630)
     finally:
         bank.close()
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_one_call_equals_stage_by_stage_randomised(seed):
+    """Random geometries: block length, bin count, modulation, overlap, noise-reference bin, window width, SNR -- the one-call
+    path and the stage-by-stage calls must agree on every number, block after block (state included)."""
+    rs = np.random.RandomState(100 + seed)
+    mod, pname = [('GMSK', 'bench_GMSK'), ('FSK', 'bench_FSK'), ('GFSK', 'bench_GFSK'), ('BPSK', 'bench_BPSK')][rs.randint(4)]
+    bs = int(rs.choice([13, 14, 15, 16, 17]))
+    ovb = int(rs.choice([9, 10, 11]))
+    D = int(rs.randint(3, 90))
+    N, ov = 1 << bs, 1 << ovb
+    conf = cfg.bench_config(pname, blockSize=bs, overlap=ovb, doppCarrierSteps=D)
+    conf['GPU']['UHF']['bitWindowWidth'] = int(rs.choice([3, 5, 7, 9]))
+    if rs.randint(2):
+        conf['Radios']['Rx']['UHF-H']['noise_measure_offset_Hz'] = float(rs.choice([-60000, 30000, 70000]))
+    one, stages = _pair(conf, pname)
+    nb = 4
+    sig = sg.s1_stream(nb, N, ov, mod, snr_db=float(rs.choice([4.0, 8.0, 14.0])), seed=seed + 50)
+    try:
+        for b in range(nb):
+            x = sig[b * (N - ov): b * (N - ov) + N]
+            ra, rb = one.uploadAndFindCarrier(x.copy()), stages.uploadAndFindCarrier(x.copy())
+            assert _same([ra[0], ra[1], ra[3]], [rb[0], rb[1], rb[3]]), (seed, b, ra, rb)
+            da, db = one.demodulate(), stages.demodulate()
+            assert all(_same(u, v) for u, v in zip(da, db)), (seed, b)
+            assert _same(one.poswinP, stages.poswinP) and _same(one.posSymEnd, stages.posSymEnd)
+    finally:
+        one.close()
+        stages.close()
