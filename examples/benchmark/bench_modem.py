@@ -21,6 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from pycusdr_amd import config as cfg, signals as sg            # noqa: E402
 from pycusdr_amd.decoder import Decoder                          # noqa: E402
 from pycusdr_amd.demodulator_process import DemodulatorRunner    # noqa: E402
+from pycusdr_amd.hostcpu import quiet_blas                       # noqa: E402
 from pycusdr_amd.protocol import loadProtocol                    # noqa: E402
 
 CHUNK = 2 ** 14
@@ -81,6 +82,9 @@ def main():
     ap.add_argument('--search', choices=['transforms', 'energy'], default='transforms')
     ap.add_argument('--out', default=None, help='write the table as JSON')
     a = ap.parse_args()
+    # the noise generator's np.linalg.norm wakes one BLAS worker per core; under a container's CPU quota their spinning gets the
+    # whole process throttled for most of a 100 ms period (profiles/r03_ber.md: one 70-83 ms block in some rows)
+    quiet_blas()
     rows = []
     for k, snr in enumerate(np.arange(a.SNR_low, a.SNR_high + a.SNR_step / 2, a.SNR_step)):
         r = run_snr(a.modulation, a.nRuns, snr, a.block_size, a.search, seed=1000 + k, doppler_bins=a.doppler_bins,

@@ -10,7 +10,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pycusdr_amd import config as cfg, signals as sg            # noqa: E402
 from pycusdr_amd.decoder import Decoder                          # noqa: E402
 from pycusdr_amd.demodulator_process import DemodulatorRunner    # noqa: E402
+from pycusdr_amd.hostcpu import quiet_blas                       # noqa: E402
 from pycusdr_amd.protocol import loadProtocol                    # noqa: E402
+
+quiet_blas()
 
 log2N = int(sys.argv[1]) if len(sys.argv) > 1 else 15
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 64
