@@ -547,11 +547,15 @@ static int seg_valid(int l, int T) {
 // Relative cost of one segment point per filter, MEASURED on MI355X at C2 (time x V / L, 48 taps, D = 256,
 // M = 8; tools/seg_probe.py): the 256-point kernel is by far the cheapest per point (one twiddled pass,
 // three waves per SIMD, phase table in LDS), so it wins whenever at least ~2/3 of a segment is valid; the
-// cost of a valid output is this divided by the segment efficiency V / L.  Checked against the other
-// shipped banks: 80 taps (BPSK) -> 256 (7.7 ms at D = 512 vs 8.9 ms at 1024), 384 taps (CC11xx at 128
-// samples per symbol) -> 4096 (5.57 ms at D = 512 vs 5.60 ms at 2048, 6.3 ms at 1024).  Figures with 32 workgroups per CU in the grid.
+// cost of a valid output is this divided by the segment efficiency V / L.  Re-measured in round 3 on two
+// devices (profiles/r03_long_filter.md): the 4096-point kernel is the one whose speed depends on the device
+// (CC11xx bank, 384 taps, D = 256: 3.42 ms on one, 2.91 on another, while 2048 points take 2.91-2.98 on both and
+// the 256-point kernel goes the other way, 1.59 / 1.88), so its figure is the slower device's: 384 taps -> 2048.
+// Checked against the other shipped banks: 80 taps (BPSK) -> 256 (4.05 ms at D = 256 vs 4.15 at 1024, 4.35 at 512, on the
+// device where the 256-point kernel is slow; 512 and 1024 points cost the same per point within the device spread).
+// Figures with 32 workgroups per CU in the grid.
 static double seg_cost(int l, int T) {
-    static const double per_point[13] = {0, 0, 0, 0, 0, 0, 0, 0, 1.35, 1.94, 2.02, 2.28, 2.44};
+    static const double per_point[13] = {0, 0, 0, 0, 0, 0, 0, 0, 1.35, 1.90, 1.90, 2.15, 2.45};
     const int V = seg_valid(l, T);
     if (!V) return 1e30;
     return per_point[l] * (double)(1 << l) / (double)V;

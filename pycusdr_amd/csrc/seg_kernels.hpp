@@ -443,6 +443,9 @@ struct SegWaves {
 
 // Variant builds only (-DMFB_SEG_TRACE, tools/xcd_trace.py): start / end time and XCC of every workgroup of the
 // branch-free search kernel, to see how evenly the grid drains over the XCDs.
+#ifndef MFB_SEG_PRIO
+#define MFB_SEG_PRIO 0
+#endif
 #ifdef MFB_SEG_TRACE
 __device__ unsigned long long g_seg_trace[3 * 65536];
 #endif
@@ -452,6 +455,21 @@ __global__ void SEG_KERNEL_ATTRS(L, PV) k_seg(SegArgs a) {
 #ifdef MFB_SEG_TRACE
     unsigned long long t0 = 0;
     if (PV >= 0 && MODE == SEG_REDUCE && threadIdx.x == 0) t0 = wall_clock64();
+#endif
+#if MFB_SEG_PRIO
+    // experiment: the two barrier teams that share a CU get different issue priorities by their wave slot
+    if (L >= 2048) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hw));
+#if MFB_SEG_PRIO == 2
+        if (blockIdx.x & 1)
+#else
+        if (hw & 1)
+#endif
+            __builtin_amdgcn_s_setprio(3);
+        else
+            __builtin_amdgcn_s_setprio(0);
+    }
 #endif
     seg_body<L, MODE, PV>(a, (int)blockIdx.x);
 #ifdef MFB_SEG_TRACE

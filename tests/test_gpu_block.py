@@ -57,7 +57,7 @@ def test_one_call_equals_stage_by_stage(mod, pname, bs, D):
 
 
 def test_one_call_with_noise_bin_wrapped_band_and_long_filters():
-    """CC11xx geometry (IF offset 148.32 kHz, 128 samples per symbol, 384-tap filters: L = 4096 segments) with the
+    """CC11xx geometry (IF offset 148.32 kHz, 128 samples per symbol, 384-tap filters: L = 2048 segments) with the
     noise-reference bin in front of the table (DB:148-159): the metric divides by its score (CU:550-554)."""
     from pycusdr_amd.protocol.CC11xx import frame_bits
     bs, sps = 17, 128
