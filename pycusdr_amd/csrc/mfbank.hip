@@ -988,7 +988,7 @@ static SegGeom seg_geom(const mfb_ctx *c) {
     g.NT = L / 16;
     g.TEAM = g.NT < 64 ? 64 : g.NT;
     g.CT = g.TEAM / g.NT;
-    g.TPW = (g.NT <= 64 ? MFB_SEG_BLOCK : 256) / g.TEAM;
+    g.TPW = seg_block_threads(g.NT) / g.TEAM;
     g.WPT = g.TEAM / 64;
     g.wave_sync = g.NT <= 64;
     return g;

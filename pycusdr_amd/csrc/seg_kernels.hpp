@@ -77,6 +77,15 @@
 #define MFB_SEG_BLOCK 256
 #endif
 static_assert(MFB_SEG_BLOCK == 64 || MFB_SEG_BLOCK == 128 || MFB_SEG_BLOCK == 256, "MFB_SEG_BLOCK: 64, 128 or 256 threads");
+// Threads per workgroup of the 2048-point kernel (two-wave barrier teams): 256 = two teams behind one s_barrier, 128 = one.
+// One team per workgroup: the s_barrier of a 256-thread workgroup keeps its two teams in step, so that all four waves
+// compute and exchange at the same moments; four independent pairs per CU instead of two coupled quadruples run the
+// 384-tap bank 5 % faster (3.05 against 3.22 ms at D = 256, same device, profiles/r03_long_filter.md).
+#ifndef MFB_SEG_BLOCK_2048
+#define MFB_SEG_BLOCK_2048 128
+#endif
+static_assert(MFB_SEG_BLOCK_2048 == 128 || MFB_SEG_BLOCK_2048 == 256, "MFB_SEG_BLOCK_2048: 128 or 256 threads");
+constexpr int seg_block_threads(int NT) { return NT <= 64 ? MFB_SEG_BLOCK : (NT == 128 ? MFB_SEG_BLOCK_2048 : 256); }
 #ifndef MFB_SEG_G0EARLY
 #define MFB_SEG_G0EARLY 1
 #endif
@@ -114,7 +123,7 @@ struct SegCfg {
     static constexpr int NT = L / 16;
     static constexpr int TEAM = NT < 64 ? 64 : NT;
     static constexpr int CT = TEAM / NT;          // segments side by side in a team
-    static constexpr int BLOCK = NT <= 64 ? MFB_SEG_BLOCK : 256;   // threads per workgroup
+    static constexpr int BLOCK = seg_block_threads(NT);   // threads per workgroup
     static constexpr int TPW = BLOCK / TEAM;      // teams per workgroup
     static constexpr int WPT = TEAM / 64;         // waves per team
     static constexpr int SYNC = NT <= 64 ? 1 : 0;
