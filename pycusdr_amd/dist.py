@@ -131,6 +131,13 @@ class DopplerShard:
         out[:, 0] = s
         return out
 
+    def _event(self, slot, k, stream):
+        """Record on ``stream`` the event of buffer k in ``slot`` (self.ready / self.free); the two events per slot are
+        created once and re-armed."""
+        if slot[k] is None:
+            slot[k] = self.torch.cuda.Event()
+        slot[k].record(stream)
+
     def _fill(self, k, block, stream):
         """Enqueue on ``stream``: buffer k <- rank 0's block, on every rank."""
         with self._on_stream(stream):
@@ -143,9 +150,7 @@ class DopplerShard:
             if self.world > 1:
                 self.dist.broadcast(self.blocks[k], src=0, group=self.bcast_group)
             if self.on_gpu:
-                ev = self.torch.cuda.Event()
-                ev.record(stream)
-                self.ready[k] = ev
+                self._event(self.ready, k, stream)
 
     def prefetch(self, block=None):
         """Start distributing the NEXT block (rank 0 passes it) while the current one is being searched."""
@@ -163,10 +168,11 @@ class DopplerShard:
             self._fill(k, block, self.stream)
         self.cur = k
         self.block = self.blocks[k]
-        with self._on_stream():
-            if self.on_gpu and self.ready[k] is not None:
-                self.stream.wait_event(self.ready[k])
-            bank.upload_device(self.blocks[k].data_ptr())
+        # the bank launches on the shard's stream by itself (attach: set_stream); torch's stream context is entered only
+        # around torch's own operations -- every entry and exit costs the host several microseconds the device idles for
+        if self.on_gpu and self.ready[k] is not None:
+            self.stream.wait_event(self.ready[k])
+        bank.upload_device(self.blocks[k].data_ptr())
 
     def search_and_pick(self, bank, row_offset, after_search=None):
         """Search this rank's bins, exchange, pick.  ``row_offset`` = first bin of this rank's slice (bin_range()[0]).
@@ -174,20 +180,18 @@ class DopplerShard:
         the place to start distributing the next block."""
         col = self.sum_all
         doff = self.doff
-        with self._on_stream():
-            if not self.even:
+        if not self.even:
+            with self._on_stream():
                 self.scores.zero_()
-            bank.search_async()
-            if self.on_gpu:                       # from here on the block buffer may be refilled
-                ev = self.torch.cuda.Event()
-                ev.record(self.stream)
-                self.free[self.cur] = ev
+        bank.search_async()
+        if self.on_gpu:                           # from here on the block buffer may be refilled
+            self._event(self.free, self.cur, self.stream)
         if after_search is not None:
             after_search()
-        with self._on_stream():
-            if self.even:
-                # [noise rows | slice] of every rank, gathered; without noise rows that IS the table
-                bank.export_rows_async(self.local.data_ptr(), 0, 0, doff + self.nloc, column_only=col)
+        if self.even:
+            # [noise rows | slice] of every rank, gathered; without noise rows that IS the table
+            bank.export_rows_async(self.local.data_ptr(), 0, 0, doff + self.nloc, column_only=col)
+            with self._on_stream():
                 if doff:
                     self.dist.all_gather_into_tensor(self.gathered, self.local, group=self.group)
                     g = self.gathered.view((self.world, doff + self.nloc) + tuple(self.gathered.shape[1:]))
@@ -195,15 +199,16 @@ class DopplerShard:
                     self.scores[doff:].view((self.world, self.nloc) + tuple(self.scores.shape[1:])).copy_(g[:, doff:])
                 else:
                     self.dist.all_gather_into_tensor(self.scores, self.local, group=self.group)
-            else:
-                nloc = bank.D
-                bank.export_rows_async(self.scores.data_ptr(), doff + row_offset, doff, nloc, column_only=col)
-                if doff and self.rank == 0:
-                    bank.export_rows_async(self.scores.data_ptr(), 0, 0, doff, column_only=col)
+        else:
+            nloc = bank.D
+            bank.export_rows_async(self.scores.data_ptr(), doff + row_offset, doff, nloc, column_only=col)
+            if doff and self.rank == 0:
+                bank.export_rows_async(self.scores.data_ptr(), 0, 0, doff, column_only=col)
+            with self._on_stream():
                 self.dist.all_reduce(self.scores, op=self.dist.ReduceOp.SUM, group=self.group)     # adds exact zeros
-            if self.sum_all:
-                return bank.pick_column(self.scores.data_ptr(), num=self.D, offset=doff)
-            return bank.pick(self.scores.data_ptr(), num=self.D, offset=doff)
+        if self.sum_all:
+            return bank.pick_column(self.scores.data_ptr(), num=self.D, offset=doff)
+        return bank.pick(self.scores.data_ptr(), num=self.D, offset=doff)
 
     def step(self, bank, row_offset, block=None, next_block=None, prefetch_next=False):
         """One block of the sharded hot path: (take the prefetched block or broadcast now), start the next block's
