@@ -68,7 +68,7 @@ def test_stream_bits_identical_to_oracle_and_packet_error_free(monkeypatch, mod,
         assert spg == spc                                                 # same FFT bin -> same float
         if snr <= 20:
             # noise floor far above fp32 round-off: symbol decisions are BIT-EXACT (north_star), fp32 device
-            # transforms against the fp64 oracle (measured with tools/decision_slack.py: 0 of ~12 000 symbols
+            # transforms against the fp64 oracle (measured with tests/tools/decision_slack.py: 0 of ~12 000 symbols
             # differ for every modulation at 6-12 dB).
             assert np.array_equal(bg, bc), f'block {b}: symbol decisions differ'
             # peak sample index: equal except where two neighbouring |xc|^2 samples tie to within fp32-vs-fp64

@@ -1,6 +1,6 @@
 """Randomised parity sweep of the search paths against the oracle at small sizes: random block length, bin count,
 filter count, tap count and window position, segment length, sum_all on/off, noise bin, decomposition knobs, span
-basis.  usage: python tools/fuzz_seg.py [cases] [seed]"""
+basis.  usage: python tests/tools/fuzz_seg.py [cases] [seed]"""
 import sys
 import numpy as np
 sys.path.insert(0, '.')

@@ -8,7 +8,15 @@ from pycusdr_amd import config as cfg, signals as sg
 from pycusdr_amd.mfbank import MFBank
 from pycusdr_amd.protocol import loadProtocol
 from pycusdr_amd.demodulator.demodulator_base import doppler_bin_table
-from oracle import mfbank_oracle as orc
+
+
+def parseval_scores(X, masks, shifts):
+    """Sanity figure for the timed scores, no inverse transform: sum_n |IFFT(P)[n]|^2 = N sum_k |P[k]|^2, in float64,
+    scaled by the 2^18 of the search (a property of the DFT, not the checker the parity tests use)."""
+    w = (np.abs(np.asarray(masks, dtype=np.complex128)) ** 2).sum(axis=0)
+    p = np.abs(np.asarray(X, dtype=np.complex128)) ** 2
+    return np.array([len(p) * np.dot(np.roll(p, -int(s)), w) / 2.0 ** 18 for s in shifts])
+
 
 log2N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 256
@@ -32,7 +40,7 @@ bank.set_filters(masks)
 bank.set_shifts(shifts)
 bank.upload(x)
 X = bank.get_spectrum()
-ref = orc.doppler_scores_parseval(X, masks, shifts)
+ref = parseval_scores(X, masks, shifts)
 print('auto:', bank.get_search_path(), flush=True)
 
 
