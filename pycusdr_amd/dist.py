@@ -45,8 +45,9 @@ class DopplerShard:
     """Glue between a bank (MFBank, or any object with its device-pointer methods) holding this rank's
     bins and the process group.  Works on CUDA/HIP tensors over RCCL and on CPU tensors over gloo."""
 
-    def __init__(self, rank=None, world=None, group=None, device=None, comm=None):
-        """``comm``: an object with torch.distributed's call surface (get_rank, get_world_size, get_backend, new_group,
+    def __init__(self, rank=None, world=None, group=None, device=None, comm=None, src=0):
+        """``src``: the PROCESS rank of this shard's rank 0 (the broadcast source; differs from 0 when ``group`` is a
+        subset of the job, GridShard).  ``comm``: an object with torch.distributed's call surface (get_rank, get_world_size, get_backend, new_group,
         broadcast, all_gather_into_tensor, all_reduce, ReduceOp); default torch.distributed itself.  A caller that
         runs several ranks inside one process (rehearsals of many-rank geometries on one device) passes its own."""
         import torch
@@ -55,6 +56,7 @@ class DopplerShard:
         self.torch, self.dist = torch, comm
         dist = comm
         self.group = group
+        self.src = int(src)
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.backend = dist.get_backend(group)
@@ -148,7 +150,7 @@ class DopplerShard:
                     raise ValueError('rank 0 must supply the block')
                 self.blocks[k].copy_(block.reshape(-1), non_blocking=True)
             if self.world > 1:
-                self.dist.broadcast(self.blocks[k], src=0, group=self.bcast_group)
+                self.dist.broadcast(self.blocks[k], src=self.src, group=self.bcast_group)
             if self.on_gpu:
                 self._event(self.ready, k, stream)
 
@@ -247,7 +249,9 @@ class BlockShard:
     """
     HEADER = 8          # float64: block index, doppler, doppler_std, SNR, spSym, symbols, clipped samples, device seconds
 
-    def __init__(self, rank=None, world=None, group=None, comm=None, root=0):
+    def __init__(self, rank=None, world=None, group=None, comm=None, root=0, ranks=None):
+        """``ranks``: the process (global rank) behind each member of this shard's world, for worlds that are a subset of
+        the job (GridShard: one member per bin group); default: member r is process r."""
         import torch
         if comm is None:
             import torch.distributed as comm
@@ -257,6 +261,9 @@ class BlockShard:
         self.root = int(root)
         if not 0 <= self.root < self.world:
             raise ValueError(f'root {root} outside the world of {self.world} ranks')
+        self.peers = list(range(self.world)) if ranks is None else [int(r) for r in ranks]
+        if len(self.peers) != self.world:
+            raise ValueError(f'{len(self.peers)} process ranks for a world of {self.world}')
         self._inflight = []
 
     def owner(self, block_index):
@@ -292,9 +299,9 @@ class BlockShard:
         torch = self.torch
         head, body = self.pack(part)
         th, tb = torch.from_numpy(head), torch.from_numpy(body)
-        works = [self.dist.isend(th, self.root, group=self.group)]
+        works = [self.dist.isend(th, self.peers[self.root], group=self.group)]
         if len(body):
-            works.append(self.dist.isend(tb, self.root, group=self.group))
+            works.append(self.dist.isend(tb, self.peers[self.root], group=self.group))
         self._inflight.append((works, th, tb))
         while len(self._inflight) > 2:
             self._wait_oldest()
@@ -312,12 +319,12 @@ class BlockShard:
         import time
         torch = self.torch
         th = torch.empty(self.HEADER, dtype=torch.float64)
-        self.dist.recv(th, src, group=self.group)
+        self.dist.recv(th, self.peers[src], group=self.group)
         head = th.numpy()
         nbytes = 9 * int(head[5]) + 8 * int(head[6])
         tb = torch.empty(nbytes, dtype=torch.uint8)
         if nbytes:
-            self.dist.recv(tb, src, group=self.group)
+            self.dist.recv(tb, self.peers[src], group=self.group)
         return self.unpack(head, tb.numpy(), time.time())
 
     # -- the loop ------------------------------------------------------------------------------------------------------
@@ -373,3 +380,51 @@ class BlockShard:
             finish(backlog.pop(0))
         self.flush()
         return results, packets
+
+
+# ---- Doppler bins x time chunks ----------------------------------------------------------------------------------------
+class GridShard:
+    """The two axes together ("two independent axes"): the job's G processes form T = G / B groups of B ranks.
+    Inside a group the Doppler bins are sharded (DopplerShard on the group's communicator: block broadcast from the group's
+    first rank, one collective on the scores, pick and demodulation on every rank); the groups take the blocks round-robin
+    (BlockShard between the groups' first ranks: one point-to-point message per block back to process 0, which runs the
+    sequential host stages and the decoder in block order).  Process rank = group * B + bin rank.
+
+        grid = GridShard(bin_ranks=4)                        # 8 processes: 2 groups x 4 bin slices
+        runner = DemodulatorRunner(conf, protocol, radio, shard=grid.doppler)
+        results, packets = grid.run(runner, chunks, decoder=Decoder(conf, protocol))
+
+    ``B = 1`` is BlockShard, ``B = G`` is DopplerShard with the streaming loop around it.  ``hand_back_backend``: backend
+    of the communicator that moves the hand-back (host arrays): gloo."""
+
+    def __init__(self, bin_ranks, device=None, comm=None, hand_back_backend='gloo'):
+        if comm is None:
+            import torch.distributed as comm
+        world, rank = comm.get_world_size(), comm.get_rank()
+        B = int(bin_ranks)
+        if B < 1 or world % B:
+            raise ValueError(f'{world} processes do not divide into groups of {bin_ranks}')
+        self.B, self.T = B, world // B
+        self.g, self.b = divmod(rank, B)
+        # every process creates every communicator, in the same order (torch.distributed's rule for new_group)
+        bin_groups = [comm.new_group(ranks=list(range(g * B, (g + 1) * B))) for g in range(self.T)]
+        roots = [g * B for g in range(self.T)]
+        root_group = comm.new_group(ranks=roots, backend=hand_back_backend)
+        self.doppler = DopplerShard(rank=self.b, world=B, group=bin_groups[self.g], device=device, comm=comm, src=self.g * B)
+        self.blocks = BlockShard(rank=self.g, world=self.T, group=root_group, comm=comm, ranks=roots) if self.b == 0 else None
+
+    def owner_group(self, block_index):
+        return int(block_index) % self.T
+
+    def run(self, runner, sample_source, sink=None, decoder=None):
+        """``runner``: a DemodulatorRunner built with ``shard=self.doppler``.  Every process iterates the same stream of
+        new-sample slices (only the first rank of a group reads the samples of the blocks its group owns; the others take
+        them from its broadcast).  Returns (results, packets) on process 0, ([], []) elsewhere."""
+        if self.blocks is not None:
+            return self.blocks.run(runner, sample_source, sink=sink, decoder=decoder)
+        for i, chunk in enumerate(sample_source):
+            if self.owner_group(i) == self.g:
+                runner.feed_device(np.asarray(chunk, dtype=np.complex64))
+            else:
+                runner.skip_block(chunk)
+        return [], []

@@ -141,14 +141,26 @@ def _worker_noise(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def _spawn(worker, world=2, timeout=100):
+def _spawn(worker, world=2, timeout=100, extra=()):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, q) + tuple(extra)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=timeout) for _ in procs]
+    import queue
+    import time
+    res, t0 = [], time.time()
+    while len(res) < world:
+        try:
+            res.append(q.get(timeout=1.0))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > timeout:      # a rank died (its peers would wait for it for ever) or time is up
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                raise AssertionError(f'ranks exited with {dead}' if dead else f'no result after {timeout} s')
     for p in procs:
         p.join(timeout=30)
     return sorted(res)
@@ -298,6 +310,72 @@ def test_block_round_robin_equals_single_process_stream(world):
     res = _spawn(_worker_blockshard, world=world, timeout=280)
     assert all(r[1] for r in res), res
     assert res[0][2] == 27
+
+
+def _worker_grid(rank, world, port, q, bin_ranks):
+    """Doppler bins x time chunks: groups of ``bin_ranks`` processes shard the bins, the groups take the blocks round-robin.
+    Process 0's results must equal one process on the whole stream with the whole bin table."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    import torch.distributed as dist
+    from oracle import mfbank_oracle as orc
+    from oracle_bank import OracleBank
+    import pycusdr_amd.demodulator.demodulator_base as dbm
+    from pycusdr_amd import config as cfg
+    from pycusdr_amd.decoder import Decoder
+    from pycusdr_amd.demodulator_process import DemodulatorRunner
+    from pycusdr_amd.dist import GridShard
+    from pycusdr_amd.protocol import loadProtocol
+    dbm.MFBank = OracleBank
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    bs, ov, D = 13, 1 << 10, 12
+    N = 1 << bs
+    nblocks = 27
+    conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=D)
+    p = loadProtocol('bench_GMSK')(conf=conf)
+    sig, _ = _hopping_stream(N, ov, nblocks, np.linspace(-3000, 3000, nblocks))
+    step = N - ov
+    chunks = [sig[ov + i * step: ov + (i + 1) * step] for i in range(nblocks)]
+    grid = GridShard(bin_ranks)
+    assert (grid.g, grid.b) == divmod(rank, bin_ranks) and grid.T * grid.B == world
+    run = DemodulatorRunner(conf, p, 'UHF-H', shard=grid.doppler)
+    assert run.demod.bank.D == len(range(*grid.doppler.bin_range(D)))          # this process holds its slice only
+    run.raw[:ov] = sig[:ov]
+    res, packets = grid.run(run, chunks, decoder=Decoder({}, p, correlator=orc.sync_correlate))
+    ok = True
+    picked = set()
+    if rank == 0:
+        plain = DemodulatorRunner(conf, p, 'UHF-H')
+        plain.raw[:ov] = sig[:ov]
+        ref, ref_packets = plain.run(chunks, decoder=Decoder({}, p, correlator=orc.sync_correlate))
+        ok &= len(res) == len(ref) == nblocks
+        for a, b in zip(res, ref):
+            ok &= a['count'] == b['count'] and a['numSyncSig'] == b['numSyncSig']
+            ok &= bool(np.array_equal([a['doppler'], a['doppler_std'], a['SNR'], a['spSymEst']],
+                                      [b['doppler'], b['doppler_std'], b['SNR'], b['spSymEst']], equal_nan=True))
+            ok &= bool(np.array_equal(a['data'], b['data']) and np.array_equal(a['trust'], b['trust']))
+            picked.add(round(a['doppler'], -2))
+        ok &= bool(np.array_equal(run.demod.poswinP, plain.demod.poswinP) and np.array_equal(run.demod.posSymEnd, plain.demod.posSymEnd))
+        ok &= len(packets) == len(ref_packets) == 1 and bool(np.array_equal(packets[0].bits, ref_packets[0].bits))
+        ok &= packets[0].checkPacketData() == ref_packets[0].checkPacketData()
+        ok &= len(picked) > 3                      # the carrier really moved through the slices
+    else:
+        ok &= res == [] and packets == [] and run.count == nblocks
+    q.put((rank, bool(ok), len(res)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize('world,bin_ranks', [(4, 2), (6, 3), (6, 2)])
+def test_bins_by_blocks_grid_equals_single_process_stream(world, bin_ranks):
+    res = _spawn(_worker_grid, world=world, timeout=380, extra=(bin_ranks,))
+    assert all(r[1] for r in res), res
+    assert res[0][2] == 27 and all(r[2] == 0 for r in res[1:])
 
 
 def test_block_shard_wire_format_round_trip():

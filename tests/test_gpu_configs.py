@@ -172,6 +172,19 @@ def test_c4_slices_four_gloo_ranks_full_size():
     _run_ranks(4, ['gloo', 20, 1024])
 
 
+def test_bins_by_blocks_grid_on_one_gpu():
+    """north_star's "Doppler-bin x time-chunk grid" (dist.GridShard): four processes on the one device (the box admits six
+    with this one) as 2 block groups x 2 bin slices, with even slices (all-gather) and with uneven ones (65 bins: all-reduce)
+    -- results, alignment state and the packet (zero bit errors) equal one process with the whole table on the whole stream.
+    Over RCCL when the node has the devices."""
+    import torch
+    res = _run_ranks(4, ['gloo', 2, 15, 64], child='grid_child.py')
+    assert sorted((q['group'], q['bin_rank']) for q in res) == [(0, 0), (0, 1), (1, 0), (1, 1)]
+    _run_ranks(4, ['gloo', 2, 15, 65], child='grid_child.py')
+    if torch.cuda.device_count() >= 8:
+        _run_ranks(8, ['nccl', 4, 18, 256], child='grid_child.py')
+
+
 def test_failed_create_frees_everything():
     """mfb_create that fails at ANY of its allocations must hand back every byte it took -- the caller gets no
     handle to destroy (reference teardown DB:517-530).  mfb_debug_fail_alloc makes the n-th allocation fail."""
