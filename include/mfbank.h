@@ -24,6 +24,7 @@
 #ifndef MFBANK_H
 #define MFBANK_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -46,7 +47,8 @@ typedef struct mfb_ctx mfb_ctx;
 #define MFB_CENTRES_IMAG 2
 
 const char *mfb_strerror(int status);
-/* Library/ABI version, bumped whenever a prototype changes. */
+/* Library/ABI version, bumped whenever a prototype changes.  No reference counterpart (its kernels are compiled from source
+ * at run time, SourceModule DB:214). */
 int mfb_abi_version(void);   /* 2: search paths, mfb_xcorr; 3: mfb_set_search_mode, mfb_sync_find_multi; 4: mfb_receive_block,
                               * mfb_export_rows_async, mfb_sync_find_packed */
 
@@ -93,7 +95,7 @@ int mfb_get_tuning(mfb_ctx *ctx, int *doppler_chunk, int *masks_per_block, int *
 int mfb_set_search_path(mfb_ctx *ctx, int path, int log2L, int wg_per_cu, int filters_per_pass);
 /* What is in force: path (TWOPASS or SEGMENT), log2L, taps T of the bank (N if it has no short
  * support), valid outputs per segment and number of segments (0 on the two-pass path).  Any pointer
- * may be NULL. */
+ * may be NULL.  No reference counterpart (one formulation only: DB:571-591). */
 int mfb_get_search_path(mfb_ctx *ctx, int *path, int *log2L, int *taps, int *valid_per_segment, int *segments);
 /* Search basis (opt-in; segment path with SUM_ALL_MASKS only).  With SUM_ALL_MASKS the search needs
  * sum_m |y_m[n]|^2 only, which is invariant under any unitary mixing of the filters; the shipped banks (all 2^k
@@ -107,9 +109,11 @@ int mfb_get_search_path(mfb_ctx *ctx, int *path, int *log2L, int *taps, int *val
 #define MFB_BASIS_FILTERS 0
 #define MFB_BASIS_SPAN    1
 int mfb_set_search_basis(mfb_ctx *ctx, int basis);
-/* Basis in force and the number of filters the search transforms per Doppler bin. */
+/* Basis in force and the number of filters the search transforms per Doppler bin.  No reference counterpart (it transforms
+ * all M, DB:578-588). */
 int mfb_get_search_basis(mfb_ctx *ctx, int *basis, int *transformed_filters);
-/* Host-only helper: dimension of the span of a bank's impulse responses (M if it has no short support). */
+/* Host-only helper: dimension of the span of a bank's impulse responses (M if it has no short support).  No reference
+ * counterpart: the reference transforms every length-N filter row (plans DB:292-338). */
 int mfb_analyze_rank(const float *masks_c64, int M, int N, int *rank);
 /* Search mode (opt-in shortcut).  The search uses only the row sums of |y|^2 over all N outputs of each circular
  * correlation (cuda_kernels.cu:421-480 after DB:578-588), and by Parseval's identity
@@ -124,16 +128,18 @@ int mfb_set_search_mode(mfb_ctx *ctx, int mode);
 int mfb_get_search_mode(mfb_ctx *ctx, int *mode);
 /* Fault injection for tests: the nth device allocation made on behalf of a handle by the calling thread
  * from now on fails as if the device were out of memory (0 disarms).  Lets a test walk the free-on-error
- * path of mfb_create allocation by allocation. */
+ * path of mfb_create allocation by allocation.  No reference counterpart (teardown on error: __del__ DB:517-530). */
 int mfb_debug_fail_alloc(int nth);
 /* Host-only helper (no device work): common circular support window [start, start+len) of the impulse
  * responses ifft(H_m) of a filter bank complex64 [M][N]; len == N when some filter has no short support.
- * This is the analysis mfb_set_filters runs; exported so it can be checked without a GPU. */
+ * This is the analysis mfb_set_filters runs; exported so it can be checked without a GPU.  No reference counterpart: the
+ * reference keeps the filters as length-N spectra only (__uploadMaskToGPU DB:246-263). */
 int mfb_analyze_filters(const float *masks_c64, int M, int N, int *support_start, int *support_len);
 
 /* Geometry the handle settled on: the two FFT factors N = N1 * N2 and, after mfb_set_filters, the number
  * of filter rows the Doppler search actually transforms (filters that are exact copies or exact
- * negatives of an earlier one are transformed once).  Any pointer may be NULL. */
+ * negatives of an earlier one are transformed once).  Any pointer may be NULL.  No reference counterpart (its cuFFT plans,
+ * DB:292-338, keep their factorisation to themselves). */
 int mfb_get_info(mfb_ctx *ctx, int *N1, int *N2, int *unique_filters);
 
 /* Upload the filter bank: host complex64 [M][N], row-major, already conj(fft(template, N)) as
@@ -152,10 +158,11 @@ int mfb_input_buffer(mfb_ctx *ctx, float **host_c64);
  * Replaces uploadToGPU DB:548-558 (cufftExecC2C FORWARD). */
 int mfb_upload(mfb_ctx *ctx);
 /* Same, from an arbitrary host array of N complex64 (pageable is fine; staged through the pinned
- * buffer). */
+ * buffer): the copy into the page-locked buffer that the reference's caller does itself (DB:555-556 in comments,
+ * Demodulator_process DP:256,287) followed by uploadToGPU DB:548-558. */
 int mfb_upload_from(mfb_ctx *ctx, const float *host_c64, int N);
-/* Same, from N complex64 already resident in device memory (no copy).  Used by bench.py so the
- * timed region starts with inputs in HBM. */
+/* Same, from N complex64 already resident in device memory (no copy): the forward transform of uploadToGPU DB:557-558 on a
+ * caller-owned device buffer.  Used by bench.py so the timed region starts with inputs in HBM, and by the sharded path. */
 int mfb_upload_device(mfb_ctx *ctx, const void *dev_c64);
 
 /* Enqueue the Doppler search (shift-multiply, inverse FFT bank, |.|^2 row sums) for this handle's
@@ -164,7 +171,8 @@ int mfb_upload_device(mfb_ctx *ctx, const void *dev_c64);
  * (DB:571-591; CU:853-857, 339-373, 421-480). */
 int mfb_search_async(mfb_ctx *ctx);
 /* Copy this handle's doppSum rows into rows [row_offset, row_offset+count) of a device array
- * float32 [*][M] (e.g. the buffer that is then all-reduced across ranks).  Asynchronous. */
+ * float32 [*][M] (e.g. the buffer that is then all-reduced across ranks).  Asynchronous.  The table is the reference's
+ * GPU_bufDoppSum (filled by blockAbsSumAtomic CU:421-480, read by findDopplerEst CU:502-597); the reference never moves it. */
 int mfb_export_scores_async(mfb_ctx *ctx, void *dev_dst, int row_offset);
 /* Doppler pick on `dev_scores` float32 [offset+num][M] (NULL = the handle's own doppSum):
  * top-2 weighted index and metric; synchronises and returns res = {idx, metric}.
@@ -232,6 +240,7 @@ typedef struct mfb_block_result {
     int32_t rate_fallback;   /* k* == 0: spSym = 10 (DB:737-740) */
     int32_t band_len[2];     /* elements of the signal / noise window; > band_capacity: not delivered, fetch with mfb_get_spectrum */
 } mfb_block_result;
+/* One block, one call: uploadAndFindCarrier (UHF.py:7-16 -> DB:548-632) + demodulate (DB:711-859, device stages). */
 int mfb_receive_block(mfb_ctx *ctx, const mfb_block_params *params, mfb_block_result *result, int32_t *sym, int32_t *centres,
                       float *magnitude, float *bands_c64);
 /* The same in two halves, so that the caller's sequential host stages of block i-1 (and the assembly of block i+1 in the
@@ -252,7 +261,7 @@ int mfb_find_centres(mfb_ctx *ctx, float spSym, float offset, int op, int count,
 /* Copy the matched-filter outputs complex64 [M][N] to the host (debug/parity; the reference does
  * this only under STORE_BITS_IN_FILE, DB:849-850). */
 int mfb_get_xcorr(mfb_ctx *ctx, float *host_c64);
-/* Copy the symbol-energy envelope float32 [N] (output of sumXCorrBuffMasks) to the host. */
+/* Copy the symbol-energy envelope float32 [N] (output of sumXCorrBuffMasks, CU:191-205; launched at DB:717-718) to the host. */
 int mfb_get_envelope(mfb_ctx *ctx, float *host_f32);
 
 /* Batched sync/preamble correlation: for each of B bit streams (uint8 0/1, length L, row-major
@@ -314,16 +323,18 @@ int mfb_sync_pinned_buffer(int device, size_t bytes, void **host);
  * of the handle are invalidated. */
 int mfb_xcorr(mfb_ctx *ctx, const float *a, int Na, const float *b, int Nb, float *out_c64);
 
-/* HIP-event stopwatch on the handle's stream (bench.py's live kernel timing). */
+/* HIP-event stopwatch on the handle's stream (bench.py's live kernel timing).  The reference times blocks with time.time()
+ * around the whole call (DP:324-333). */
 int mfb_timer_start(mfb_ctx *ctx);
 int mfb_timer_stop(mfb_ctx *ctx, float *elapsed_ms);
 /* Per-kernel accounting: when enabled, every launch of the search kernels is bracketed by HIP
  * events on the handle's stream; mfb_profile_read synchronises and returns launch counts and
  * summed milliseconds, then clears them: slot 0 = pass 1 (two-pass) or the segment kernel,
- * slot 1 = pass 2 (two-pass; stays 0 on the segment path). */
+ * slot 1 = pass 2 (two-pass; stays 0 on the segment path).  No reference counterpart (the reference logs block rates only,
+ * DP:324-333). */
 int mfb_profile_enable(mfb_ctx *ctx, int on);
 int mfb_profile_read(mfb_ctx *ctx, int counts[2], float total_ms[2]);
-/* Block until all work enqueued on the handle's stream has finished. */
+/* Block until all work enqueued on the handle's stream has finished (the reference: cuda.Context.synchronize(), DB:651). */
 int mfb_sync(mfb_ctx *ctx);
 
 #ifdef __cplusplus

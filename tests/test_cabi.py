@@ -28,6 +28,35 @@ def test_header_declares_the_expected_surface():
         assert must in names
 
 
+def test_header_is_self_contained_c_and_cpp():
+    """include/mfbank.h alone, as C99 and as C++17 (a binding generator or a cgo preamble includes nothing before it)."""
+    import shutil
+    import subprocess
+    hdr = os.path.join(ROOT, 'include', 'mfbank.h')
+    for cc, lang, std in (('gcc', 'c', '-std=gnu99'), ('g++', 'c++', '-std=c++17')):
+        if shutil.which(cc) is None:
+            pytest.skip(f'no {cc}')
+        r = subprocess.run([cc, '-fsyntax-only', '-x', lang, std, '-Wall', '-Wextra', '-Werror', hdr], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+
+
+def test_every_declaration_names_what_it_replaces():
+    """Every entry point's comment cites the reference interface it replaces (file:line), or says that there is none."""
+    text = open(os.path.join(ROOT, 'include', 'mfbank.h')).read()
+    cite = re.compile(r'(?:DB|CU|DP|DEC|CUFFT|\w+\.py|cuda_kernels\.cu):\s*\d+|[Nn]o reference counterpart|reference has no')
+    last, seen, missing = '', set(), []
+    # walk the header: a declaration belongs to the last comment block before it (declarations may share one)
+    for m in re.finditer(r'(/\*.*?\*/)|\b(mfb_[a-z_0-9]+)\s*\(', text, re.S):
+        if m.group(1):
+            last = m.group(1)
+        elif m.group(2) not in seen:
+            seen.add(m.group(2))
+            if not cite.search(last):
+                missing.append(m.group(2))
+    assert not missing, f'no citation in the comment above: {missing}'
+    assert seen >= set(_declared_functions())
+
+
 def test_library_exports_every_declared_symbol(lib_path):
     lib = ctypes.CDLL(lib_path)
     for name in _declared_functions():
