@@ -74,6 +74,9 @@ struct Bank {
 // complex64 rounding of H_m puts ~1.2e-15 * E_m / N of noise energy on every sample; 1e-13 is 80x
 // that (never crossed by the noise) while everything left outside sums to < 1e-13 * E_m, i.e. < 3.2e-7
 // of the output amplitude in the worst case and ~3e-8 (the rounding noise itself) in practice.
+// (A spectrum that is periodic in k -- a pure delay by a multiple of a large power of two -- has periodic rounding
+// errors, whose energy lands on a few samples and can cross the threshold there: the window then comes out longer than
+// the support.  Slower, never wrong: the window only ever grows.  tests/csrc/taps_sanitize.cpp has the case.)
 static constexpr double REL = 1e-13;
 static constexpr int ROW_TAPS_MAX = 16384;
 
