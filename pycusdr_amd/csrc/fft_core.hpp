@@ -243,7 +243,6 @@ struct TwRegs {
 
 template <int L, bool LTW, int S = 0>
 DEVI void load_twiddles(TwRegs<L, LTW> &tw, const cf *__restrict__ table, const int g) {
-    constexpr int l = ilog2c(L);
     if constexpr (S < TwRegs<L, LTW>::NREG) {
         constexpr int Lcur = L >> (4 * S);
         constexpr int Lnext = Lcur / 16;

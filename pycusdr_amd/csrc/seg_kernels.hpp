@@ -225,7 +225,6 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
     const auto lor = mk_rsrc(a.twLo, (unsigned)(1u << a.lo) * sizeof(cf));
     const auto hir = mk_rsrc(a.twHi, (unsigned)(a.N >> a.lo) * sizeof(cf));
     const auto gr = mk_rsrc(a.G, (unsigned)a.Grows * (unsigned)(L * sizeof(cf)));   // whole G; rows via the scalar offset
-    const int vo_g = g * (int)sizeof(cf);
     constexpr int so_g = NT * (int)sizeof(cf);
     const int vo_g2 = g * 2 * (int)sizeof(cf);          // slot-pair layout of G
     constexpr int so_g2 = NT * 2 * (int)sizeof(cf);

@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) k_sync_find(const uint8_t *bits, const in
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const int v = __shfl_up(incl, o, 64);
-        if ((threadIdx.x & 63) >= o) incl += v;
+        if ((int)(threadIdx.x & 63) >= o) incl += v;
     }
     const int wid = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 63) wsum[wid] = incl;
@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(256) k_sync_small(const uint8_t *bits, const i
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int v = __shfl_up(incl, o, 64);
-            if ((threadIdx.x & 63) >= o) incl += v;
+            if ((int)(threadIdx.x & 63) >= o) incl += v;
         }
         const int wid = threadIdx.x >> 6;
         if ((threadIdx.x & 63) == 63) wsum[wid] = incl;
