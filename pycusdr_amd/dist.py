@@ -45,8 +45,9 @@ class DopplerShard:
     """Glue between a bank (MFBank, or any object with its device-pointer methods) holding this rank's
     bins and the process group.  Works on CUDA/HIP tensors over RCCL and on CPU tensors over gloo."""
 
-    def __init__(self, rank=None, world=None, group=None, device=None, comm=None, src=0):
-        """``src``: the PROCESS rank of this shard's rank 0 (the broadcast source; differs from 0 when ``group`` is a
+    def __init__(self, rank=None, world=None, group=None, device=None, comm=None, src=0, bcast_group=None):
+        """``bcast_group``: a second communicator over the same ranks for the block broadcast, so that it runs beside the
+        exchange of the scores instead of queueing behind it (made here when ``group`` is None).  ``src``: the PROCESS rank of this shard's rank 0 (the broadcast source; differs from 0 when ``group`` is a
         subset of the job, GridShard).  ``comm``: an object with torch.distributed's call surface (get_rank, get_world_size, get_backend, new_group,
         broadcast, all_gather_into_tensor, all_reduce, ReduceOp); default torch.distributed itself.  A caller that
         runs several ranks inside one process (rehearsals of many-rank geometries on one device) passes its own."""
@@ -72,7 +73,10 @@ class DopplerShard:
         # block distribution ahead of time: its own stream and its own communicator, so that the broadcast of
         # the next block runs beside the search and the all-reduce of the current one
         self.comm = torch.cuda.Stream(self.device) if self.on_gpu else None
-        self.bcast_group = dist.new_group(backend=self.backend) if (self.world > 1 and group is None) else group
+        if bcast_group is not None:
+            self.bcast_group = bcast_group
+        else:
+            self.bcast_group = dist.new_group(backend=self.backend) if (self.world > 1 and group is None) else group
 
     def _on_stream(self, which=None):
         which = self.stream if which is None else which
@@ -408,9 +412,11 @@ class GridShard:
         self.g, self.b = divmod(rank, B)
         # every process creates every communicator, in the same order (torch.distributed's rule for new_group)
         bin_groups = [comm.new_group(ranks=list(range(g * B, (g + 1) * B))) for g in range(self.T)]
+        bcast_groups = [comm.new_group(ranks=list(range(g * B, (g + 1) * B))) for g in range(self.T)] if B > 1 else bin_groups
         roots = [g * B for g in range(self.T)]
         root_group = comm.new_group(ranks=roots, backend=hand_back_backend)
-        self.doppler = DopplerShard(rank=self.b, world=B, group=bin_groups[self.g], device=device, comm=comm, src=self.g * B)
+        self.doppler = DopplerShard(rank=self.b, world=B, group=bin_groups[self.g], device=device, comm=comm, src=self.g * B,
+                                    bcast_group=bcast_groups[self.g])
         self.blocks = BlockShard(rank=self.g, world=self.T, group=root_group, comm=comm, ranks=roots) if self.b == 0 else None
 
     def owner_group(self, block_index):
