@@ -8,6 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location('bench_modem', os.path.join(ROOT, 'examples', 'benchmark', 'bench_modem.py'))
 bm = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(bm)
+bm.quiet_blas()          # numpy's BLAS workers must not spend the container's CPU quota (pycusdr_amd/hostcpu.py)
 log2N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 D = int(sys.argv[3]) if len(sys.argv) > 3 else 256
