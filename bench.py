@@ -132,7 +132,7 @@ def segment_roofline_core(info, Dl, Mu, launches, kernel_ms_total):
             'flops_per_launch': fl}
 
 
-def bank_figure(dev, local_rank, protocol, D, log2N, blocks, esz, nblocks, steps=6, warmup=2):
+def bank_figure(dev, local_rank, protocol, D, log2N, blocks, esz, nblocks, steps=10, warmup=2):
     """Untimed-region figure of another BASELINE bank on the same device: its own handle, the same step as the headline
     (forward FFT, search over D bins, pick, 8-byte read-back), HIP-event kernel time, the same flop formula."""
     import torch
@@ -162,8 +162,13 @@ def bank_figure(dev, local_rank, protocol, D, log2N, blocks, esz, nblocks, steps
         def one(i):
             bank.upload_device(blocks.data_ptr() + (i % nblocks) * esz)
             return bank.find_carrier()
-        for i in range(1 + warmup):
+        # untimed: at least `warmup` steps and at least 50 ms of them -- building the handle (filter generation and analysis on
+        # the host) left the device idle, and it needs ~30 ms of work to settle its clock again (tools/ramp_probe.py)
+        t_w, i = time.perf_counter(), 0
+        while i < 1 + warmup or time.perf_counter() - t_w < 0.05:
             one(i)
+            i += 1
+        settle = i
         torch.cuda.synchronize(dev)
         bank.profile_enable(True)
         t0 = time.perf_counter()
@@ -174,7 +179,7 @@ def bank_figure(dev, local_rank, protocol, D, log2N, blocks, esz, nblocks, steps
         counts, kms = bank.profile_read()
         bank.profile_enable(False)
         out = {'protocol': protocol, 'D': D, 'M': M, 'M_unique': Mu, 'samplesPerSym': sps, 'taps': info['taps'], 'path': info,
-               'steps': steps, 'ms_per_step': round(dt * 1e3, 4), 'msamples': round((N - ov) / dt / 1e6, 2),
+               'steps': steps, 'untimed_steps_before': settle, 'ms_per_step': round(dt * 1e3, 4), 'msamples': round((N - ov) / dt / 1e6, 2),
                'filter_generation_s': round(t_gen, 2), 'mfb_set_filters_s': round(t_set, 2),
                'rangeRateMax_used': rr, 'signal': 'S1 blocks of the headline (throughput only: the stimulus does not match this bank)'}
         if info['path'] == 'segment':
@@ -288,7 +293,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=40)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=25,
+                    help='untimed steps before the clock starts; after an idle spell the device needs ~30 ms of work to settle its '
+                         'clock (tools/ramp_probe.py: 1.92 -> 1.60 ms per search at C2), hence 25 x 1.6 ms by default')
     ap.add_argument('--log2n', type=int, default=20)
     ap.add_argument('--bins', type=int, default=256, help='Doppler bins per GPU')
     ap.add_argument('--protocol', default='bench_GMSK')

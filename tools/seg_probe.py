@@ -47,10 +47,18 @@ print('auto:', bank.get_search_path(), flush=True)
 def run(tag):
     bank.find_carrier()
     reps = 5
-    bank.timer_start()
-    for _ in range(reps):
-        bank.search_async()
-    ms_ = bank.timer_stop() / reps
+    # The device needs ~30 ms of work after an idle spell (handle construction, filter analysis, set_search_path) to settle
+    # its clock (tools/ramp_probe.py: 1.92 -> 1.60 ms per search at C2): time groups of `reps` until one is no faster than
+    # the one before it, and report the last.
+    prev = None
+    for _ in range(12):
+        bank.timer_start()
+        for _ in range(reps):
+            bank.search_async()
+        ms_ = bank.timer_stop() / reps
+        if prev is not None and ms_ > 0.995 * prev:
+            break
+        prev = ms_
     ds = bank.get_scores()[:, 0].astype(np.float64)
     err = np.abs(ds - ref).max() / max(ref.max(), 1e-30)
     print(f'{tag:34s} {ms_:8.3f} ms/block  {(N - 1024) / ms_ / 1e3:8.2f} Msamp/s   parseval rel err {err:.2e}', flush=True)
