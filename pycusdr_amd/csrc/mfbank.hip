@@ -547,15 +547,14 @@ static int seg_valid(int l, int T) {
 // Relative cost of one segment point per filter, MEASURED on MI355X at C2 (time x V / L, 48 taps, D = 256,
 // M = 8; tools/seg_probe.py): the 256-point kernel is by far the cheapest per point (one twiddled pass,
 // three waves per SIMD, phase table in LDS), so it wins whenever at least ~2/3 of a segment is valid; the
-// cost of a valid output is this divided by the segment efficiency V / L.  Re-measured in round 3 on two
-// devices (profiles/r03_long_filter.md): the 4096-point kernel is the one whose speed depends on the device
-// (CC11xx bank, 384 taps, D = 256: 3.42 ms on one, 2.91 on another, while 2048 points take 2.91-2.98 on both and
-// the 256-point kernel goes the other way, 1.59 / 1.88), so its figure is the slower device's: 384 taps -> 2048.
-// Checked against the other shipped banks: 80 taps (BPSK) -> 256 (4.05 ms at D = 256 vs 4.15 at 1024, 4.35 at 512, on the
-// device where the 256-point kernel is slow; 512 and 1024 points cost the same per point within the device spread).
-// Figures with 32 workgroups per CU in the grid.
+// cost of a valid output is this divided by the segment efficiency V / L.  Re-measured late in round 3 at the settled
+// clock and with a quiet host (profiles/r03_ramp.md: the first ~30 ms after an idle spell run 8-20 % slow, and a probe whose
+// own BLAS threads get the process throttled starves the device the same way -- some earlier tables carried both effects):
+// GMSK bank, 256 ... 4096 points: 1.597 / 2.128 / 2.070 / 2.443 / 2.648 ms; CC11xx bank (384 taps) on five devices:
+// 2048 points 2.69-2.77 ms, 4096 points 2.90-2.96 ms (the 2048-point kernel gained 5 % from one team per workgroup);
+// BPSK bank (80 taps), 256 / 512 / 1024 points: 3.74 / 4.28 / 4.15 ms.  Figures with 32 workgroups per CU in the grid.
 static double seg_cost(int l, int T) {
-    static const double per_point[13] = {0, 0, 0, 0, 0, 0, 0, 0, 1.35, 1.90, 1.90, 2.15, 2.45};
+    static const double per_point[13] = {0, 0, 0, 0, 0, 0, 0, 0, 1.35, 1.94, 2.02, 2.20, 2.55};
     const int V = seg_valid(l, T);
     if (!V) return 1e30;
     return per_point[l] * (double)(1 << l) / (double)V;
@@ -1006,13 +1005,11 @@ static SegPlan plan_seg(const mfb_ctx *c, int dc, int nfilters, int nslots, int 
     if (mpb > nfilters) mpb = nfilters;
     p.mgroups = (nfilters + mpb - 1) / mpb;
     p.mpb = (nfilters + p.mgroups - 1) / p.mgroups;   // balanced
-    // Workgroups in the grid per CU.  Many more than are resident at once (3 / 2 per CU) on purpose: the surplus is
-    // dealt out as workgroups retire, which evens out CUs that run at different speeds -- and devices differ in how
-    // uneven they are.  Measured at C2, L = 256, on a device where it matters: 12 per CU 1.90 ms, 16: 1.71, 24: 1.67,
-    // 32: 1.655, 40: 1.66 (on an even device: 12: 1.64, 16: 1.63); 1024 bins: 12: 6.97, 32: 6.50; BPSK bank, 512 bins:
-    // 16: 7.99, 32: 7.66; L = 512 / 1024: 6: 2.56 / 2.48, 32: 2.21 / 2.16; CC11xx bank, L = 2048 / 4096: 4: 6.2 / 6.0,
-    // 16: 6.07 / 5.77, 32: 5.60 / 5.57, 48: 5.87 / 5.72.  Small blocks are unaffected (the grid never has more teams than
-    // (bin, slot) units).
+    // Workgroups in the grid per CU.  More than are resident at once (3 / 2 per CU): the surplus is dealt out as workgroups
+    // retire, which evens out CUs that finish at different times.  Measured at C2, L = 256, settled clock, quiet host
+    // (tools/seg_probe.py): 8 per CU 1.615 ms, 12: 1.615, 16: 1.613, 24: 1.604, 32: 1.596, 48: 1.595 -- about 1 %.  (Round 2's
+    // table here -- 12: 1.90, 16: 1.71, 32: 1.655 "on an uneven device" -- was mostly the probe: its first variant ran in the
+    // clock ramp after the handle was built.)  Small blocks are unaffected (the grid never has more teams than (bin, slot) units).
     const int wpc = c->seg_wpc > 0 ? c->seg_wpc : 32;
     // workgroups per group: wpc 256-thread workgroups' worth of teams per CU, over the device's CUs
     const int teams = wpc * c->num_cus * (256 / g.TEAM);       // teams in the whole grid

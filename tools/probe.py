@@ -2,6 +2,8 @@
 import sys, time
 import numpy as np
 sys.path.insert(0, '.')
+from pycusdr_amd.hostcpu import quiet_blas  # noqa: E402
+quiet_blas()          # numpy's BLAS workers must not spend the container's CPU quota: a throttled host starves the device
 from pycusdr_amd.mfbank import MFBank
 
 

@@ -4,6 +4,8 @@ usage: python tools/seg_probe.py [log2N] [D] [protocol] [l-list] [wpc-list]"""
 import sys
 import numpy as np
 sys.path.insert(0, '.')
+from pycusdr_amd.hostcpu import quiet_blas  # noqa: E402
+quiet_blas()          # numpy's BLAS workers must not spend the container's CPU quota: a throttled host starves the device
 from pycusdr_amd import config as cfg, signals as sg
 from pycusdr_amd.mfbank import MFBank
 from pycusdr_amd.protocol import loadProtocol

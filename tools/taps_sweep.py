@@ -7,6 +7,8 @@ import sys
 import numpy as np
 
 sys.path.insert(0, '.')
+from pycusdr_amd.hostcpu import quiet_blas  # noqa: E402
+quiet_blas()          # numpy's BLAS workers must not spend the container's CPU quota: a throttled host starves the device
 from pycusdr_amd.mfbank import MFBank        # noqa: E402
 
 log2N, D, M = 20, 256, 8
