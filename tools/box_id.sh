@@ -1,6 +1,6 @@
 #!/bin/bash
 # Which device is this, and how fast are the three segment kernels on it at the settled clock?  One line per box for
-# profiles/r03_devices.md: GPU uuid, firmware versions, ms per search of the GMSK (256 points) and CC11xx (2048 / 4096 points) banks.
+# profiles/r03_ramp.md: GPU uuid, firmware versions, ms per search of the GMSK (256 points) and CC11xx (2048 / 4096 points) banks.
 uuid=$(rocminfo 2>/dev/null | grep -i "Uuid:.*GPU" | head -1 | awk '{print $2}')
 fw=$(rocm-smi --showfwinfo 2>/dev/null | grep -iE "MEC |MEC2|RLC |SMC|SDMA |PSP SOS|VBIOS|TA XGMI" | sed 's/GPU\[0\]\s*:\s*//' | tr -s ' \t' ' ' | tr '\n' ';')
 vb=$(rocm-smi --showvbios 2>/dev/null | grep -i vbios | sed 's/GPU\[0\]\s*:\s*//' | tr -s ' \t' ' ' | head -1)
