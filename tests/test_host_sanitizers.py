@@ -26,5 +26,8 @@ def test_filter_analysis_under_sanitizers(tmp_path, name, flags):
     env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=0', UBSAN_OPTIONS='print_stacktrace=1',
                TSAN_OPTIONS='halt_on_error=1')
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=500, env=env)
+    if run.returncode != 0 and ('unexpected memory mapping' in run.stderr or 'Shadow memory range interleaves' in run.stderr
+                                or 'ReserveShadowMemoryRange failed' in run.stderr):
+        pytest.skip('this kernel\'s address-space layout does not admit the sanitizer runtime: ' + run.stderr[-200:])
     assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
     assert run.stdout.strip().endswith('banks ok')
