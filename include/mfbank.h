@@ -50,7 +50,7 @@ const char *mfb_strerror(int status);
 /* Library/ABI version, bumped whenever a prototype changes.  No reference counterpart (its kernels are compiled from source
  * at run time, SourceModule DB:214). */
 int mfb_abi_version(void);   /* 2: search paths, mfb_xcorr; 3: mfb_set_search_mode, mfb_sync_find_multi; 4: mfb_receive_block,
-                              * mfb_export_rows_async, mfb_sync_find_packed */
+                              * mfb_export_rows_async, mfb_sync_find_packed; 5: mfb_debug_block_scalars */
 
 /* Create a handle on HIP device `device` for blocks of N = 2^log2N samples, `num_dopplers`
  * Doppler bins plus `doppler_offset` leading noise-reference bins (DB:150-159), M matched
@@ -252,6 +252,19 @@ int mfb_receive_block_begin(mfb_ctx *ctx, const mfb_block_params *params, int sl
 int mfb_receive_block_end(mfb_ctx *ctx, int slot, mfb_block_result *result, int32_t *sym, int32_t *centres, float *magnitude,
                           float *bands_c64);
 int mfb_input_buffer2(mfb_ctx *ctx, float **host_c64);
+/* Test seam of the one-call path.  mfb_receive_block moved two pieces of the reference's float64 HOST arithmetic onto the
+ * device: the shift interpolation and the bounds of computeSNR's spectrum windows behind the pick (DB:609-620, 635-667), and
+ * samples per symbol / code phase / clamp / symbol count behind the rate argmax (DB:733-752, 994-999).  This call runs exactly
+ * those two device stages (the same device functions, one thread per item) on n INJECTED device results instead of the ones
+ * the search and the argmax produced -- picks float[n][2] = {index, metric} as findDopplerEst writes them, triples float[n][3]
+ * = {k*, arg P[k*], |P[k*]|^2} as findCodeRateAndPhase writes them -- with the handle's shift table and block length.  That is
+ * the point at which the reference's own code can be fed the same values (a recording fake of its memcpy_dtoh,
+ * tests/golden/make_golden_host.py), so reference-run fixtures gate this arithmetic bit for bit (tests/test_gpu_pins_host.py).
+ * results[n]: as mfb_receive_block fills them (no symbols are decided); launch_args float[n][2] (optional): the two float32
+ * values findCentres is launched with (DB:997); band_pieces int32[n][2][2][2] (optional): [signal | noise][piece][start, length]
+ * of the spectrum windows.  No effect on the handle's state. */
+int mfb_debug_block_scalars(mfb_ctx *ctx, int n, const float *picks, const float *triples, int spsym_min, int snr_window,
+                            int max_symbols, mfb_block_result *results, float *launch_args, int32_t *band_pieces);
 
 /* Symbol centres on the matched-filter outputs left by mfb_demodulate.  Replaces findCentres
  * (CU:78-146) + the three memcpy_dtoh of cudaFindCentres (DB:996-1006).  Writes `count` =

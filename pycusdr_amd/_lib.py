@@ -83,6 +83,7 @@ PROTOTYPES = {
     'mfb_receive_block_begin': (_i, [_vp, C.POINTER(BlockParams), _i]),
     'mfb_receive_block_end': (_i, [_vp, _i, C.POINTER(BlockResult), _vp, _vp, _vp, _vp]),
     'mfb_input_buffer2': (_i, [_vp, C.POINTER(_fp)]),
+    'mfb_debug_block_scalars': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, C.POINTER(BlockResult), _vp, _vp]),
     'mfb_pick_column': (_i, [_vp, _vp, _i, _i, _fp]),
     'mfb_find_carrier': (_i, [_vp, _fp]),
     'mfb_get_scores': (_i, [_vp, _vp]),

@@ -178,7 +178,7 @@ extern "C" const char *mfb_strerror(int s) {
         default: return "unknown status";
     }
 }
-extern "C" int mfb_abi_version(void) { return 4; }
+extern "C" int mfb_abi_version(void) { return 5; }
 
 static void make_twiddles(std::vector<cf> &v, int count, double denom, double stepmul) {
     v.resize(count);
@@ -260,7 +260,10 @@ static size_t blkout_bytes(int bcap, int nthreads) {
 static int blkout_reserve(mfb_ctx *c, int bcap) {
     if (c->d_blkout && bcap <= c->band_cap) return MFB_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->d_blkout) HIPCHK(hipFree(c->d_blkout));
+    if (c->d_blkout) {
+        ++c->epoch;          // captured block graphs hold the old record's address (and d_scal): none of them may replay
+        HIPCHK(hipFree(c->d_blkout));
+    }
     c->d_blkout = nullptr;
     c->band_cap = 0;
     HIPCHK(dev_alloc((void **)&c->d_blkout, blkout_bytes(bcap, c->cap)));
@@ -1700,6 +1703,62 @@ extern "C" int mfb_receive_block(mfb_ctx *c, const mfb_block_params *p, mfb_bloc
     const int rc = block_begin(c, p, 0);
     if (rc) return rc;
     return block_end(c, 0, r, sym, cen, mag, bands_c64);
+}
+
+// Test seam of the one-call path (include/mfbank.h): block_pick_body / block_rate_body on injected device results.
+extern "C" int mfb_debug_block_scalars(mfb_ctx *c, int n, const float *picks, const float *triples, int spsym_min, int snr_window,
+                                       int max_symbols, mfb_block_result *results, float *launch_args, int32_t *band_pieces) {
+    if (!c || n < 1 || !picks || !triples || !results || spsym_min < 2 || snr_window < 0 || max_symbols < 1) return MFB_ERR_ARG;
+    if (!c->have_shifts) return MFB_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    float *d_in = nullptr;
+    BlockScalars *d_out = nullptr;
+    std::vector<BlockScalars> h((size_t)n);
+    int rc = MFB_OK;
+    const size_t in_bytes = (size_t)n * 5 * sizeof(float);
+    if (hipMalloc((void **)&d_in, in_bytes) != hipSuccess || hipMalloc((void **)&d_out, (size_t)n * sizeof(BlockScalars)) != hipSuccess) {
+        rc = MFB_ERR_ALLOC;
+    } else if (hipMemcpy(d_in, picks, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+               hipMemcpy(d_in + 2 * (size_t)n, triples, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        rc = MFB_ERR_HIP;
+    } else {
+        const int capacity = max_symbols < c->cap ? max_symbols : c->cap;
+        hipLaunchKernelGGL(k_block_scalars_debug, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, (const float *)d_in,
+                           (const float *)(d_in + 2 * (size_t)n), (const int *)c->d_shifts, c->Dtot, c->N, snr_window, spsym_min, capacity,
+                           d_out);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
+            hipMemcpy(h.data(), d_out, (size_t)n * sizeof(BlockScalars), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = MFB_ERR_HIP;
+    }
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        const BlockScalars &hs = h[(size_t)i];
+        mfb_block_result &r = results[i];
+        r.pick[0] = hs.pick[0];
+        r.pick[1] = hs.pick[1];
+        r.pick_valid = hs.pick_valid;
+        r.shift = hs.shift;
+        r.low = hs.low;
+        r.high = hs.high;
+        r.frac = hs.frac;
+        r.cr[0] = hs.cr[0];
+        r.cr[1] = hs.cr[1];
+        r.cr[2] = hs.cr[2];
+        r.spSym = hs.spSym;
+        r.codeOffset = hs.codeOffset;
+        r.count = hs.count;
+        r.rate_fallback = hs.rate_fallback;
+        r.band_len[0] = hs.band_len[0];
+        r.band_len[1] = hs.band_len[1];
+        if (launch_args) {
+            launch_args[2 * i] = hs.spSymF;
+            launch_args[2 * i + 1] = hs.offsetF;
+        }
+        if (band_pieces) memcpy(band_pieces + 8 * (size_t)i, &hs.band[0][0][0], 8 * sizeof(int32_t));
+    }
+    return MFB_OK;
 }
 
 extern "C" int mfb_input_buffer2(mfb_ctx *c, float **p) {

@@ -463,6 +463,18 @@ DEVI void block_rate_body(const float *cr, int N, int spsym_min, int capacity, B
     out->count = count;
 }
 
+// Test seam (mfb_debug_block_scalars): the two single-thread stages above on n INJECTED device results -- thread i takes pick i
+// and rate triple i -- so that fixtures recorded from the reference's own host code gate this arithmetic bit for bit.
+__global__ void k_block_scalars_debug(int n, const float *picks, const float *triples, const int *shifts, int Dtot, int N, int w,
+                                      int spsym_min, int capacity, BlockScalars *out) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    BlockScalars sc;
+    block_pick_body(picks + 2 * i, shifts, Dtot, N, w, &sc);
+    block_rate_body(triples + 3 * i, N, spsym_min, capacity, &sc);
+    out[i] = sc;
+}
+
 // findCentres with its two float arguments taken from the block scalars
 __global__ void k_centres_block(int *outSym, int *outIdx, float *mag, const cf *sig, const BlockScalars *sc, int lenSig, int M, int W,
                                 int op, int capacity) {

@@ -180,11 +180,10 @@ class Demodulator:
         self._one_call = bool(hip_cfg.get('one_call', True)) and shard is None and hasattr(self.bank, 'receive_block')
         self._pending = None
         if self._one_call:
-            # room for the two spectrum windows computeSNR reads (DB:635-667): the widest gap between neighbouring bins + margins
-            sh = self.doppCyperSymNorm.astype(np.int64)
-            gap = int(np.abs(np.diff(sh)).max()) if len(sh) > 1 else 0
-            gap = min(gap, self.Nfft - gap) + 2 * 5 + 2
-            self.bank.BAND_CAPACITY = int(min(1 << 16, max(256, 1 << int(np.ceil(np.log2(gap))))))
+            # room for the two spectrum windows computeSNR reads (DB:635-667), whichever neighbouring pair of bins the pick
+            # falls between: the block call then always delivers them, and nothing ever has to be fetched from a spectrum
+            # that a later block may already have replaced
+            self.bank.BAND_CAPACITY = self._snr_band_capacity(5)
 
         # windowed argmax range of the symbol-rate estimate (reference DB:508-512)
         self.symsTolLow = 0.9 * spsym
@@ -363,6 +362,24 @@ class Demodulator:
             SNR = 0.
         return freqOffset, sdev_Hz, self.clippedPeakIPure, SNR
 
+    def _snr_band_capacity(self, windowWidth):
+        """Longest spectrum window ``computeSNR`` can ask for (reference DB:635-667), over every (low, high) the pick can
+        produce: high = low or low + 1.  Rounded up to a power of two, at least 256 elements."""
+        N, sh = self.Nfft, self.doppCyperSymNorm.astype(np.int64)
+        lo = np.concatenate((sh, sh[:-1]))
+        hi = np.concatenate((sh, sh[1:]))
+
+        def lengths(a, b):
+            # X[a-w:b+w], or X[a-w:] + X[:b+w] when the band wraps (a > b), with numpy's slice semantics
+            def sl(start, stop):
+                start = np.where(start < 0, np.maximum(start + N, 0), np.minimum(start, N))
+                stop = np.where(stop < 0, np.maximum(stop + N, 0), np.minimum(stop, N))
+                return np.maximum(stop - start, 0)
+            w = windowWidth
+            return np.where(a > b, sl(a - w, np.full_like(a, N)) + sl(np.zeros_like(b), b + w), sl(a - w, b + w))
+        longest = int(max(lengths(lo, hi).max(), lengths((lo + N // 2) % N, (hi + N // 2) % N).max(), 1))
+        return int(min(N, max(256, 1 << int(np.ceil(np.log2(longest))))))
+
     def _spectrum_slice(self, a, b):
         """``X[a:b]`` with numpy slice semantics, fetching only that window from the device."""
         start, stop, _ = slice(a, b).indices(self.Nfft)
@@ -376,6 +393,10 @@ class Demodulator:
         if bands is not None:
             with np.errstate(divide='ignore', invalid='ignore'):
                 return 20 * np.log10(np.mean(np.abs(bands[0])) / np.mean(np.abs(bands[1])) - 1)
+        if getattr(self.bank, 'flights', 0) > 0:
+            # a later block is on the device already: its spectrum has replaced (or is replacing) this block's
+            log.error('[%s]: the SNR windows of this block were not delivered with it and its spectrum is gone: SNR = nan', self.radioName)
+            return float('nan')
         lo = int(self.doppCyperSymNorm[doppMatchLow])
         hi = int(self.doppCyperSymNorm[doppMatchHigh])
         nlo = (lo + int(self.Nfft // 2)) % self.Nfft

@@ -71,11 +71,12 @@ class DemodulatorRunner:
     def feed_resident(self, device_ptr):
         """``feed_device`` for a whole block (N complex64 samples, overlap included) that already sits in device memory
         at ``device_ptr``: no host copy, no overlap carry."""
+        if self.radioBackend != 'UHF':
+            # the STX back end starts with peak clipping of the samples on the host (reference STX.py:13, DB:670-707)
+            raise ValueError('device-resident blocks are only supported by the UHF back end: STX clips the samples on the host first')
         stamp = time.time()
         part = {'count': self.count, 'timestamp': stamp}
         part['doppler'], part['doppler_std'], _, part['SNR'] = self.demod.uploadAndFindCarrier(None, device_ptr=device_ptr)
-        if self.radioBackend != 'UHF':
-            self.demod.dopplerIdxlast = self.demod.doppOffsetIdx
         part['rec'] = self.demod.demodulateDevice()
         part['time_device'] = time.time() - stamp
         self.count += 1
@@ -108,6 +109,19 @@ class DemodulatorRunner:
         self.count += 1
         return part
 
+    def _block_buffers(self):
+        """The library's two page-locked input buffers, by the NAME the library knows them under ('pinned' = index 0,
+        'pinned2' = index 1), and the index of the one ``self.raw`` -- where the next block is being assembled, carried
+        overlap included -- currently is.  Buffer identity comes from the library, never from the order of earlier calls:
+        a stream may end on either buffer and the next call must go on there."""
+        bank = self.demod.bank
+        bufs = (bank.input, bank.input2)
+        if self.raw is not bufs[0] and self.raw.ctypes.data == bufs[1].ctypes.data:
+            return bufs, 1
+        if self.raw is not bufs[0] and self.raw.ctypes.data != bufs[0].ctypes.data:
+            raise RuntimeError('the block buffer of this runner is not one of the library\'s page-locked input buffers')
+        return bufs, 0
+
     def feed_device_begin(self, new_samples):
         """``feed_device`` in two halves: enqueue the block's device work and return at once (``feed_device_end`` collects it).
         One block in flight per runner.  Falls back to the synchronous call where the one-call block path is not in use (STX,
@@ -117,17 +131,14 @@ class DemodulatorRunner:
         if not (self.radioBackend == 'UHF' and getattr(self.demod, '_one_call', False)):
             self._flight = ('done', self.feed_device(new_samples))
             return
-        if getattr(self, '_bufs', None) is None:
-            self._bufs = [self.raw, self.demod.bank.input2]
-            self._cur = 0 if self.raw is self._bufs[0] else 1
-        cur = self._cur
-        raw = self._bufs[cur]
+        bufs, cur = self._block_buffers()
+        raw = bufs[cur]
         raw[self.overlap:] = new_samples
         stamp = time.time()
         self.demod.beginBlock(cur, source=('pinned', 'pinned2')[cur])
-        other = self._bufs[1 - cur]
+        other = bufs[1 - cur]
         other[:self.overlap] = raw[-self.overlap:]      # overlap carry: the next block is assembled in the other buffer
-        self._cur, self.raw = 1 - cur, other
+        self.raw = other
         self._flight = ('flying', cur, self.count, stamp)
         self.count += 1
 
@@ -146,7 +157,12 @@ class DemodulatorRunner:
         """A block another rank processes: keep the overlap carry and the block counter in step."""
         if len(new_samples) != self.samplesPerSlice:
             raise ValueError(f'expected {self.samplesPerSlice} new samples per block, got {len(new_samples)}')
-        self.raw[:self.overlap] = new_samples[-self.overlap:]
+        ov, sps = self.overlap, self.samplesPerSlice
+        if ov <= sps:
+            self.raw[:ov] = new_samples[-ov:]
+        else:           # the overlap is longer than a slice: the tail of the old overlap stays part of the new one
+            self.raw[:ov - sps] = self.raw[sps:ov].copy()
+            self.raw[ov - sps:ov] = new_samples
         self.count += 1
 
     def feed_host(self, part):
@@ -197,10 +213,9 @@ class DemodulatorRunner:
         # Overlapped form: block i is on the device while this thread runs the sequential host stages and the decoder of
         # block i-1 and assembles block i+1 in the other page-locked buffer.  Same calls in the same order on the same data
         # as the plain loop, so the same results; only the waiting moves.
-        bufs = (self.raw, self.demod.bank.input2)
-        bufs[1][:self.overlap] = 0
+        bufs, cur = self._block_buffers()       # goes on in the buffer (and behind the overlap) the last call ended in
         names = ('pinned', 'pinned2')
-        asm = BlockAssembler(bufs[0], self.overlap)
+        asm = BlockAssembler(bufs[cur], self.overlap)
         results, packets = [], []
         flying = None                    # (slot, count, timestamp)
 
@@ -243,7 +258,6 @@ class DemodulatorRunner:
                 packets.extend(pk)
             deliver(d)
 
-        cur = 0
         try:
             for chunk in chunk_source:
                 for _ in asm.push(chunk):
@@ -251,10 +265,12 @@ class DemodulatorRunner:
                     started = (cur, self.count, time.time())
                     self.count += 1
                     cur = 1 - cur
-                    asm.retarget(bufs[cur])
+                    # block i-1 lives in bufs[cur]: collect it (its host-to-device copy is then certainly over) BEFORE the
+                    # overlap of block i is written into that buffer
                     if flying is not None:
                         fl, flying = flying, None
                         collect(fl)
+                    asm.retarget(bufs[cur])
                     flying = started
             if flying is not None:
                 fl, flying = flying, None

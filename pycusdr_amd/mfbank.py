@@ -248,6 +248,33 @@ class MFBank:
                    'mfb_receive_block')
         return self._block_result(R, fixed_shift is None)
 
+    def debug_block_scalars(self, picks, triples, spsym_min, snr_window=5, max_symbols=None):
+        """Test seam (mfb_debug_block_scalars): the one-call path's two float64 device stages on injected picks
+        float32[n][2] and rate triples float32[n][3].  Returns a list of dicts with the scalar fields of ``receive_block``
+        plus 'spSymF' / 'offsetF' (what findCentres is launched with) and 'band_pieces' int32[2][2][2]."""
+        picks = np.ascontiguousarray(picks, dtype=np.float32).reshape(-1, 2)
+        triples = np.ascontiguousarray(triples, dtype=np.float32).reshape(-1, 3)
+        n = len(picks)
+        if len(triples) != n:
+            raise ValueError('one rate triple per pick')
+        R = (_lib.BlockResult * n)()
+        args = np.empty((n, 2), np.float32)
+        pieces = np.empty((n, 2, 2, 2), np.int32)
+        _lib.check(self._lib.mfb_debug_block_scalars(self._h, n, _ptr(picks), _ptr(triples), int(spsym_min), int(snr_window),
+                                                     int(self.N // 2 if max_symbols is None else max_symbols), R, _ptr(args),
+                                                     _ptr(pieces)), 'mfb_debug_block_scalars')
+        return [{'pick': (np.float32(r.pick[0]), np.float32(r.pick[1])), 'pick_valid': bool(r.pick_valid), 'shift': int(r.shift),
+                 'low': int(r.low), 'high': int(r.high), 'frac': float(r.frac),
+                 'cr': (np.float32(r.cr[0]), np.float32(r.cr[1]), np.float32(r.cr[2])), 'spSym': float(r.spSym),
+                 'codeOffset': float(r.codeOffset), 'count': int(r.count), 'rate_fallback': bool(r.rate_fallback),
+                 'band_len': (int(r.band_len[0]), int(r.band_len[1])), 'spSymF': args[i, 0], 'offsetF': args[i, 1],
+                 'band_pieces': pieces[i]} for i, r in enumerate(R)]
+
+    @property
+    def flights(self):
+        """Blocks begun and not yet collected."""
+        return len(getattr(self, '_flying', ()))
+
     @property
     def input2(self):
         """The second page-locked input buffer: while the device works on the block in one buffer, the caller assembles
@@ -265,13 +292,17 @@ class MFBank:
         _lib.check(self._lib.mfb_receive_block_begin(self._h, C.byref(P), int(slot)), 'mfb_receive_block_begin')
         self._searched = getattr(self, '_searched', {})
         self._searched[int(slot)] = fixed_shift is None
+        self._flying = getattr(self, '_flying', set()) | {int(slot)}
 
     def end_block(self, slot):
         """Second half: wait for the block begun in ``slot`` and return its results (same dict as ``receive_block``)."""
         R = _lib.BlockResult()
         sym, cen, mag, bands = self._block_arrays()
-        _lib.check(self._lib.mfb_receive_block_end(self._h, int(slot), C.byref(R), _ptr(sym), _ptr(cen), _ptr(mag), _ptr(bands)),
-                   'mfb_receive_block_end')
+        try:
+            _lib.check(self._lib.mfb_receive_block_end(self._h, int(slot), C.byref(R), _ptr(sym), _ptr(cen), _ptr(mag), _ptr(bands)),
+                       'mfb_receive_block_end')
+        finally:            # collected, or failed: either way the slot holds no block any more
+            self._flying = getattr(self, '_flying', set()) - {int(slot)}
         return self._block_result(R, self._searched.get(int(slot), True))
 
     def get_xcorr(self):

@@ -270,3 +270,41 @@ def test_ber_bench_script_runs_the_whole_chain():
         r = bm.run_snr(mod, 2, 14.0, 15, search, seed=5)
         assert r['packets'] == 2 and r['BER'] < 1e-3, r
     assert abs(bm.bandwidth('GMSK', 9600) - 9600 / 0.7) < 1e-9 and bm.bandwidth('FSK', 9600) == 28800
+
+
+@pytest.mark.parametrize('first', [3, 4])
+def test_one_runner_streams_twice(first):
+    """A runner is a long-lived object: ``run_stream`` (and ``feed_device_begin``) called again go on in the page-locked
+    buffer -- and behind the overlap -- the previous call ended in, whichever of the two that is (an odd number of blocks
+    ends on the second one).  One stream cut in two calls, then continued block by block through the begin / end pair,
+    equals the same stream in one call."""
+    from pycusdr_amd.demodulator_process import DemodulatorRunner
+    bs, ov = 15, 1 << 10
+    N = 1 << bs
+    conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=32)
+    p = loadProtocol('bench_GMSK')(conf=conf)
+    sig = sg.awgn(np.concatenate((sg.get_padded_packet('GMSK')[0], np.zeros(2 * N))), 12.0, rng=np.random.RandomState(4)).astype(np.complex64)
+    step = N - ov
+    nblk = len(sig) // step
+    assert nblk >= first + 4
+    one = DemodulatorRunner(conf, p, 'UHF-H')
+    ref, ref_packets = one.run_stream([sig[:nblk * step]], decoder=Decoder(conf, p))
+    one.close()
+    run, dec = DemodulatorRunner(conf, p, 'UHF-H'), Decoder(conf, p)
+    got, packets = run.run_stream([sig[:first * step]], decoder=dec)
+    assert run.raw is (run.demod.bank.input2 if first % 2 else run.demod.bank.input)
+    more, pk = run.run_stream([sig[first * step:(first + 3) * step]], decoder=dec)
+    got, packets = got + more, packets + pk
+    for i in range(first + 3, nblk):          # ... and on through the two-halves call, one block in flight
+        run.feed_device_begin(sig[i * step:(i + 1) * step])
+        d = run.feed_host(run.feed_device_end())
+        pk, _, d['numSyncSig'] = dec.findFrames(d['data'], 0)
+        got.append(d)
+        packets += pk
+    run.close()
+    assert [d['count'] for d in got] == list(range(nblk)) and len(packets) == len(ref_packets) == 1
+    assert packets[0].checkPacketData() == 0
+    for a, b in zip(ref, got):
+        assert np.array_equal(a['data'], b['data']) and np.array_equal(a['trust'], b['trust'])
+        assert a['doppler'] == b['doppler'] and a['spSymEst'] == b['spSymEst']
+        assert np.array_equal(np.float64(a['SNR']), np.float64(b['SNR']), equal_nan=True)
