@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12        # B/s, MI355X spec (MI355X_MICROARCH.md)
 VALU_FP32_PEAK = 157.3e12  # FLOP/s, MI355X fp32 vector peak (MI355X_MICROARCH.md)
 PARITY_TOL = 1e-5        # north_star: correlation magnitudes within 1e-5
+SETTLE_S = 0.05          # untimed work before the clock starts (profiles/r03_ramp.md: the clock settles within ~30 ms)
 
 
 def b_alg(D, M, N):
@@ -294,8 +295,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=25,
-                    help='untimed steps before the clock starts; after an idle spell the device needs ~30 ms of work to settle its '
-                         'clock (tools/ramp_probe.py: 1.92 -> 1.60 ms per search at C2), hence 25 x 1.6 ms by default')
+                    help='untimed steps before the clock starts; whatever the value, untimed steps go on until 50 ms of work have '
+                         'passed: after an idle spell the device needs ~30 ms to settle its clock (tools/ramp_probe.py)')
+    ap.add_argument('--repeats', type=int, default=5,
+                    help='the --steps loop is timed this many times back to back; value / ms_per_step are the median repeat, '
+                         'config.ms_per_step_min / _max the extremes')
     ap.add_argument('--log2n', type=int, default=20)
     ap.add_argument('--bins', type=int, default=256, help='Doppler bins per GPU')
     ap.add_argument('--protocol', default='bench_GMSK')
@@ -423,27 +427,49 @@ def main():
         torch.cuda.synchronize(dev)
 
     step(0)            # initialisation: first launches load the code objects and touch the workspaces
+    torch.cuda.synchronize(dev)
+    t_w = time.perf_counter()
     for i in range(1, 1 + args.warmup):     # one running block counter: a prefetched block is always the next one used
         res = step(i)
-    barrier()
+    # ... and keep going, untimed, until at least SETTLE_S of work have passed since the initialisation, whatever --warmup says:
+    # after an idle spell the device runs its first ~30 ms 8-20 % slow (profiles/r03_ramp.md), and a receiver on a
+    # continuous stream is never there.  Every rank runs the same number of steps (the sharded step is collective).
+    first = 1 + args.warmup
+    while True:
+        busy = torch.tensor([time.perf_counter() - t_w], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(busy, op=dist.ReduceOp.MIN)
+        if float(busy.item()) >= SETTLE_S and first > 1:
+            break
+        for _ in range(8):
+            res = step(first)
+            first += 1
+    # the clock: EXACTLY --steps steps between barrier + synchronize on both sides, maximum over ranks -- taken args.repeats times
+    # back to back; the line reports the median repeat and the extremes beside it
     bank.profile_enable(True)
     bank.timer_start()
-    t0 = time.perf_counter()
-    first = 1 + args.warmup
-    for i in range(first, first + args.steps):
-        res = step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    times = []
+    for rep in range(args.repeats):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(first, first + args.steps):
+            res = step(i)
+        barrier()
+        dt_rep = time.perf_counter() - t0
+        first += args.steps
+        if dist is not None:
+            t = torch.tensor([dt_rep], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_rep = float(t.item())
+        times.append(dt_rep)
     ev_ms = bank.timer_stop()
     counts, kms = bank.profile_read()
     bank.profile_enable(False)
+    elapsed = float(np.median(times))
+    timed_steps = args.steps * args.repeats
     # scores of the LAST timed block, read before anything else touches the handle (parity spot check)
-    last_block = block_index(first + args.steps - 1)
+    last_block = block_index(first - 1)
     gscores = bank.get_scores()[:, 0].astype(np.float64)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     # live sanity: the pick must land on the +fs/4 carrier
     frac_idx = float(res[0])
@@ -606,7 +632,7 @@ def main():
         Dl = hi - lo
         tun = bank.get_tuning()
         Mu = bank.get_info()[2]          # filter rows the search really transforms (exact duplicates/negatives once)
-        t_block_dev = ev_ms / args.steps * 1e-3
+        t_block_dev = ev_ms / timed_steps * 1e-3
 
         def twopass_roofline(Dl_, counts_, kms_, tun_, nsteps):
             dom = 0 if kms_[0] >= kms_[1] else 1
@@ -662,7 +688,7 @@ def main():
         if pinfo['path'] == 'segment':
             roof = segment_roofline(pinfo, Dl, counts, kms)
         else:
-            roof = twopass_roofline(Dl, counts, kms, tun, args.steps)
+            roof = twopass_roofline(Dl, counts, kms, tun, timed_steps)
         roof['pipeline'] = {'device_ms_per_block': round(t_block_dev * 1e3, 4),
                             'B_alg_twopass_per_block': b_alg(Dl, Mu, N), 'B_ref_unfused_per_block': b_ref(Dl, M, N)}
         if G == 1 and log2N == 20 and args.bins == 256 and args.protocol == 'bench_GMSK':
@@ -697,6 +723,23 @@ def main():
             'roofline': roof,
         }
         out['config'].update(extras)
+        # the same figures as flat scalars (a reader that keeps only scalar config keys still sees every single-GPU config)
+        per_step = (N - ov) * G / 1e6
+        out['config'].update({
+            'repeats': args.repeats, 'untimed_steps_before': first - timed_steps,
+            'ms_per_step_min': round(min(times) / args.steps * 1e3, 4), 'ms_per_step_max': round(max(times) / args.steps * 1e3, 4),
+            'value_min': round(per_step / (max(times) / args.steps), 3), 'value_max': round(per_step / (min(times) / args.steps), 3),
+            'roofline_frac': roof.get('frac'), 'roofline_bound': roof.get('bound')})
+        for key, fig in [(b['protocol'].replace('bench_', '').lower(), b) for b in extras.get('other_banks', [])] + \
+                        ([('c3', extras['c3'])] if 'c3' in extras else []):
+            out['config'][f'{key}_msamples'] = fig['msamples']
+            out['config'][f'{key}_ms_per_step'] = fig['ms_per_step']
+            out['config'][f'{key}_roofline_frac'] = fig.get('roofline', {}).get('frac')
+        if 'sync_correlator' in extras:
+            out['config']['sync_streams_per_s'] = extras['sync_correlator']['streams_per_s']
+        for key in ('span_basis_search', 'energy_search'):
+            if key in extras:
+                out['config'][f'{key}_msamples'] = extras[key]['msamples']
         if other is not None:
             o_info, o_t, o_counts, o_kms, o_tun, osteps = other
             o_roof = (segment_roofline(o_info, Dl, o_counts, o_kms) if o_info['path'] == 'segment'
@@ -704,6 +747,10 @@ def main():
             o_roof['ms_per_step'] = round(o_t * 1e3, 4)
             o_roof['msamples'] = round((N - ov) / o_t / 1e6, 2)
             out['roofline_other_path'] = {'path': o_info['path'], **o_roof}
+            out['config'][f"{o_info['path']}_msamples"] = o_roof['msamples']
+            out['config'][f"{o_info['path']}_{'hbm' if o_roof['bound'] == 'hbm' else 'valu'}_frac"] = o_roof['frac']
+            if o_roof.get('traffic') and o_roof.get('alg_bytes_per_launch'):
+                out['config'][f"{o_info['path']}_traffic_over_alg"] = round(o_roof['traffic'] / o_roof['alg_bytes_per_launch'], 3)
         if not args.no_cpu_baseline and G == 1:
             cb, cscores, single = cpu_baseline(masks, shifts[lo:hi], host_blocks[last_block], N, ov, Dl)
             # the bounded CPU sample doubles as a full-size parity spot check of the last timed block

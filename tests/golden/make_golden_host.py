@@ -259,7 +259,7 @@ def spectrum(N, seed):
 
 
 def g16_pick(out, objs):
-    for name in ('bench_b15_d64', 'zero_if', 'neg_if', 'noise_neg', 'noise_pos', 'cc11xx_b16_s16', 'bench_b20_d256'):
+    for name in ('bench_b15_d64', 'zero_if', 'neg_if', 'noise_neg', 'noise_pos', 'cc11xx_b16_s16', 'cc11xx_b17_s128', 'bench_b20_d256'):
         obj = objs[name]
         N, Dtot = obj.Nfft, obj.doppIdxArrayLen
         seed = 1000 + sum(map(ord, name))

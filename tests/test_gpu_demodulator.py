@@ -283,7 +283,7 @@ def test_one_runner_streams_twice(first):
     N = 1 << bs
     conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=32)
     p = loadProtocol('bench_GMSK')(conf=conf)
-    sig = sg.awgn(np.concatenate((sg.get_padded_packet('GMSK')[0], np.zeros(2 * N))), 12.0, rng=np.random.RandomState(4)).astype(np.complex64)
+    sig = sg.awgn(np.concatenate((sg.get_padded_packet('GMSK')[0], np.zeros(4 * N))), 12.0, rng=np.random.RandomState(4)).astype(np.complex64)
     step = N - ov
     nblk = len(sig) // step
     assert nblk >= first + 4

@@ -41,7 +41,9 @@ def windows(X, pieces):
     return tuple(np.concatenate([X[s:s + n] for s, n in band]) for band in pieces)
 
 
-@pytest.mark.parametrize('name', ['bench_b15_d64', 'zero_if', 'neg_if', 'noise_neg', 'noise_pos', 'cc11xx_b16_s16', 'bench_b20_d256'])
+# (the fixture case cc11xx_b16_s16 -- an IF offset beyond the sample rate, shifts outside [0, N) -- is host-only:
+# mfb_set_shifts refuses such a table, where the reference's kernel would read out of bounds)
+@pytest.mark.parametrize('name', ['bench_b15_d64', 'zero_if', 'neg_if', 'noise_neg', 'noise_pos', 'cc11xx_b17_s128', 'bench_b20_d256'])
 def test_pick_stage_of_the_block_path_equals_reference(hg, name):
     """DB:604-667 with the shift interpolation and the window bounds computed ON THE DEVICE: frequency offset, SNR (same
     elements in the same order as the reference's numpy slices, wrapped bands included), dopplerIdxlast, NaN => block skipped."""
@@ -76,7 +78,7 @@ def test_rate_stage_of_the_block_path_equals_reference(hg, name):
     picks = np.tile(np.float32([1.0, 0.0]), (len(ks), 1))
     out = d.bank.debug_block_scalars(picks, triples, d.spsymMin, 5, max_symbols=d.Nfft)
     L = {f: hg[p + 'legacy/' + f] for f in ('spSym', 'codeOffset', 'spSymF', 'phaseF', 'count')}
-    cap = d.Nfft // 3          # the handle's symbol capacity (N / 3 >= N / spsymMin for every shipped protocol)
+    cap = d.Nfft // 2          # the handle's symbol capacity
     assert same(np.array([r['spSym'] for r in out]), L['spSym'])
     assert same(np.array([r['codeOffset'] for r in out]), L['codeOffset'])
     assert same(np.array([r['spSymF'] for r in out], np.float32), L['spSymF'])

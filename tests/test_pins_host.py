@@ -98,7 +98,8 @@ def test_constructor_scalars_equal_reference(hg, name, monkeypatch):
     assert int(d.Nfft / d.spsymMin) == int(hg[f'g15/{name}/centres_capacity'])
 
 
-@pytest.mark.parametrize('name', ['bench_b15_d64', 'zero_if', 'neg_if', 'noise_neg', 'noise_pos', 'cc11xx_b16_s16', 'bench_b20_d256'])
+@pytest.mark.parametrize('name', ['bench_b15_d64', 'zero_if', 'neg_if', 'noise_neg', 'noise_pos', 'cc11xx_b16_s16', 'cc11xx_b17_s128',
+                                  'bench_b20_d256'])
 def test_find_carrier_host_half_equals_reference(hg, name, monkeypatch):
     """A7 host half + A8 (DB:604-667) on injected findDopplerEst results: integer and fractional indices, both ends of the
     table, bins either side of 0 Hz (shift interpolation across the wrap), noise-reference bin in front, NaN (block skipped)."""
