@@ -313,6 +313,12 @@ def main():
                     help='N>1: bins = C4, Doppler bins sharded 256/GPU + RCCL exchange per block (default); '
                          'blocks = every GPU runs the full 256-bin bank on different time blocks, no collective')
     ap.add_argument('--no-prefetch', action='store_true', help='N>1: broadcast every block right before its search instead of one block ahead')
+    ap.add_argument('--single-comm', action='store_true',
+                    help='N>1: the block broadcast shares the communicator and the stream of the score exchange (one program order of '
+                         'collectives per rank) instead of running beside the search on a communicator of its own')
+    ap.add_argument('--watchdog', type=float, default=120.0,
+                    help='N>1 / --force-dist: seconds without a completed step after which a rank prints what it is stuck in and '
+                         'exits with status 3 (0 disables)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="process-group backend; 'gloo' lets several ranks share ONE GPU (rehearsal of the N>1 path on a 1-GPU box)")
     ap.add_argument('--force-dist', action='store_true', help='run the sharded/RCCL path even with one rank (rehearsal)')
@@ -397,7 +403,7 @@ def main():
     pinfo = bank.get_search_path()
     shard = None
     if (G > 1 or args.force_dist) and not by_blocks:
-        shard = DopplerShard(rank=rank, world=G, device=dev)
+        shard = DopplerShard(rank=rank, world=G, device=dev, concurrent_broadcast=not args.single_comm)
         shard.attach(bank, D_total, M, sum_all=True)
 
     # synthetic input S1: the reference's GMSK bench packet at +fs/4, tiled, AWGN 10 dB, resident in HBM
@@ -425,6 +431,17 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
+
+    if shard is not None and args.watchdog > 0:
+        # a collective some rank never joins waits for ever: say which one and leave with a non-zero status instead
+        from pycusdr_amd.dist import StepWatchdog
+        dog = StepWatchdog(args.watchdog, rank=rank, describe=shard.describe)
+        plain_step = step
+
+        def step(i, src=None):              # noqa: F811
+            out_ = plain_step(i, src)
+            dog.beat(i)
+            return out_
 
     step(0)            # initialisation: first launches load the code objects and touch the workspaces
     torch.cuda.synchronize(dev)
@@ -465,6 +482,8 @@ def main():
     ev_ms = bank.timer_stop()
     counts, kms = bank.profile_read()
     bank.profile_enable(False)
+    if shard is not None and args.watchdog > 0:
+        dog.stop()
     elapsed = float(np.median(times))
     timed_steps = args.steps * args.repeats
     # scores of the LAST timed block, read before anything else touches the handle (parity spot check)
@@ -624,6 +643,14 @@ def main():
                                  for p in ('CC11xx', 'bench_BPSK') if p != args.protocol]
         extras['c3'] = bank_figure(dev, local_rank, args.protocol, 1024, log2N, blocks, esz, nblocks, steps=4, warmup=1)
 
+    # who took part: one entry per rank (process rank, device index, device uuid / name), gathered over the communicator
+    props = torch.cuda.get_device_properties(dev)
+    me = {'rank': rank, 'device': local_rank, 'uuid': str(getattr(props, 'uuid', '')), 'name': props.name}
+    rank_devices = [me]
+    if dist is not None:
+        rank_devices = [None] * dist.get_world_size()
+        dist.all_gather_object(rank_devices, me)
+
     out = None
     rc = 0
     if rank == 0:
@@ -645,19 +672,17 @@ def main():
             else:
                 k_bytes = 8.0 * bins_per_launch * Mu * N + 4.0 * bins_per_launch * Mu  # Z read + partial sums
             k_avg_s = kms_[dom] / launches * 1e-3
-            traffic = None
+            traffic, tsrc = None, None
             tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
             if os.path.exists(tfile):
                 try:
-                    rec = json.load(open(tfile))
-                    key = f'D{Dl_}_M{M}_N{log2N}_chunk{tun_[0]}'
-                    traffic = rec.get(key, {}).get('pass1' if dom == 0 else 'pass2')
+                    rec = json.load(open(tfile)).get(f'D{Dl_}_M{M}_N{log2N}_chunk{tun_[0]}', {})
+                    traffic, tsrc = rec.get('pass1' if dom == 0 else 'pass2'), rec.get('source')
                 except Exception:
-                    traffic = None
+                    traffic, tsrc = None, None
             return {'bound': 'hbm', 'kernel': names[dom], 'achieved': round(k_bytes / k_avg_s / 1e9, 2), 'peak': HBM_PEAK / 1e9,
-                    'unit': 'GB/s', 'frac': round(k_bytes / k_avg_s / HBM_PEAK, 4), 'traffic': traffic,
-                    'traffic_source': 'profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round 1 '
-                                      '(commit 717e07a), not measured by this run',
+                    'unit': 'GB/s', 'frac': round(k_bytes / k_avg_s / HBM_PEAK, 4), 'traffic': traffic, 'traffic_source': tsrc,
+                    'traffic_over_alg': round(traffic / k_bytes, 3) if traffic else None,
                     'launches': launches, 'avg_launch_ms': round(k_avg_s * 1e3, 4), 'alg_bytes_per_launch': k_bytes,
                     'other_kernel_avg_ms': round(kms_[1 - dom] / max(counts_[1 - dom], 1), 4)}
 
@@ -718,6 +743,11 @@ def main():
                 'units': 'samples through a 256-bin bank, summed over ranks',
                 'stream_msamples': round((N - ov) / (elapsed / args.steps) / 1e6, 3) if not by_blocks else round(value, 3),
                 'world_size': G, 'backend': (('nccl (RCCL)' if args.backend == 'nccl' else 'gloo (rehearsal)') if dist is not None else None),
+                'rccl_world': (dist.get_world_size() if dist is not None and args.backend == 'nccl' else None),
+                'rank_devices': rank_devices, 'distinct_devices': len({(d['device'], d['uuid']) for d in rank_devices}),
+                'broadcast_mode': (None if shard is None else ('own communicator and stream, one block ahead' if not args.single_comm
+                                                               else 'single communicator, single stream')
+                                   + ('' if not args.no_prefetch else ', no prefetch')),
                 'carrier_found': carrier_ok if carrier_ok is None else bool(carrier_ok),
             },
             'roofline': roof,

@@ -41,12 +41,59 @@ def bin_owner(num_bins, world, bin_index):
     raise ValueError(f'bin {bin_index} outside [0, {num_bins})')
 
 
+class StepWatchdog:
+    """Turns a hang of the sharded loop into a diagnosis and a NON-ZERO EXIT.  A collective that some rank never joins does
+    not fail, it waits -- RCCL inside a kernel on the device (the host notices at the next read-back), gloo inside the call.
+    The loop calls ``beat()`` once per step; a daemon thread that sees no beat for ``timeout_s`` seconds writes, to stderr,
+    the rank, the step, what the shard was doing (``describe()``: the phase and the collectives enqueued since the last
+    completed synchronisation) and leaves the process with ``exit_code`` -- the launcher then tears the other ranks down.
+    Leaving is ``os._exit``: nothing is re-executed, so it is safe in a process that has touched the GPU."""
+
+    def __init__(self, timeout_s, rank=0, describe=None, exit_code=3, stream=None):
+        import threading
+        import time
+        self.timeout_s, self.rank, self.describe, self.exit_code = float(timeout_s), int(rank), describe, int(exit_code)
+        self._time, self._last, self.step, self._stop = time, time.monotonic(), -1, threading.Event()
+        self._out = stream
+        self._thread = threading.Thread(target=self._watch, name='mfb-step-watchdog', daemon=True)
+        if self.timeout_s > 0:
+            self._thread.start()
+
+    def beat(self, step=None):
+        self._last = self._time.monotonic()
+        self.step = self.step + 1 if step is None else int(step)
+
+    def stop(self):
+        self._stop.set()
+
+    def _watch(self):
+        import os
+        import sys
+        while not self._stop.wait(min(0.25, self.timeout_s / 4)):
+            idle = self._time.monotonic() - self._last
+            if idle > self.timeout_s:
+                what = ''
+                try:
+                    what = self.describe() if self.describe is not None else ''
+                except Exception as e:      # noqa: BLE001 -- the diagnosis must not keep the process alive
+                    what = f'(no description: {e})'
+                out = self._out or sys.stderr
+                out.write(f'[mfb watchdog] rank {self.rank}: no progress for {idle:.1f} s after step {self.step}; {what}\n')
+                out.flush()
+                os._exit(self.exit_code)
+
+
 class DopplerShard:
     """Glue between a bank (MFBank, or any object with its device-pointer methods) holding this rank's
     bins and the process group.  Works on CUDA/HIP tensors over RCCL and on CPU tensors over gloo."""
 
-    def __init__(self, rank=None, world=None, group=None, device=None, comm=None, src=0, bcast_group=None):
-        """``bcast_group``: a second communicator over the same ranks for the block broadcast, so that it runs beside the
+    def __init__(self, rank=None, world=None, group=None, device=None, comm=None, src=0, bcast_group=None,
+                 concurrent_broadcast=True):
+        """``concurrent_broadcast`` False: SINGLE-COMMUNICATOR mode -- the block broadcast uses the communicator and the
+        stream of the score exchange, so every rank issues every collective of the job in one program order on one stream
+        (what NCCL / RCCL guarantee to be deadlock-free); a prefetched block then queues behind the running search instead
+        of travelling beside it.  True (default): the broadcast has a communicator and a stream of its own.
+        ``bcast_group``: a second communicator over the same ranks for the block broadcast, so that it runs beside the
         exchange of the scores instead of queueing behind it (made here when ``group`` is None).  ``src``: the PROCESS rank of this shard's rank 0 (the broadcast source; differs from 0 when ``group`` is a
         subset of the job, GridShard).  ``comm``: an object with torch.distributed's call surface (get_rank, get_world_size, get_backend, new_group,
         broadcast, all_gather_into_tensor, all_reduce, ReduceOp); default torch.distributed itself.  A caller that
@@ -72,11 +119,23 @@ class DopplerShard:
         self.stream = torch.cuda.Stream(self.device) if self.on_gpu else None
         # block distribution ahead of time: its own stream and its own communicator, so that the broadcast of
         # the next block runs beside the search and the all-reduce of the current one
-        self.comm = torch.cuda.Stream(self.device) if self.on_gpu else None
-        if bcast_group is not None:
-            self.bcast_group = bcast_group
+        self.concurrent_broadcast = bool(concurrent_broadcast)
+        if not self.concurrent_broadcast:
+            self.comm, self.bcast_group = self.stream, group
         else:
-            self.bcast_group = dist.new_group(backend=self.backend) if (self.world > 1 and group is None) else group
+            self.comm = torch.cuda.Stream(self.device) if self.on_gpu else None
+            if bcast_group is not None:
+                self.bcast_group = bcast_group
+            else:
+                self.bcast_group = dist.new_group(backend=self.backend) if (self.world > 1 and group is None) else group
+        # for the watchdog: what this rank is doing, and the collectives enqueued since the last completed synchronisation
+        import collections
+        self.phase, self.ops = 'idle', collections.deque(maxlen=8)
+
+    def describe(self):
+        return (f'phase: {self.phase}; collectives enqueued since the last completed synchronisation: '
+                f'{list(self.ops) or "none"} (backend {self.backend}, world {self.world}, '
+                f'{"own" if self.concurrent_broadcast else "shared"} broadcast communicator)')
 
     def _on_stream(self, which=None):
         which = self.stream if which is None else which
@@ -154,6 +213,8 @@ class DopplerShard:
                     raise ValueError('rank 0 must supply the block')
                 self.blocks[k].copy_(block.reshape(-1), non_blocking=True)
             if self.world > 1:
+                self.phase = f'broadcast of a block into buffer {k} from rank {self.src}'
+                self.ops.append(f'broadcast(buffer {k})')
                 self.dist.broadcast(self.blocks[k], src=self.src, group=self.bcast_group)
             if self.on_gpu:
                 self._event(self.ready, k, stream)
@@ -198,6 +259,8 @@ class DopplerShard:
             # [noise rows | slice] of every rank, gathered; without noise rows that IS the table
             bank.export_rows_async(self.local.data_ptr(), 0, 0, doff + self.nloc, column_only=col)
             with self._on_stream():
+                self.phase = 'all-gather of the per-bin scores'
+                self.ops.append('all_gather(scores)')
                 if doff:
                     self.dist.all_gather_into_tensor(self.gathered, self.local, group=self.group)
                     g = self.gathered.view((self.world, doff + self.nloc) + tuple(self.gathered.shape[1:]))
@@ -211,10 +274,21 @@ class DopplerShard:
             if doff and self.rank == 0:
                 bank.export_rows_async(self.scores.data_ptr(), 0, 0, doff, column_only=col)
             with self._on_stream():
+                self.phase = 'all-reduce of the per-bin scores'
+                self.ops.append('all_reduce(scores)')
                 self.dist.all_reduce(self.scores, op=self.dist.ReduceOp.SUM, group=self.group)     # adds exact zeros
+        self.phase = 'pick read-back (waits on the stream for the block, the search and the exchange of the scores)'
         if self.sum_all:
-            return bank.pick_column(self.scores.data_ptr(), num=self.D, offset=doff)
-        return bank.pick(self.scores.data_ptr(), num=self.D, offset=doff)
+            res = bank.pick_column(self.scores.data_ptr(), num=self.D, offset=doff)
+        else:
+            res = bank.pick(self.scores.data_ptr(), num=self.D, offset=doff)
+        # the read-back synchronised the shard's stream: everything enqueued on it has completed (a prefetched broadcast on
+        # the side stream, started after the search, may still be in flight -- it stays listed)
+        pending = [o for o in self.ops if o.startswith('broadcast') and self.pending is not None and self.concurrent_broadcast][-1:]
+        self.ops.clear()
+        self.ops.extend(pending)
+        self.phase = 'between steps'
+        return res
 
     def step(self, bank, row_offset, block=None, next_block=None, prefetch_next=False):
         """One block of the sharded hot path: (take the prefetched block or broadcast now), start the next block's
@@ -269,6 +343,10 @@ class BlockShard:
         if len(self.peers) != self.world:
             raise ValueError(f'{len(self.peers)} process ranks for a world of {self.world}')
         self._inflight = []
+        self.phase = 'idle'
+
+    def describe(self):
+        return f'phase: {self.phase} (time-block shard: rank {self.rank} of {self.world}, root {self.root})'
 
     def owner(self, block_index):
         return int(block_index) % self.world
@@ -311,9 +389,11 @@ class BlockShard:
             self._wait_oldest()
 
     def _wait_oldest(self):
-        works, _, _ = self._inflight.pop(0)
+        works, th, _ = self._inflight.pop(0)
+        self.phase = f'waiting for the send of block {int(th[0])} to the root (rank {self.root}) to complete'
         for w in works:
             w.wait()
+        self.phase = 'between blocks'
 
     def flush(self):
         while self._inflight:
@@ -323,12 +403,14 @@ class BlockShard:
         import time
         torch = self.torch
         th = torch.empty(self.HEADER, dtype=torch.float64)
+        self.phase = f'recv of the next block record from rank {src} (process {self.peers[src]})'
         self.dist.recv(th, self.peers[src], group=self.group)
         head = th.numpy()
         nbytes = 9 * int(head[5]) + 8 * int(head[6])
         tb = torch.empty(nbytes, dtype=torch.uint8)
         if nbytes:
             self.dist.recv(tb, self.peers[src], group=self.group)
+        self.phase = 'between blocks'
         return self.unpack(head, tb.numpy(), time.time())
 
     # -- the loop ------------------------------------------------------------------------------------------------------
@@ -401,7 +483,7 @@ class GridShard:
     ``B = 1`` is BlockShard, ``B = G`` is DopplerShard with the streaming loop around it.  ``hand_back_backend``: backend
     of the communicator that moves the hand-back (host arrays): gloo."""
 
-    def __init__(self, bin_ranks, device=None, comm=None, hand_back_backend='gloo'):
+    def __init__(self, bin_ranks, device=None, comm=None, hand_back_backend='gloo', concurrent_broadcast=True):
         if comm is None:
             import torch.distributed as comm
         world, rank = comm.get_world_size(), comm.get_rank()
@@ -412,11 +494,12 @@ class GridShard:
         self.g, self.b = divmod(rank, B)
         # every process creates every communicator, in the same order (torch.distributed's rule for new_group)
         bin_groups = [comm.new_group(ranks=list(range(g * B, (g + 1) * B))) for g in range(self.T)]
-        bcast_groups = [comm.new_group(ranks=list(range(g * B, (g + 1) * B))) for g in range(self.T)] if B > 1 else bin_groups
+        bcast_groups = ([comm.new_group(ranks=list(range(g * B, (g + 1) * B))) for g in range(self.T)]
+                        if B > 1 and concurrent_broadcast else bin_groups)
         roots = [g * B for g in range(self.T)]
         root_group = comm.new_group(ranks=roots, backend=hand_back_backend)
         self.doppler = DopplerShard(rank=self.b, world=B, group=bin_groups[self.g], device=device, comm=comm, src=self.g * B,
-                                    bcast_group=bcast_groups[self.g])
+                                    bcast_group=bcast_groups[self.g], concurrent_broadcast=concurrent_broadcast)
         self.blocks = BlockShard(rank=self.g, world=self.T, group=root_group, comm=comm, ranks=roots) if self.b == 0 else None
 
     def owner_group(self, block_index):

@@ -27,12 +27,11 @@ def nfds():
     return len(os.listdir('/proc/self/fd'))
 
 
-def main():
+def soak(cycles=40, per=30, long_blocks=4000, budget_s=None, min_cycles=12, log=print):
+    """Run the soak; returns a dict of the measured growth figures and 'ok'.  ``budget_s``: stop the create / stream / close
+    cycles early (never before ``min_cycles``) once that many seconds have passed."""
     import torch
     quiet_blas()
-    cycles = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    per = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-    long_blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 4000
     bs = 15
     N = 1 << bs
     sig, _ = sg.get_padded_packet('GMSK', 16, 153600)
@@ -53,6 +52,8 @@ def main():
 
     protos = ['bench_GMSK', 'bench_FSK', 'bench_BPSK']
     marks = []
+    t_start = time.perf_counter()
+    done = 0
     for c in range(cycles):
         pname = protos[c % len(protos)]
         conf = cfg.bench_config(pname, blockSize=bs, doppCarrierSteps=32 + 16 * (c % 3))
@@ -61,36 +62,51 @@ def main():
         dec = Decoder(conf, proto)
         dec.prepare()
         res, pk = run.run_stream(stream(per), decoder=dec)
+        if c % 2:                   # the same runner again (it goes on in whichever page-locked buffer the first call ended in)
+            run.run_stream(stream(3), decoder=dec)
         run.close()
         dec.close() if hasattr(dec, 'close') else None
         del run, dec
-        if c in (2, cycles // 2, cycles - 1):
-            marks.append((c,) + snapshot())
-            print(f'cycle {c}: device free {marks[-1][1]:.0f} MiB, rss {marks[-1][2]:.0f} MiB, fds {marks[-1][3]}', flush=True)
+        done = c + 1
+        marks.append((c,) + snapshot())
+        if budget_s is not None and done >= min_cycles and time.perf_counter() - t_start > budget_s:
+            break
     # first half: allocator pools and code objects settle; a leak keeps growing through the second half
-    d_dev = marks[1][1] - marks[-1][1]
-    d_rss = marks[-1][2] - marks[1][2]
-    d_fd = marks[-1][3] - marks[1][3]
-    n = marks[-1][0] - marks[1][0]
-    print(f'per cycle over the second half: device {d_dev / n:+.3f} MiB, rss {d_rss / n:+.3f} MiB, fds {d_fd / n:+.2f}')
+    mid, last = marks[len(marks) // 2], marks[-1]
+    for m in (marks[min(2, len(marks) - 1)], mid, last):
+        log(f'cycle {m[0]}: device free {m[1]:.0f} MiB, rss {m[2]:.0f} MiB, fds {m[3]}')
+    n = max(last[0] - mid[0], 1)
+    d_dev, d_rss, d_fd = (mid[1] - last[1]) / n, (last[2] - mid[2]) / n, (last[3] - mid[3]) / n
+    log(f'{done} cycles in {time.perf_counter() - t_start:.1f} s; per cycle over the second half: device {d_dev:+.3f} MiB, rss {d_rss:+.3f} MiB, fds {d_fd:+.2f}')
     # one long stream on one handle
     conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=64)
     proto = loadProtocol('bench_GMSK')(conf=conf)
     run = DemodulatorRunner(conf, proto, 'UHF-H')
     dec = Decoder(conf, proto)
     dec.prepare()
-    run.run_stream(stream(50), decoder=dec)
+    run.run_stream(stream(51), decoder=dec)          # an odd number of blocks: the long stream starts in the second buffer
     a = snapshot()
     t0 = time.perf_counter()
     res, pk = run.run_stream(stream(long_blocks), decoder=dec)
     dt = time.perf_counter() - t0
     b = snapshot()
-    print(f'long stream: {len(res)} blocks, {len(pk)} packets, {len(res) * step / dt / 1e6:.0f} Msamples/s; device {a[0] - b[0]:+.1f} MiB, '
-          f'rss {b[1] - a[1]:+.1f} MiB, fds {b[2] - a[2]:+d}')
+    log(f'long stream: {len(res)} blocks, {len(pk)} packets, {len(res) * step / dt / 1e6:.0f} Msamples/s; device {a[0] - b[0]:+.1f} MiB, '
+        f'rss {b[1] - a[1]:+.1f} MiB, fds {b[2] - a[2]:+d}')
     run.close()
-    ok = abs(d_dev / n) < 0.5 and d_rss / n < 1.0 and d_fd / n < 0.5 and abs(a[0] - b[0]) < 8 and (b[2] - a[2]) == 0
-    print('ok' if ok else 'GROWTH')
-    return 0 if ok else 1
+    out = {'cycles': done, 'device_mib_per_cycle': d_dev, 'rss_mib_per_cycle': d_rss, 'fds_per_cycle': d_fd,
+           'long_blocks': len(res), 'long_packets': len(pk), 'long_device_mib': a[0] - b[0], 'long_rss_mib': b[1] - a[1],
+           'long_fds': b[2] - a[2], 'long_msamples': len(res) * step / dt / 1e6}
+    out['ok'] = bool(abs(d_dev) < 0.5 and d_rss < 1.0 and d_fd < 0.5 and abs(out['long_device_mib']) < 8 and out['long_fds'] == 0)
+    return out
+
+
+def main():
+    cycles = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    per = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+    long_blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 4000
+    out = soak(cycles, per, long_blocks, log=lambda m: print(m, flush=True))
+    print('ok' if out['ok'] else 'GROWTH')
+    return 0 if out['ok'] else 1
 
 
 if __name__ == '__main__':
