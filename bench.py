@@ -221,18 +221,25 @@ def run_block_shard(args, dist, rank, G, local_rank, dev):
     def feed(i):
         return runner.feed_resident(blocks.data_ptr() + (i % nblocks) * esz)
 
+    def feed_begin(i):
+        runner.feed_resident_begin(blocks.data_ptr() + (i % nblocks) * esz)
+
     def skip(i):
         runner.count += 1
 
     def barrier():
         dist.barrier()
         torch.cuda.synchronize(dev)
-    shard.run(runner, range((1 + args.warmup) * G), decoder=decoder, feed=feed, skip=skip)
+    from pycusdr_amd.dist import StepWatchdog
+    dog = StepWatchdog(args.watchdog, rank=rank, describe=shard.describe) if args.watchdog > 0 else None
+    shard.run(runner, range((1 + args.warmup) * G), decoder=decoder, feed=feed, skip=skip, watchdog=dog, feed_begin=feed_begin)
     barrier()
     runner.demod.bank.profile_enable(True)
     t0 = time.perf_counter()
-    res, packets = shard.run(runner, range(args.steps * G), decoder=decoder, feed=feed, skip=skip)
+    res, packets = shard.run(runner, range(args.steps * G), decoder=decoder, feed=feed, skip=skip, watchdog=dog, feed_begin=feed_begin)
     barrier()
+    if dog is not None:
+        dog.stop()
     elapsed = time.perf_counter() - t0
     counts, kms = runner.demod.bank.profile_read()
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
@@ -249,8 +256,8 @@ def run_block_shard(args, dist, rank, G, local_rank, dev):
                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': {'workload': f'block round-robin (BlockShard): each of {G} GPUs runs the full D={args.bins} bank of {args.protocol} '
                                       f'(N=2^{log2N}) on every {G}th block -- search, pick, matched filters at the found shift, symbol '
-                                      f'decisions --, rank 0 runs the ordered host stages and the decoder; blocks resident in HBM, one '
-                                      f'point-to-point message per block, no collective',
+                                      f'decisions, bit lookup and alignment (the previous block\'s tail comes from its owner) --, rank 0 '
+                                      f'runs the decoder in block order; blocks resident in HBM, two point-to-point messages per block, no collective',
                           'shard': 'blocks', 'world_size': G, 'backend': args.backend, 'blocks_timed': nb, 'path': pinfo,
                           'packets_found': len(packets), 'mean_block_ms_device_plus_host_on_root': host_ms,
                           'units': 'samples of the one physical stream (every block is processed once)'},

@@ -294,13 +294,14 @@ class Demodulator:
                                                 source=source, device_ptr=device_ptr)
         return self._pending
 
-    def beginBlock(self, slot, source='pinned', fixed_shift=None):
+    def beginBlock(self, slot, source='pinned', fixed_shift=None, device_ptr=None):
         """Enqueue the whole device side of the block assembled in input buffer ``source`` ('pinned' / 'pinned2') and
         return at once; ``endBlock(slot)`` collects it.  Lets the caller run the sequential host stages of the previous
         block (and assemble the next one in the other buffer) while the device works -- the blocks themselves still
         execute, and are collected, strictly in order."""
         self.bank.begin_block(slot, self.codeRateAndPhaseOffsetHigh, self.codeRateAndPhaseOffsetLow - self.codeRateAndPhaseOffsetHigh,
-                              self.spsymMin, op=Operations.CENTRES_ABS.value, snr_window=5, fixed_shift=fixed_shift, source=source)
+                              self.spsymMin, op=Operations.CENTRES_ABS.value, snr_window=5, fixed_shift=fixed_shift, source=source,
+                              device_ptr=device_ptr)
 
     def endBlock(self, slot):
         """(freqOffset_Hz, metric, clippedPeakIdx, SNR_dB) of the block begun in ``slot`` -- what ``uploadAndFindCarrier``
@@ -464,15 +465,39 @@ class Demodulator:
         return {'spSym': spSym, 'symbols': idxSymbol, 'centres': centres, 'trust': trustSymbol,
                 'clipped': np.asarray(self.clippedPeakIPure, dtype=np.int64)}
 
-    def demodulateHost(self, rec):
+    def hostBits(self, rec):
+        """A12 on a block's device record: (bits of every symbol, number of impossible NRZ-S transitions).  Depends on this block
+        alone; kept in the record so that the tail and the host stage share it."""
+        if '_bits' not in rec:
+            idxSymbol, centres = rec['symbols'], rec['centres']
+            if self._bitLUT_u8 is not None:
+                rec['_bits'] = (self._bitLUT_u8[idxSymbol], 0)
+            else:
+                dataBits, symError_t = self.extractBits(centres, idxSymbol)
+                rec['_bits'] = (dataBits, len(symError_t))
+        return rec['_bits']
+
+    def overlapTail(self, rec):
+        """What the NEXT block's alignment needs of this one (reference DB:977-979): the bits behind this block's window
+        (``poswinP``) and the last ``overlapOffset + 1`` bits inside it (``posSymEnd``).  Both are functions of this block's
+        device results alone -- the +-1 adjustment of the window's START (DB:938-957) cannot reach its last bits -- so
+        the owner of block i can hand them to the owner of block i + 1 without waiting for block i - 1 (time-chunk sharding,
+        dist.BlockShard).  'exact' is False for windows too short for that argument (fewer than overlapOffset + 2 symbols)."""
+        dataBits, _ = self.hostBits(rec)
+        centres = rec['centres']
+        start = _first_true(centres >= self.sigOverlapWin)
+        end = _first_true(centres > (self.Nfft - self.sigOverlapWin))
+        o = self.overlapOffset
+        return {'post': dataBits[end:], 'end': dataBits[start:end][-o - 1:], 'exact': bool(end - start >= o + 2)}
+
+    def demodulateHost(self, rec, prev_tail=None):
         """The sequential half (reference DB:1012-1051, 863-988, 817-859): bit lookup, alignment against the previous
-        block (stateful: ``poswinP``, ``posSymEnd``), clipped-peak tagging, uint8 casts.  Must see the blocks in order."""
+        block (stateful: ``poswinP``, ``posSymEnd``), clipped-peak tagging, uint8 casts.  Must see the blocks in order --
+        or be given the previous block's ``overlapTail`` as ``prev_tail`` (then any process may run any block)."""
         spSym, idxSymbol, centres, trustSymbol = rec['spSym'], rec['symbols'], rec['centres'], rec['trust']
-        if self._bitLUT_u8 is not None:
-            dataBits, symError_t = self._bitLUT_u8[idxSymbol], []
-        else:
-            dataBits, symError_t = self.extractBits(centres, idxSymbol)
-        noError = len(symError_t)
+        dataBits, noError = self.hostBits(rec)
+        if prev_tail is not None:
+            self.poswinP, self.posSymEnd = prev_tail['post'], prev_tail['end']
         centresWin, dataBitsWin, trustSymbolWin, _ = self.checkSymbolOverlap(noError, centres, idxSymbol, dataBits, trustSymbol)
 
         # tag symbols next to clipped interference peaks (reference DB:830-837)

@@ -82,6 +82,16 @@ class DemodulatorRunner:
         self.count += 1
         return part
 
+    def feed_resident_begin(self, device_ptr):
+        """``feed_resident`` in two halves (``feed_device_end`` collects): the block's device work is enqueued and the call returns."""
+        if not (self.radioBackend == 'UHF' and getattr(self.demod, '_one_call', False)):
+            self._flight = ('done', self.feed_resident(device_ptr))
+            return
+        stamp = time.time()
+        self.demod.beginBlock(0, source='device', device_ptr=device_ptr)
+        self._flight = ('flying', 0, self.count, stamp)
+        self.count += 1
+
     def feed_device(self, new_samples=None):
         """Device half of one block (A3..A11): overlap carry, Doppler search, matched filters at the found shift, symbol
         decisions.  Carries no block-to-block state besides the overlap samples, so with time-chunk sharding
@@ -165,24 +175,28 @@ class DemodulatorRunner:
             self.raw[ov - sps:ov] = new_samples
         self.count += 1
 
-    def feed_host(self, part):
+    def feed_host(self, part, prev_tail=None):
         """Sequential half of one block (A12, A13): bits, alignment against the previous block, trust tagging, and the
-        result dict that goes to the decoder.  Must be called in block order."""
+        result dict that goes to the decoder.  Must be called in block order -- or with the previous block's
+        ``Demodulator.overlapTail`` as ``prev_tail`` (time-chunk sharding: the owner of a block runs this stage itself)."""
         t0 = time.time()
-        stamp = part['timestamp']
-        # every key of the reference's result dict (DP:259-276), including the two it initialises and never
-        # updates ('rangerateEst', 'baudRate_est': its loop writes 'rangerate' and 'baudrate_est' instead, DP:299,303)
-        data = {'workerId': self.workerId, 'count': part['count'], 'timestamp': stamp, 'voteGroup': self.voteGroup,
-                'doppler': 0, 'doppler_std': 0, 'data': np.array([]), 'trust': np.array([]), 'spSymEst': 0, 'SNR': float(0),
+        bits, centres, trust, spSym = self.demod.demodulateHost(part['rec'], prev_tail=prev_tail)
+        spent = part['time_device'] + (time.time() - t0)
+        return self.compose_result(part['count'], part['timestamp'], part['doppler'], part['doppler_std'], part['SNR'], bits, trust,
+                                   spSym, spent)
+
+    def compose_result(self, count, timestamp, doppler, doppler_std, SNR, bits, trust, spSym, spent):
+        """The result dict of a block from its finished pieces: every key of the reference's dict (DP:259-276), including the
+        two it initialises and never updates ('rangerateEst', 'baudRate_est': its loop writes 'rangerate' and 'baudrate_est'
+        instead, DP:299,303)."""
+        data = {'workerId': self.workerId, 'count': count, 'timestamp': timestamp, 'voteGroup': self.voteGroup,
+                'doppler': doppler, 'doppler_std': doppler_std, 'data': bits, 'trust': trust, 'spSymEst': spSym, 'SNR': SNR,
                 'rangerateEst': 0, 'baudRate': self.baudRate, 'baudRate_est': 0, 'sample_rate': self.Fs,
                 'protocol': self.decoderProtocol}
-        data['doppler'], data['doppler_std'], data['SNR'] = part['doppler'], part['doppler_std'], part['SNR']
-        data['data'], centres, data['trust'], data['spSymEst'] = self.demod.demodulateHost(part['rec'])
         data['baudrate_est'] = self.Fs / data['spSymEst'] if data['spSymEst'] else 0.0
         # range rate implied by the measured frequency offset (reference computeTxFreqOffset, DP:359-379)
         fc = self.confRadio['frequency_Hz']
         data['rangerate'] = -data['doppler'] / fc * 299792458.0
-        spent = part['time_device'] + (time.time() - t0)
         self.computeMATime(spent)
         data['time_ms'] = spent * 1e3
         data['rate_ksps'] = self.samplesPerSlice / spent / 1000

@@ -311,13 +311,21 @@ def allreduce_scores_host(local_scores, row_offset, num_bins_total, group=None):
 
 
 # ---- time-chunk sharding ---------------------------------------------------------------------------------------------
+_TAIL_DTYPES = (np.uint8, np.bool_, np.float64)
+
+
 class BlockShard:
     """Blocks dealt round-robin over the ranks (SURVEY 8e "Alternative"; best when one GPU holds the whole bin table):
-    rank r runs the device stages (forward FFT, Doppler search, pick, matched filters at the found shift, symbol
-    decisions: A3..A11) of blocks r, r + G, ...; the ROOT runs the sequential host stages -- bit lookup, alignment
-    against the previous block (reference demodulator_base.py:977-979), the decoder with its overlap buffer (reference
-    decoder.py:89-90) -- strictly in block order on what the owners hand back.  No collective on the data path: one
-    point-to-point message per block (symbol decisions, a few hundred KiB at most), in block order.
+    rank r runs ALL stages but the decoder of blocks r, r + G, ... -- the device stages (forward FFT, Doppler search, pick,
+    matched filters at the found shift, symbol decisions: A3..A11) and the host stages (bit lookup, alignment against the
+    previous block, trust tagging: A12 / A13).  The alignment of block i looks at block i - 1 only through its ``overlapTail``
+    -- the ~50 bits around the end of its window (reference demodulator_base.py:977-979), a function of that block's device
+    results alone -- so the owner of block i - 1 forwards those bits to the owner of block i (one small point-to-point message),
+    and nobody waits for a chain.  The ROOT receives finished bit slices in block order and runs only what really is
+    sequential: the decoder with its overlap buffer (reference decoder.py:89-90).  No collective on the data path.
+
+    (Round 3 ran A12 / A13 on the root: 0.24 ms per C2 block of sequential work, a ceiling of about six GPUs' worth of blocks.
+    What is left on the root is the decoder, 0.05 ms per block.)
 
     Every rank reads the same sample stream (in the reference any number of processes may subscribe to the SDR's ZeroMQ
     publisher, pyCuSDR.py:245-251 starts one Demodulator_process per radio on it); a rank copies only the overlap tail of
@@ -325,7 +333,9 @@ class BlockShard:
     ``group``: a process group whose backend moves CPU tensors (gloo) -- with an RCCL default group pass
     ``torch.distributed.new_group(backend='gloo')``.
     """
-    HEADER = 8          # float64: block index, doppler, doppler_std, SNR, spSym, symbols, clipped samples, device seconds
+    HEADER = 12         # float64: block index, doppler, doppler_std, SNR, spSym, kept symbols, device + host seconds, tail: post, end,
+    #                     dtype code, exact flag; one spare
+    TAIL_HEADER = 5     # float64: block index, post, end, dtype code, exact flag
 
     def __init__(self, rank=None, world=None, group=None, comm=None, root=0, ranks=None):
         """``ranks``: the process (global rank) behind each member of this shard's world, for worlds that are a subset of
@@ -351,46 +361,56 @@ class BlockShard:
     def owner(self, block_index):
         return int(block_index) % self.world
 
-    # -- wire format: a fixed header, then one byte string (symbols int32 | centres int32 | trust int8 | clipped int64) ----
-    def pack(self, part):
-        rec = part['rec']
-        sym = np.ascontiguousarray(rec['symbols'], dtype=np.int32)
-        cen = np.ascontiguousarray(rec['centres'], dtype=np.int32)
-        tru = np.ascontiguousarray(rec['trust'], dtype=np.int8)
-        clip = np.ascontiguousarray(rec['clipped'], dtype=np.int64)
-        if not (len(sym) == len(cen) == len(tru)):
-            raise ValueError('symbol arrays of unequal length')
-        head = np.array([part['count'], part['doppler'], part['doppler_std'], part['SNR'], rec['spSym'], len(sym), len(clip),
-                         part['time_device']], dtype=np.float64)
-        body = np.concatenate((sym.view(np.uint8), cen.view(np.uint8), tru.view(np.uint8), clip.view(np.uint8)))
-        return head, body
+    # -- wire formats ----------------------------------------------------------------------------------------------------
+    @staticmethod
+    def pack_tail(index, tail):
+        """Owner of block ``index`` -> owner of the next block: a fixed header, then the two bit runs as bytes."""
+        post, end = np.asarray(tail['post']), np.asarray(tail['end'])
+        code = [i for i, t in enumerate(_TAIL_DTYPES) if post.dtype == t]
+        if not code or end.dtype != post.dtype:
+            raise TypeError(f'bit arrays of type {post.dtype} / {end.dtype} cannot travel')
+        head = np.array([index, len(post), len(end), code[0], 1.0 if tail['exact'] else 0.0], dtype=np.float64)
+        return head, np.concatenate((post.astype(np.uint8), end.astype(np.uint8)))
 
     @staticmethod
-    def unpack(head, body, timestamp):
-        S, C = int(head[5]), int(head[6])
-        sym = body[:4 * S].view(np.int32)
-        cen = body[4 * S:8 * S].view(np.int32)
-        tru = body[8 * S:9 * S].view(np.int8)
-        clip = body[9 * S:9 * S + 8 * C].view(np.int64)
-        return {'count': int(head[0]), 'timestamp': timestamp, 'doppler': float(head[1]), 'doppler_std': float(head[2]),
-                'SNR': float(head[3]), 'time_device': float(head[7]),
-                'rec': {'spSym': float(head[4]), 'symbols': sym, 'centres': cen, 'trust': tru, 'clipped': clip}}
+    def unpack_tail(head, body):
+        n_post, n_end, dt = int(head[1]), int(head[2]), _TAIL_DTYPES[int(head[3])]
+        return int(head[0]), {'post': body[:n_post].astype(dt), 'end': body[n_post:n_post + n_end].astype(dt), 'exact': bool(head[4])}
 
-    def send_part(self, part):
-        """Owner -> root, asynchronously; at most two blocks of this rank are in flight."""
+    def pack(self, d, tail, time_device):
+        """Owner -> root: the finished block -- estimates, the kept symbols' bits / centres / trust (uint8 each, as the
+        caller gets them, DB:859), and the block's tail (the root carries it as its own alignment state)."""
+        bits, trust = np.ascontiguousarray(d['data'], dtype=np.uint8), np.ascontiguousarray(d['trust'], dtype=np.uint8)
+        if len(bits) != len(trust):
+            raise ValueError('bit and trust arrays of unequal length')
+        th, tb = self.pack_tail(d['count'], tail)
+        head = np.array([d['count'], d['doppler'], d['doppler_std'], d['SNR'], d['spSymEst'], len(bits), d['time_ms'] * 1e-3,
+                         th[1], th[2], th[3], th[4], time_device], dtype=np.float64)
+        return head, np.concatenate((bits, trust, tb))
+
+    @staticmethod
+    def unpack(head, body):
+        S = int(head[5])
+        _, tail = BlockShard.unpack_tail(np.array([head[0], head[7], head[8], head[9], head[10]]), body[2 * S:])
+        return {'count': int(head[0]), 'doppler': float(head[1]), 'doppler_std': float(head[2]), 'SNR': float(head[3]),
+                'spSym': float(head[4]), 'spent': float(head[6]), 'bits': body[:S], 'trust': body[S:2 * S], 'tail': tail}
+
+    # -- transport -------------------------------------------------------------------------------------------------------
+    TAG_TAIL, TAG_RESULT = 1, 2      # two message kinds may travel between one pair of ranks: matched by tag, not by order
+
+    def _isend(self, head, body, dst, tag):
         torch = self.torch
-        head, body = self.pack(part)
-        th, tb = torch.from_numpy(head), torch.from_numpy(body)
-        works = [self.dist.isend(th, self.peers[self.root], group=self.group)]
+        th, tb = torch.from_numpy(head), torch.from_numpy(np.ascontiguousarray(body))
+        works = [self.dist.isend(th, self.peers[dst], group=self.group, tag=tag)]
         if len(body):
-            works.append(self.dist.isend(tb, self.peers[self.root], group=self.group))
-        self._inflight.append((works, th, tb))
-        while len(self._inflight) > 2:
+            works.append(self.dist.isend(tb, self.peers[dst], group=self.group, tag=tag))
+        self._inflight.append((works, th, tb, dst))
+        while len(self._inflight) > 4:
             self._wait_oldest()
 
     def _wait_oldest(self):
-        works, th, _ = self._inflight.pop(0)
-        self.phase = f'waiting for the send of block {int(th[0])} to the root (rank {self.root}) to complete'
+        works, th, _, dst = self._inflight.pop(0)
+        self.phase = f'waiting for a send of block {int(th[0])} to rank {dst} to complete'
         for w in works:
             w.wait()
         self.phase = 'between blocks'
@@ -399,42 +419,78 @@ class BlockShard:
         while self._inflight:
             self._wait_oldest()
 
-    def recv_part(self, src):
-        import time
+    def _recv(self, src, header_len, body_len, what, tag):
         torch = self.torch
-        th = torch.empty(self.HEADER, dtype=torch.float64)
-        self.phase = f'recv of the next block record from rank {src} (process {self.peers[src]})'
-        self.dist.recv(th, self.peers[src], group=self.group)
+        th = torch.empty(header_len, dtype=torch.float64)
+        self.phase = f'recv of {what} from rank {src} (process {self.peers[src]})'
+        self.dist.recv(th, self.peers[src], group=self.group, tag=tag)
         head = th.numpy()
-        nbytes = 9 * int(head[5]) + 8 * int(head[6])
+        nbytes = body_len(head)
         tb = torch.empty(nbytes, dtype=torch.uint8)
         if nbytes:
-            self.dist.recv(tb, self.peers[src], group=self.group)
+            self.dist.recv(tb, self.peers[src], group=self.group, tag=tag)
         self.phase = 'between blocks'
-        return self.unpack(head, tb.numpy(), time.time())
+        return head, tb.numpy()
+
+    def send_tail(self, index, tail):
+        head, body = self.pack_tail(index, tail)
+        self._isend(head, body, self.owner(index + 1), self.TAG_TAIL)
+
+    def recv_tail(self, index):
+        head, body = self._recv(self.owner(index), self.TAIL_HEADER, lambda h: int(h[1]) + int(h[2]), f'the tail of block {index}', self.TAG_TAIL)
+        got, tail = self.unpack_tail(head, body)
+        if got != index:
+            raise RuntimeError(f'tail of block {got} arrived where block {index} was expected')
+        return tail
+
+    def send_result(self, d, tail, time_device):
+        head, body = self.pack(d, tail, time_device)
+        self._isend(head, body, self.root, self.TAG_RESULT)
+
+    def recv_result(self, index):
+        head, body = self._recv(self.owner(index), self.HEADER, lambda h: 2 * int(h[5]) + int(h[7]) + int(h[8]),
+                                f'the finished block {index}', self.TAG_RESULT)
+        return self.unpack(head, body)
 
     # -- the loop ------------------------------------------------------------------------------------------------------
-    def run(self, runner, sample_source, sink=None, decoder=None, feed=None, skip=None):
+    def run(self, runner, sample_source, sink=None, decoder=None, feed=None, skip=None, watchdog=None, feed_begin=None):
         """Drive ``runner`` (a DemodulatorRunner on this rank's device) over the stream of new-sample slices.  Returns
         (results, packets) on the root -- the same as ``DemodulatorRunner.run`` of one process on the whole stream -- and
         ([], []) elsewhere.  ``feed(item) -> part`` / ``skip(item)`` replace ``runner.feed_device`` / ``runner.skip_block``
-        for sources that do not yield host sample slices (bench.py: blocks already resident in device memory).
+        for sources that do not yield host sample slices (bench.py: blocks already resident in device memory);
+        ``feed_begin(item)`` is the enqueue-only form of ``feed`` (collected with ``runner.feed_device_end``).
+        ``watchdog``: a StepWatchdog; it gets one beat per block of the stream.
 
-        The root runs the host stages ``world - 1`` blocks behind the stream: its own block is enqueued on its device
-        (``feed_device_begin``) and collected only when the host stages of the blocks before it -- which the other ranks
-        computed meanwhile -- are done, so its device and its host work overlap."""
+        An owner enqueues its block on its device (``feed_device_begin``) and collects it when its next block comes up, so
+        its host stage runs while its device works; the tail of a block is forwarded the moment its device results are in
+        and the next block is known to exist.  The root decodes 2 G - 1 blocks behind the stream (G - 1 with a synchronous
+        ``feed``): by then the owner of the block it wants has long sent it."""
         results, packets = [], []
-        own_async = feed is None and hasattr(runner, 'feed_device_begin')
+        demod = runner.demod
+        G = self.world
+        use_async = feed_begin is not None or (feed is None and hasattr(runner, 'feed_device_begin'))
+        feed_begin = feed_begin or (lambda c: runner.feed_device_begin(np.asarray(c, dtype=np.complex64)))
         feed = feed or (lambda c: runner.feed_device(np.asarray(c, dtype=np.complex64)))
         skip = skip or runner.skip_block
         is_root = self.rank == self.root
-        backlog = []                     # root: blocks whose host stages are still to run, oldest first: (index, part or None)
+        lag = (2 * G - 1) if use_async else (G - 1)
+        state = {'flying': None,         # own block enqueued on the device: its index
+                 'tail': None,           # (index, tail) of the own block whose tail waits for block index + 1 to show up
+                 'local_tail': None,     # (index, tail) of the last own block: the next block's predecessor when G == 1
+                 'seen': -1}             # index of the last block of the stream seen so far
+        backlog = []                     # root: blocks to decode, oldest first: (index, finished dict or None = to be received)
+        first = [None]
 
-        def finish(entry):
-            i, part = entry
-            if part is None:
-                part = runner.feed_device_end() if self.owner(i) == self.rank else self.recv_part(self.owner(i))
-            d = runner.feed_host(part)
+        def deliver(entry):
+            i, fin = entry
+            if fin is None:
+                r = self.recv_result(i)
+                d = runner.compose_result(r['count'], time.time(), r['doppler'], r['doppler_std'], r['SNR'], r['bits'], r['trust'],
+                                          r['spSym'], r['spent'])
+                tail = r['tail']
+            else:
+                d, tail = fin
+            demod.poswinP, demod.posSymEnd = tail['post'], tail['end']          # the root carries the stream's alignment state
             if decoder is not None:
                 pk, _, nsync = decoder.findFrames(d['data'], 0)
                 d['numSyncSig'] = nsync
@@ -444,26 +500,72 @@ class BlockShard:
             else:
                 results.append(d)
 
+        def finish_own(i, part):
+            """Device results of own block i are in: tail out, predecessor's tail in, host stage, hand over."""
+            tail = demod.overlapTail(part['rec'])
+            if not tail['exact']:
+                raise ValueError('time-chunk sharding needs windows of at least overlapOffset + 2 symbols per block')
+            if G > 1 and state['seen'] > i:
+                self.send_tail(i, tail)
+            else:
+                state['tail'] = (i, tail)                      # block i + 1 has not shown up yet (or is this rank's own)
+            if i == first[0]:
+                prev = None                                    # the stream's first block: the runner's own state
+            elif G == 1:
+                prev = state['local_tail'][1]
+            else:
+                prev = self.recv_tail(i - 1)
+            state['local_tail'] = (i, tail)
+            d = runner.feed_host(part, prev_tail=prev)
+            if is_root:
+                return d, tail
+            self.send_result(d, tail, part['time_device'])
+            return None
+
+        def collect_flying():
+            if state['flying'] is None:
+                return
+            i, state['flying'] = state['flying'], None
+            fin = finish_own(i, runner.feed_device_end())
+            if is_root:
+                for k, (j, q) in enumerate(backlog):
+                    if j == i:
+                        backlog[k] = (j, fin)
+
+        import time
         for i, chunk in enumerate(sample_source):
+            if first[0] is None:
+                first[0] = i
+            state['seen'] = i
             own = self.owner(i) == self.rank
-            part = None
-            if own and is_root and own_async:
-                # nothing of this runner may be in flight: the previous own block is world blocks back, its host stage has run
-                while any(self.owner(j) == self.rank for j, q in backlog if q is None):
-                    finish(backlog.pop(0))
-                runner.feed_device_begin(np.asarray(chunk, dtype=np.complex64))
-            elif own:
-                part = feed(chunk)
+            # a tail that waited for this block to show up
+            if state['tail'] is not None and state['tail'][0] == i - 1 and G > 1:
+                self.send_tail(*state['tail'])
+                state['tail'] = None
+            if own:
+                collect_flying()                               # this rank's previous block: G blocks back
+                if use_async:
+                    feed_begin(chunk)
+                    state['flying'] = i
+                    if is_root:
+                        backlog.append((i, 'flying'))
+                else:
+                    fin = finish_own(i, feed(chunk))
+                    if is_root:
+                        backlog.append((i, fin))
             else:
                 skip(chunk)
+                if is_root:
+                    backlog.append((i, None))
             if is_root:
-                backlog.append((i, part))
-                while len(backlog) > max(self.world - 1, 0) if own_async else backlog:
-                    finish(backlog.pop(0))
-            elif own:
-                self.send_part(part)
+                while len(backlog) > lag and backlog[0][1] != 'flying':
+                    deliver(backlog.pop(0))
+            if watchdog is not None:
+                watchdog.beat(i)
+        collect_flying()
+        state['tail'] = None                                   # the stream's last block has no successor
         while backlog:
-            finish(backlog.pop(0))
+            deliver(backlog.pop(0))
         self.flush()
         return results, packets
 
@@ -505,15 +607,20 @@ class GridShard:
     def owner_group(self, block_index):
         return int(block_index) % self.T
 
-    def run(self, runner, sample_source, sink=None, decoder=None):
+    def describe(self):
+        return self.doppler.describe() + ('' if self.blocks is None else '; ' + self.blocks.describe())
+
+    def run(self, runner, sample_source, sink=None, decoder=None, watchdog=None):
         """``runner``: a DemodulatorRunner built with ``shard=self.doppler``.  Every process iterates the same stream of
         new-sample slices (only the first rank of a group reads the samples of the blocks its group owns; the others take
         them from its broadcast).  Returns (results, packets) on process 0, ([], []) elsewhere."""
         if self.blocks is not None:
-            return self.blocks.run(runner, sample_source, sink=sink, decoder=decoder)
+            return self.blocks.run(runner, sample_source, sink=sink, decoder=decoder, watchdog=watchdog)
         for i, chunk in enumerate(sample_source):
             if self.owner_group(i) == self.g:
                 runner.feed_device(np.asarray(chunk, dtype=np.complex64))
             else:
                 runner.skip_block(chunk)
+            if watchdog is not None:
+                watchdog.beat(i)
         return [], []

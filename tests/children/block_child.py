@@ -15,7 +15,7 @@ import torch.distributed as dist               # noqa: E402
 from pycusdr_amd import config as cfg, signals as sg   # noqa: E402
 from pycusdr_amd.decoder import Decoder        # noqa: E402
 from pycusdr_amd.demodulator_process import DemodulatorRunner   # noqa: E402
-from pycusdr_amd.dist import BlockShard        # noqa: E402
+from pycusdr_amd.dist import BlockShard, StepWatchdog        # noqa: E402
 from pycusdr_amd.protocol import loadProtocol  # noqa: E402
 
 rank, world, local = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), int(os.environ['LOCAL_RANK'])
@@ -33,7 +33,10 @@ nblocks = (len(sig) - ov) // step
 chunks = [sig[ov + i * step: ov + (i + 1) * step] for i in range(nblocks)]
 run = DemodulatorRunner(conf, p, 'UHF-H')
 run.raw[:ov] = sig[:ov]
-res, packets = BlockShard().run(run, chunks, decoder=Decoder(conf, p))
+shard = BlockShard()
+dog = StepWatchdog(120.0, rank=rank, describe=shard.describe)       # a hand-back that never arrives: diagnosis + exit 3
+res, packets = shard.run(run, chunks, decoder=Decoder(conf, p), watchdog=dog)
+dog.stop()
 ok, why = True, []
 if rank == 0:
     plain = DemodulatorRunner(conf, p, 'UHF-H')

@@ -18,7 +18,7 @@ import torch                                   # noqa: E402
 import torch.distributed as dist               # noqa: E402
 from c5_common import c5_instance              # noqa: E402
 from pycusdr_amd.demodulator import UHF        # noqa: E402
-from pycusdr_amd.dist import DopplerShard      # noqa: E402
+from pycusdr_amd.dist import DopplerShard, StepWatchdog      # noqa: E402
 
 rank, world, local = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), int(os.environ['LOCAL_RANK'])
 backend = sys.argv[1] if len(sys.argv) > 1 else 'gloo'
@@ -39,8 +39,10 @@ for name in ('CC11xx', 'bench_BPSK'):
     sharded[name] = UHF.Demodulator(conf, inst[name]['proto'], 'UHF-H', shard=DopplerShard(group=group, device=dev))
     if rank == 0:
         plain[name] = UHF.Demodulator(conf, inst[name]['proto'], 'UHF-H')
+dog = StepWatchdog(180.0, rank=rank, describe=lambda: ' | '.join(f'{n}: {d.shard.describe()}' for n, d in sharded.items()))
 for rep in range(2):
     for name in ('CC11xx', 'bench_BPSK'):                      # the two streams alternate on the same devices
+        dog.beat()
         x = inst[name]['x']
         res = sharded[name].uploadAndFindCarrier(x if rank == 0 else None)
         full = sharded[name].shard.full_scores()
@@ -59,6 +61,7 @@ for rep in range(2):
         g = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(g, t)
         ok &= all(bool(torch.equal(g[0], q)) for q in g)
+dog.stop()
 print(json.dumps({'rank': rank, 'ok': bool(ok), 'failed': '; '.join(failed)}), flush=True)
 for d in list(sharded.values()) + list(plain.values()):
     d.close()

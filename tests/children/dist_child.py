@@ -15,7 +15,7 @@ import torch                                   # noqa: E402
 import torch.distributed as dist               # noqa: E402
 from pycusdr_amd import config as cfg, signals as sg   # noqa: E402
 from pycusdr_amd.demodulator import UHF        # noqa: E402
-from pycusdr_amd.dist import DopplerShard      # noqa: E402
+from pycusdr_amd.dist import DopplerShard, StepWatchdog      # noqa: E402
 from pycusdr_amd.protocol import loadProtocol  # noqa: E402
 
 rank, world, local = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), int(os.environ['LOCAL_RANK'])
@@ -39,7 +39,9 @@ spacing = float(np.median(np.abs(np.diff(sharded.doppCyperSymNorm[noise:].astype
 sig = sg.s1_stream(nblk, N, 1 << 10, 'GMSK', snr_db=12.0, seed=5)
 ok = True
 failed = []
+dog = StepWatchdog(120.0, rank=rank, describe=sharded.shard.describe)     # a collective nobody joins: diagnosis + exit 3
 for b in range(nblk):
+    dog.beat(b)
     x = sig[b * (N - 1024): b * (N - 1024) + N]
     res = sharded.uploadAndFindCarrier(x if rank == 0 else None)     # only rank 0 owns the stream
     full = sharded.shard.full_scores()
@@ -59,6 +61,7 @@ for b in range(nblk):
     g = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(g, t)
     ok &= all(bool(torch.equal(g[0], q)) for q in g)  # ... and every rank picked and demodulated the same
+dog.stop()
 print(json.dumps({'rank': rank, 'ok': bool(ok), 'failed': '; '.join(failed), 'even': bool(sharded.shard.even), 'noise_rows': int(sharded.doppIdxArrayOffset)}), flush=True)
 sharded.close()
 if plain is not None:

@@ -17,7 +17,7 @@ import torch.distributed as dist               # noqa: E402
 from pycusdr_amd import config as cfg, signals as sg   # noqa: E402
 from pycusdr_amd.decoder import Decoder        # noqa: E402
 from pycusdr_amd.demodulator_process import DemodulatorRunner   # noqa: E402
-from pycusdr_amd.dist import GridShard         # noqa: E402
+from pycusdr_amd.dist import GridShard, StepWatchdog         # noqa: E402
 from pycusdr_amd.protocol import loadProtocol  # noqa: E402
 
 rank, world, local = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), int(os.environ['LOCAL_RANK'])
@@ -40,7 +40,9 @@ chunks = [sig[ov + i * step: ov + (i + 1) * step] for i in range(nblocks)]
 grid = GridShard(bin_ranks, device=torch.device('cuda', local))
 run = DemodulatorRunner(conf, p, 'UHF-H', shard=grid.doppler)
 run.raw[:ov] = sig[:ov]
-res, packets = grid.run(run, chunks, decoder=Decoder(conf, p))
+dog = StepWatchdog(120.0, rank=rank, describe=grid.describe)      # a collective nobody joins: diagnosis + exit 3
+res, packets = grid.run(run, chunks, decoder=Decoder(conf, p), watchdog=dog)
+dog.stop()
 ok, why = True, []
 if rank == 0:
     plain = DemodulatorRunner(conf, p, 'UHF-H')

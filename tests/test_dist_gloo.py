@@ -29,7 +29,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, concurrent=True):
     """One rank: DopplerShard itself (CPU tensors over gloo) around the OracleBank stand-in: rank 0 broadcasts the
     block, every rank searches its bin slice, one all-reduce, the pick on every rank."""
     import sys
@@ -54,7 +54,8 @@ def _worker(rank, world, port, q):
     ok = True
     for sum_all, D in ((True, 10), (False, 10), (True, 7), (False, 7)):    # even slices: all-gather; uneven: all-reduce
         shifts = rs.randint(0, N, D)
-        shard = DopplerShard(device=torch.device('cpu'))
+        shard = DopplerShard(device=torch.device('cpu'), concurrent_broadcast=concurrent)
+        ok &= (shard.bcast_group is shard.group) == (not concurrent)        # single-communicator mode: ONE communicator
         lo, hi = shard.bin_range(D)
         bank = OracleBank(log2N, hi - lo, M, sum_all_masks=sum_all)
         bank.set_filters(masks)
@@ -62,6 +63,7 @@ def _worker(rank, world, port, q):
         shard.attach(bank, D, M, sum_all=sum_all)
         block = torch.from_numpy(x.view(np.float32).copy()) if rank == 0 else None
         idx, metric = shard.step(bank, lo, block)
+        ok &= shard.phase == 'between steps' and 'phase:' in shard.describe()
         single = orc.doppler_scores(X, masks, shifts, sum_all).astype(np.float32)
         sidx, smetric = orc.find_doppler_est(single, D, 0, sum_all)
         ok &= bool(np.array_equal(shard.full_scores(), single))       # adding exact zeros
@@ -86,11 +88,14 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(120)
-def test_sharded_scores_allreduce_world2():
+@pytest.mark.parametrize('concurrent', [True, False])
+def test_sharded_scores_allreduce_world2(concurrent):
+    """Both broadcast modes: a communicator of its own for the block broadcast (default), or the exchange's (single-communicator
+    mode: one program order of collectives per rank)."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, concurrent)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=100) for _ in procs]
@@ -250,10 +255,25 @@ def test_sharded_stream_is_contiguous_when_the_owner_changes():
     assert res[0][4] == res[1][4] > 10000 and res[0][5] == res[1][5] == 1      # one packet, on every rank
 
 
-def _worker_blockshard(rank, world, port, q):
-    """Time-chunk sharding: rank r runs the device stages of blocks r, r + G, ...; the root runs the sequential host stages
-    and the decoder in block order.  The bit stream, the alignment state and the packets must equal those of one process
-    running the whole stream."""
+def _plant_slips(run, slips):
+    """Make the symbol grid of chosen blocks start one symbol early / late (centres moved by -+ one symbol): what a timing
+    estimate that lands in the neighbouring symbol does.  The alignment against the previous block (DB:938-957) must repair
+    it -- drop or re-insert one bit at the window's start -- or the bit stream gains / loses a symbol there."""
+    orig = run.demod.demodulateDevice
+
+    def slipped():
+        rec = orig()
+        k = slips.get(run.count, 0)                # demodulateDevice runs before the runner counts the block
+        if k:
+            rec['centres'] = rec['centres'] + np.int32(k * 16)
+        return rec
+    run.demod.demodulateDevice = slipped
+
+
+def _worker_blockshard(rank, world, port, q, slips=None):
+    """Time-chunk sharding: rank r runs the device AND host stages of blocks r, r + G, ... (the previous block's tail comes
+    from its owner); the root runs the decoder in block order.  The bit stream, the alignment state and the packets must
+    equal those of one process running the whole stream."""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
@@ -265,7 +285,7 @@ def _worker_blockshard(rank, world, port, q):
     from pycusdr_amd import config as cfg
     from pycusdr_amd.decoder import Decoder
     from pycusdr_amd.demodulator_process import DemodulatorRunner
-    from pycusdr_amd.dist import BlockShard
+    from pycusdr_amd.dist import BlockShard, StepWatchdog
     from pycusdr_amd.protocol import loadProtocol
     dbm.MFBank = OracleBank
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -282,11 +302,18 @@ def _worker_blockshard(rank, world, port, q):
     shard = BlockShard()
     run = DemodulatorRunner(conf, p, 'UHF-H')
     run.raw[:ov] = sig[:ov]
-    res, packets = shard.run(run, chunks, decoder=Decoder({}, p, correlator=orc.sync_correlate))
+    if slips:
+        _plant_slips(run, slips)
+    dog = StepWatchdog(120.0, rank=rank, describe=shard.describe)
+    res, packets = shard.run(run, chunks, decoder=Decoder({}, p, correlator=orc.sync_correlate), watchdog=dog)
+    dog.stop()
     ok = True
+    repaired = 0
     if rank == 0:
         plain = DemodulatorRunner(conf, p, 'UHF-H')
         plain.raw[:ov] = sig[:ov]
+        if slips:
+            _plant_slips(plain, slips)
         ref, ref_packets = plain.run(chunks, decoder=Decoder({}, p, correlator=orc.sync_correlate))
         ok &= len(res) == len(ref) == nblocks
         for a, b in zip(res, ref):
@@ -297,9 +324,18 @@ def _worker_blockshard(rank, world, port, q):
         ok &= bool(np.array_equal(run.demod.poswinP, plain.demod.poswinP) and np.array_equal(run.demod.posSymEnd, plain.demod.posSymEnd))
         ok &= len(packets) == len(ref_packets) == 1 and bool(np.array_equal(packets[0].bits, ref_packets[0].bits))
         ok &= packets[0].checkPacketData() == ref_packets[0].checkPacketData()
+        if slips:
+            # the planted slips were really there and really repaired: blocks hand over a bit more or less than they do on
+            # the undisturbed grid, and yet the concatenated stream is the undisturbed stream, bit for bit
+            clean = DemodulatorRunner(conf, p, 'UHF-H')
+            clean.raw[:ov] = sig[:ov]
+            base, _ = clean.run(chunks)
+            moved = sum(1 for a, b in zip(res, base) if len(a['data']) != len(b['data']))
+            same = np.array_equal(np.concatenate([d['data'] for d in res]), np.concatenate([d['data'] for d in base]))
+            repaired = moved if same else -1
     else:
         ok &= res == [] and packets == [] and run.count == nblocks
-    q.put((rank, bool(ok), len(res)))
+    q.put((rank, bool(ok), len(res), repaired))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -310,6 +346,18 @@ def test_block_round_robin_equals_single_process_stream(world):
     res = _spawn(_worker_blockshard, world=world, timeout=280)
     assert all(r[1] for r in res), res
     assert res[0][2] == 27
+
+
+@pytest.mark.timeout(400)
+def test_block_round_robin_world8_repairs_slips_at_ownership_changes():
+    """Eight owners (C2-shaped work on a whole node), the alignment done by the owners: a symbol slip planted in the first
+    block of rank 0's second turn (block 8: its predecessor is rank 7's), in blocks 15, 16 (both sides of the next change from rank 7 to rank 0) and 23 is repaired exactly as
+    one process repairs it -- the tails forwarded between owners carry everything the repair needs."""
+    slips = {8: 1, 15: 1, 16: 1, 23: 1}
+    res = _spawn(_worker_blockshard, world=8, timeout=380, extra=(slips,))
+    assert all(r[1] for r in res), res
+    root = [r for r in res if r[0] == 0][0]
+    assert root[2] == 27 and root[3] >= len(slips)        # every slip moved at least one block boundary, and all were repaired
 
 
 def _worker_grid(rank, world, port, q, bin_ranks):
@@ -379,20 +427,28 @@ def test_bins_by_blocks_grid_equals_single_process_stream(world, bin_ranks):
 
 
 def test_block_shard_wire_format_round_trip():
-    """What an owner sends to the root: every array comes back with its dtype and values (INT32_MIN markers included)."""
+    """What travels under time-chunk sharding: the tail of a block (owner -> next owner) and the finished block (owner -> root);
+    every array comes back with its dtype and values."""
     from pycusdr_amd.dist import BlockShard
     rs = np.random.RandomState(3)
     S = 777
-    rec = {'spSym': 15.987654321, 'symbols': rs.randint(-2 ** 31, 8, S).astype(np.int32), 'centres': rs.randint(0, 1 << 20, S).astype(np.int32),
-           'trust': rs.randint(-128, 128, S).astype(np.int8), 'clipped': rs.randint(0, 1 << 20, 5).astype(np.int64)}
-    part = {'count': 41, 'timestamp': 0.0, 'doppler': -123.456, 'doppler_std': 7.5, 'SNR': float('nan'), 'time_device': 1e-3, 'rec': rec}
+    for dt in (np.uint8, np.bool_, np.float64):
+        tail = {'post': rs.randint(0, 2, 33).astype(dt), 'end': rs.randint(0, 2, 21).astype(dt), 'exact': True}
+        th, tb = BlockShard.pack_tail(17, tail)
+        assert th.dtype == np.float64 and len(th) == BlockShard.TAIL_HEADER and tb.dtype == np.uint8 and len(tb) == 54
+        i, back = BlockShard.unpack_tail(th, tb)
+        assert i == 17 and back['exact'] and all(back[k].dtype == dt and np.array_equal(back[k], tail[k]) for k in ('post', 'end'))
+    with pytest.raises(TypeError):
+        BlockShard.pack_tail(0, {'post': np.zeros(3, np.int32), 'end': np.zeros(3, np.int32), 'exact': True})
+    d = {'count': 41, 'doppler': -123.456, 'doppler_std': 7.5, 'SNR': float('nan'), 'spSymEst': 15.987654321, 'time_ms': 2.5,
+         'data': rs.randint(0, 2, S).astype(np.uint8), 'trust': rs.randint(0, 256, S).astype(np.uint8)}
     sh = BlockShard.__new__(BlockShard)
-    head, body = BlockShard.pack(sh, part)
-    assert head.dtype == np.float64 and len(head) == BlockShard.HEADER and body.dtype == np.uint8 and len(body) == 9 * S + 8 * 5
-    back = BlockShard.unpack(head, body, 1.0)
-    assert back['count'] == 41 and back['doppler'] == -123.456 and np.isnan(back['SNR']) and back['rec']['spSym'] == rec['spSym']
-    for k in ('symbols', 'centres', 'trust', 'clipped'):
-        assert back['rec'][k].dtype == rec[k].dtype and np.array_equal(back['rec'][k], rec[k]), k
-    empty = dict(part, rec=dict(rec, symbols=rec['symbols'][:0], centres=rec['centres'][:0], trust=rec['trust'][:0], clipped=rec['clipped'][:0]))
-    h2, b2 = BlockShard.pack(sh, empty)
-    assert len(b2) == 0 and len(BlockShard.unpack(h2, b2, 0.0)['rec']['symbols']) == 0
+    head, body = BlockShard.pack(sh, d, tail, 1e-3)
+    assert head.dtype == np.float64 and len(head) == BlockShard.HEADER and body.dtype == np.uint8 and len(body) == 2 * S + 54
+    back = BlockShard.unpack(head, body)
+    assert back['count'] == 41 and back['doppler'] == -123.456 and np.isnan(back['SNR']) and back['spSym'] == d['spSymEst']
+    assert np.array_equal(back['bits'], d['data']) and np.array_equal(back['trust'], d['trust']) and back['spent'] == 2.5e-3
+    assert all(np.array_equal(back['tail'][k], tail[k]) and back['tail'][k].dtype == tail[k].dtype for k in ('post', 'end'))
+    empty = dict(d, data=d['data'][:0], trust=d['trust'][:0])
+    h2, b2 = BlockShard.pack(sh, empty, {'post': tail['post'][:0], 'end': tail['end'][:0], 'exact': True}, 0.0)
+    assert len(b2) == 0 and len(BlockShard.unpack(h2, b2)['bits']) == 0
