@@ -181,8 +181,8 @@ DEVI cf mul_w16_1(cf x) { return cmul(x, mkc(MFB_C, MFB_S)); }
 DEVI cf mul_w16_3(cf x) { return cmul(x, mkc(MFB_S, MFB_C)); }
 DEVI cf mul_w16_9(cf x) { return cmul(x, mkc(-MFB_C, -MFB_S)); }
 
-template <int R, int O>
-DEVI void bfly(cf (&v)[16]) {
+template <int R, int O, int NV>
+DEVI void bfly(cf (&v)[NV]) {
     if constexpr (R == 2) {
         b2(v[O], v[O + 1]);
     } else if constexpr (R == 4) {
@@ -197,7 +197,7 @@ DEVI void bfly(cf (&v)[16]) {
         b2_bi(v[O + 4], v[O + 5]);  // v[O+5] carries W8^2 = i, folded into the butterfly
         b2(v[O + 6], v[O + 7]);
     } else {
-        static_assert(R == 16 && O == 0, "radix");
+        static_assert(R == 16 && O == 0 && NV == 16, "radix");
         b4(v[0], v[4], v[8], v[12]);
         b4(v[1], v[5], v[9], v[13]);
         b4(v[2], v[6], v[10], v[14]);
@@ -218,6 +218,7 @@ DEVI void bfly(cf (&v)[16]) {
         b4(v[12], v[13], v[14], v[15]);
     }
 }
+
 
 // ---- pass chain ----------------------------------------------------------------------------
 // Twiddles.  Every pass but the last multiplies output p of butterfly (prefix, t') by
@@ -286,6 +287,143 @@ DEVI void xsync() {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+}
+
+// ---- wave-local 2048-point transform: 32 points per lane, ONE exchange (seg_kernels.hpp, MFB_SEG_W32) --------------------
+// 2048 = 32 (registers) x 64 (lanes).  Lane l stands at position g = pi(l) = (l >> 1) + 32 (l & 1); register i of the input
+// holds element g + 64 i.
+//   1. 32-point transform over i, in registers  ->  B[g][p]
+//   2. twiddle W_2048^(g p) (31 per-lane factors, registers), row p of the exchange buffer <- B[g][p] (lane-contiguous stores)
+//   3. lane l' = 2 p' + h reads row p' sixteen bytes at a time: (C[j][p'], C[32 + j][p']), j < 32 -- the values the lanes 2j and
+//      2j + 1 wrote -- and combines them: h = 0: C1 + C2, h = 1: (C1 - C2) W_64^j  (the radix-2 level across the lane pair, done
+//      on the data the exchange delivers anyway; its twiddle comes from a 2 x 32 table in LDS)
+//   4. 32-point transform over j, in registers  ->  output m' of lane l' is element pi(l') + 64 m': the INPUT layout again.
+// (tests/test_fft_algebra.py holds the numpy model of exactly this.)  One LDS round trip per transform instead of the two of
+// the radix-16 chain, no cross-wave synchronisation at all.
+
+// a * (S w), a * (S conj(w)), a * (S i w), a * (S i conj(w)) with S = +-1, w wave-uniform (SGPR pair: the twiddles inside the
+// 32-point butterfly are a handful of constants; in VGPRs they would cost two registers each)
+template <int CONJ, int ROT, int NEG>
+DEVI cf cmul_k(cf a, cf w) {
+    cf p, d;
+    if constexpr (!CONJ && !ROT && !NEG)         // w
+        asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[0,1]\n\t"
+            "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d), "=&v"(p) : "v"(a), "s"(w));
+    else if constexpr (!CONJ && !ROT && NEG)     // -w = (-wx, -wy)
+        asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "=v"(d), "=&v"(p) : "v"(a), "s"(w));
+    else if constexpr (CONJ && !ROT && NEG)      // -conj(w) = (-wx, wy)
+        asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[0,1] neg_lo:[0,1]\n\t"
+            "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(d), "=&v"(p) : "v"(a), "s"(w));
+    else if constexpr (!CONJ && ROT && !NEG)     // i w = (-wy, wx)
+        asm("v_pk_mul_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,1]\n\t"
+            "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(d), "=&v"(p) : "v"(a), "s"(w));
+    else if constexpr (CONJ && ROT && !NEG)      // i conj(w) = (wy, wx)
+        asm("v_pk_mul_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[0,0]\n\t"
+            "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0]" : "=v"(d), "=&v"(p) : "v"(a), "s"(w));
+    else {                                       // -i conj(w) = (-wy, -wx)
+        static_assert(CONJ && ROT && NEG, "twiddle variant");
+        asm("v_pk_mul_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_hi:[0,1,0]" : "=v"(d), "=&v"(p) : "v"(a), "s"(w));
+    }
+    return d;
+}
+// i * x = (-x.y, x.x)
+DEVI cf mul_i(cf x) {
+    cf d;
+    asm("v_pk_add_f32 %0, 0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(x));
+    return d;
+}
+
+#define MFB_C32_1X 0.98078528040323044913f   // cos(pi/16), sin(pi/16)
+#define MFB_C32_1Y 0.19509032201612826785f
+#define MFB_C32_3X 0.83146961230254523708f   // cos(3 pi/16), sin(3 pi/16)
+#define MFB_C32_3Y 0.55557023301960222474f
+// register slot that holds output p = p1 + 4 p2 of the in-register 32-point transform below
+constexpr int slot32(int p) { return 8 * (p % 4) + rev(8, p / 4); }
+
+// 32-point inverse-sign transform in registers: 8 radix-4 butterflies over (t, t+8, t+16, t+24), twiddles W_32^(t p1), 4 radix-8
+// butterflies.  Output p sits in slot slot32(p).
+DEVI void bfly32(cf (&v)[32]) {
+    sfor<0, 8>([&](auto t) { constexpr int T = decltype(t)::value; b4(v[T], v[T + 8], v[T + 16], v[T + 24]); });
+    const cf c1 = mkc(MFB_C32_1X, MFB_C32_1Y), c2 = mkc(MFB_C, MFB_S), c3 = mkc(MFB_C32_3X, MFB_C32_3Y);
+    // slot t + 8 p1 carries W_32^(t p1)
+    v[1 + 8] = cmul_k<0, 0, 0>(v[1 + 8], c1);     // 1
+    v[1 + 16] = cmul_k<0, 0, 0>(v[1 + 16], c2);   // 2
+    v[1 + 24] = cmul_k<0, 0, 0>(v[1 + 24], c3);   // 3
+    v[2 + 8] = cmul_k<0, 0, 0>(v[2 + 8], c2);     // 2
+    v[2 + 16] = mul_w8_1(v[2 + 16]);              // 4
+    v[2 + 24] = cmul_k<1, 1, 0>(v[2 + 24], c2);   // 6 = i conj(W^2)
+    v[3 + 8] = cmul_k<0, 0, 0>(v[3 + 8], c3);     // 3
+    v[3 + 16] = cmul_k<1, 1, 0>(v[3 + 16], c2);   // 6
+    v[3 + 24] = cmul_k<0, 1, 0>(v[3 + 24], c1);   // 9 = i W^1
+    v[4 + 8] = mul_w8_1(v[4 + 8]);                // 4
+    v[4 + 16] = mul_i(v[4 + 16]);                 // 8 = i
+    v[4 + 24] = mul_w8_3(v[4 + 24]);              // 12
+    v[5 + 8] = cmul_k<1, 1, 0>(v[5 + 8], c3);     // 5 = i conj(W^3)
+    v[5 + 16] = cmul_k<0, 1, 0>(v[5 + 16], c2);   // 10 = i W^2
+    v[5 + 24] = cmul_k<1, 0, 1>(v[5 + 24], c1);   // 15 = -conj(W^1)
+    v[6 + 8] = cmul_k<1, 1, 0>(v[6 + 8], c2);     // 6
+    v[6 + 16] = mul_w8_3(v[6 + 16]);              // 12
+    v[6 + 24] = cmul_k<0, 0, 1>(v[6 + 24], c2);   // 18 = -W^2
+    v[7 + 8] = cmul_k<1, 1, 0>(v[7 + 8], c1);     // 7 = i conj(W^1)
+    v[7 + 16] = cmul_k<1, 0, 1>(v[7 + 16], c2);   // 14 = -conj(W^2)
+    v[7 + 24] = cmul_k<1, 1, 1>(v[7 + 24], c3);   // 21 = -i conj(W^3)
+    sfor<0, 4>([&](auto p1) { bfly<8, 8 * decltype(p1)::value>(v); });
+}
+
+struct W32Cfg {
+    static constexpr int ROW = 66;                 // complex elements per row of the exchange buffer (64 + 2: conflict-free both ways)
+    static constexpr int XCHG = 32 * ROW;          // per wave
+    static constexpr int TW2_STRIDE = 33;          // [h][j]: the two rows on different banks
+    static constexpr int TW2_ELEMS = 2 * TW2_STRIDE;
+};
+struct W32Regs {
+    cf tw1[32];          // W_2048^(pi(lane) p)
+    cf sig;              // (+1, +1) on even lanes, (-1, -1) on odd ones
+    const cf *tw2;       // this lane's row of the small table: [h][j] = h ? W_64^j : 1
+};
+// table: W_2048^j (inverse sign); ltw2: TW2_ELEMS elements of LDS, filled here by the whole workgroup (the caller synchronises)
+DEVI void w32_setup(W32Regs &r, const cf *__restrict__ table, cf *ltw2, const int lane, const int tid, const int nthreads) {
+    const int g = (lane >> 1) + 32 * (lane & 1);
+    sfor<1, 32>([&](auto p) { r.tw1[decltype(p)::value] = table[(g * decltype(p)::value) & 2047]; });
+    const float s = (lane & 1) ? -1.f : 1.f;
+    r.sig = mkc(s, s);
+    for (int e = tid; e < 64; e += nthreads) ltw2[(e >> 5) * W32Cfg::TW2_STRIDE + (e & 31)] = (e >> 5) ? table[32 * (e & 31)] : mkc(1.f, 0.f);
+    r.tw2 = ltw2 + (lane & 1) * W32Cfg::TW2_STRIDE;
+}
+// v: slot i holds element pi(lane) + 64 i.  store(n, value, slot, nu) as in fft_passes: natural index n = nu + pi(lane), nu = 64 m'.
+template <class Store>
+DEVI void fft_w32(cf (&v)[32], cf *xbuf, const int lane, const W32Regs &r, Store &store) {
+    bfly32(v);
+    {
+        cf *wr = xbuf + lane;
+        sfor<0, 32>([&](auto p) {
+            constexpr int P = decltype(p)::value;
+            cf val = v[slot32(P)];
+            if constexpr (P > 0) val = cmul(val, r.tw1[P]);
+            wr[P * W32Cfg::ROW] = val;
+        });
+    }
+    xsync<1>();
+    {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 *rd = reinterpret_cast<const f4 *>(xbuf + (lane >> 1) * W32Cfg::ROW);
+        sfor<0, 32>([&](auto j) {
+            constexpr int J = decltype(j)::value;
+            const f4 q = rd[J];
+            const cf c1 = mkc(q.x, q.y), c2 = mkc(q.z, q.w);
+            cf t = __builtin_elementwise_fma(c2, r.sig, c1);
+            if constexpr (J > 0) t = cmul(t, r.tw2[J]);
+            v[J] = t;
+        });
+    }
+    xsync<1>();      // the rows are rewritten by the next transform of this wave
+    bfly32(v);
+    sfor<0, 32>([&](auto m) {
+        constexpr int M = decltype(m)::value;
+        store(64 * M + ((lane >> 1) + 32 * (lane & 1)), v[slot32(M)], std::integral_constant<int, M>{}, std::integral_constant<int, 64 * M>{});
+    });
 }
 
 // v    : the thread's 16 points; on entry of pass 0 slot i holds element g + (L/16)*i

@@ -185,9 +185,10 @@ static inline cd tap(const Bank &b, int m, int r) {
 // for a layout length Te >= T (the kernel rounds the valid count L - Te + 1 down to whole register slots).
 // With this rotation the valid outputs of a segment that starts at sample b0 are i = 0 .. L-Te and
 // output i is y[(b0 + i + start + Te - 1) mod N] of the length-N formulation.
-// Storage order: [m][ii][g][e] = G_m[g + NT*(2*ii + e)], NT = L/16 -- the two register slots 2*ii, 2*ii+1
-// of transform lane g side by side, so that the kernel fetches them with one 16-byte load.
-static inline void segment_spectra(const Bank &b, int L, int Te, std::vector<float> *out) {
+// Storage order: [m][ii][g][e] = G_m[g + NT*(2*ii + e)], NT = L/ppl (ppl = points per transform lane: 16, or 32 for the
+// wave-local 2048-point kernel) -- the two register slots 2*ii, 2*ii+1 of transform lane g side by side, so that the kernel
+// fetches them with one 16-byte load.
+static inline void segment_spectra(const Bank &b, int L, int Te, std::vector<float> *out, int ppl = 16) {
     const Fft plan(L);
     out->assign((size_t)b.M * 2 * L, 0.f);
     std::vector<cd> buf(L);
@@ -197,8 +198,8 @@ static inline void segment_spectra(const Bank &b, int L, int Te, std::vector<flo
         for (int r = 0; r < b.T; ++r) buf[(r - (Te - 1)) & (L - 1)] = tap(b, m, r);
         plan.run(buf.data(), -1);
         float *o = out->data() + (size_t)m * 2 * L;
-        const int NT = L / 16;
-        for (int ii = 0; ii < 8; ++ii)
+        const int NT = L / ppl;
+        for (int ii = 0; ii < ppl / 2; ++ii)
             for (int g = 0; g < NT; ++g)
                 for (int e = 0; e < 2; ++e) {
                     const cd v = buf[g + NT * (2 * ii + e)] * scale;

@@ -300,15 +300,21 @@ static int attr_seg() {
     HIPCHK(hipFuncSetAttribute((const void *)k_seg<L, SEG_STORE, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
 #define MFB_ATTR_PV(PV_) HIPCHK(hipFuncSetAttribute((const void *)k_seg<L, SEG_REDUCE, PV_>, hipFuncAttributeMaxDynamicSharedMemorySize, b))
     MFB_ATTR_PV(-1);
-    MFB_ATTR_PV(8);
-    MFB_ATTR_PV(9);
-    MFB_ATTR_PV(10);
-    MFB_ATTR_PV(11);
-    MFB_ATTR_PV(12);
-    MFB_ATTR_PV(13);
-    MFB_ATTR_PV(14);
-    MFB_ATTR_PV(15);
-    MFB_ATTR_PV(16);
+    if constexpr (seg_ppl(L) == 32) {
+        MFB_ATTR_PV(16); MFB_ATTR_PV(17); MFB_ATTR_PV(18); MFB_ATTR_PV(19); MFB_ATTR_PV(20); MFB_ATTR_PV(21); MFB_ATTR_PV(22);
+        MFB_ATTR_PV(23); MFB_ATTR_PV(24); MFB_ATTR_PV(25); MFB_ATTR_PV(26); MFB_ATTR_PV(27); MFB_ATTR_PV(28); MFB_ATTR_PV(29);
+        MFB_ATTR_PV(30); MFB_ATTR_PV(31); MFB_ATTR_PV(32);
+    } else {
+        MFB_ATTR_PV(8);
+        MFB_ATTR_PV(9);
+        MFB_ATTR_PV(10);
+        MFB_ATTR_PV(11);
+        MFB_ATTR_PV(12);
+        MFB_ATTR_PV(13);
+        MFB_ATTR_PV(14);
+        MFB_ATTR_PV(15);
+        MFB_ATTR_PV(16);
+    }
 #undef MFB_ATTR_PV
     return MFB_OK;
 }
@@ -543,9 +549,9 @@ extern "C" int mfb_get_info(mfb_ctx *c, int *N1, int *N2, int *unique_filters) {
 // Valid outputs per complete segment: the largest multiple of NT = L/16 not above L - T + 1, so that
 // they are whole register slots (seg_kernels.hpp); 0 if fewer than half of a segment would be valid.
 static int seg_valid(int l, int T) {
-    const int L = 1 << l, NT = L / 16;
+    const int L = 1 << l, ppl = seg_ppl(L), NT = L / ppl;
     const int pv = (L - T + 1) / NT;
-    return pv >= 8 ? pv * NT : 0;
+    return pv >= ppl / 2 ? pv * NT : 0;
 }
 // Relative cost of one segment point per filter, MEASURED on MI355X at C2 (time x V / L, 48 taps, D = 256,
 // M = 8; tools/seg_probe.py): the 256-point kernel is by far the cheapest per point (one twiddled pass,
@@ -600,7 +606,7 @@ static int resolve_path(mfb_ctx *c) {
         const int L = 1 << l;
         if (c->segl != l || !c->d_G) {
             std::vector<float> G;
-            taps::segment_spectra(*c->bank, L, L - seg_valid(l, T) + 1, &G);
+            taps::segment_spectra(*c->bank, L, L - seg_valid(l, T) + 1, &G, seg_ppl(L));
             if (c->d_G) HIPCHK(hipFree(c->d_G));
             c->d_G = nullptr;
             HIPCHK(dev_alloc((void **)&c->d_G, G.size() * sizeof(float)));
@@ -623,7 +629,7 @@ static int resolve_path(mfb_ctx *c) {
                 taps::Bank sb;
                 c->MB = taps::span_basis(*c->bank, &sb);
                 std::vector<float> G;
-                if (c->MB > 0) taps::segment_spectra(sb, L, L - seg_valid(l, T) + 1, &G);
+                if (c->MB > 0) taps::segment_spectra(sb, L, L - seg_valid(l, T) + 1, &G, seg_ppl(L));
                 if (c->d_Gb) HIPCHK(hipFree(c->d_Gb));
                 c->d_Gb = nullptr;
                 c->gb_l = 0;
@@ -948,23 +954,27 @@ static int launch_seg_k(mfb_ctx *c, const SegArgs &a, int grid) {
     HIPCHK(hipGetLastError());
     return MFB_OK;
 }
-// pv: valid register slots of a complete segment (8..16) for the branch-free instantiation, -1 = masked
+// pv: valid register slots of a complete segment (half of the points per lane ... all of them) for the branch-free
+// instantiation, -1 = masked
+template <int L, int PV0, int PV1>
+static int launch_seg_pv(mfb_ctx *c, const SegArgs &a, int grid, int pv) {
+    if constexpr (PV0 > PV1) {
+        return MFB_ERR_UNSUPPORTED;
+    } else {
+        if (pv == PV0) return launch_seg_k<L, SEG_REDUCE, PV0>(c, a, grid);
+        return launch_seg_pv<L, PV0 + 1, PV1>(c, a, grid, pv);
+    }
+}
 template <int L>
 static int launch_seg_l(mfb_ctx *c, const SegArgs &a, int grid, int mode, int pv) {
     if (mode == SEG_STORE) return launch_seg_k<L, SEG_STORE, -1>(c, a, grid);
-    switch (pv) {
-        case -1: return launch_seg_k<L, SEG_REDUCE, -1>(c, a, grid);
-        case 8: return launch_seg_k<L, SEG_REDUCE, 8>(c, a, grid);
-        case 9: return launch_seg_k<L, SEG_REDUCE, 9>(c, a, grid);
-        case 10: return launch_seg_k<L, SEG_REDUCE, 10>(c, a, grid);
-        case 11: return launch_seg_k<L, SEG_REDUCE, 11>(c, a, grid);
-        case 12: return launch_seg_k<L, SEG_REDUCE, 12>(c, a, grid);
-        case 13: return launch_seg_k<L, SEG_REDUCE, 13>(c, a, grid);
-        case 14: return launch_seg_k<L, SEG_REDUCE, 14>(c, a, grid);
-        case 15: return launch_seg_k<L, SEG_REDUCE, 15>(c, a, grid);
-        case 16: return launch_seg_k<L, SEG_REDUCE, 16>(c, a, grid);
+    if constexpr (seg_ppl(L) == 32) {
+        if (pv == -1) return launch_seg_k<L, SEG_REDUCE, -1>(c, a, grid);
+        return launch_seg_pv<L, 16, 32>(c, a, grid, pv);
+    } else {
+        if (pv == -1) return launch_seg_k<L, SEG_REDUCE, -1>(c, a, grid);
+        return launch_seg_pv<L, 8, 16>(c, a, grid, pv);
     }
-    return MFB_ERR_UNSUPPORTED;
 }
 static int launch_seg(mfb_ctx *c, const SegArgs &a, int grid, int mode, int pv) {
     switch (c->segl) {
@@ -987,7 +997,7 @@ struct SegGeom {
 static SegGeom seg_geom(const mfb_ctx *c) {
     SegGeom g;
     const int L = 1 << c->segl;
-    g.NT = L / 16;
+    g.NT = L / seg_ppl(L);
     g.TEAM = g.NT < 64 ? 64 : g.NT;
     g.CT = g.TEAM / g.NT;
     g.TPW = seg_block_threads(g.NT) / g.TEAM;
@@ -1003,7 +1013,8 @@ static SegPlan plan_seg(const mfb_ctx *c, int dc, int nfilters, int nslots, int 
     SegPlan p;
     p.nsg = nslots >= 64 ? 8 : 1;
     // L = 256 runs three workgroups per CU only while a workgroup's LDS stays under 53 KiB: 8 filters per pass
-    int mpb = mpb_want > 0 ? mpb_want : (c->segl <= 8 ? 8 : SEG_MPB_MAX);
+    // (the wave-local 2048-point kernel keeps two workgroups per CU only while a workgroup's LDS stays under 80 KiB: 8 per pass)
+    int mpb = mpb_want > 0 ? mpb_want : ((c->segl <= 8 || seg_ppl(1 << c->segl) == 32) ? 8 : SEG_MPB_MAX);
     if (mpb > SEG_MPB_MAX) mpb = SEG_MPB_MAX;
     if (mpb > nfilters) mpb = nfilters;
     p.mgroups = (nfilters + mpb - 1) / mpb;

@@ -89,6 +89,13 @@ constexpr int seg_block_threads(int NT) { return NT <= 64 ? MFB_SEG_BLOCK : (NT 
 #ifndef MFB_SEG_G0EARLY
 #define MFB_SEG_G0EARLY 1
 #endif
+// 2048-point segments as ONE wave per segment, 32 points per lane, one LDS exchange per transform (fft_core.hpp, fft_w32)
+// instead of two-wave barrier teams with 16 points per lane and two exchanges.
+#ifndef MFB_SEG_W32
+#define MFB_SEG_W32 1
+#endif
+// points per lane of the L-point segment kernel
+constexpr int seg_ppl(int L) { return (L == 2048 && MFB_SEG_W32) ? 32 : 16; }
 
 struct SegArgs {
     const cf *x;         // time-domain block, complex64 [N]
@@ -120,7 +127,9 @@ struct SegArgs {
 
 template <int L>
 struct SegCfg {
-    static constexpr int NT = L / 16;
+    static constexpr int PPL = seg_ppl(L);        // points per lane
+    static constexpr bool W32 = PPL == 32;
+    static constexpr int NT = L / PPL;
     static constexpr int TEAM = NT < 64 ? 64 : NT;
     static constexpr int CT = TEAM / NT;          // segments side by side in a team
     static constexpr int BLOCK = seg_block_threads(NT);   // threads per workgroup
@@ -139,17 +148,17 @@ struct SegCfg {
     static constexpr bool DUAL = !SYNC && MFB_SEG_DUAL && !LONG3;
     static constexpr bool PP = !SYNC && MFB_SEG_PP && !LONG3 && !DUAL;
     static constexpr bool TWO_BUFFERS = PP || DUAL;
-    static constexpr bool PREFETCH = MFB_SEG_PREFETCH && !LONG3 && !DUAL;
+    static constexpr bool PREFETCH = MFB_SEG_PREFETCH && !LONG3 && !DUAL && !W32;
     static constexpr bool LTW = LONG3;
-    static constexpr int LTW_ELEMS = TwRegs<L, LTW>::LDS_ELEMS;
-    static constexpr int HALF = padlen(L) * CT;
+    static constexpr int LTW_ELEMS = W32 ? W32Cfg::TW2_ELEMS : TwRegs<L, LTW>::LDS_ELEMS;
+    static constexpr int HALF = W32 ? W32Cfg::XCHG : padlen(L) * CT;
     static constexpr int LDS_PER_TEAM = HALF * (TWO_BUFFERS ? 2 : 1);
     static constexpr int LDS_ELEMS = LDS_PER_TEAM * TPW;
-    static constexpr int STEP_ELEMS = (BLOCK / 64) * 16;     // 16 step phasors per wave
+    static constexpr int STEP_ELEMS = (BLOCK / 64) * PPL;    // one step phasor per register slot, per wave
     // Doppler search, L = 256: per-wave table of the relative mixing phasors W_N^(s*j), j < L (2 KiB a wave)
     static constexpr bool PHASE_TABLE = L <= 256;
     static constexpr int PHASE_ELEMS = PHASE_TABLE ? (BLOCK / 64) * L : 0;
-    static constexpr int WAVES = L <= 256 ? MFB_SEG_WAVES_SHORT : (SYNC ? MFB_SEG_WAVES_MID : MFB_SEG_WAVES_LONG);   // per SIMD
+    static constexpr int WAVES = L <= 256 ? MFB_SEG_WAVES_SHORT : (W32 ? 2 : (SYNC ? MFB_SEG_WAVES_MID : MFB_SEG_WAVES_LONG));   // per SIMD
     static constexpr size_t lds_bytes(int mpb) {   // mpb = 0: STORE mode (no phase table, no reduction stash)
         return (size_t)(LDS_ELEMS + STEP_ELEMS + LTW_ELEMS + (mpb ? PHASE_ELEMS : 0)) * sizeof(cf) +
                (size_t)(BLOCK / 64) * mpb * SEG_ACC_STRIDE * sizeof(float);
@@ -162,7 +171,8 @@ struct SegCfg {
 template <int L, int MODE, int PV>
 DEVI void seg_body(const SegArgs &a, const int blk) {
     using Cfg = SegCfg<L>;
-    constexpr int NT = Cfg::NT, CT = Cfg::CT, TPW = Cfg::TPW, TEAM = Cfg::TEAM, SYNC = Cfg::SYNC;
+    constexpr int NT = Cfg::NT, CT = Cfg::CT, TPW = Cfg::TPW, TEAM = Cfg::TEAM, SYNC = Cfg::SYNC, PPL = Cfg::PPL;
+    constexpr bool W32 = Cfg::W32;
     constexpr bool MASKED = PV < 0;
     static_assert(MODE == SEG_REDUCE || MASKED, "the STORE mode masks per lane");
     extern __shared__ __attribute__((aligned(16))) cf lds[];
@@ -177,21 +187,33 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int lt = tid % TEAM;
-    const int g = lt % NT;
-    const int col = lt / NT;
+    // position of this lane inside a transform (W32: lane pairs stand 32 apart, fft_core.hpp)
+    const int g = W32 ? ((lane >> 1) + 32 * (lane & 1)) : lt % NT;
+    const int col = W32 ? 0 : lt / NT;
     cf *mylds = lds + team * Cfg::LDS_PER_TEAM + col * padlen(L);
-    cf *mystep = lstep + wave * 16;
+    cf *mystep = lstep + wave * PPL;
     [[maybe_unused]] cf *myphase = lphase + wave * L;
     [[maybe_unused]] float *lacc = reinterpret_cast<float *>(lphase + (REL ? Cfg::PHASE_ELEMS : 0)) + wave * (a.mpb * SEG_ACC_STRIDE);
     int ebuf = 0;
 
-    TwRegs<L, Cfg::LTW> twr;
-    load_twiddles<L, Cfg::LTW>(twr, a.twL, g);
-    twr.ltab = ltw;
-    if constexpr (Cfg::LTW) {
-        fill_lds_twiddles<L>(ltw, a.twL, tid, Cfg::BLOCK);
+    TwRegs<W32 ? 16 : L, Cfg::LTW> twr;
+    [[maybe_unused]] W32Regs w32;
+    if constexpr (W32) {
+        w32_setup(w32, a.twL, ltw, lane, tid, Cfg::BLOCK);
         __syncthreads();
+    } else {
+        load_twiddles<L, Cfg::LTW>(twr, a.twL, g);
+        twr.ltab = ltw;
+        if constexpr (Cfg::LTW) {
+            fill_lds_twiddles<L>(ltw, a.twL, tid, Cfg::BLOCK);
+            __syncthreads();
+        }
     }
+    // one transform of this team on v; store(n, value, slot, nu) gets natural output n = nu + g
+    auto transform = [&](cf (&vv)[PPL], auto &store) {
+        if constexpr (W32) fft_w32(vv, mylds, lane, w32, store);
+        else fft_passes<L, 1, 0, true, Cfg::PP, Cfg::HALF, SYNC>(vv, mylds, ebuf, g, 0, twr, a.twL, store);
+    };
 
     // ---- which Doppler bins and which slots this team owns -----------------------------------
     int grp, mg, bstream, ssub;
@@ -240,35 +262,35 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
 #pragma unroll
             for (int r = 0; r < L / 64; ++r) myphase[lane + 64 * r] = phasor(((unsigned)shift * (unsigned)(lane + 64 * r)) & nmask);
         } else {
-            // step phasors W_N^(shift * NT * i), i < 16: the same for every lane, segment and filter of this bin
-            if (lane < 16) mystep[lane] = phasor(((unsigned)shift * (unsigned)(NT * lane)) & nmask);
+            // step phasors W_N^(shift * NT * i), i < PPL: the same for every lane, segment and filter of this bin
+            if (lane < PPL) mystep[lane] = phasor(((unsigned)shift * (unsigned)(NT * lane)) & nmask);
             if constexpr (REL) pg = phasor(((unsigned)shift * (unsigned)g) & nmask);
         }
         xsync<1>();     // wave-local: every wave fills and reads its own copy
 
         // x of a slot -> 16 registers (immediate offsets unless the slot wraps past the end of the block)
-        auto load_x = [&](cf (&dst)[16], int slot_) {
+        auto load_x = [&](cf (&dst)[PPL], int slot_) {
             const unsigned e0_ = (unsigned)(slot_ * CT + col) * (unsigned)a.V + (unsigned)g;
             const unsigned last = (unsigned)(slot_ * CT + CT - 1) * (unsigned)a.V + (unsigned)L;   // team-uniform
             if (__builtin_amdgcn_readfirstlane(last <= (unsigned)a.N ? 1 : 0)) {
                 const int vo_x = (int)(e0_ * sizeof(cf));
 #pragma unroll
-                for (int i = 0; i < 16; ++i) dst[i] = buf_load_cf(xr, vo_x, i * so_g);
+                for (int i = 0; i < PPL; ++i) dst[i] = buf_load_cf(xr, vo_x, i * so_g);
             } else {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) dst[i] = buf_load_cf(xr, (int)(((e0_ + (unsigned)(NT * i)) & nmask) * sizeof(cf)), 0);
+                for (int i = 0; i < PPL; ++i) dst[i] = buf_load_cf(xr, (int)(((e0_ + (unsigned)(NT * i)) & nmask) * sizeof(cf)), 0);
             }
         };
-        auto load_g = [&](cf (&dst)[16], int row) {
+        auto load_g = [&](cf (&dst)[PPL], int row) {
 #pragma unroll
-            for (int ii = 0; ii < 8; ++ii) buf_load_cf2(gr, vo_g2, row * (L * (int)sizeof(cf)) + ii * so_g2, dst[2 * ii], dst[2 * ii + 1]);
+            for (int ii = 0; ii < PPL / 2; ++ii) buf_load_cf2(gr, vo_g2, row * (L * (int)sizeof(cf)) + ii * so_g2, dst[2 * ii], dst[2 * ii + 1]);
         };
         // One set of 16 prefetch registers (MFB_SEG_PREFETCH) receives the first filter's spectrum while the forward
         // transform runs and the next filter's spectrum during every inverse transform.  (Also tried, one MI355X,
         // A/B of two builds: the next slot's x in the same registers during the last filter -- no gain, 20 spilled
         // VGPRs at the 3-wave budget; the next filter's product in the shadow of the LDS exchange -- 7 % slower than
         // the compiler's own schedule.)
-        [[maybe_unused]] cf gk[16];
+        [[maybe_unused]] cf gk[Cfg::PREFETCH ? PPL : 1];
 
         for (int it = 0; it < niter; ++it) {
             const int slot = s0 + it;
@@ -278,28 +300,28 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
             const unsigned e0 = b0 + (unsigned)g;
 
             // ---- the segment, mixed with e^{-2 pi i s n / N} and conjugated (forward via inverse) ----
-            cf v[16];
+            cf v[PPL];
             {
                 load_x(v, slot);
                 // conj(x) * W_N^{+t} = conj(x * e^{-2 pi i t / N})
                 if constexpr (PTAB) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = cmul_cj(v[i], myphase[g + NT * i]);
+                    for (int i = 0; i < PPL; ++i) v[i] = cmul_cj(v[i], myphase[g + NT * i]);
                 } else {
                     cf ph0 = pg;
                     if constexpr (!REL) ph0 = phasor(((unsigned)shift * e0) & nmask);   // N | 2^32: wrap-around is harmless
                     v[0] = cmul_cj(v[0], ph0);
 #pragma unroll
-                    for (int i = 1; i < 16; ++i) v[i] = cmul_cj(v[i], cmul(ph0, mystep[i]));
+                    for (int i = 1; i < PPL; ++i) v[i] = cmul_cj(v[i], cmul(ph0, mystep[i]));
                 }
             }
             const int r0 = a.rows ? a.rows[m0] : m0;
             if constexpr (Cfg::PREFETCH && MFB_SEG_G0EARLY) load_g(gk, r0);    // lands while the forward transform runs
-            cf A[16];                             // A[k] = conj(U[g + NT*k])
+            cf A[PPL];                            // A[k] = conj(U[g + NT*k])
             {
                 auto keep = [&](int, cf val, auto, auto nu) { A[decltype(nu)::value / NT] = val; };
                 if constexpr (Cfg::DUAL) xsync<SYNC>();        // the previous slot's last pair may still be read by other waves
-                fft_passes<L, 1, 0, true, Cfg::PP, Cfg::HALF, SYNC>(v, mylds, ebuf, g, 0, twr, a.twL, keep);
+                transform(v, keep);
             }
             if constexpr (Cfg::PREFETCH && !MFB_SEG_G0EARLY) load_g(gk, r0);
 
@@ -309,10 +331,10 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                 const int vseg = active ? min(a.V, a.N - (int)b0) : 0;     // <= 0 beyond the last segment
                 lim = vseg - g;                   // output slot k is valid for this lane iff k*NT < lim
             }
-            [[maybe_unused]] float envacc[16];
+            [[maybe_unused]] float envacc[PPL];
             if constexpr (MODE == SEG_STORE) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) envacc[k] = 0.f;
+                for (int k = 0; k < PPL; ++k) envacc[k] = 0.f;
             }
             int mi_first = 0;
             if constexpr (Cfg::DUAL && MODE == SEG_REDUCE) {
@@ -360,14 +382,14 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
             }
             for (int mi = mi_first; mi < nm; ++mi) {
                 const int rm = a.rows ? a.rows[m0 + mi] : (m0 + mi);
-                cf w[16];
+                cf w[PPL];
                 if constexpr (Cfg::PREFETCH) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) w[i] = cmul_cj(A[i], gk[i]);    // conj(A) * G = U * G
+                    for (int i = 0; i < PPL; ++i) w[i] = cmul_cj(A[i], gk[i]);    // conj(A) * G = U * G
                     if (mi + 1 < nm) load_g(gk, a.rows ? a.rows[m0 + mi + 1] : (m0 + mi + 1));
                 } else {
 #pragma unroll
-                    for (int ii = 0; ii < 8; ++ii) {
+                    for (int ii = 0; ii < PPL / 2; ++ii) {
                         cf g0, g1;
                         buf_load_cf2(gr, vo_g2, rm * (L * (int)sizeof(cf)) + ii * so_g2, g0, g1);
                         w[2 * ii] = cmul_cj(A[2 * ii], g0);
@@ -387,7 +409,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                             racc[k & 3] = __builtin_elementwise_fma(val, val, racc[k & 3]);
                         }
                     };
-                    fft_passes<L, 1, 0, true, Cfg::PP, Cfg::HALF, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, acc);
+                    transform(w, acc);
                     const cf rsum = (racc[0] + racc[1]) + (racc[2] + racc[3]);
                     lacc[mi * SEG_ACC_STRIDE + lane] = rsum.x + rsum.y;       // reduced over the lanes after the last filter
                 } else {
@@ -400,7 +422,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                         // same fp32 order as k_envelope: s = s + fma(re, re, im * im), filters ascending
                         if (in_env) envacc[k] = __fadd_rn(envacc[k], __fmaf_rn(val.x, val.x, __fmul_rn(val.y, val.y)));
                     };
-                    fft_passes<L, 1, 0, true, Cfg::PP, Cfg::HALF, SYNC>(w, mylds, ebuf, g, 0, twr, a.twL, put);
+                    transform(w, put);
                 }
             }
             if constexpr (MODE == SEG_REDUCE) {
@@ -428,7 +450,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                 if (a.env) {
                     const unsigned o0 = e0 + (unsigned)a.out_off;
 #pragma unroll
-                    for (int k = 0; k < 16; ++k)
+                    for (int k = 0; k < PPL; ++k)
                         if (k * NT < lim) a.env[(o0 + (unsigned)(k * NT)) & nmask] = envacc[k];
                 }
             }

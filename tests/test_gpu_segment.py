@@ -48,7 +48,8 @@ def test_segment_scores_match_oracle_and_twopass(log2L, sum_all):
         bank.set_search_path('segment', log2L)
         info = bank.get_search_path()
         L = 1 << log2L
-        assert info['log2L'] == log2L and info['valid_per_segment'] == ((L - 47) // (L // 16)) * (L // 16)   # whole register slots
+        nt = L // (32 if L == 2048 else 16)      # transform lanes: 16 points per lane; 32 in the wave-local 2048-point kernel
+        assert info['log2L'] == log2L and info['valid_per_segment'] == ((L - 47) // nt) * nt   # whole register slots
         bank.upload(x)
         idx, metric = bank.find_carrier()
         ds = bank.get_scores()
