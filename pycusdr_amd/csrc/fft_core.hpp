@@ -375,7 +375,7 @@ DEVI void bfly32(cf (&v)[32]) {
 struct W32Cfg {
     static constexpr int ROW = 66;                 // complex elements per row of the exchange buffer (64 + 2: conflict-free both ways)
     static constexpr int XCHG = 32 * ROW;          // per wave
-    static constexpr int TW2_STRIDE = 33;          // [h][j]: the two rows on different banks
+    static constexpr int TW2_STRIDE = 34;          // [h][j]: 16-byte aligned rows on different banks (read two factors at a time)
     static constexpr int TW2_ELEMS = 2 * TW2_STRIDE;
 };
 struct W32Regs {
@@ -406,18 +406,43 @@ DEVI void fft_w32(cf (&v)[32], cf *xbuf, const int lane, const W32Regs &r, Store
         });
     }
     xsync<1>();
+#ifndef MFB_W32_READS
+#define MFB_W32_READS 1
+#endif
+#if MFB_W32_READS == 1
     {
+        // (16-byte reads throughout: ds_read_b128 moves 16 bytes per lane in 4 LDS cycles, ds_read2_b64 -- what the compiler
+        // makes of two adjacent 8-byte reads -- in 8)
         typedef float f4 __attribute__((ext_vector_type(4)));
         const f4 *rd = reinterpret_cast<const f4 *>(xbuf + (lane >> 1) * W32Cfg::ROW);
+        const f4 *tw = reinterpret_cast<const f4 *>(r.tw2);
+        sfor<0, 16>([&](auto jj) {
+            constexpr int J = 2 * decltype(jj)::value;
+            const f4 q0 = rd[J], q1 = rd[J + 1], f = tw[J / 2];
+            cf t0 = __builtin_elementwise_fma(mkc(q0.z, q0.w), r.sig, mkc(q0.x, q0.y));
+            cf t1 = __builtin_elementwise_fma(mkc(q1.z, q1.w), r.sig, mkc(q1.x, q1.y));
+            if constexpr (J > 0) t0 = cmul(t0, mkc(f.x, f.y));
+            t1 = cmul(t1, mkc(f.z, f.w));
+            v[J] = t0;
+            v[J + 1] = t1;
+        });
+    }
+#else
+    {
+        // two sweeps of 8-byte reads: all 32 first halves go straight into v (every read in flight at once: no temporaries),
+        // then the second halves are folded in as they arrive.  (One 16-byte read per point needs four registers per read in
+        // flight beside v: the compiler kept three or four in flight and the wave sat in s_waitcnt.)
+        const cf *rd = xbuf + (lane >> 1) * W32Cfg::ROW;
+        sfor<0, 32>([&](auto j) { v[decltype(j)::value] = rd[2 * decltype(j)::value]; });
+        __builtin_amdgcn_sched_barrier(0);
         sfor<0, 32>([&](auto j) {
             constexpr int J = decltype(j)::value;
-            const f4 q = rd[J];
-            const cf c1 = mkc(q.x, q.y), c2 = mkc(q.z, q.w);
-            cf t = __builtin_elementwise_fma(c2, r.sig, c1);
+            cf t = __builtin_elementwise_fma(rd[2 * J + 1], r.sig, v[J]);
             if constexpr (J > 0) t = cmul(t, r.tw2[J]);
             v[J] = t;
         });
     }
+#endif
     xsync<1>();      // the rows are rewritten by the next transform of this wave
     bfly32(v);
     sfor<0, 32>([&](auto m) {

@@ -464,9 +464,11 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
 // s_waitcnt vmcnt(0).
 // The masked instantiations (tail of the search, demodulation) carry the per-lane limits and are not on the
 // critical path: they get the 2-wave budget (no spills).
+// (the masked forms of the wave-local 2048-point kernel hold 32 points, the spectrum, 31 twiddles AND the per-lane limits:
+// they get the whole register file -- one wave per SIMD -- instead of spilling 50 registers at the two-wave budget)
 template <int L, int PV>
 struct SegWaves {
-    static constexpr int value = PV < 0 ? 2 : SegCfg<L>::WAVES;
+    static constexpr int value = PV < 0 ? (SegCfg<L>::W32 ? 1 : 2) : SegCfg<L>::WAVES;
 };
 #define SEG_KERNEL_ATTRS(L_, PV_) \
     __launch_bounds__(SegCfg<L_>::BLOCK) __attribute__((amdgpu_waves_per_eu(SegWaves<L_, PV_>::value, SegWaves<L_, PV_>::value)))
