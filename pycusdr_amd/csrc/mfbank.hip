@@ -546,7 +546,7 @@ extern "C" int mfb_get_info(mfb_ctx *c, int *N1, int *N2, int *unique_filters) {
 }
 
 // ---- search path ---------------------------------------------------------------------------------
-// Valid outputs per complete segment: the largest multiple of NT = L/16 not above L - T + 1, so that
+// Valid outputs per complete segment: the largest multiple of NT = L / (points per lane) not above L - T + 1, so that
 // they are whole register slots (seg_kernels.hpp); 0 if fewer than half of a segment would be valid.
 static int seg_valid(int l, int T) {
     const int L = 1 << l, ppl = seg_ppl(L), NT = L / ppl;
@@ -562,8 +562,10 @@ static int seg_valid(int l, int T) {
 // GMSK bank, 256 ... 4096 points: 1.597 / 2.128 / 2.070 / 2.443 / 2.648 ms; CC11xx bank (384 taps) on five devices:
 // 2048 points 2.69-2.77 ms, 4096 points 2.90-2.96 ms (the 2048-point kernel gained 5 % from one team per workgroup);
 // BPSK bank (80 taps), 256 / 512 / 1024 points: 3.74 / 4.28 / 4.15 ms.  Figures with 32 workgroups per CU in the grid.
+// Round 4: the 2048-point kernel became one wave per segment with one LDS exchange per transform (seg_kernels.hpp, W32):
+// 2.51 against 2.72 ms on one device for the 384-tap bank (profiles/r04_long_filter.md), hence 2.20 -> 2.03.
 static double seg_cost(int l, int T) {
-    static const double per_point[13] = {0, 0, 0, 0, 0, 0, 0, 0, 1.35, 1.94, 2.02, 2.20, 2.55};
+    static const double per_point[13] = {0, 0, 0, 0, 0, 0, 0, 0, 1.35, 1.94, 2.02, MFB_SEG_W32 ? 2.03 : 2.20, 2.55};
     const int V = seg_valid(l, T);
     if (!V) return 1e30;
     return per_point[l] * (double)(1 << l) / (double)V;

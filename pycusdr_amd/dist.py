@@ -481,7 +481,10 @@ class BlockShard:
         backlog = []                     # root: blocks to decode, oldest first: (index, finished dict or None = to be received)
         first = [None]
 
+        self.stats = {'root_s': 0.0, 'root_blocks': 0, 'host_s': 0.0, 'own_blocks': 0}      # where the host time of this run went
+
         def deliver(entry):
+            t_in = time.perf_counter()
             i, fin = entry
             if fin is None:
                 r = self.recv_result(i)
@@ -499,9 +502,12 @@ class BlockShard:
                 sink(d)
             else:
                 results.append(d)
+            self.stats['root_s'] += time.perf_counter() - t_in
+            self.stats['root_blocks'] += 1
 
         def finish_own(i, part):
             """Device results of own block i are in: tail out, predecessor's tail in, host stage, hand over."""
+            t_in = time.perf_counter()
             tail = demod.overlapTail(part['rec'])
             if not tail['exact']:
                 raise ValueError('time-chunk sharding needs windows of at least overlapOffset + 2 symbols per block')
@@ -517,10 +523,11 @@ class BlockShard:
                 prev = self.recv_tail(i - 1)
             state['local_tail'] = (i, tail)
             d = runner.feed_host(part, prev_tail=prev)
-            if is_root:
-                return d, tail
-            self.send_result(d, tail, part['time_device'])
-            return None
+            if not is_root:
+                self.send_result(d, tail, part['time_device'])
+            self.stats['host_s'] += time.perf_counter() - t_in
+            self.stats['own_blocks'] += 1
+            return (d, tail) if is_root else None
 
         def collect_flying():
             if state['flying'] is None:

@@ -73,3 +73,102 @@ def test_two_level_twiddle_table():
     th = np.exp(2j * np.pi * np.arange(N >> lo) * (1 << lo) / N)
     t = np.arange(N)
     assert np.abs(th[t >> lo] * tl[t & ((1 << lo) - 1)] - np.exp(2j * np.pi * t / N)).max() < 1e-13
+
+
+# ---- the wave-local 2048-point transform (fft_core.hpp: bfly32, fft_w32; seg_kernels.hpp MFB_SEG_W32) ----------------------
+# Register-level model: 64 lanes x 32 registers, the same slot maps, exchange addresses, lane-pair combination and twiddles.
+def _b2(v, a, b):
+    t = v[a]
+    v[a], v[b] = t + v[b], t - v[b]
+
+
+def _b2_bi(v, a, b):
+    t, u = v[a], v[b]
+    v[a], v[b] = t + 1j * u, t - 1j * u
+
+
+def _b4(v, i0, i1, i2, i3):
+    a0, a1, a2, a3 = v[i0], v[i1], v[i2], v[i3]
+    t0, t1, t2, t3 = a0 + a2, a0 - a2, a1 + a3, a1 - a3
+    v[i0], v[i2], v[i1], v[i3] = t0 + t2, t0 - t2, t1 + 1j * t3, t1 - 1j * t3
+
+
+def _r8(v, O):
+    _b4(v, O, O + 2, O + 4, O + 6)
+    _b4(v, O + 1, O + 3, O + 5, O + 7)
+    v[O + 3] = v[O + 3] * np.exp(1j * np.pi / 4)
+    v[O + 7] = v[O + 7] * np.exp(3j * np.pi / 4)
+    _b2(v, O, O + 1)
+    _b2(v, O + 2, O + 3)
+    _b2_bi(v, O + 4, O + 5)
+    _b2(v, O + 6, O + 7)
+
+
+def _slot32(p):
+    """Register slot of output p = p1 + 4 p2 (slot32 of fft_core.hpp; rev(8, p2) = 2 (p2 % 4) + p2 / 4)."""
+    p1, p2 = p % 4, p // 4
+    return 8 * p1 + 2 * (p2 % 4) + p2 // 4
+
+
+# the 21 twiddles between the radix-4 and the radix-8 butterflies, as the kernel writes them: (slot, variant of c1/c2/c3/W8)
+_C = {1: np.exp(2j * np.pi / 32), 2: np.exp(4j * np.pi / 32), 3: np.exp(6j * np.pi / 32)}
+_TW32 = {(1, 1): _C[1], (1, 2): _C[2], (1, 3): _C[3], (2, 1): _C[2], (2, 2): np.exp(1j * np.pi / 4), (2, 3): 1j * np.conj(_C[2]),
+         (3, 1): _C[3], (3, 2): 1j * np.conj(_C[2]), (3, 3): 1j * _C[1], (4, 1): np.exp(1j * np.pi / 4), (4, 2): 1j,
+         (4, 3): np.exp(3j * np.pi / 4), (5, 1): 1j * np.conj(_C[3]), (5, 2): 1j * _C[2], (5, 3): -np.conj(_C[1]),
+         (6, 1): 1j * np.conj(_C[2]), (6, 2): np.exp(3j * np.pi / 4), (6, 3): -_C[2], (7, 1): 1j * np.conj(_C[1]),
+         (7, 2): -np.conj(_C[2]), (7, 3): -1j * np.conj(_C[3])}
+
+
+def _bfly32(v):
+    for t in range(8):
+        _b4(v, t, t + 8, t + 16, t + 24)
+    for (t, p1), w in _TW32.items():
+        assert abs(w - np.exp(2j * np.pi * t * p1 / 32)) < 1e-15       # every variant IS W_32^(t p1)
+        v[t + 8 * p1] = v[t + 8 * p1] * w
+    for p1 in range(4):
+        _r8(v, 8 * p1)
+
+
+def test_in_register_32_point_butterfly():
+    rs = np.random.RandomState(32)
+    x = rs.standard_normal(32) + 1j * rs.standard_normal(32)
+    v = [np.array([x[i]]) for i in range(32)]
+    _bfly32(v)
+    out = np.array([v[_slot32(p)][0] for p in range(32)])
+    assert np.abs(out - np.fft.ifft(x) * 32).max() < 1e-13
+    assert sorted(_slot32(p) for p in range(32)) == list(range(32))
+
+
+def w32_transform(x):
+    L, ROW = 2048, 66
+    lane = np.arange(64)
+    pos = (lane >> 1) + 32 * (lane & 1)                       # pi(lane)
+    v = [x[pos + 64 * i].astype(complex) for i in range(32)]  # register i of every lane
+    _bfly32(v)
+    lds = np.zeros(32 * ROW, complex)
+    for p in range(32):
+        lds[p * ROW + lane] = v[_slot32(p)] * np.exp(2j * np.pi * pos * p / L)       # tw1, lane-contiguous row p
+    row, h = lane >> 1, lane & 1
+    w = []
+    for j in range(32):
+        c1, c2 = lds[row * ROW + 2 * j], lds[row * ROW + 2 * j + 1]                  # ONE 16-byte read: lanes 2j and 2j + 1 wrote them
+        sig = np.where(h == 0, 1.0, -1.0)
+        tw2 = np.where(h == 0, 1.0, np.exp(2j * np.pi * j / 64))
+        w.append((c1 + sig * c2) * tw2)
+    _bfly32(w)
+    out = np.zeros(L, complex)
+    for m in range(32):
+        out[pos + 64 * m] = w[_slot32(m)]                     # output m' of lane l is element pi(l) + 64 m': the input layout
+    return out
+
+
+def test_wave_local_2048_point_transform_is_an_inverse_dft():
+    rs = np.random.RandomState(2048)
+    x = rs.standard_normal(2048) + 1j * rs.standard_normal(2048)
+    ref = np.fft.ifft(x) * 2048
+    assert np.abs(w32_transform(x) - ref).max() / np.abs(ref).max() < 1e-13
+    # exchange image: rows of 66 elements keep the 16-lane store groups and the 16-lane b128 read groups on distinct banks
+    ROW = 66
+    for grp in ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], list(range(4, 12)) + [16, 17, 18, 19, 28, 29, 30, 31]):
+        slots = {(((l >> 1) * ROW * 2) % 64) // 4 for l in grp}          # 16-byte slot (of 16 per 256-byte line) each pair reads, j = 0
+        assert len(slots) == len({l >> 1 for l in grp})

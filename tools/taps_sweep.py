@@ -1,7 +1,7 @@
 """Throughput of the Doppler search against filter length: random banks of T taps at C2's geometry (D = 256, M = 8, N = 2^20),
 the path the library chooses by itself and the two-pass path beside it.  Shows how the segment path runs out towards its limit
 (T <= 2049: at least half of a 4096-point segment valid) and what the fall to the two-pass path beyond it amounts to.
-usage: python tools/taps_sweep.py [T ...]"""
+usage: python tools/taps_sweep.py [T ...] [--also l,l,...]   (--also: segment lengths 2^l forced beside the chosen one)"""
 import sys
 
 import numpy as np
@@ -13,6 +13,11 @@ from pycusdr_amd.mfbank import MFBank        # noqa: E402
 
 log2N, D, M = 20, 256, 8
 N = 1 << log2N
+also = []
+if '--also' in sys.argv:
+    k = sys.argv.index('--also')
+    also = [int(v) for v in sys.argv[k + 1].split(',')]
+    del sys.argv[k:k + 2]
 taps = [int(t) for t in sys.argv[1:]] or [16, 48, 80, 100, 160, 256, 384, 512, 768, 1025, 1536, 2049, 2050, 4096]
 rs = np.random.RandomState(0)
 x = (rs.standard_normal(N) + 1j * rs.standard_normal(N)).astype(np.complex64)
@@ -55,5 +60,12 @@ for T in taps:
     assert rel < 1e-5, (T, rel)
     name = f"segment, L = {1 << info['log2L']}" if info['path'] == 'segment' else 'two-pass'
     v = info.get('valid_per_segment', 0) if info['path'] == 'segment' else '-'
-    print(f"| {T} | {name} | {v} | {ms:.2f} | {(N - 1024) / ms / 1e3:.0f} | {ms2:.2f} | {(N - 1024) / ms2 / 1e3:.0f} |", flush=True)
+    forced = ''
+    for l in also:
+        try:
+            bank.set_search_path('segment', l)
+            forced += f" L = {1 << l}: {timed():.2f} ms |"
+        except ValueError:
+            forced += f" L = {1 << l}: refused |"
+    print(f"| {T} | {name} | {v} | {ms:.2f} | {(N - 1024) / ms / 1e3:.0f} | {ms2:.2f} | {(N - 1024) / ms2 / 1e3:.0f} |" + forced, flush=True)
 bank.close()
