@@ -261,8 +261,10 @@ def run_block_shard(args, dist, rank, G, local_rank, dev):
                           'shard': 'blocks', 'world_size': G, 'backend': args.backend, 'blocks_timed': nb, 'path': pinfo,
                           'packets_found': len(packets), 'mean_block_ms_device_plus_host_on_root': host_ms,
                           'root_ms_per_block': round(shard.stats['root_s'] / max(shard.stats['root_blocks'], 1) * 1e3, 4),
+                          'root_wait_ms_per_block': round(shard.stats['root_wait_s'] / max(shard.stats['root_blocks'], 1) * 1e3, 4),
                           'owner_host_ms_per_own_block': round(shard.stats['host_s'] / max(shard.stats['own_blocks'], 1) * 1e3, 4),
-                          'root_note': 'root_ms_per_block: receive + result dict + decoder, the only work the root does for EVERY block; '
+                          'root_note': 'root_ms_per_block: result dict + decoder, the only work the root does for EVERY block (root_wait_ms_per_block: '
+                                       'time it sat in the receive of a block that had not arrived yet); '
                                        'owner_host_ms_per_own_block: tail exchange + bit lookup + alignment + hand-over, done by each owner for its own blocks',
                           'units': 'samples of the one physical stream (every block is processed once)'},
                'roofline': segment_roofline_core(pinfo, args.bins, Mu, counts[0], kms[0]) if pinfo['path'] == 'segment' else None,

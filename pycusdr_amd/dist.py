@@ -481,27 +481,54 @@ class BlockShard:
         backlog = []                     # root: blocks to decode, oldest first: (index, finished dict or None = to be received)
         first = [None]
 
-        self.stats = {'root_s': 0.0, 'root_blocks': 0, 'host_s': 0.0, 'own_blocks': 0}      # where the host time of this run went
+        # where the host time of this run went: the root's work per block (result dict + decoder) apart from its waiting for
+        # the block to arrive; an owner's work per own block (tail exchange, bit lookup, alignment, hand-over)
+        self.stats = {'root_s': 0.0, 'root_wait_s': 0.0, 'root_blocks': 0, 'host_s': 0.0, 'own_blocks': 0}
+
+        split = decoder is not None and hasattr(decoder, 'findFrames_begin')
+        if split and hasattr(decoder, 'prepare'):
+            decoder.prepare()
+        searching = []                   # the result dict whose bits the decoder is searching right now
+
+        def emit(d):
+            if sink is not None:
+                sink(d)
+            else:
+                results.append(d)
+
+        def finish_search():
+            if searching:
+                d = searching.pop()
+                pk, _, nsync = decoder.findFrames_end()
+                d['numSyncSig'] = nsync
+                packets.extend(pk)
+                emit(d)
 
         def deliver(entry):
             t_in = time.perf_counter()
             i, fin = entry
             if fin is None:
                 r = self.recv_result(i)
+                self.stats['root_wait_s'] += time.perf_counter() - t_in
+                t_in = time.perf_counter()
                 d = runner.compose_result(r['count'], time.time(), r['doppler'], r['doppler_std'], r['SNR'], r['bits'], r['trust'],
                                           r['spSym'], r['spent'])
                 tail = r['tail']
             else:
                 d, tail = fin
             demod.poswinP, demod.posSymEnd = tail['post'], tail['end']          # the root carries the stream's alignment state
-            if decoder is not None:
-                pk, _, nsync = decoder.findFrames(d['data'], 0)
-                d['numSyncSig'] = nsync
-                packets.extend(pk)
-            if sink is not None:
-                sink(d)
+            if split:
+                # the decoder's two searches of this block run on the device while the root goes on; their hits are collected,
+                # and the packet state machine run, right before the next block's bits go in (as run_stream does)
+                finish_search()
+                decoder.findFrames_begin(d['data'], 0)
+                searching.append(d)
             else:
-                results.append(d)
+                if decoder is not None:
+                    pk, _, nsync = decoder.findFrames(d['data'], 0)
+                    d['numSyncSig'] = nsync
+                    packets.extend(pk)
+                emit(d)
             self.stats['root_s'] += time.perf_counter() - t_in
             self.stats['root_blocks'] += 1
 
@@ -573,6 +600,10 @@ class BlockShard:
         state['tail'] = None                                   # the stream's last block has no successor
         while backlog:
             deliver(backlog.pop(0))
+        if is_root:
+            t_in = time.perf_counter()
+            finish_search()
+            self.stats['root_s'] += time.perf_counter() - t_in
         self.flush()
         return results, packets
 
