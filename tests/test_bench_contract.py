@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_stored_bench_line_follows_the_contract():
-    line = open(os.path.join(ROOT, 'profiles', 'r03_bench.json')).read().strip().splitlines()[-1]
+    line = open(os.path.join(ROOT, 'profiles', 'r04_bench.json')).read().strip().splitlines()[-1]
     d = json.loads(line)
     base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
     assert base['metric'].startswith(d['metric']) and d['unit'] == 'Msamples/s'      # BASELINE adds "at 1/2/4/8 GPUs"; n_gpus says which
@@ -35,5 +35,14 @@ def test_stored_bench_line_follows_the_contract():
     assert set(banks) == {'CC11xx', 'bench_BPSK'} and d['config']['c3']['D'] == 1024
     for b in list(banks.values()) + [d['config']['c3']]:
         assert b['path']['path'] == 'segment' and 0 < b['roofline']['frac'] < 1 and b['ms_per_step'] > b['roofline']['avg_launch_ms']
+    # the same figures as flat scalars (what a reader that drops nested config objects still sees), and the repeat statistics
+    c = d['config']
+    assert c['repeats'] >= 5 and c['ms_per_step_min'] <= d['ms_per_step'] <= c['ms_per_step_max'] and c['untimed_steps_before'] >= d['warmup']
+    assert c['ms_per_step_max'] / c['ms_per_step_min'] < 1.05                           # taken at the settled clock
+    assert c['cc11xx_msamples'] == banks['CC11xx']['msamples'] and c['cc11xx_roofline_frac'] == banks['CC11xx']['roofline']['frac']
+    assert c['bpsk_msamples'] == banks['bench_BPSK']['msamples'] and c['c3_roofline_frac'] == c['c3']['roofline']['frac']
+    assert c['twopass_msamples'] > 100 and 0.4 < c['twopass_hbm_frac'] < 1 and 1.0 <= c['twopass_traffic_over_alg'] < 1.3
+    assert c['sync_streams_per_s'] == c['sync_correlator']['streams_per_s'] and c['roofline_frac'] == r['frac']
+    assert banks['CC11xx']['path']['log2L'] == 11 and banks['CC11xx']['roofline']['frac'] > 0.46      # the wave-local 2048-point kernel
     sc = d['config']['sync_correlator']
     assert sc['exact_vs_np_convolve_stream0'] and sc['device_ms'] < sc['call_ms'] and 0 < sc['pcie_frac_of_63GBps'] < 1
