@@ -597,7 +597,19 @@ class BlockShard:
             if watchdog is not None:
                 watchdog.beat(i)
         collect_flying()
-        state['tail'] = None                                   # the stream's last block has no successor
+        state['tail'] = None                                   # the stream's last block has no successor in this call ...
+        # ... but the NEXT call's first block (index 0 again: rank 0's) continues the stream: rank 0 must end up with the last
+        # block's tail as its alignment state.  The root gets it with the finished block; any other rank 0 gets it from the owner.
+        last = state['seen']
+        if G > 1 and last >= 0 and self.root != 0 and self.owner(last) != 0:
+            if self.owner(last) == self.rank:
+                head, body = self.pack_tail(last, state['local_tail'][1])
+                self._isend(head, body, 0, self.TAG_TAIL)
+            elif self.rank == 0:
+                head, body = self._recv(self.owner(last), self.TAIL_HEADER, lambda h: int(h[1]) + int(h[2]),
+                                        f'the tail of the last block {last}', self.TAG_TAIL)
+                tail = self.unpack_tail(head, body)[1]
+                demod.poswinP, demod.posSymEnd = tail['post'], tail['end']
         while backlog:
             deliver(backlog.pop(0))
         if is_root:

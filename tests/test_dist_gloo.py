@@ -270,7 +270,7 @@ def _plant_slips(run, slips):
     run.demod.demodulateDevice = slipped
 
 
-def _worker_blockshard(rank, world, port, q, slips=None):
+def _worker_blockshard(rank, world, port, q, slips=None, root_rank=0, cut=None):
     """Time-chunk sharding: rank r runs the device AND host stages of blocks r, r + G, ... (the previous block's tail comes
     from its owner); the root runs the decoder in block order.  The bit stream, the alignment state and the packets must
     equal those of one process running the whole stream."""
@@ -299,17 +299,23 @@ def _worker_blockshard(rank, world, port, q, slips=None):
     sig, _ = _hopping_stream(N, ov, nblocks, np.linspace(-3000, 3000, nblocks))
     step = N - ov
     chunks = [sig[ov + i * step: ov + (i + 1) * step] for i in range(nblocks)]
-    shard = BlockShard()
+    shard = BlockShard(root=root_rank)
     run = DemodulatorRunner(conf, p, 'UHF-H')
     run.raw[:ov] = sig[:ov]
     if slips:
         _plant_slips(run, slips)
     dog = StepWatchdog(120.0, rank=rank, describe=shard.describe)
-    res, packets = shard.run(run, chunks, decoder=Decoder({}, p, correlator=orc.sync_correlate), watchdog=dog)
+    dec = Decoder({}, p, correlator=orc.sync_correlate)
+    if cut is None:
+        res, packets = shard.run(run, chunks, decoder=dec, watchdog=dog)
+    else:           # the stream in two calls: the second call's first block continues the first call's last
+        res, packets = shard.run(run, chunks[:cut], decoder=dec, watchdog=dog)
+        more, pk = shard.run(run, chunks[cut:], decoder=dec, watchdog=dog)
+        res, packets = res + more, packets + pk
     dog.stop()
     ok = True
     repaired = 0
-    if rank == 0:
+    if rank == root_rank:
         plain = DemodulatorRunner(conf, p, 'UHF-H')
         plain.raw[:ov] = sig[:ov]
         if slips:
@@ -346,6 +352,16 @@ def test_block_round_robin_equals_single_process_stream(world):
     res = _spawn(_worker_blockshard, world=world, timeout=280)
     assert all(r[1] for r in res), res
     assert res[0][2] == 27
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('root,cut', [(0, 13), (1, 14), (2, 10)])
+def test_block_round_robin_stream_in_two_calls_any_root(root, cut):
+    """The stream handed over in two ``run`` calls (the second call's block 0 continues the first call's last block, whoever owned
+    it), with the root on any rank: the same blocks, alignment state and packet as one process on the whole stream."""
+    res = _spawn(_worker_blockshard, world=3, timeout=280, extra=(None, root, cut))
+    assert all(r[1] for r in res), res
+    assert [r[2] for r in res] == [27 if r[0] == root else 0 for r in res]
 
 
 @pytest.mark.timeout(400)
