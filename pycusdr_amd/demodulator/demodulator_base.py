@@ -366,7 +366,8 @@ class Demodulator:
     def _snr_band_capacity(self, windowWidth):
         """Longest spectrum window ``computeSNR`` can ask for (reference DB:635-667), over every (low, high) the pick can
         produce: high = low or low + 1.  Rounded up to a power of two, at least 256 elements."""
-        N, sh = self.Nfft, self.doppCyperSymNorm.astype(np.int64)
+        # (the noise-reference rows in front of the table never take part in a pick: its index starts behind them, CU:536)
+        N, sh = self.Nfft, self.doppCyperSymNorm[self.doppIdxArrayOffset:].astype(np.int64)
         lo = np.concatenate((sh, sh[:-1]))
         hi = np.concatenate((sh, sh[1:]))
 

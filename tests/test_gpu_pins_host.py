@@ -53,7 +53,10 @@ def test_pick_stage_of_the_block_path_equals_reference(hg, name):
     picks = np.stack((hg[p + 'pick'], hg[p + 'metric']), axis=1)
     triples = np.tile(np.float32([d.Nfft / d.spsym, 0.5, 1.0]), (len(picks), 1))
     out = d.bank.debug_block_scalars(picks, triples, d.spsymMin, 5)
-    assert d.bank.BAND_CAPACITY >= max(max(r['band_len']) for r in out)           # the capacity rule covers every pick
+    # the capacity rule covers every pick the device can produce (an index in front of the first Doppler bin -- between the
+    # noise-reference row and the table -- cannot come out of findDopplerEst; such injected values exercise the arithmetic only)
+    doff = d.doppIdxArrayOffset
+    assert d.bank.BAND_CAPACITY >= max(max(r['band_len']) for r, pk in zip(out, picks) if not pk[0] < doff)
     for i, r in enumerate(out):
         blk = dict(r, bands=windows(X, r['band_pieces']))
         assert [len(b) for b in blk['bands']] == list(r['band_len'])
