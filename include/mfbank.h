@@ -81,7 +81,7 @@ int mfb_get_tuning(mfb_ctx *ctx, int *doppler_chunk, int *masks_per_block, int *
  * implementations with identical results (within fp32 rounding, ~1e-7):
  *   MFB_PATH_SEGMENT  single-pass overlap-save: mfb_set_filters measures the impulse-response support
  *                     T of the bank (every shipped protocol: 48...640 taps); for T <= L/2 the block is cut
- *                     into L-point segments (L = 2^log2L, 256...4096), each mixed to the Doppler shift in
+ *                     into L-point segments (L = 2^log2L, 256...8192), each mixed to the Doppler shift in
  *                     time, transformed, multiplied by the L-point filter spectra, transformed back and
  *                     reduced -- in registers and LDS, with no length-N intermediate in HBM.
  *   MFB_PATH_TWOPASS  length-N two-pass transforms through an HBM intermediate (any filter).

@@ -296,7 +296,7 @@ static int attr_p2() {
 }
 template <int L>
 static int attr_seg() {
-    const int b = (int)SegCfg<L>::lds_bytes(SEG_MPB_MAX);
+    const int b = (int)SegCfg<L>::lds_bytes(L == 8192 ? 8 : SEG_MPB_MAX);     // (8192 points: 157 KiB with 8 filters per pass is all a CU has)
     HIPCHK(hipFuncSetAttribute((const void *)k_seg<L, SEG_STORE, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
 #define MFB_ATTR_PV(PV_) HIPCHK(hipFuncSetAttribute((const void *)k_seg<L, SEG_REDUCE, PV_>, hipFuncAttributeMaxDynamicSharedMemorySize, b))
     MFB_ATTR_PV(-1);
@@ -337,7 +337,8 @@ static int set_kernel_attributes(const mfb_ctx *c) {
     if ((rc = attr_seg<512>())) return rc;
     if ((rc = attr_seg<1024>())) return rc;
     if ((rc = attr_seg<2048>())) return rc;
-    return attr_seg<4096>();
+    if ((rc = attr_seg<4096>())) return rc;
+    return attr_seg<8192>();
 }
 
 static int create_impl(mfb_ctx *c) {
@@ -548,6 +549,8 @@ extern "C" int mfb_get_info(mfb_ctx *c, int *N1, int *N2, int *unique_filters) {
 // ---- search path ---------------------------------------------------------------------------------
 // Valid outputs per complete segment: the largest multiple of NT = L / (points per lane) not above L - T + 1, so that
 // they are whole register slots (seg_kernels.hpp); 0 if fewer than half of a segment would be valid.
+#define SEG_LOG2L_MAX 13      // 8192-point segments: filters of up to 4097 taps
+#define SEG_TWOPASS_COST 6.45  // the two-pass path in the units of seg_cost (ms per block at C2's geometry)
 static int seg_valid(int l, int T) {
     const int L = 1 << l, ppl = seg_ppl(L), NT = L / ppl;
     const int pv = (L - T + 1) / NT;
@@ -563,18 +566,20 @@ static int seg_valid(int l, int T) {
 // 2048 points 2.69-2.77 ms, 4096 points 2.90-2.96 ms (the 2048-point kernel gained 5 % from one team per workgroup);
 // BPSK bank (80 taps), 256 / 512 / 1024 points: 3.74 / 4.28 / 4.15 ms.  Figures with 32 workgroups per CU in the grid.
 // Round 4: the 2048-point kernel became one wave per segment with one LDS exchange per transform (seg_kernels.hpp, W32):
-// 2.51 against 2.72 ms on one device for the 384-tap bank (profiles/r04_long_filter.md), hence 2.20 -> 2.03.
+// 2.51 against 2.72 ms on one device for the 384-tap bank (profiles/r04_long_filter.md), hence 2.20 -> 2.03.  8192 points (one
+// eight-wave team per CU, four passes): 4.67 ms at 2049 taps, 5.05 at 2050, 5.48 at 3000, 6.61 at 4097 -> 3.45 per point; in
+// these units the two-pass path costs 6.45 whatever the filter (6.5 ms), so the longest filters of the range stay there.
 static double seg_cost(int l, int T) {
-    static const double per_point[13] = {0, 0, 0, 0, 0, 0, 0, 0, 1.35, 1.94, 2.02, MFB_SEG_W32 ? 2.03 : 2.20, 2.55};
+    static const double per_point[14] = {0, 0, 0, 0, 0, 0, 0, 0, 1.35, 1.94, 2.02, MFB_SEG_W32 ? 2.03 : 2.20, 2.55, 3.45};
     const int V = seg_valid(l, T);
     if (!V) return 1e30;
     return per_point[l] * (double)(1 << l) / (double)V;
 }
 
-static int choose_segl(const mfb_ctx *c, int T) {
+static int choose_segl(const mfb_ctx *c, int T, bool may_decline) {
     int best = 0;
     double bc = 1e30;
-    for (int l = 8; l <= 12; ++l) {
+    for (int l = 8; l <= SEG_LOG2L_MAX; ++l) {
         if (!seg_valid(l, T) || (4 << l) > c->N) continue;    // at least half of every segment valid, >= 4 segments
         const double cost = seg_cost(l, T);
         if (cost < bc) {
@@ -582,6 +587,8 @@ static int choose_segl(const mfb_ctx *c, int T) {
             best = l;
         }
     }
+    // barely half of an 8192-point segment valid: the two-pass path is no slower (unless the caller insists on segments)
+    if (may_decline && bc > SEG_TWOPASS_COST) return 0;
     return best;
 }
 
@@ -593,9 +600,9 @@ static int resolve_path(mfb_ctx *c) {
     int l = 0;
     if (c->path_req != MFB_PATH_TWOPASS) {
         if (c->segl_req) {
-            if (c->segl_req >= 8 && c->segl_req <= 12 && seg_valid(c->segl_req, T) && (2 << c->segl_req) <= c->N) l = c->segl_req;
+            if (c->segl_req >= 8 && c->segl_req <= SEG_LOG2L_MAX && seg_valid(c->segl_req, T) && (2 << c->segl_req) <= c->N) l = c->segl_req;
         } else {
-            l = choose_segl(c, T);
+            l = choose_segl(c, T, c->path_req == MFB_PATH_AUTO);
         }
     }
     if (c->path_req == MFB_PATH_SEGMENT && !l) return MFB_ERR_UNSUPPORTED;
@@ -667,7 +674,7 @@ extern "C" int mfb_set_search_path(mfb_ctx *c, int path, int log2L, int wg_per_c
     if (!c || path < 0 || path > MFB_PATH_SEGMENT || log2L < 0 || wg_per_cu < 0 || wg_per_cu > 64 || filters_per_pass < 0 ||
         filters_per_pass > SEG_MPB_MAX)
         return MFB_ERR_ARG;
-    if (log2L && (log2L < 8 || log2L > 12)) return MFB_ERR_UNSUPPORTED;
+    if (log2L && (log2L < 8 || log2L > SEG_LOG2L_MAX)) return MFB_ERR_UNSUPPORTED;
     HIPCHK(hipSetDevice(c->device));
     const int old_path = c->path_req, old_l = c->segl_req, old_wpc = c->seg_wpc, old_mpb = c->seg_mpb;
     c->path_req = path;
@@ -985,6 +992,7 @@ static int launch_seg(mfb_ctx *c, const SegArgs &a, int grid, int mode, int pv) 
         case 10: return launch_seg_l<1024>(c, a, grid, mode, pv);
         case 11: return launch_seg_l<2048>(c, a, grid, mode, pv);
         case 12: return launch_seg_l<4096>(c, a, grid, mode, pv);
+        case 13: return launch_seg_l<8192>(c, a, grid, mode, pv);
     }
     return MFB_ERR_UNSUPPORTED;
 }
@@ -1016,7 +1024,9 @@ static SegPlan plan_seg(const mfb_ctx *c, int dc, int nfilters, int nslots, int 
     p.nsg = nslots >= 64 ? 8 : 1;
     // L = 256 runs three workgroups per CU only while a workgroup's LDS stays under 53 KiB: 8 filters per pass
     // (the wave-local 2048-point kernel keeps two workgroups per CU only while a workgroup's LDS stays under 80 KiB: 8 per pass)
-    int mpb = mpb_want > 0 ? mpb_want : ((c->segl <= 8 || seg_ppl(1 << c->segl) == 32) ? 8 : SEG_MPB_MAX);
+    // (so does the 8192-point kernel: its one team per CU has 157 KiB with 8 filters per pass)
+    int mpb = mpb_want > 0 ? mpb_want : ((c->segl <= 8 || c->segl == 13 || seg_ppl(1 << c->segl) == 32) ? 8 : SEG_MPB_MAX);
+    if (c->segl == 13 && mpb > 8) mpb = 8;
     if (mpb > SEG_MPB_MAX) mpb = SEG_MPB_MAX;
     if (mpb > nfilters) mpb = nfilters;
     p.mgroups = (nfilters + mpb - 1) / mpb;
@@ -1028,7 +1038,7 @@ static SegPlan plan_seg(const mfb_ctx *c, int dc, int nfilters, int nslots, int 
     // clock ramp after the handle was built.)  Small blocks are unaffected (the grid never has more teams than (bin, slot) units).
     const int wpc = c->seg_wpc > 0 ? c->seg_wpc : 32;
     // workgroups per group: wpc 256-thread workgroups' worth of teams per CU, over the device's CUs
-    const int teams = wpc * c->num_cus * (256 / g.TEAM);       // teams in the whole grid
+    const int teams = wpc * c->num_cus * 256 / g.TEAM;         // teams in the whole grid
     int wpg = teams / g.TPW / p.nsg;
     if (wpg < 1) wpg = 1;
     // never more teams than (bin, slot) units in a group

@@ -85,7 +85,8 @@ static_assert(MFB_SEG_BLOCK == 64 || MFB_SEG_BLOCK == 128 || MFB_SEG_BLOCK == 25
 #define MFB_SEG_BLOCK_2048 128
 #endif
 static_assert(MFB_SEG_BLOCK_2048 == 128 || MFB_SEG_BLOCK_2048 == 256, "MFB_SEG_BLOCK_2048: 128 or 256 threads");
-constexpr int seg_block_threads(int NT) { return NT <= 64 ? MFB_SEG_BLOCK : (NT == 128 ? MFB_SEG_BLOCK_2048 : 256); }
+// (8192 points: one eight-wave team, 512 threads)
+constexpr int seg_block_threads(int NT) { return NT <= 64 ? MFB_SEG_BLOCK : (NT == 128 ? MFB_SEG_BLOCK_2048 : (NT == 512 ? 512 : 256)); }
 #ifndef MFB_SEG_G0EARLY
 #define MFB_SEG_G0EARLY 1
 #endif
@@ -148,7 +149,8 @@ struct SegCfg {
     static constexpr bool DUAL = !SYNC && MFB_SEG_DUAL && !LONG3;
     static constexpr bool PP = !SYNC && MFB_SEG_PP && !LONG3 && !DUAL;
     static constexpr bool TWO_BUFFERS = PP || DUAL;
-    static constexpr bool PREFETCH = MFB_SEG_PREFETCH && !LONG3 && !DUAL && !W32;
+    // (8192 points: three twiddle sets are 90 registers; the spectrum prefetch registers would spill)
+    static constexpr bool PREFETCH = MFB_SEG_PREFETCH && !LONG3 && !DUAL && !W32 && L < 8192;
     static constexpr bool LTW = LONG3;
     static constexpr int LTW_ELEMS = W32 ? W32Cfg::TW2_ELEMS : TwRegs<L, LTW>::LDS_ELEMS;
     static constexpr int HALF = W32 ? W32Cfg::XCHG : padlen(L) * CT;

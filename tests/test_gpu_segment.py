@@ -30,7 +30,7 @@ def _short_masks(rs, M, N, T, start):
     return (np.fft.fft(h, axis=1)).astype(np.complex64)
 
 
-@pytest.mark.parametrize('log2L', [8, 9, 10, 11, 12])
+@pytest.mark.parametrize('log2L', [8, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize('sum_all', [True, False])
 def test_segment_scores_match_oracle_and_twopass(log2L, sum_all):
     log2N, D = 14, 11
@@ -72,7 +72,7 @@ def test_segment_scores_match_oracle_and_twopass(log2L, sum_all):
 
 
 @pytest.mark.parametrize('log2L,wpc,fpp', [(8, 1, 1), (8, 3, 3), (9, 2, 5), (10, 1, 8), (10, 3, 2), (11, 2, 3), (12, 1, 7), (12, 3, 16),
-                                            (8, 64, 2), (9, 48, 0), (12, 64, 4)])
+                                            (8, 64, 2), (9, 48, 0), (12, 64, 4), (13, 2, 3), (13, 32, 8)])
 def test_segment_decompositions_do_not_change_results(log2L, wpc, fpp):
     """Workgroups per CU and filters per pass only regroup the work: scores stay within rounding of the
     default decomposition (the partial sums are regrouped) and the pick stays put."""
@@ -104,7 +104,7 @@ def test_segment_decompositions_do_not_change_results(log2L, wpc, fpp):
 
 
 @pytest.mark.parametrize('log2L,T,start', [(8, 1, 0), (8, 128, 5), (9, 200, 16000), (10, 512, 16384 - 100), (11, 777, 3),
-                                           (12, 2048, 9000), (12, 33, 16383)])
+                                           (12, 2048, 9000), (12, 33, 16383), (13, 4097, 5), (13, 2500, 14000)])
 def test_segment_any_support_window_scores_and_xcorr(log2L, T, start):
     """Taps anywhere on the circle (wrapping included), from 1 tap up to L/2: scores (REDUCE mode) and the
     natural-order matched-filter outputs (STORE mode) against the oracle."""
@@ -184,7 +184,9 @@ def test_segment_refused_for_long_filters_and_small_blocks():
             bank.set_search_path('segment')
         assert bank.get_search_path()['path'] == 'twopass'     # previous setting stays in force
         with pytest.raises(ValueError):
-            bank.set_search_path('segment', 13)
+            bank.set_search_path('segment', 14)
+        with pytest.raises(ValueError):
+            bank.set_search_path('segment', 13)                # 8192-point segments need N >= 2^14
         bank.set_filters(_short_masks(rs, M, N, 700, 0))       # 700 taps in a 4096-sample block: L would be 2048 > N/4
         assert bank.get_search_path()['path'] == 'twopass'
         bank.set_filters(_short_masks(rs, M, N, 20, 7))
