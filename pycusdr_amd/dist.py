@@ -49,10 +49,13 @@ class StepWatchdog:
     completed synchronisation) and leaves the process with ``exit_code`` -- the launcher then tears the other ranks down.
     Leaving is ``os._exit``: nothing is re-executed, so it is safe in a process that has touched the GPU."""
 
-    def __init__(self, timeout_s, rank=0, describe=None, exit_code=3, stream=None):
+    def __init__(self, timeout_s, rank=0, describe=None, exit_code=3, stream=None, first_grace_s=300.0):
+        """``first_grace_s``: until the first beat the limit is at least this long -- the first step of a job creates the
+        communicators and loads the code objects."""
         import threading
         import time
         self.timeout_s, self.rank, self.describe, self.exit_code = float(timeout_s), int(rank), describe, int(exit_code)
+        self.first_grace_s, self._beats = float(first_grace_s), 0
         self._time, self._last, self.step, self._stop = time, time.monotonic(), -1, threading.Event()
         self._out = stream
         self._thread = threading.Thread(target=self._watch, name='mfb-step-watchdog', daemon=True)
@@ -60,6 +63,7 @@ class StepWatchdog:
             self._thread.start()
 
     def beat(self, step=None):
+        self._beats += 1
         self._last = self._time.monotonic()
         self.step = self.step + 1 if step is None else int(step)
 
@@ -71,7 +75,7 @@ class StepWatchdog:
         import sys
         while not self._stop.wait(min(0.25, self.timeout_s / 4)):
             idle = self._time.monotonic() - self._last
-            if idle > self.timeout_s:
+            if idle > (self.timeout_s if self._beats else max(self.timeout_s, self.first_grace_s)):
                 what = ''
                 try:
                     what = self.describe() if self.describe is not None else ''

@@ -31,7 +31,7 @@ bank = OracleBank(log2N, hi - lo, M, sum_all_masks=True)
 bank.set_filters(masks)
 bank.set_shifts(shifts[lo:hi])
 shard.attach(bank, D, M, sum_all=True)
-dog = StepWatchdog(2.0, rank=rank, describe=shard.describe)
+dog = StepWatchdog(2.0, rank=rank, describe=shard.describe, first_grace_s=20.0)
 x = (rs.standard_normal(N) + 1j * rs.standard_normal(N)).astype(np.complex64)
 for i in range(6):
     if rank == withheld and i == stall_at:
