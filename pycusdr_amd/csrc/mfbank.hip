@@ -1017,8 +1017,9 @@ static SegGeom seg_geom(const mfb_ctx *c) {
 }
 struct SegPlan {
     int nsg, wpg, bsplit, ssplit, mpb, mgroups, grid;
+    int igroups;      // > 1: the filter groups are walked inside a team (REDUCE launches of large problems), mgroups == 1
 };
-static SegPlan plan_seg(const mfb_ctx *c, int dc, int nfilters, int nslots, int mpb_want) {
+static SegPlan plan_seg(const mfb_ctx *c, int dc, int nfilters, int nslots, int mpb_want, bool inner_groups = false) {
     const SegGeom g = seg_geom(c);
     SegPlan p;
     p.nsg = nslots >= 64 ? 8 : 1;
@@ -1031,6 +1032,7 @@ static SegPlan plan_seg(const mfb_ctx *c, int dc, int nfilters, int nslots, int 
     if (mpb > nfilters) mpb = nfilters;
     p.mgroups = (nfilters + mpb - 1) / mpb;
     p.mpb = (nfilters + p.mgroups - 1) / p.mgroups;   // balanced
+    p.igroups = 1;
     // Workgroups in the grid per CU.  More than are resident at once (3 / 2 per CU): the surplus is dealt out as workgroups
     // retire, which evens out CUs that finish at different times.  Measured at C2, L = 256, settled clock, quiet host
     // (tools/seg_probe.py): 8 per CU 1.615 ms, 12: 1.615, 16: 1.613, 24: 1.604, 32: 1.596, 48: 1.595 -- about 1 %.  (Round 2's
@@ -1044,6 +1046,12 @@ static SegPlan plan_seg(const mfb_ctx *c, int dc, int nfilters, int nslots, int 
     // never more teams than (bin, slot) units in a group
     const long long units = (long long)dc * ((nslots + p.nsg - 1) / p.nsg);
     while (wpg > 1 && (long long)wpg * g.TPW > units) wpg >>= 1;
+    // Several filter groups and plenty of (bin, slot) units: a team walks the groups itself on ONE forward transform per
+    // segment instead of a workgroup per group each repeating it (1 of 18 transforms of the BPSK bank).  REDUCE launches only.
+    if (inner_groups && p.mgroups > 1 && units >= 4LL * wpg * g.TPW) {
+        p.igroups = p.mgroups;
+        p.mgroups = 1;
+    }
     p.wpg = wpg;
     // bsplit * ssplit = wpg * TPW teams; barrier teams of one workgroup must share the Doppler stream.
     // Of all factorisations take the one whose busiest team has the least (bins x slots) to do;
@@ -1081,6 +1089,7 @@ static SegArgs seg_base(mfb_ctx *c, const SegPlan &p) {
     a.V = c->V;
     a.mpb = p.mpb;
     a.mgroups = p.mgroups;
+    a.igroups = p.igroups;
     a.nsg = p.nsg;
     a.bsplit = p.bsplit;
     a.ssplit = p.ssplit;
@@ -1200,7 +1209,7 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
         const int MU = span ? c->MB : c->MU;     // filters transformed per bin (shadows the two-pass count above on purpose)
         int nfull, ntotal;
         seg_slots(c, &nfull, &ntotal);
-        const SegPlan pm = plan_seg(c, c->Dtot, MU, nfull > 0 ? nfull : 1, c->seg_mpb);
+        const SegPlan pm = plan_seg(c, c->Dtot, MU, nfull > 0 ? nfull : 1, c->seg_mpb, true);
         // the tail is a handful of units: spread the filters too (2 per pass) so that it is short
         const SegPlan pt = plan_seg(c, c->Dtot, MU, ntotal - nfull > 0 ? ntotal - nfull : 1, c->seg_mpb > 0 && c->seg_mpb < 2 ? c->seg_mpb : 2);
         // one partial per (bin, filter, slot, wave of the team): the index depends on the slot alone (seg_kernels.hpp)

@@ -117,6 +117,7 @@ struct SegArgs {
     int MU;              // filter slots per Doppler bin
     int Grows;           // rows of G (all M filters)
     int mpb, mgroups;    // filters per team pass, passes (workgroup groups) needed for MU
+    int igroups;         // REDUCE: > 1 = the filter groups are walked INSIDE a team (one forward transform per segment for all of them; mgroups == 1)
     int nsg;             // segment groups (blockIdx % nsg)
     int bsplit, ssplit;  // a group's teams = bsplit Doppler streams x ssplit segment sub-ranges
     int j0, dc;          // Doppler bins [j0, j0 + dc) of the shift table
@@ -240,8 +241,9 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
     const int s1 = a.slot0 + gs0 + (int)((long long)(ssub + 1) * glen / a.ssplit);
     // barrier teams run the longest range of the group (surplus iterations contribute nothing)
     const int niter = __builtin_amdgcn_readfirstlane(SYNC ? (s1 - s0) : (glen + a.ssplit - 1) / a.ssplit);
-    const int m0 = mg * a.mpb;
-    const int nm = __builtin_amdgcn_readfirstlane(min(a.mpb, a.MU - m0));
+    // filter groups: one per workgroup (mg from the grid), or -- Doppler search with several groups -- all of them in turn on the
+    // forward spectrum of the segment, which is then computed once (the BPSK bank: 16 unique filters, 8 per pass)
+    const int ngrp = __builtin_amdgcn_readfirstlane((MODE == SEG_REDUCE && a.igroups > 1) ? a.igroups : 1);
 
     const unsigned nmask = (unsigned)a.N - 1u;
     const unsigned lomask = (1u << a.lo) - 1u;
@@ -317,7 +319,8 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                     for (int i = 1; i < PPL; ++i) v[i] = cmul_cj(v[i], cmul(ph0, mystep[i]));
                 }
             }
-            const int r0 = a.rows ? a.rows[m0] : m0;
+            const int mfirst = (ngrp > 1 ? 0 : mg) * a.mpb;
+            const int r0 = a.rows ? a.rows[mfirst] : mfirst;
             if constexpr (Cfg::PREFETCH && MFB_SEG_G0EARLY) load_g(gk, r0);    // lands while the forward transform runs
             cf A[PPL];                            // A[k] = conj(U[g + NT*k])
             {
@@ -337,6 +340,12 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
             if constexpr (MODE == SEG_STORE) {
 #pragma unroll
                 for (int k = 0; k < PPL; ++k) envacc[k] = 0.f;
+            }
+            for (int gi = 0; gi < ngrp; ++gi) {
+            const int m0 = (ngrp > 1 ? gi : mg) * a.mpb;
+            const int nm = __builtin_amdgcn_readfirstlane(min(a.mpb, a.MU - m0));
+            if constexpr (Cfg::PREFETCH) {
+                if (gi > 0) load_g(gk, a.rows ? a.rows[m0] : m0);
             }
             int mi_first = 0;
             if constexpr (Cfg::DUAL && MODE == SEG_REDUCE) {
@@ -446,8 +455,9 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                 s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
                 if (j == 0 && f < nm && active)
                     a.partials[((size_t)(a.part_row0 + jl) * a.MU + (m0 + f)) * a.parts + (slot * Cfg::WPT + (lt >> 6))] = s * a.scale;
-                xsync<1>();     // the rows are rewritten by the next slot
+                xsync<1>();     // the rows are rewritten by the next group / slot
             }
+            }       // filter groups
             if constexpr (MODE == SEG_STORE) {
                 if (a.env) {
                     const unsigned o0 = e0 + (unsigned)a.out_off;
