@@ -1048,7 +1048,7 @@ static SegPlan plan_seg(const mfb_ctx *c, int dc, int nfilters, int nslots, int 
     while (wpg > 1 && (long long)wpg * g.TPW > units) wpg >>= 1;
     // Several filter groups and plenty of (bin, slot) units: a team walks the groups itself on ONE forward transform per
     // segment instead of a workgroup per group each repeating it (1 of 18 transforms of the BPSK bank).  REDUCE launches only.
-    if (inner_groups && p.mgroups > 1 && units >= 4LL * wpg * g.TPW) {
+    if (inner_groups && c->segl <= 8 && p.mgroups > 1 && units >= 4LL * wpg * g.TPW) {      // (the 256-point kernel only: seg_kernels.hpp)
         p.igroups = p.mgroups;
         p.mgroups = 1;
     }
