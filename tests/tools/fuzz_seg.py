@@ -17,7 +17,7 @@ for case in range(cases):
     M = int(rs.choice([1, 2, 3, 5, 8, 13, 16, 17, 33, 64]))
     sum_all = bool(rs.randint(0, 2))
     doff = int(rs.randint(0, 2))
-    lmax = min(12, log2N - 2)
+    lmax = min(13, log2N - 2)
     l = int(rs.randint(8, lmax + 1))
     L = 1 << l
     T = int(rs.randint(1, L // 2 + 2))
