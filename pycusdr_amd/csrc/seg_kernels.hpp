@@ -13,12 +13,12 @@
 // 8 MiB block (served from L2 / Infinity Cache thereafter) plus a few KiB of partial sums, so the kernel
 // is bound by the fp32 vector rate, not by HBM.
 //
-// Work layout.  One transform is run by NT = L/16 threads holding 16 points each (fft_core.hpp).  A
-// "team" is the set of threads that must synchronise for a transform: one wavefront carrying CT = 64/NT
-// segments side by side for L <= 1024 (no s_barrier anywhere: LDS exchanges are wave-local), or NT
-// threads (2 or 4 waves, workgroup barrier) for L = 2048 / 4096.  Teams never talk to each other: every
-// wave writes one partial sum per slot, added up in fixed order by k_finalize (bit-reproducible, and
-// independent of the grid decomposition: see the store below).
+// Work layout.  One transform is run by NT = L/P threads holding P points each (fft_core.hpp): P = 16 and radix-16 passes chained
+// through one LDS exchange each, or -- L = 2048 -- P = 32 and two 32-point in-register butterflies around ONE exchange (fft_w32).  A
+// "team" is the set of threads that must synchronise for a transform: one wavefront carrying CT = 64/NT segments side by side
+// for L <= 2048 (no s_barrier anywhere: LDS exchanges are wave-local), or NT threads behind workgroup barriers for L = 4096 (4
+// waves) and 8192 (8 waves, one team per CU).  Teams never talk to each other: every wave writes one partial sum per slot, added up
+// in fixed order by k_finalize (bit-reproducible, and independent of the grid decomposition: see the store below).
 // The grid is decoded XCD-aware: workgroups with equal blockIdx % nsg share a contiguous range of
 // segments, i.e. one eighth of the block, which stays in that XCD's L2 while every Doppler bin passes
 // over it (placement affects speed only).
