@@ -194,8 +194,9 @@ class DemodulatorRunner:
                 'rangerateEst': 0, 'baudRate': self.baudRate, 'baudRate_est': 0, 'sample_rate': self.Fs,
                 'protocol': self.decoderProtocol}
         data['baudrate_est'] = self.Fs / data['spSymEst'] if data['spSymEst'] else 0.0
-        # range rate implied by the measured frequency offset (reference computeTxFreqOffset, DP:359-379)
-        fc = self.confRadio['frequency_Hz']
+        # range rate implied by the measured frequency offset (reference computeTxFreqOffset, DP:359-379): against the carrier the
+        # receiver is really tuned to, frequency_Hz minus the IF offset, as an integer (DP:146) -- pinned by fixture G19
+        fc = float(int(self.confRadio['frequency_Hz'] - self.confRadio['frequencyOffset_Hz']))
         data['rangerate'] = -data['doppler'] / fc * 299792458.0
         self.computeMATime(spent)
         data['time_ms'] = spent * 1e3

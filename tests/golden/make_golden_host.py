@@ -20,6 +20,9 @@ unmodified code -- constructor included -- on values injected at the exact point
        cudaFindCentres                 findCentres launch gets (float32 casts, grid, symbol count)
   G18  demodulate (UHF / STX)          injected rate triple, symbols, centres, magnitudes, over        DB:765-859, 863-1051
                                        consecutive blocks: bits / centres / trust as returned
+  G19  Demodulator_process.run         the caller's loop itself over its own SigFIFO (fake SUB socket,  DP:192-379, sigFIFO.py:108-181
+                                       4095/4096-sample chunks) and Demodulator: block assembly, overlap
+                                       carry, the result dict sent to the decoder
 
 numpy's scalar promotion.  DB:623, DB:735 and DB:745 combine a float32 array element with a Python scalar.  The
 reference uses ``np.float`` / ``np.int`` (DB:898, 1049; removed in numpy 1.24), i.e. it was written for and only runs
@@ -70,6 +73,7 @@ class Buf:
 class Tape:
     log = []          # (name, scalar arguments ...)
     inject = {}       # source buffer -> array whose BYTES a memcpy_dtoh from it delivers
+    by_tag = {}       # buffer tag -> deque of such arrays, one per copy (objects built where the harness cannot reach them: G19)
 
 
 def _scalars(args):
@@ -139,7 +143,8 @@ def _install_recording_fake():
             return Kernel(name)
 
     def memcpy_dtoh(dest, src):
-        val = np.ascontiguousarray(Tape.inject[src])
+        val = Tape.inject[src] if src in Tape.inject else Tape.by_tag[src.tag].popleft()
+        val = np.ascontiguousarray(val)
         dest.view(np.uint8).reshape(-1)[:] = val.view(np.uint8).reshape(-1)[:dest.nbytes]
         Tape.log.append(('memcpy_dtoh', src.tag, int(dest.nbytes)))
 
@@ -438,6 +443,133 @@ def g18_demodulate(out, objs):
             out[f'g18/{sname}/nblocks'] = np.int64(len(sc['slips']))
 
 
+
+# ---- G19 ------------------------------------------------------------------------------------------------------------
+def _install_fake_zmq(chunks, sent, on_empty):
+    """The transport the reference's loop talks to, as far as the loop can tell: a SUB socket that delivers ``chunks`` (bytes) and
+    then times out, a PUSH socket that keeps what is sent."""
+    import copy
+    z = sys.modules['zmq']
+    z.SUB, z.PUSH, z.POLLIN, z.SUBSCRIBE, z.LINGER, z.NOBLOCK = 2, 8, 1, 6, 17, 1
+    z.error = types.SimpleNamespace(Again=type('Again', (Exception,), {}))
+    pending = list(chunks)
+
+    class Socket:
+        def connect(self, addr):
+            pass
+
+        def setsockopt_string(self, *a):
+            pass
+
+        def setsockopt(self, *a):
+            pass
+
+        def recv(self):
+            return pending.pop(0)
+
+        def send_pyobj(self, obj, flags=0):
+            sent.append(copy.deepcopy(obj))
+
+        def close(self):
+            pass
+
+    class Poller:
+        def register(self, *a):
+            pass
+
+        def poll(self, timeout):
+            if pending:
+                return [(None, 1)]
+            on_empty()
+            return []
+
+    z.Context = lambda: types.SimpleNamespace(socket=lambda kind: Socket())
+    z.Poller = Poller
+
+
+def g19_process_loop(out):
+    """Demodulator_process.run (DP:192-357) itself: the reference's loop over its own SigFIFO (fed by a fake SUB socket with
+    GNU-Radio-sized chunks) and its own Demodulator (under the recording fake, device results injected per block).  Pins the
+    caller's side of the path: block assembly and overlap carry (hash of the buffer every block is uploaded from), the
+    result dict that goes to the decoder -- keys, the constant entries, rangerate (computeTxFreqOffset DP:359-379),
+    baudrate_est, the block counter."""
+    import collections
+    import demodulator_process as dp
+    import demodulator.UHF as uhf
+    from pycusdr_amd import config as cfg
+    conf = cfg.bench_config('bench_GMSK', blockSize=13, doppCarrierSteps=16)
+    conf['Demodulator'] = {'timeoutSeconds': 1}
+    conf['Interfaces'] = {'Internal': {'demodOut': 'inproc://demod'}}
+    conf['Radios']['Rx']['UHF-H']['RxInPort'] = 'inproc://rx'
+    proto = ref_protocol('bench_GMSK', conf)
+    N, ov, nblocks = 1 << 13, 1 << 10, 6
+    rs = np.random.RandomState(19)
+    stream = (rs.standard_normal(nblocks * (N - ov) + 777) + 1j * rs.standard_normal(nblocks * (N - ov) + 777)).astype(np.complex64)
+    sizes, pos, chunks = [4095, 4096], 0, []
+    while pos < len(stream):                       # GNU Radio hands over ~4095-4096 samples at a time (sigFIFO.py:160)
+        n = sizes[len(chunks) % 2]
+        chunks.append(stream[pos:pos + n].tobytes())
+        pos += n
+    cap = int(N / int(16 / 2))
+    picks = [(3.5, 10.0), (7.25, 12.5), (7.0, 11.0), (np.nan, 0.0), (8.75, 9.0), (4.0, 14.0)]
+    ks = [N // 16, N // 16 + 1, N // 16 - 1, N // 16, N // 16 + 2, N // 16]
+    orig = uhf.Demodulator
+    for reading in ('nep50', 'legacy'):            # see the module docstring: the read-back buffer as the reference has it / widened
+        sent, raws = [], []
+        dt = np.float32 if reading == 'nep50' else np.float64
+
+        class Tapped(orig):
+            def __init__(self, *a):
+                orig.__init__(self, *a)
+                _tag_buffers(self)
+                _widen(self, reading)
+
+            def uploadAndFindCarrier(self, samples):
+                raws.append(mg.sha(np.asarray(samples)))
+                return orig.uploadAndFindCarrier(self, samples)
+        uhf.Demodulator = Tapped
+        try:
+            proc = dp.Demodulator_process(conf, proto, 'UHF-H')
+            _install_fake_zmq(chunks, sent, on_empty=proc.runStatus.clear)
+            Tape.by_tag = {k: collections.deque() for k in ('GPU_bufDoppResult', 'GPU_bufCodeAndPhaseResult', 'GPU_symbols', 'GPU_centres',
+                                                             'GPU_magnitude')}
+            for b in range(nblocks):
+                sym, cen, mag = device_symbols(N, cap, 8, 16, b, ov, [0, 0, 1, 0, 0, -1][b], 1900 + b)
+                triple = np.array([ks[b], 0.4 * b - 1.0, 1e6], dtype=np.float32)
+                Tape.by_tag['GPU_bufDoppResult'].append(np.array(picks[b], dtype=np.float32))
+                Tape.by_tag['GPU_bufCodeAndPhaseResult'].append(triple.astype(dt))
+                Tape.by_tag['GPU_symbols'].append(sym)
+                Tape.by_tag['GPU_centres'].append(cen)
+                Tape.by_tag['GPU_magnitude'].append(mag)
+                out[f'g19/b{b}/pick'] = np.array(picks[b], dtype=np.float32)
+                out[f'g19/b{b}/triple'] = triple
+                out[f'g19/b{b}/symbols'], out[f'g19/b{b}/centres_dev'], out[f'g19/b{b}/magnitudes'] = sym, cen, mag
+            with warnings.catch_warnings(), np.errstate(all='ignore'):
+                warnings.simplefilter('ignore')
+                proc.run()
+        finally:
+            uhf.Demodulator = orig
+            Tape.by_tag = {}
+        assert len(sent) == len(raws) == nblocks, (len(sent), len(raws))
+        out['g19/keys'] = np.array(sorted(sent[0].keys()))
+        out['g19/raw_sha'] = np.array(raws)
+        for k in ('workerId', 'voteGroup', 'baudRate', 'sample_rate', 'protocol', 'rangerateEst', 'baudRate_est'):
+            assert all(d[k] == sent[0][k] for d in sent)
+            out[f'g19/const/{k}'] = np.array(sent[0][k])
+        for b, d in enumerate(sent):
+            for k in ('count', 'doppler', 'doppler_std', 'SNR', 'rangerate'):       # independent of the reading
+                out[f'g19/b{b}/{k}'] = np.float64(d[k])
+            for k in ('spSymEst', 'baudrate_est'):
+                out[f'g19/b{b}/{reading}/{k}'] = np.float64(d[k])
+            out[f'g19/b{b}/{reading}/data'] = np.asarray(d['data'])
+            out[f'g19/b{b}/{reading}/trust'] = np.asarray(d['trust'])
+    out['g19/conf'] = np.array(json.dumps(conf))
+    out['g19/stream_seed'] = np.int64(19)
+    out['g19/stream_len'] = np.int64(len(stream))
+    out['g19/chunk_sizes'] = np.array(sizes)
+    out['g19/nblocks'] = np.int64(nblocks)
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit('reference not mounted; fixtures can only be regenerated in the authoring container')
@@ -447,6 +579,7 @@ def main():
     g16_pick(out, objs)
     g17_rate(out, objs)
     g18_demodulate(out, objs)
+    g19_process_loop(out)
     flat = {k.replace('/', '__'): v for k, v in out.items()}
     path = os.path.join(HERE, 'ref_goldens_host.npz')
     np.savez_compressed(path, **flat)

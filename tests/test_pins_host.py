@@ -199,3 +199,54 @@ def test_demodulate_host_chain_equals_reference(hg, sname, monkeypatch):
         assert list(hg[p + 'legacy/out_dtypes']) == ['uint8'] * 3
         if sname == 'stx':
             assert np.count_nonzero(tw == 254) >= 4                              # the -2 tags next to the clipped peaks
+
+
+def test_streaming_loop_equals_reference_process_loop(hg, monkeypatch):
+    """N1 against the reference's own loop (G19: ``Demodulator_process.run`` over its own SigFIFO, fed 4095 / 4096-sample chunks by
+    a fake SUB socket, and its own Demodulator under the recording fake): every block is assembled from the same samples
+    behind the same overlap (hash of the buffer each block is uploaded from), and the result dict handed to the decoder has
+    the reference's keys and values -- block counter, estimates, bits, trust, baudrate_est, rangerate (DP:359-379), the
+    constant entries, and a NaN pick as a skipped block."""
+    import hashlib
+    from pycusdr_amd.demodulator_process import DemodulatorRunner
+    conf = json.loads(str(hg['g19/conf']))
+    proto = loadProtocol('bench_GMSK')(conf=conf)
+    with monkeypatch.context() as m:
+        m.setattr(dbm, 'MFBank', ReplayBank)
+        run = DemodulatorRunner(conf, proto, 'UHF-H')
+    bank = run.demod.bank
+    nblocks = int(hg['g19/nblocks'])
+    rs = np.random.RandomState(int(hg['g19/stream_seed']))
+    L = int(hg['g19/stream_len'])
+    stream = (rs.standard_normal(L) + 1j * rs.standard_normal(L)).astype(np.complex64)
+    sizes, pos, chunks = [int(v) for v in hg['g19/chunk_sizes']], 0, []
+    while pos < L:
+        n = sizes[len(chunks) % 2]
+        chunks.append(stream[pos:pos + n])
+        pos += n
+    seen = []
+
+    def on_upload(samples):
+        b = len(seen)
+        seen.append(hashlib.sha256(np.ascontiguousarray(samples).tobytes()).hexdigest())
+        p = f'g19/b{b}/'
+        bank.pick, bank.triple = hg[p + 'pick'], hg[p + 'triple']
+        bank.sym, bank.cen, bank.mag = hg[p + 'symbols'], hg[p + 'centres_dev'], hg[p + 'magnitudes']
+    bank.on_upload = on_upload
+    bank.X = np.zeros(run.demod.Nfft, np.complex64)      # the spectrum buffer nobody wrote to in the reference run either
+    with np.errstate(all='ignore'):
+        results, _ = run.run_stream(chunks)
+    assert len(results) == nblocks and seen == [str(v) for v in hg['g19/raw_sha']]          # same blocks, same overlap carry
+    assert set(str(k) for k in hg['g19/keys']) <= set(results[0])
+    for k in ('workerId', 'voteGroup', 'baudRate', 'sample_rate', 'protocol', 'rangerateEst', 'baudRate_est'):
+        assert all(np.asarray(d[k]) == hg[f'g19/const/{k}'] for d in results), k
+    for b, d in enumerate(results):
+        p = f'g19/b{b}/'
+        for k in ('count', 'doppler', 'doppler_std', 'rangerate'):
+            assert same(np.float64(d[k]), hg[p + k]), (b, k, d[k], hg[p + k])
+        for k in ('spSymEst', 'baudrate_est'):                                           # promotion-dependent: the legacy reading
+            assert same(np.float64(d[k]), hg[p + 'legacy/' + k]), (b, k, d[k], hg[p + 'legacy/' + k])
+            assert same(np.float32(d[k]), np.float32(hg[p + 'nep50/' + k])) or k == 'baudrate_est'
+        assert same(np.float64(d['SNR']), hg[p + 'SNR']) or (b == 3 and d['SNR'] == 0)
+        assert d['data'].dtype == np.uint8 and same(d['data'], hg[p + 'legacy/data']) and same(d['trust'], hg[p + 'legacy/trust'])
+    assert np.isnan(hg['g19/b3/pick'][0]) and results[3]['doppler'] == 0          # the skipped block still goes to the decoder
