@@ -18,12 +18,12 @@ log = logging.getLogger('pycusdr_amd.demodulator_process')
 
 
 def radioBackendVoteGroupIDX(radioBackend):
-    """Back-end name -> (module, vote group), as the reference maps it (DP:25-36)."""
-    if radioBackend == 'UHF':
-        return demod_backends.UHF, 0
-    if radioBackend in ('STX', 'SBAND'):
-        return demod_backends.STX, 1
-    raise TypeError(f'Invalid radio mode {radioBackend}')
+    """Back-end name -> (module, vote group), as the reference maps it (DP:20-36): UHF 0, STX 1, STX1 2, STX2 3."""
+    groups = {'UHF': (demod_backends.UHF, 0), 'STX': (demod_backends.STX, 1), 'STX1': (demod_backends.STX, 2),
+              'STX2': (demod_backends.STX, 3), 'SBAND': (demod_backends.STX, 1)}
+    if radioBackend not in groups:
+        raise Exception('radioBackend {} not defined in voteGroup'.format(radioBackend))
+    return groups[radioBackend]
 
 
 class DemodulatorRunner:

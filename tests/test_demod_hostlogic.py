@@ -211,6 +211,6 @@ def test_streaming_runner_on_oracle_backend(oracle_backend):
     run2.run_stream((sig[i:i + (1 << 14)] for i in range(0, 3 * step, 1 << 14)), sink=seen2.append)
     assert len(seen2) == 3 and all(np.array_equal(a['data'], b['data']) and a['doppler'] == b['doppler']
                                    for a, b in zip(seen, seen2))
-    assert radioBackendVoteGroupIDX('STX')[1] == 1
-    with pytest.raises(TypeError):
+    assert [radioBackendVoteGroupIDX(b)[1] for b in ('UHF', 'STX', 'STX1', 'STX2')] == [0, 1, 2, 3]      # reference DP:20-36
+    with pytest.raises(Exception, match='not defined in voteGroup'):
         radioBackendVoteGroupIDX('LBAND')
