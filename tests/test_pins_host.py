@@ -250,3 +250,21 @@ def test_streaming_loop_equals_reference_process_loop(hg, monkeypatch):
         assert same(np.float64(d['SNR']), hg[p + 'SNR']) or (b == 3 and d['SNR'] == 0)
         assert d['data'].dtype == np.uint8 and same(d['data'], hg[p + 'legacy/data']) and same(d['trust'], hg[p + 'legacy/trust'])
     assert np.isnan(hg['g19/b3/pick'][0]) and results[3]['doppler'] == 0          # the skipped block still goes to the decoder
+    # the three-thread form goes through this repo's SigFIFO / RingBuffer instead of the in-place assembler: same blocks, same dicts
+    with monkeypatch.context() as m:
+        m.setattr(dbm, 'MFBank', ReplayBank)
+        run2 = DemodulatorRunner(conf, proto, 'UHF-H')
+    bank2, seen2 = run2.demod.bank, []
+
+    def on_upload2(samples):
+        b = len(seen2)
+        seen2.append(hashlib.sha256(np.ascontiguousarray(samples).tobytes()).hexdigest())
+        p = f'g19/b{b}/'
+        bank2.pick, bank2.triple = hg[p + 'pick'], hg[p + 'triple']
+        bank2.sym, bank2.cen, bank2.mag = hg[p + 'symbols'], hg[p + 'centres_dev'], hg[p + 'magnitudes']
+    bank2.on_upload = on_upload2
+    bank2.X = np.zeros(run2.demod.Nfft, np.complex64)
+    with np.errstate(all='ignore'):
+        piped, _ = run2.run_stream(chunks, pipelined=True)
+    assert seen2 == seen and len(piped) == nblocks
+    assert all(same(a['data'], b['data']) and same(np.float64(a['rangerate']), np.float64(b['rangerate'])) for a, b in zip(results, piped))
