@@ -247,6 +247,9 @@ def run_block_shard(args, dist, rank, G, local_rank, dev):
     elapsed = float(t.item())
     pinfo = runner.demod.bank.get_search_path()
     Mu = runner.demod.bank.get_info()[2]
+    props = torch.cuda.get_device_properties(dev)
+    rank_devices = [None] * G
+    dist.all_gather_object(rank_devices, {'rank': rank, 'device': local_rank, 'uuid': str(getattr(props, 'uuid', '')), 'name': props.name})
     if rank == 0:
         nb = args.steps * G
         host_ms = float(np.mean([d['time_ms'] for d in res])) if res else None
@@ -259,6 +262,8 @@ def run_block_shard(args, dist, rank, G, local_rank, dev):
                                       f'decisions, bit lookup and alignment (the previous block\'s tail comes from its owner) --, rank 0 '
                                       f'runs the decoder in block order; blocks resident in HBM, two point-to-point messages per block, no collective',
                           'shard': 'blocks', 'world_size': G, 'backend': args.backend, 'blocks_timed': nb, 'path': pinfo,
+                          'rccl_world': dist.get_world_size() if args.backend == 'nccl' else None, 'rank_devices': rank_devices,
+                          'distinct_devices': len({(d['device'], d['uuid']) for d in rank_devices}),
                           'packets_found': len(packets), 'mean_block_ms_device_plus_host_on_root': host_ms,
                           'root_ms_per_block': round(shard.stats['root_s'] / max(shard.stats['root_blocks'], 1) * 1e3, 4),
                           'root_wait_ms_per_block': round(shard.stats['root_wait_s'] / max(shard.stats['root_blocks'], 1) * 1e3, 4),
