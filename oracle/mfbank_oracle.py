@@ -12,7 +12,10 @@ unpinned** against the reference: it follows the reference's source text (citati
 is checked by invariants (Parseval, known carrier bin, zero bit errors on the reference's own
 bench packet).  The host-side stages that *can* be pinned are pinned by fixtures generated from
 the importable numpy parts of the reference (tests/golden/make_golden.py): filter banks, LUTs,
-decoder templates, Decoder.findFrames, bench stimulus, checkSymbolOverlap, extractBitsNRZs.
+decoder templates, Decoder.findFrames, bench stimulus, checkSymbolOverlap, extractBitsNRZs -- and, since round 4,
+by fixtures recorded from the reference's own constructor / uploadAndFindCarrier / demodulate run under a recording
+fake of its driver (tests/golden/make_golden_host.py, G15-G17): ``doppler_table``, ``interpolate_doppler``,
+``compute_snr`` and ``code_rate_host`` below reproduce those bit for bit (tests/test_oracle.py).
 
 Citations are file:line under /root/reference/pyCuSDR/ with
   DB = demodulator/demodulator_base.py,  CU = demodulator/cuda_kernels.cu,  DEC = decoder.py.

@@ -194,3 +194,48 @@ def test_frequency_domain_bank_equals_time_domain_matched_filter():
     # and the per-bin score is the energy of that correlation, scaled by N^2 / 2^18
     score = orc.doppler_scores(np.fft.fft(x), mask[None, :], [s], True)[0, 0]
     assert np.isclose(score, N * N * np.sum(np.abs(direct) ** 2) / 262144.0, rtol=1e-9)
+
+
+# ---- the oracle's HOST restatements against the reference-run fixtures G15-G17 (tests/golden/ref_goldens_host.npz) -----------
+def _hg():
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_goldens_host.npz'), allow_pickle=False)
+    return {k.replace('__', '/'): z[k] for k in z.files}
+
+
+def test_oracle_host_functions_equal_reference_runs():
+    """doppler_table (DB:130-165), interpolate_doppler (DB:609-622), compute_snr (DB:635-667) and code_rate_host (DB:733-752) of the
+    oracle against what the reference's own code computed under the recording fake (legacy reading of the rate arithmetic)."""
+    import json
+    hg = _hg()
+    for name in sorted({k.split('/')[1] for k in hg if k.startswith('g15/')}):
+        conf = json.loads(str(hg[f'g15/{name}/conf']))
+        r = conf['Radios']['Rx']['UHF-H']
+        t = orc.doppler_table(r['frequency_Hz'], r['frequencyOffset_Hz'], r['baud'], r['samplesPerSym'], conf['Radios']['rangeRateMax'],
+                              r['doppCarrierSteps'], int(hg[f'g15/{name}/Nfft']), r.get('noise_measure_offset_Hz', False))
+        assert np.array_equal(t['shifts'], hg[f'g15/{name}/doppCyperSymNorm']) and np.array_equal(t['doppHzLUT'], hg[f'g15/{name}/doppHzLUT'])
+        assert t['doppOffsetIdx'] == int(hg[f'g15/{name}/doppOffsetIdx']) and t['offset_count'] == int(hg[f'g15/{name}/doppIdxArrayOffset'])
+    for name in ('bench_b15_d64', 'zero_if', 'noise_pos', 'cc11xx_b17_s128'):
+        p = f'g16/{name}/'
+        N = int(hg[f'g15/{name}/Nfft'])
+        rs = np.random.RandomState(int(hg[p + 'spectrum_seed']))
+        X = (rs.standard_normal(N) + 1j * rs.standard_normal(N)).astype(np.complex64)
+        X[N // 4 - 40:N // 4 + 40] *= 25
+        X[:24] *= 9
+        X[-24:] *= 9
+        shifts, hz = hg[f'g15/{name}/doppCyperSymNorm'], hg[f'g15/{name}/doppHzLUT']
+        for i, pick in enumerate(hg[p + 'pick']):
+            got = orc.interpolate_doppler(pick, shifts, hz, float(hg[f'g15/{name}/centreFreqOffset']))
+            if np.isnan(pick):
+                assert got is None and hg[p + 'dopplerIdxlast'][i] == 0
+                continue
+            assert got['dopplerIdxlast'] == int(hg[p + 'dopplerIdxlast'][i]) and got['freqOffset'] == hg[p + 'freqOffset'][i]
+            with np.errstate(all='ignore'):
+                snr = orc.compute_snr(X, shifts, got['low'], got['high'], 5, N)
+            assert np.array_equal(np.float64(snr), hg[p + 'SNR'][i], equal_nan=True)
+    for name in ('bench_b15_d64', 'cc11xx_b17_s128'):
+        p = f'g17/{name}/'
+        N = int(hg[f'g15/{name}/Nfft'])
+        for i in range(0, len(hg[p + 'k']), 7):
+            sp, off = orc.code_rate_host(hg[p + 'k'][i], hg[p + 'arg'][i], N)
+            assert sp == hg[p + 'legacy/spSym'][i] and np.array_equal(np.float64(off), hg[p + 'legacy/codeOffset'][i], equal_nan=True)
