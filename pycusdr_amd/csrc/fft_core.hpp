@@ -407,7 +407,10 @@ DEVI void fft_w32(cf (&v)[32], cf *xbuf, const int lane, const W32Regs &r, Store
     }
     xsync<1>();
 #ifndef MFB_W32_READS
-#define MFB_W32_READS 1
+#define MFB_W32_READS 3      // 1: 16-byte reads in the compiler's order; 2: two sweeps of 8-byte reads; 3: 16-byte reads, pipelined by hand
+#endif
+#ifndef MFB_W32_DEPTH
+#define MFB_W32_DEPTH 3
 #endif
 #if MFB_W32_READS == 1
     {
@@ -425,6 +428,43 @@ DEVI void fft_w32(cf (&v)[32], cf *xbuf, const int lane, const W32Regs &r, Store
             t1 = cmul(t1, mkc(f.z, f.w));
             v[J] = t0;
             v[J + 1] = t1;
+        });
+    }
+#elif MFB_W32_READS == 3
+    {
+        // The same 16-byte reads, software-pipelined by hand: the reads of pair k + DEPTH are issued before pair k is combined,
+        // and the order is pinned with scheduling barriers.  (Left to itself the scheduler issues the two reads of a pair and
+        // waits for them at once -- the register pressure of the region puts it in its pressure-first mode -- so every pair
+        // exposed a full LDS round trip: ~16 x 100+ cycles per transform that only the other wave of the SIMD could cover.)
+        // Pairs go out in the order the second butterfly's first radix-4 level consumes them (j, j + 8, j + 16, j + 24).
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 *rd = reinterpret_cast<const f4 *>(xbuf + (lane >> 1) * W32Cfg::ROW);
+        const f4 *tw = reinterpret_cast<const f4 *>(r.tw2);
+        constexpr int DEPTH = MFB_W32_DEPTH;
+        f4 q0[16], q1[16], f[16];
+        auto issue = [&](auto kk) {
+            constexpr int K = decltype(kk)::value;
+            constexpr int J = 2 * (K >> 2) + 8 * (K & 3);           // k-th pair issued -> elements J, J + 1
+            q0[K] = rd[J];
+            q1[K] = rd[J + 1];
+            f[K] = tw[J / 2];
+        };
+        sfor<0, DEPTH>([&](auto kk) { issue(kk); });
+        __builtin_amdgcn_sched_barrier(0);
+        sfor<0, 16>([&](auto kk) {
+            constexpr int K = decltype(kk)::value;
+            constexpr int J = 2 * (K >> 2) + 8 * (K & 3);
+            if constexpr (K + DEPTH < 16) {
+                issue(std::integral_constant<int, K + DEPTH>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            cf t0 = __builtin_elementwise_fma(mkc(q0[K].z, q0[K].w), r.sig, mkc(q0[K].x, q0[K].y));
+            cf t1 = __builtin_elementwise_fma(mkc(q1[K].z, q1[K].w), r.sig, mkc(q1[K].x, q1[K].y));
+            if constexpr (J > 0) t0 = cmul(t0, mkc(f[K].x, f[K].y));
+            t1 = cmul(t1, mkc(f[K].z, f[K].w));
+            v[J] = t0;
+            v[J + 1] = t1;
+            __builtin_amdgcn_sched_barrier(0);
         });
     }
 #else

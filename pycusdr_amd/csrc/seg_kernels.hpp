@@ -405,7 +405,12 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
 #pragma unroll
                     for (int ii = 0; ii < PPL / 2; ++ii) {
                         cf g0, g1;
+#ifdef MFB_SEG_NOG     // timing-only variant (wrong numbers): no spectrum loads at all = the bound of a perfect prefetch
+                        g0 = A[(2 * ii + 1) % PPL];
+                        g1 = A[(2 * ii + 2) % PPL];
+#else
                         buf_load_cf2(gr, vo_g2, rm * (L * (int)sizeof(cf)) + ii * so_g2, g0, g1);
+#endif
                         w[2 * ii] = cmul_cj(A[2 * ii], g0);
                         w[2 * ii + 1] = cmul_cj(A[2 * ii + 1], g1);
                     }
