@@ -44,22 +44,24 @@ DEVI cf sub_i(cf a, cf b) {
 }
 // complex product: (a.x*w.x - a.y*w.y, a.x*w.y + a.y*w.x) in two packed ops
 // (one asm statement: the hazard recogniser pads every use of an asm-defined register that follows
-// within one wait state with an s_nop, which between the two halves of a product is pure loss)
+// within one wait state with an s_nop, which between the two halves of a product is pure loss.  The
+// first half goes straight into the destination: a separate temporary is the same physical register
+// in two products that follow each other, and the recogniser then pads between THEM.)
 DEVI cf cmul(cf a, cf w) {
-    cf p, d;
-    asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[0,1]\n\t"
-        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
-        : "=v"(d), "=&v"(p)
+    cf d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(d)
         : "v"(a), "v"(w));
     return d;
 }
 // conj(a) * w = (a.x*w.x + a.y*w.y, a.x*w.y - a.y*w.x): the forward transform of the segment search is
 // run as conj(IFFT(conj(u))), and both conjugations fold into the multiplies next to it
 DEVI cf cmul_cj(cf a, cf w) {
-    cf p, d;
-    asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[0,1]\n\t"
-        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]"
-        : "=v"(d), "=&v"(p)
+    cf d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]"
+        : "=&v"(d)
         : "v"(a), "v"(w));
     return d;
 }
@@ -305,26 +307,26 @@ DEVI void xsync() {
 // 32-point butterfly are a handful of constants; in VGPRs they would cost two registers each)
 template <int CONJ, int ROT, int NEG>
 DEVI cf cmul_k(cf a, cf w) {
-    cf p, d;
+    cf d;
     if constexpr (!CONJ && !ROT && !NEG)         // w
-        asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[0,1]\n\t"
-            "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d), "=&v"(p) : "v"(a), "s"(w));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+            "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=&v"(d) : "v"(a), "s"(w));
     else if constexpr (!CONJ && !ROT && NEG)     // -w = (-wx, -wy)
-        asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-            "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "=v"(d), "=&v"(p) : "v"(a), "s"(w));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "=&v"(d) : "v"(a), "s"(w));
     else if constexpr (CONJ && !ROT && NEG)      // -conj(w) = (-wx, wy)
-        asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[0,1] neg_lo:[0,1]\n\t"
-            "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(d), "=&v"(p) : "v"(a), "s"(w));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[0,1]\n\t"
+            "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=&v"(d) : "v"(a), "s"(w));
     else if constexpr (!CONJ && ROT && !NEG)     // i w = (-wy, wx)
-        asm("v_pk_mul_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,1]\n\t"
-            "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(d), "=&v"(p) : "v"(a), "s"(w));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,1]\n\t"
+            "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=&v"(d) : "v"(a), "s"(w));
     else if constexpr (CONJ && ROT && !NEG)      // i conj(w) = (wy, wx)
-        asm("v_pk_mul_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[0,0]\n\t"
-            "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0]" : "=v"(d), "=&v"(p) : "v"(a), "s"(w));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0]\n\t"
+            "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0]" : "=&v"(d) : "v"(a), "s"(w));
     else {                                       // -i conj(w) = (-wy, -wx)
         static_assert(CONJ && ROT && NEG, "twiddle variant");
-        asm("v_pk_mul_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-            "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_hi:[0,1,0]" : "=v"(d), "=&v"(p) : "v"(a), "s"(w));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_hi:[0,1,0]" : "=&v"(d) : "v"(a), "s"(w));
     }
     return d;
 }
