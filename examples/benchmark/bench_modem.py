@@ -32,11 +32,13 @@ def bandwidth(modulation, baud):
     return {'GMSK': baud / 0.7, 'BPSK': baud * 1.5, 'FSK': 2 * baud + 2 * (baud / 2), 'GFSK': 2 * baud + 2 * (baud / 2)}[modulation]
 
 
-def run_snr(modulation, n_runs, snr, block_size, search, seed, doppler_bins=64, pipelined=False):
+def run_snr(modulation, n_runs, snr, block_size, search, seed, doppler_bins=64, pipelined=False, blocks_per_call=1, decode=True):
     spSym, baud = 16, 9600
     fs = spSym * baud
     pname = 'bench_' + modulation
     conf = cfg.bench_config(pname, blockSize=block_size, doppCarrierSteps=doppler_bins)
+    if blocks_per_call > 1:         # B consecutive blocks per device call (mfb_receive_blocks_*)
+        conf['GPU']['UHF'].setdefault('HIP', {})['blocks_per_call'] = int(blocks_per_call)
     proto = loadProtocol(pname)(conf=conf)
     sig, bit_data = sg.get_padded_packet(modulation, spSym, fs)
     bw = bandwidth(modulation, baud)
@@ -57,8 +59,8 @@ def run_snr(modulation, n_runs, snr, block_size, search, seed, doppler_bins=64, 
     dec = Decoder(conf, proto)
     dec.prepare()
     t0 = time.perf_counter()
-    results, packets = run.run_stream((stream[i:i + CHUNK] for i in range(0, len(stream), CHUNK)), decoder=dec,
-                                          pipelined=pipelined)
+    results, packets = run.run_stream((stream[i:i + CHUNK] for i in range(0, len(stream), CHUNK)), decoder=dec if decode else None,
+                                      pipelined=pipelined)
     dt = time.perf_counter() - t0
     run.close()
     errs = [p.checkPacketData() for p in packets]
@@ -80,6 +82,7 @@ def main():
     ap.add_argument('--doppler-bins', type=int, default=64)
     ap.add_argument('--pipelined', action='store_true', help='source, demodulator and decoder as three threads (the reference: three processes)')
     ap.add_argument('--search', choices=['transforms', 'energy'], default='transforms')
+    ap.add_argument('--blocks-per-call', type=int, default=1, help='consecutive blocks handed to the device per call')
     ap.add_argument('--out', default=None, help='write the table as JSON')
     a = ap.parse_args()
     # the noise generator's np.linalg.norm wakes one BLAS worker per core; under a container's CPU quota their spinning gets the
@@ -88,7 +91,7 @@ def main():
     rows = []
     for k, snr in enumerate(np.arange(a.SNR_low, a.SNR_high + a.SNR_step / 2, a.SNR_step)):
         r = run_snr(a.modulation, a.nRuns, snr, a.block_size, a.search, seed=1000 + k, doppler_bins=a.doppler_bins,
-                    pipelined=a.pipelined)
+                    pipelined=a.pipelined, blocks_per_call=a.blocks_per_call)
         rows.append(r)
         print(f"SNR {r['SNR']:5.1f} dB:\tEB/N0 {r['EBN0']:.2f} dB\tpackets {r['packets']}/{r['sent']}\tavg. BER {r['BER']:.3e}"
               f"\t({r['ksamples_per_s']:.0f} ksamples/s through the chain)", flush=True)

@@ -50,7 +50,8 @@ const char *mfb_strerror(int status);
 /* Library/ABI version, bumped whenever a prototype changes.  No reference counterpart (its kernels are compiled from source
  * at run time, SourceModule DB:214). */
 int mfb_abi_version(void);   /* 2: search paths, mfb_xcorr; 3: mfb_set_search_mode, mfb_sync_find_multi; 4: mfb_receive_block,
-                              * mfb_export_rows_async, mfb_sync_find_packed; 5: mfb_debug_block_scalars */
+                              * mfb_export_rows_async, mfb_sync_find_packed; 5: mfb_debug_block_scalars; 6: mfb_receive_blocks_*,
+                              * mfb_window_buffer, mfb_block_params.block_stride */
 
 /* Create a handle on HIP device `device` for blocks of N = 2^log2N samples, `num_dopplers`
  * Doppler bins plus `doppler_offset` leading noise-reference bins (DB:150-159), M matched
@@ -214,7 +215,8 @@ int mfb_demodulate(mfb_ctx *ctx, int shift, int k_offset, int k_len, float res[3
  * sequence mfb_upload, mfb_find_carrier, mfb_get_spectrum, mfb_demodulate, mfb_find_centres with the reference's host
  * arithmetic in between (tests/test_gpu_block.py). */
 enum { MFB_BLOCK_SEARCH = 0, MFB_BLOCK_FIXED_SHIFT = 1 };            /* UHF: Doppler search; STX: shift = IF offset (STX.py:21-24) */
-enum { MFB_INPUT_PINNED = 0, MFB_INPUT_DEVICE = 1, MFB_INPUT_UPLOADED = 2, MFB_INPUT_PINNED2 = 3 };
+enum { MFB_INPUT_PINNED = 0, MFB_INPUT_DEVICE = 1, MFB_INPUT_UPLOADED = 2, MFB_INPUT_PINNED2 = 3,
+       MFB_INPUT_WINDOW = 4, MFB_INPUT_WINDOW2 = 5 };    /* batches: the two page-locked sample windows of mfb_window_buffer */
 typedef struct mfb_block_params {
     int32_t mode;            /* MFB_BLOCK_* */
     int32_t input;           /* MFB_INPUT_PINNED(2): H2D of the (second) pinned input buffer first; _DEVICE: N complex64 at device_block;
@@ -227,6 +229,8 @@ typedef struct mfb_block_params {
     int32_t snr_window;      /* computeSNR's windowWidth (DB:618: 5) */
     int32_t max_symbols;     /* capacity of sym / cen / mag */
     int32_t band_capacity;   /* complex64 elements per SNR window in bands_c64 [2][band_capacity]; 0 = no windows */
+    int32_t block_stride;    /* mfb_receive_blocks_* only: samples from the start of a block to the start of the next (N - overlap);
+                              * 0 with MFB_INPUT_WINDOW(2) = what the window was made for */
 } mfb_block_params;
 typedef struct mfb_block_result {
     float pick[2];           /* {index, metric} of findDopplerEst */
@@ -252,6 +256,28 @@ int mfb_receive_block_begin(mfb_ctx *ctx, const mfb_block_params *params, int sl
 int mfb_receive_block_end(mfb_ctx *ctx, int slot, mfb_block_result *result, int32_t *sym, int32_t *centres, float *magnitude,
                           float *bands_c64);
 int mfb_input_buffer2(mfb_ctx *ctx, float **host_c64);
+/* B consecutive blocks per call.  The reference's own configurations run blocks of 2^15 ... 2^17 samples over 64 bins
+ * (config/base.json:13,33; config/benchmark/bench_base.json:26; config/CC11xx.json:50) and hand the device ONE block per turn of
+ * the receive loop (Demodulator_process.run, DP:284-338: popBlock, uploadAndFindCarrier, demodulate, send): a few tens of
+ * microseconds of device work per turn.  These calls take `nblocks` consecutive blocks of the stream at once, as ONE contiguous
+ * window of nblocks * block_stride + (N - block_stride) complex64 samples (block_stride = N - overlap; block b starts at sample
+ * b * block_stride, so neighbouring blocks share their overlap samples as storage -- nothing is copied twice and the caller
+ * carries the overlap once per window instead of once per block, DP:256,287,337), and run them through one set of launches:
+ * batched forward FFT, ONE search launch over nblocks x bins streams, nblocks picks, ONE matched-filter launch at the nblocks
+ * shifts, batched envelope FFT, rate estimates, symbol centres, ONE device-to-host copy of nblocks result records.  Every
+ * number of every block equals what mfb_receive_block returns for that block alone, bit for bit (tests/test_gpu_blocks.py).
+ *   mfb_window_buffer     page-locked window `which` (0 / 1) for up to max_blocks blocks (owned by the handle, zero-filled,
+ *                         with a device copy of its own); asking for another geometry re-allocates both windows.
+ *   _begin                params as for mfb_receive_block with input = MFB_INPUT_WINDOW / _WINDOW2 (or MFB_INPUT_DEVICE:
+ *                         device_block = the window in device memory, block_stride required); enqueues and returns.  Two
+ *                         batches may be in flight (slot 0 / 1, shared with mfb_receive_block_begin).  Segment search path and
+ *                         MFB_SEARCH_TRANSFORMS only (else MFB_ERR_UNSUPPORTED: use the one-block calls).
+ *   _end                  waits; results[nblocks]; block b's symbols / centres / magnitudes at sym + b * symbol_stride (...),
+ *                         its two SNR windows at bands_c64 + b * 4 * band_capacity floats. */
+int mfb_window_buffer(mfb_ctx *ctx, int which, int max_blocks, int block_stride, float **host_c64);
+int mfb_receive_blocks_begin(mfb_ctx *ctx, const mfb_block_params *params, int nblocks, int slot);
+int mfb_receive_blocks_end(mfb_ctx *ctx, int slot, mfb_block_result *results, int32_t *sym, int32_t *centres, float *magnitude,
+                           int symbol_stride, float *bands_c64);
 /* Test seam of the one-call path.  mfb_receive_block moved two pieces of the reference's float64 HOST arithmetic onto the
  * device: the shift interpolation and the bounds of computeSNR's spectrum windows behind the pick (DB:609-620, 635-667), and
  * samples per symbol / code phase / clamp / symbol count behind the rate argmax (DB:733-752, 994-999).  This call runs exactly

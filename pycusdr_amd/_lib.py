@@ -39,7 +39,7 @@ class BlockParams(C.Structure):
     """mfb_block_params of include/mfbank.h."""
     _fields_ = [('mode', C.c_int32), ('input', C.c_int32), ('device_block', C.c_void_p), ('fixed_shift', C.c_int32),
                 ('k_offset', C.c_int32), ('k_len', C.c_int32), ('spsym_min', C.c_int32), ('op', C.c_int32),
-                ('snr_window', C.c_int32), ('max_symbols', C.c_int32), ('band_capacity', C.c_int32)]
+                ('snr_window', C.c_int32), ('max_symbols', C.c_int32), ('band_capacity', C.c_int32), ('block_stride', C.c_int32)]
 
 
 class BlockResult(C.Structure):
@@ -83,6 +83,9 @@ PROTOTYPES = {
     'mfb_receive_block_begin': (_i, [_vp, C.POINTER(BlockParams), _i]),
     'mfb_receive_block_end': (_i, [_vp, _i, C.POINTER(BlockResult), _vp, _vp, _vp, _vp]),
     'mfb_input_buffer2': (_i, [_vp, C.POINTER(_fp)]),
+    'mfb_window_buffer': (_i, [_vp, _i, _i, _i, C.POINTER(_fp)]),
+    'mfb_receive_blocks_begin': (_i, [_vp, C.POINTER(BlockParams), _i, _i]),
+    'mfb_receive_blocks_end': (_i, [_vp, _i, C.POINTER(BlockResult), _vp, _vp, _vp, _i, _vp]),
     'mfb_debug_block_scalars': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, C.POINTER(BlockResult), _vp, _vp]),
     'mfb_pick_column': (_i, [_vp, _vp, _i, _i, _fp]),
     'mfb_find_carrier': (_i, [_vp, _fp]),

@@ -52,9 +52,11 @@
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-struct BlockFlight {      // one block between mfb_receive_block_begin and _end
+struct BlockFlight {      // one block -- or one batch of nb blocks -- between mfb_receive_block(s)_begin and _end
     bool active;
     int mode, nthreads, bcap, shift, op;
+    int nb;               // 0: a single block (mfb_receive_block_begin); > 0: a batch (mfb_receive_blocks_begin)
+    size_t rec;           // bytes per block record in the staging buffer (batches)
     size_t off[5];
     unsigned long long seq;
 };
@@ -63,6 +65,7 @@ struct BlockGraph {
     hipGraph_t graph;
     hipGraphExec_t exec;
     mfb_block_params params;
+    int nb;               // blocks of the batch the graph was recorded for (0: single block)
     unsigned long long epoch;
     bool seen, failed;
 };
@@ -135,6 +138,16 @@ struct mfb_ctx {
     BlockScalars *d_scal;     // = d_blkout
     int band_cap;
     bool W_valid;
+    // batches of blocks (mfb_receive_blocks_*): B consecutive blocks of ONE contiguous window of samples per launch set
+    int win_blocks, win_stride;   // capacity in blocks and block advance (N - overlap) the windows were made for
+    cf *h_win[2], *d_win[2];      // page-locked windows of win_blocks * win_stride + (N - win_stride) samples, and their device copies
+    hipEvent_t ev_wh2d[2], ev_wfree[2];
+    int bat_cap;                  // blocks the batch work buffers below hold
+    cf *d_Xb, *d_xcb, *d_Pb;      // spectra [B][N], matched-filter outputs [B][M][N], envelope spectra [B][N]
+    float *d_envb, *d_sumb, *d_resb, *d_crb;   // envelopes [B][N], doppSum [B][Dtot][M], picks [B][2], rate triples [B][3]
+    uint8_t *d_batout;            // result records [B][rec]
+    size_t batout_cap;
+    BlockGraph wgraph[2][2];      // [window][slot]
     std::vector<hipEvent_t> ev[2];
     std::vector<hipEvent_t> ev_pool;
 };
@@ -178,7 +191,7 @@ extern "C" const char *mfb_strerror(int s) {
         default: return "unknown status";
     }
 }
-extern "C" int mfb_abi_version(void) { return 5; }
+extern "C" int mfb_abi_version(void) { return 6; }
 
 static void make_twiddles(std::vector<cf> &v, int count, double denom, double stepmul) {
     v.resize(count);
@@ -242,6 +255,7 @@ static int reserve_partials(mfb_ctx *c, size_t floats) {
     if (c->part_cap >= floats) return MFB_OK;
     if (c->d_part) {
         HIPCHK(hipStreamSynchronize(c->stream));
+        ++c->epoch;          // recorded block graphs hold the old address
         HIPCHK(hipFree(c->d_part));
         c->d_part = nullptr;
         c->part_cap = 0;
@@ -469,12 +483,20 @@ extern "C" int mfb_destroy(mfb_ctx *c) {
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     void *bufs[] = {c->d_uniq, c->d_rep, c->d_x,  c->d_X,    c->d_masks, c->d_Z,   c->d_xc,  c->d_P,   c->d_env, c->d_shifts, c->d_tw1,
                     c->d_tw2, c->d_twLo, c->d_twHi,  c->d_part, c->d_sum, c->d_res, c->d_cr,  c->d_sym,    c->d_cen, c->d_mag,
-                    c->d_G, c->d_twL, c->d_Gb, c->d_pow, c->d_W, c->d_blkout, c->d_x2};
+                    c->d_G, c->d_twL, c->d_Gb, c->d_pow, c->d_W, c->d_blkout, c->d_x2,
+                    c->d_win[0], c->d_win[1], c->d_Xb, c->d_xcb, c->d_Pb, c->d_envb, c->d_sumb, c->d_resb, c->d_crb, c->d_batout};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_in2) (void)hipHostFree(c->h_in2);
+    for (int i = 0; i < 2; ++i) {
+        if (c->h_win[i]) (void)hipHostFree(c->h_win[i]);
+        if (c->ev_wh2d[i]) (void)hipEventDestroy(c->ev_wh2d[i]);
+        if (c->ev_wfree[i]) (void)hipEventDestroy(c->ev_wfree[i]);
+    }
     for (auto &row : c->bgraph)
+        for (auto &g : row) graph_drop(g);
+    for (auto &row : c->wgraph)
         for (auto &g : row) graph_drop(g);
     for (int i = 0; i < 2; ++i) {
         if (c->h_blk[i]) (void)hipHostFree(c->h_blk[i]);
@@ -934,24 +956,27 @@ static int launch_transpose(mfb_ctx *c, cf *dst, int rows, int conj) {
     return MFB_OK;
 }
 
-// forward FFT of one row: complex (src_c) or real (src_r) input -> dst natural order
-static int forward_fft(mfb_ctx *c, const cf *src_c, const float *src_r, cf *dst, int conj_out = 1);
-static int forward_fft(mfb_ctx *c, const cf *src_c, const float *src_r, cf *dst, int conj_out) {
+// forward FFT of `rows` rows (a batch of blocks: row r reads its input in_stride elements behind row r - 1 and goes to
+// dst + r * N): complex (src_c) or real (src_r) input -> dst natural order.  d_Z must hold `rows` rows.
+static int forward_fft(mfb_ctx *c, const cf *src_c, const float *src_r, cf *dst, int conj_out = 1, int rows = 1, size_t in_stride = 0);
+static int forward_fft(mfb_ctx *c, const cf *src_c, const float *src_r, cf *dst, int conj_out, int rows, size_t in_stride) {
+    if (rows < 1 || (size_t)rows > c->z_rows || in_stride > 0x7fffffffu) return MFB_ERR_ARG;
     P1Args a = p1_base(c);
     a.X = src_c;
     a.Xr = src_r;
     a.ntiles = c->N2 / TILE;
     a.mgroups = 1;
-    a.jsplit = 1;
-    dim3 g1(a.ntiles, 1, 1);
+    a.jsplit = rows;
+    a.in_stride = (int)in_stride;
+    dim3 g1(a.ntiles * rows, 1, 1);
     int rc = src_c ? launch_p1<KIND_FWDC>(c, a, g1) : launch_p1<KIND_FWDR>(c, a, g1);
     if (rc) return rc;
     P2Args b = p2_base(c);
     p2_store_split(c, b, 1);
-    dim3 g2(b.parts, 1, 1);
+    dim3 g2(b.parts, rows, 1);
     rc = launch_p2<MODE_STORE>(c, b, g2);
     if (rc) return rc;
-    return launch_transpose(c, dst, 1, conj_out);   // conj_out = 0 leaves conj(fft(src)) (real input only)
+    return launch_transpose(c, dst, rows, conj_out);   // conj_out = 0 leaves conj(fft(src)) (real input only)
 }
 
 
@@ -1172,6 +1197,60 @@ extern "C" int mfb_upload_device(mfb_ctx *c, const void *dev) {
     return MFB_OK;
 }
 
+// The segment-path search of nb blocks in ONE launch (+ the masked tail launch + k_finalize): stream jl of the launch is bin
+// jl % Dtot of block jl / Dtot, block b's samples start at x + b * xstride, its doppSum rows at dsum + b * Dtot * M.  nb = 1 is
+// the plain search of one block.  A score depends on the block, the shift and the filter only (seg_kernels.hpp), so a
+// block's rows come out bit for bit the same whichever batch it is part of.
+static int seg_search_enqueue(mfb_ctx *c, int nb, const cf *x, int xstride, float *dsum) {
+    // all bins in ONE launch: nothing of length N is written, so there is nothing to chunk.  A second,
+    // tiny launch of the masked instantiation covers the slots that hold incomplete segments.
+    const bool span = c->basis == MFB_BASIS_SPAN;
+    const int MU = span ? c->MB : c->MU;     // filters transformed per bin
+    const int rows = nb * c->Dtot;           // Doppler streams of the launch
+    int nfull, ntotal;
+    seg_slots(c, &nfull, &ntotal);
+    const SegPlan pm = plan_seg(c, rows, MU, nfull > 0 ? nfull : 1, c->seg_mpb, true);
+    // the tail is a handful of units: spread the filters too (2 per pass) so that it is short
+    const SegPlan pt = plan_seg(c, rows, MU, ntotal - nfull > 0 ? ntotal - nfull : 1, c->seg_mpb > 0 && c->seg_mpb < 2 ? c->seg_mpb : 2);
+    // one partial per (bin, filter, slot, wave of the team): the index depends on the slot alone (seg_kernels.hpp)
+    const int parts = ntotal * seg_geom(c).WPT;
+    int rc = reserve_partials(c, (size_t)rows * MU * parts);
+    if (rc) return rc;
+    SegArgs am = seg_base(c, pm), at = seg_base(c, pt);
+    for (SegArgs *q : {&am, &at}) {
+        if (span) {
+            q->G = c->d_Gb;
+            q->Grows = c->MB;
+        }
+        q->x = x;
+        q->rows = (!span && MU < c->M) ? c->d_uniq : nullptr;
+        q->shifts = c->d_shifts;
+        q->partials = c->d_part;
+        q->MU = MU;
+        q->dc = rows;
+        q->parts = parts;
+        if (nb > 1) {
+            q->dper = c->Dtot;
+            q->xstride = xstride;
+        }
+    }
+    am.slot0 = 0;
+    am.nslots = nfull;
+    at.slot0 = nfull;
+    at.nslots = ntotal - nfull;
+    const int pv = c->V / seg_geom(c).NT;
+    prof_mark(c, 0);
+    // (both roles inside one grid were tried: the merged kernel ran 8-10 % slower than two launches)
+    if (nfull > 0) rc = launch_seg(c, am, pm.grid, SEG_REDUCE, pv);
+    if (!rc && ntotal > nfull) rc = launch_seg(c, at, pt.grid, SEG_REDUCE, -1);
+    if (rc) return rc;
+    prof_mark(c, 0);
+    hipLaunchKernelGGL(k_finalize, dim3(rows), dim3(fin_threads(MU)), 0, c->stream, c->d_part, dsum, rows, c->M, MU,
+                       span ? (const int *)nullptr : (const int *)c->d_rep, parts, c->sum_all);
+    HIPCHK(hipGetLastError());
+    return MFB_OK;
+}
+
 extern "C" int mfb_search_async(mfb_ctx *c) {
     if (!c) return MFB_ERR_ARG;
     if (!c->have_filters || !c->have_shifts || !c->have_input) return MFB_ERR_STATE;
@@ -1202,49 +1281,7 @@ extern "C" int mfb_search_async(mfb_ctx *c) {
         HIPCHK(hipGetLastError());
         return MFB_OK;
     }
-    if (c->path == MFB_PATH_SEGMENT) {
-        // all bins in ONE launch: nothing of length N is written, so there is nothing to chunk.  A second,
-        // tiny launch of the masked instantiation covers the slots that hold incomplete segments.
-        const bool span = c->basis == MFB_BASIS_SPAN;
-        const int MU = span ? c->MB : c->MU;     // filters transformed per bin (shadows the two-pass count above on purpose)
-        int nfull, ntotal;
-        seg_slots(c, &nfull, &ntotal);
-        const SegPlan pm = plan_seg(c, c->Dtot, MU, nfull > 0 ? nfull : 1, c->seg_mpb, true);
-        // the tail is a handful of units: spread the filters too (2 per pass) so that it is short
-        const SegPlan pt = plan_seg(c, c->Dtot, MU, ntotal - nfull > 0 ? ntotal - nfull : 1, c->seg_mpb > 0 && c->seg_mpb < 2 ? c->seg_mpb : 2);
-        // one partial per (bin, filter, slot, wave of the team): the index depends on the slot alone (seg_kernels.hpp)
-        const int parts = ntotal * seg_geom(c).WPT;
-        int rc = reserve_partials(c, (size_t)c->Dtot * MU * parts);
-        if (rc) return rc;
-        SegArgs am = seg_base(c, pm), at = seg_base(c, pt);
-        for (SegArgs *q : {&am, &at}) {
-            if (span) {
-                q->G = c->d_Gb;
-                q->Grows = c->MB;
-            }
-            q->rows = (!span && MU < c->M) ? c->d_uniq : nullptr;
-            q->shifts = c->d_shifts;
-            q->partials = c->d_part;
-            q->MU = MU;
-            q->dc = c->Dtot;
-            q->parts = parts;
-        }
-        am.slot0 = 0;
-        am.nslots = nfull;
-        at.slot0 = nfull;
-        at.nslots = ntotal - nfull;
-        const int pv = c->V / seg_geom(c).NT;
-        prof_mark(c, 0);
-        // (both roles inside one grid were tried: the merged kernel ran 8-10 % slower than two launches)
-        if (nfull > 0) rc = launch_seg(c, am, pm.grid, SEG_REDUCE, pv);
-        if (!rc && ntotal > nfull) rc = launch_seg(c, at, pt.grid, SEG_REDUCE, -1);
-        if (rc) return rc;
-        prof_mark(c, 0);
-        hipLaunchKernelGGL(k_finalize, dim3(c->Dtot), dim3(fin_threads(MU)), 0, c->stream, c->d_part, c->d_sum, c->Dtot, c->M, MU,
-                           span ? (const int *)nullptr : (const int *)c->d_rep, parts, c->sum_all);
-        HIPCHK(hipGetLastError());
-        return MFB_OK;
-    }
+    if (c->path == MFB_PATH_SEGMENT) return seg_search_enqueue(c, 1, c->d_in, 0, c->d_sum);
     const int mpb = c->mpb < MU ? c->mpb : MU;
     const int mgroups = (MU + mpb - 1) / mpb;
     for (int j0 = 0; j0 < c->Dtot; j0 += c->chunk) {
@@ -1391,12 +1428,33 @@ extern "C" int mfb_get_spectrum(mfb_ctx *c, float *host, int start, int count) {
     return enable_mirror(c);          // a caller that reads the spectrum once will read it again after every block
 }
 
-// A9 + A10 enqueued on the handle's stream: matched filters at one shift (a value, or -- shift_dev != nullptr -- an int the
-// device has just computed), envelope, its spectrum, windowed argmax into d_cr.  No synchronisation.
-static int demod_enqueue(mfb_ctx *c, int shift, const int *shift_dev, int k_offset, int k_len, int spsym_min = 0, int capacity = 0,
-                         BlockScalars *scal = nullptr) {
+// Where a block -- or a batch of nb blocks -- lives on the device while it goes through the block path.
+struct BlkBufs {
+    int nb;              // blocks
+    const cf *x;         // samples: block b starts at x + b * xstride
+    int xstride;
+    cf *X;               // spectra [nb][N]
+    float *sum;          // doppSum [nb][Dtot][M]
+    float *res;          // picks [nb][2]
+    cf *xc;              // matched-filter outputs [nb][M][N]
+    float *env;          // symbol-energy envelopes [nb][N]
+    cf *P;               // their spectra [nb][N]
+    float *cr;           // rate triples [nb][3]
+    uint8_t *out;        // result records [nb][rec]
+    size_t rec;
+};
+static BlkBufs single_bufs(mfb_ctx *c) {
+    return BlkBufs{1, c->d_in, 0, c->d_X, c->d_sum, c->d_res, c->d_xc, c->d_env, c->d_P, c->d_cr, c->d_blkout, 0};
+}
+
+// A9 + A10 enqueued on the handle's stream: matched filters at one shift per block (a value, or -- shift_dev != nullptr -- an
+// int the device has just computed; for a batch, block b's sits shift_stride ints behind block b - 1's), envelope, its
+// spectrum, windowed argmax into cr.  No synchronisation.
+static int demod_enqueue(mfb_ctx *c, const BlkBufs &bb, int shift, const int *shift_dev, int shift_stride, int k_offset, int k_len,
+                         int spsym_min = 0, int capacity = 0, BlockScalars *scal = nullptr) {
     // A9: matched filters at one shift -> xc[M][N] natural order
     int rc;
+    const int nb = bb.nb;
     if (c->path == MFB_PATH_SEGMENT) {
         // the same segment kernel, storing y in natural order instead of reducing it (no transpose)
         int nfull, ntotal;
@@ -1405,27 +1463,35 @@ static int demod_enqueue(mfb_ctx *c, int shift, const int *shift_dev, int k_offs
         // sums the symbol-energy envelope (sumXCorrBuffMasks, CU:191-205) in the same pass; otherwise the filters are
         // spread too and k_envelope follows
         const bool fused_env = c->M <= SEG_MPB_MAX;
-        const SegPlan p = plan_seg(c, 1, c->M, ntotal, fused_env ? c->M : 4);
+        const SegPlan p = plan_seg(c, nb, c->M, ntotal, fused_env ? c->M : 4);
         SegArgs sa = seg_base(c, p);
-        sa.out = c->d_xc;
+        sa.x = bb.x;
+        sa.out = bb.xc;
         if (fused_env) {
-            sa.env = c->d_env;
+            sa.env = bb.env;
             sa.env_lo = c->cs_off;
             sa.env_hi = c->M - c->cs_off;
         }
         sa.MU = c->M;
-        sa.dc = 1;
+        sa.dc = nb;
         sa.slot0 = 0;
         sa.nslots = ntotal;
         sa.shifts = shift_dev;
         sa.j0 = 0;
         sa.fixed_shift = shift;
         sa.out_off = (c->win_start + c->T - 1) & (c->N - 1);
+        if (nb > 1) {
+            sa.dper = 1;
+            sa.xstride = bb.xstride;
+            sa.sstride = shift_stride;
+            sa.ostride = (long long)c->M * c->N;
+        }
         rc = launch_seg(c, sa, p.grid, SEG_STORE, -1);
         if (rc) return rc;
     } else {
+        if (nb != 1) return MFB_ERR_UNSUPPORTED;        // batches of blocks run on the segment path
         P1Args a = p1_base(c);
-        a.X = c->d_X;
+        a.X = bb.X;
         a.shifts = shift_dev;
         a.j0 = 0;
         a.fixed_shift = shift;
@@ -1440,20 +1506,21 @@ static int demod_enqueue(mfb_ctx *c, int shift, const int *shift_dev, int k_offs
         p2_store_split(c, b, c->M);
         rc = launch_p2<MODE_STORE>(c, b, dim3(b.parts, c->M, 1));
         if (rc) return rc;
-        rc = launch_transpose(c, c->d_xc, c->M, 0);
+        rc = launch_transpose(c, bb.xc, c->M, 0);
         if (rc) return rc;
     }
     // A10: envelope (unless the matched-filter launch already summed it), spectrum of the envelope, windowed argmax
     if (!(c->path == MFB_PATH_SEGMENT && c->M <= SEG_MPB_MAX)) {
-        hipLaunchKernelGGL(k_envelope, dim3(1024), dim3(256), 0, c->stream, c->d_xc, c->d_env, c->N, c->M, c->cs_off);
+        hipLaunchKernelGGL(k_envelope, dim3(1024, nb), dim3(256), 0, c->stream, (const cf *)bb.xc, bb.env, c->N, c->M, c->cs_off);
         HIPCHK(hipGetLastError());
     }
-    rc = forward_fft(c, nullptr, c->d_env, c->d_P);
+    rc = forward_fft(c, nullptr, bb.env, bb.P, 1, nb, (size_t)c->N);
     if (rc) return rc;
     if (scal)
-        hipLaunchKernelGGL(k_code_rate_block, dim3(1), dim3(1024), 0, c->stream, c->d_P, c->d_cr, k_offset, k_len, c->N, spsym_min, capacity, scal);
+        hipLaunchKernelGGL(k_code_rate_block, dim3(nb), dim3(1024), 0, c->stream, (const cf *)bb.P, bb.cr, k_offset, k_len, c->N, spsym_min,
+                           capacity, scal, bb.rec);
     else
-        hipLaunchKernelGGL(k_code_rate, dim3(1), dim3(1024), 0, c->stream, c->d_P, c->d_cr, k_offset, k_len);
+        hipLaunchKernelGGL(k_code_rate, dim3(1), dim3(1024), 0, c->stream, (const cf *)bb.P, bb.cr, k_offset, k_len);
     HIPCHK(hipGetLastError());
     return MFB_OK;
 }
@@ -1464,7 +1531,7 @@ extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, fl
     if (k_offset < 0 || k_len < 0 || k_offset + k_len > c->N) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     shift = ((shift % c->N) + c->N) % c->N;
-    int rc = demod_enqueue(c, shift, nullptr, k_offset, k_len);
+    int rc = demod_enqueue(c, single_bufs(c), shift, nullptr, 0, k_offset, k_len);
     if (rc) return rc;
     const BackPiece bp = {res, c->d_cr, 3 * sizeof(float)};
     if ((rc = read_back(c, &bp, 1))) return rc;
@@ -1477,26 +1544,30 @@ extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, fl
 // stream of launches and ONE synchronisation: [H2D of the pinned input buffer,] forward FFT, Doppler search, pick, shift
 // interpolation (k_block_pick), the two spectrum windows of computeSNR, matched filters at that shift, envelope, its
 // spectrum, rate/phase argmax, the float64 arithmetic behind it (k_block_rate), symbol centres -- then one packed read-back.
-// The launches of one block, from the input copy to the ONE device-to-host copy of the result record.
-static int block_enqueue(mfb_ctx *c, const mfb_block_params *p, int slot, int nthreads, int bcap, int capacity, int *shift_out) {
+// The same launches take a BATCH of bb.nb consecutive blocks of one window of samples (mfb_receive_blocks_*): every kernel
+// gets a block index in its grid, nothing else changes -- a block's numbers are those of the one-block call, bit for bit.
+// The launches of one block / batch, from the forward FFT to the ONE device-to-host copy of the result record(s).
+static int block_enqueue(mfb_ctx *c, const mfb_block_params *p, const BlkBufs &bb, uint8_t *h_dst, int nthreads, int bcap, int capacity,
+                         int *shift_out) {
     int rc;
-    if (p->input == MFB_INPUT_PINNED || p->input == MFB_INPUT_PINNED2) {
-        // the samples are (being) copied by block_input_copy on the input stream; this stream waits for them there
-        c->d_in = p->input == MFB_INPUT_PINNED ? c->d_x : c->d_x2;
-    } else if (p->input == MFB_INPUT_DEVICE) {
-        if (!p->device_block) return MFB_ERR_ARG;
-        c->d_in = (const cf *)p->device_block;
-    } else if (p->input != MFB_INPUT_UPLOADED || !c->have_input) {
-        return p->input == MFB_INPUT_UPLOADED ? MFB_ERR_STATE : MFB_ERR_ARG;
+    const int nb = bb.nb;
+    const bool batch = bb.rec != 0;
+    if (!batch && p->input == MFB_INPUT_UPLOADED) {
+        if (!c->have_input) return MFB_ERR_STATE;
+    } else {
+        if (!batch) {
+            if ((rc = before_fft(c))) return rc;
+        }
+        if ((rc = forward_fft(c, bb.x, nullptr, bb.X, 1, nb, (size_t)bb.xstride))) return rc;
+        if (!batch) {
+            if ((rc = after_fft(c))) return rc;
+            c->have_input = true;
+            c->have_xc = false;
+        }
     }
-    if (p->input != MFB_INPUT_UPLOADED) {
-        if ((rc = before_fft(c))) return rc;
-        if ((rc = forward_fft(c, c->d_in, nullptr, c->d_X))) return rc;
-        if ((rc = after_fft(c))) return rc;
-        c->have_input = true;
-        c->have_xc = false;
-    }
-    uint8_t *d = c->d_blkout;
+    const size_t rec = batch ? bb.rec : blkout_bytes(bcap, nthreads);
+    uint8_t *d = bb.out;
+    BlockScalars *scal = (BlockScalars *)d;
     cf *d_bands = (cf *)(d + BLK_HEAD);
     int *d_sym = (int *)(d + BLK_HEAD + align16((size_t)2 * bcap * sizeof(cf)));
     int *d_cen = (int *)((uint8_t *)d_sym + align16((size_t)nthreads * sizeof(int)));
@@ -1504,23 +1575,28 @@ static int block_enqueue(mfb_ctx *c, const mfb_block_params *p, int slot, int nt
     const int *shift_dev = nullptr;
     int shift = 0;
     if (p->mode == MFB_BLOCK_SEARCH) {
-        if ((rc = mfb_search_async(c))) return rc;
-        hipLaunchKernelGGL(k_pick_block, dim3(1), dim3(64), 0, c->stream, (const float *)c->d_sum, c->d_res, c->D, c->Doff, c->M, c->sum_all,
-                           (const int *)c->d_shifts, c->Dtot, c->N, p->snr_window, (const cf *)c->d_X, c->d_scal, d_bands, bcap);
+        if (batch) {
+            if (c->path != MFB_PATH_SEGMENT || c->search_mode != MFB_SEARCH_TRANSFORMS) return MFB_ERR_UNSUPPORTED;
+            if ((rc = seg_search_enqueue(c, nb, bb.x, bb.xstride, bb.sum))) return rc;
+        } else if ((rc = mfb_search_async(c))) {
+            return rc;
+        }
+        hipLaunchKernelGGL(k_pick_block, dim3(nb), dim3(64), 0, c->stream, (const float *)bb.sum, bb.res, c->D, c->Doff, c->M, c->sum_all,
+                           (const int *)c->d_shifts, c->Dtot, c->N, p->snr_window, (const cf *)bb.X, scal, d_bands, bcap, rec);
         HIPCHK(hipGetLastError());
-        shift_dev = &c->d_scal->shift;
+        shift_dev = &scal->shift;
     } else {
-        hipLaunchKernelGGL(k_block_clear, dim3(1), dim3(1), 0, c->stream, c->d_scal);
+        hipLaunchKernelGGL(k_block_clear, dim3(nb), dim3(1), 0, c->stream, scal, rec);
         HIPCHK(hipGetLastError());
         shift = ((p->fixed_shift % c->N) + c->N) % c->N;
     }
-    if ((rc = demod_enqueue(c, shift, shift_dev, p->k_offset, p->k_len, p->spsym_min, capacity, c->d_scal))) return rc;
+    if ((rc = demod_enqueue(c, bb, shift, shift_dev, (int)(rec / sizeof(int)), p->k_offset, p->k_len, p->spsym_min, capacity, scal))) return rc;
     // (entries past nthreads are not part of the record: the kernel's capacity bounds what it writes; the k* == 0 fallback --
     // spSym = 10, DB:737-740, unreachable while the rate window starts above bin 0 -- is completed in block_end)
-    hipLaunchKernelGGL(k_centres_block, dim3((nthreads + 255) / 256), dim3(256), 0, c->stream, d_sym, d_cen, d_mag, (const cf *)c->d_xc,
-                       (const BlockScalars *)c->d_scal, c->N, c->M, c->W, p->op, nthreads);
+    hipLaunchKernelGGL(k_centres_block, dim3((nthreads + 255) / 256, nb), dim3(256), 0, c->stream, d_sym, d_cen, d_mag, (const cf *)bb.xc,
+                       (const BlockScalars *)scal, c->N, c->M, c->W, p->op, nthreads, rec);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->h_blk[slot], d, blkout_bytes(bcap, nthreads), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(h_dst, d, rec * nb, hipMemcpyDeviceToHost, c->stream));
     *shift_out = shift;
     return MFB_OK;
 }
@@ -1529,23 +1605,24 @@ static int block_enqueue(mfb_ctx *c, const mfb_block_params *p, int slot, int nt
 // last block that read that device copy is done -- i.e. while the block before this one is still being searched -- and the
 // handle's stream picks it up with an event.  (With one device buffer and one stream the copy of an 8 MiB block, 0.15 ms,
 // sat between two searches.)
-static int block_input_copy(mfb_ctx *c, int which) {
-    const cf *src = which ? c->h_in2 : c->h_in;
-    cf *dst = which ? c->d_x2 : c->d_x;
+static int input_copy(mfb_ctx *c, const cf *src, cf *dst, size_t samples, hipEvent_t *ev_h2d, hipEvent_t *ev_free, int which) {
     if (!src || !dst) return MFB_ERR_STATE;
     if (!c->in_stream) HIPCHK(hipStreamCreateWithFlags(&c->in_stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) {
-        if (!c->ev_h2d[i]) HIPCHK(hipEventCreateWithFlags(&c->ev_h2d[i], hipEventDisableTiming));
-        if (!c->ev_xfree[i]) {
-            HIPCHK(hipEventCreateWithFlags(&c->ev_xfree[i], hipEventDisableTiming));
-            HIPCHK(hipEventRecord(c->ev_xfree[i], c->stream));
+        if (!ev_h2d[i]) HIPCHK(hipEventCreateWithFlags(&ev_h2d[i], hipEventDisableTiming));
+        if (!ev_free[i]) {
+            HIPCHK(hipEventCreateWithFlags(&ev_free[i], hipEventDisableTiming));
+            HIPCHK(hipEventRecord(ev_free[i], c->stream));
         }
     }
-    HIPCHK(hipStreamWaitEvent(c->in_stream, c->ev_xfree[which], 0));
-    HIPCHK(hipMemcpyAsync(dst, src, (size_t)c->N * sizeof(cf), hipMemcpyHostToDevice, c->in_stream));
-    HIPCHK(hipEventRecord(c->ev_h2d[which], c->in_stream));
-    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_h2d[which], 0));
+    HIPCHK(hipStreamWaitEvent(c->in_stream, ev_free[which], 0));
+    HIPCHK(hipMemcpyAsync(dst, src, samples * sizeof(cf), hipMemcpyHostToDevice, c->in_stream));
+    HIPCHK(hipEventRecord(ev_h2d[which], c->in_stream));
+    HIPCHK(hipStreamWaitEvent(c->stream, ev_h2d[which], 0));
     return MFB_OK;
+}
+static int block_input_copy(mfb_ctx *c, int which) {
+    return input_copy(c, which ? c->h_in2 : c->h_in, which ? c->d_x2 : c->d_x, (size_t)c->N, c->ev_h2d, c->ev_xfree, which);
 }
 
 // A block whose input is one of the handle's two page-locked buffers is the same sequence of launches with the same
@@ -1567,60 +1644,30 @@ static void graph_drop(BlockGraph &g) {
 static bool same_params(const mfb_block_params &a, const mfb_block_params &b) {
     return a.mode == b.mode && a.input == b.input && a.fixed_shift == b.fixed_shift && a.k_offset == b.k_offset && a.k_len == b.k_len &&
            a.spsym_min == b.spsym_min && a.op == b.op && a.snr_window == b.snr_window && a.max_symbols == b.max_symbols &&
-           a.band_capacity == b.band_capacity;
+           a.band_capacity == b.band_capacity && a.block_stride == b.block_stride;
 }
 
-// Enqueue: everything up to and including the ONE device-to-host copy into the flight's page-locked staging; no wait.
-static int block_begin(mfb_ctx *c, const mfb_block_params *p, int slot) {
-    if (!c || !p || slot < 0 || slot > 1) return MFB_ERR_ARG;
-    if (!c->have_filters || (p->mode == MFB_BLOCK_SEARCH && !c->have_shifts)) return MFB_ERR_STATE;
-    if (p->mode != MFB_BLOCK_SEARCH && p->mode != MFB_BLOCK_FIXED_SHIFT) return MFB_ERR_ARG;
-    if (p->k_offset < 0 || p->k_len < 0 || p->k_offset + p->k_len > c->N || p->spsym_min < 2 || p->op < 0 || p->op > 2 ||
-        p->max_symbols < 1 || p->snr_window < 0 || p->band_capacity < 0)
-        return MFB_ERR_ARG;
-    HIPCHK(hipSetDevice(c->device));
-    BlockFlight &f = c->flight[slot];
-    if (f.active) return MFB_ERR_STATE;          // its results have not been collected
+// Launch the block's (batch's) work: replay its graph, record it (second occurrence of these settings), or plain launches.
+template <class Enqueue>
+static int graph_or_launch(mfb_ctx *c, BlockGraph &g, const mfb_block_params *p, int nb, bool allowed, Enqueue &&enqueue) {
     int rc;
-    const int bcap = p->mode == MFB_BLOCK_SEARCH ? p->band_capacity : 0;
-    if ((rc = blkout_reserve(c, bcap > c->band_cap ? bcap : c->band_cap))) return rc;
-    const int capacity = p->max_symbols < c->cap ? p->max_symbols : c->cap;
-    // every symbol the rate window admits (k* < k_offset + k_len  =>  count <= k_offset + k_len), bounded by the capacity
-    int nthreads = p->k_offset + p->k_len + 1;
-    if (nthreads > capacity) nthreads = capacity;
-    const size_t need = blkout_bytes(bcap, nthreads);
-    if (need > c->blk_cap[slot]) {
-        for (auto &row : c->bgraph) graph_drop(row[slot]);          // the staging address is baked into the graphs
-        if (c->h_blk[slot]) HIPCHK(hipHostFree(c->h_blk[slot]));
-        c->h_blk[slot] = nullptr;
-        c->blk_cap[slot] = 0;
-        HIPCHK(hipHostMalloc((void **)&c->h_blk[slot], need, hipHostMallocDefault));
-        c->blk_cap[slot] = need;
-    }
-    if (!c->ev_blk[slot]) HIPCHK(hipEventCreateWithFlags(&c->ev_blk[slot], hipEventDisableTiming));
-    int shift = p->mode == MFB_BLOCK_FIXED_SHIFT ? ((p->fixed_shift % c->N) + c->N) % c->N : 0;
-    const bool pinned_in = p->input == MFB_INPUT_PINNED || p->input == MFB_INPUT_PINNED2;
-    const int which = p->input == MFB_INPUT_PINNED2 ? 1 : 0;
-    if (pinned_in && (rc = block_input_copy(c, which))) return rc;
-    bool done = false;
-    if (pinned_in && graphs_allowed() && !c->prof && !c->mirror && (p->input == MFB_INPUT_PINNED || c->h_in2)) {
-        BlockGraph &g = c->bgraph[p->input == MFB_INPUT_PINNED ? 0 : 1][slot];
-        if (g.epoch != c->epoch || !same_params(g.params, *p)) {
+    if (allowed) {
+        if (g.epoch != c->epoch || g.nb != nb || !same_params(g.params, *p)) {
             graph_drop(g);
             g.epoch = c->epoch;
             g.params = *p;
+            g.nb = nb;
             g.failed = false;
         }
         if (g.exec) {
             HIPCHK(hipGraphLaunch(g.exec, c->stream));
-            c->d_in = which ? c->d_x2 : c->d_x;
-            c->have_input = true;
-            done = true;
-        } else if (g.seen) {
+            return MFB_OK;
+        }
+        if (g.seen) {
             // second block with these settings: record it (the first one went out as plain launches, so every workspace
             // it needs exists already -- nothing is allocated inside the capture)
             HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
-            rc = block_enqueue(c, p, slot, nthreads, bcap, capacity, &shift);
+            rc = enqueue();
             hipGraph_t graph = nullptr;
             const hipError_t ce = hipStreamEndCapture(c->stream, &graph);
             if (rc || ce != hipSuccess || !graph) {
@@ -1635,19 +1682,72 @@ static int block_begin(mfb_ctx *c, const mfb_block_params *p, int slot) {
                     g.graph = graph;
                     g.exec = exec;
                     HIPCHK(hipGraphLaunch(g.exec, c->stream));
-                    done = true;
-                } else {
-                    (void)hipGraphDestroy(graph);
-                    (void)hipGetLastError();
-                    g.seen = false;
-                    g.failed = true;
+                    return MFB_OK;
                 }
+                (void)hipGraphDestroy(graph);
+                (void)hipGetLastError();
+                g.seen = false;
+                g.failed = true;
             }
         } else if (!g.failed) {
             g.seen = true;
         }
     }
-    if (!done && (rc = block_enqueue(c, p, slot, nthreads, bcap, capacity, &shift))) return rc;
+    return enqueue();
+}
+
+static int check_block_params(const mfb_ctx *c, const mfb_block_params *p) {
+    if (!c->have_filters || (p->mode == MFB_BLOCK_SEARCH && !c->have_shifts)) return MFB_ERR_STATE;
+    if (p->mode != MFB_BLOCK_SEARCH && p->mode != MFB_BLOCK_FIXED_SHIFT) return MFB_ERR_ARG;
+    if (p->k_offset < 0 || p->k_len < 0 || p->k_offset + p->k_len > c->N || p->spsym_min < 2 || p->op < 0 || p->op > 2 ||
+        p->max_symbols < 1 || p->snr_window < 0 || p->band_capacity < 0)
+        return MFB_ERR_ARG;
+    return MFB_OK;
+}
+// page-locked staging of a flight: at least `need` bytes (the address is baked into the slot's graphs)
+static int staging_reserve(mfb_ctx *c, int slot, size_t need) {
+    if (need <= c->blk_cap[slot]) return MFB_OK;
+    for (auto &row : c->bgraph) graph_drop(row[slot]);
+    for (auto &row : c->wgraph) graph_drop(row[slot]);
+    if (c->h_blk[slot]) HIPCHK(hipHostFree(c->h_blk[slot]));
+    c->h_blk[slot] = nullptr;
+    c->blk_cap[slot] = 0;
+    HIPCHK(hipHostMalloc((void **)&c->h_blk[slot], need, hipHostMallocDefault));
+    c->blk_cap[slot] = need;
+    return MFB_OK;
+}
+
+// Enqueue: everything up to and including the ONE device-to-host copy into the flight's page-locked staging; no wait.
+static int block_begin(mfb_ctx *c, const mfb_block_params *p, int slot) {
+    if (!c || !p || slot < 0 || slot > 1) return MFB_ERR_ARG;
+    int rc = check_block_params(c, p);
+    if (rc) return rc;
+    if (p->input != MFB_INPUT_PINNED && p->input != MFB_INPUT_PINNED2 && p->input != MFB_INPUT_DEVICE && p->input != MFB_INPUT_UPLOADED)
+        return MFB_ERR_ARG;
+    if (p->input == MFB_INPUT_DEVICE && !p->device_block) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    BlockFlight &f = c->flight[slot];
+    if (f.active) return MFB_ERR_STATE;          // its results have not been collected
+    const int bcap = p->mode == MFB_BLOCK_SEARCH ? p->band_capacity : 0;
+    if ((rc = blkout_reserve(c, bcap > c->band_cap ? bcap : c->band_cap))) return rc;
+    const int capacity = p->max_symbols < c->cap ? p->max_symbols : c->cap;
+    // every symbol the rate window admits (k* < k_offset + k_len  =>  count <= k_offset + k_len), bounded by the capacity
+    int nthreads = p->k_offset + p->k_len + 1;
+    if (nthreads > capacity) nthreads = capacity;
+    if ((rc = staging_reserve(c, slot, blkout_bytes(bcap, nthreads)))) return rc;
+    if (!c->ev_blk[slot]) HIPCHK(hipEventCreateWithFlags(&c->ev_blk[slot], hipEventDisableTiming));
+    int shift = p->mode == MFB_BLOCK_FIXED_SHIFT ? ((p->fixed_shift % c->N) + c->N) % c->N : 0;
+    const bool pinned_in = p->input == MFB_INPUT_PINNED || p->input == MFB_INPUT_PINNED2;
+    const int which = p->input == MFB_INPUT_PINNED2 ? 1 : 0;
+    if (pinned_in && (rc = block_input_copy(c, which))) return rc;
+    // the samples of a page-locked buffer are (being) copied by block_input_copy on the input stream; this stream waits there
+    if (pinned_in) c->d_in = which ? c->d_x2 : c->d_x;
+    else if (p->input == MFB_INPUT_DEVICE) c->d_in = (const cf *)p->device_block;
+    const bool allowed = pinned_in && graphs_allowed() && !c->prof && !c->mirror && (p->input == MFB_INPUT_PINNED || c->h_in2);
+    rc = graph_or_launch(c, c->bgraph[which][slot], p, 0, allowed,
+                         [&]() { return block_enqueue(c, p, single_bufs(c), c->h_blk[slot], nthreads, bcap, capacity, &shift); });
+    if (rc) return rc;
+    c->have_input = true;
     HIPCHK(hipEventRecord(c->ev_blk[slot], c->stream));
     if (pinned_in) HIPCHK(hipEventRecord(c->ev_xfree[which], c->stream));      // this device copy may be overwritten from here on
     const size_t sym_off = BLK_HEAD + align16((size_t)2 * bcap * sizeof(cf)), arr = align16((size_t)nthreads * sizeof(int));
@@ -1663,15 +1763,36 @@ static int block_begin(mfb_ctx *c, const mfb_block_params *p, int slot) {
     f.shift = shift;
     f.seq = ++c->blk_seq;
     f.op = p->op;
+    f.nb = 0;
+    f.rec = 0;
     c->have_xc = true;
     return MFB_OK;
+}
+
+static void fill_result(mfb_block_result *r, const BlockScalars &hs, int mode, int fixed_shift) {
+    r->pick[0] = hs.pick[0];
+    r->pick[1] = hs.pick[1];
+    r->pick_valid = hs.pick_valid;
+    r->shift = mode == MFB_BLOCK_SEARCH ? hs.shift : fixed_shift;
+    r->low = hs.low;
+    r->high = hs.high;
+    r->frac = hs.frac;
+    r->cr[0] = hs.cr[0];
+    r->cr[1] = hs.cr[1];
+    r->cr[2] = hs.cr[2];
+    r->spSym = hs.spSym;
+    r->codeOffset = hs.codeOffset;
+    r->count = hs.count;
+    r->rate_fallback = hs.rate_fallback;
+    r->band_len[0] = hs.band_len[0];
+    r->band_len[1] = hs.band_len[1];
 }
 
 // Collect: wait for the flight's event, hand the results out.
 static int block_end(mfb_ctx *c, int slot, mfb_block_result *r, int32_t *sym, int32_t *cen, float *mag, float *bands_c64) {
     if (!c || slot < 0 || slot > 1 || !r || !sym || !cen || !mag) return MFB_ERR_ARG;
     BlockFlight &f = c->flight[slot];
-    if (!f.active) return MFB_ERR_STATE;
+    if (!f.active || f.nb) return MFB_ERR_STATE;
     if (f.bcap > 0 && f.mode == MFB_BLOCK_SEARCH && !bands_c64) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventSynchronize(c->ev_blk[slot]));
@@ -1705,22 +1826,7 @@ static int block_end(mfb_ctx *c, int slot, mfb_block_result *r, int32_t *sym, in
         memcpy(bands_c64, h + f.off[4], (size_t)l0 * sizeof(cf));
         memcpy(bands_c64 + (size_t)2 * f.bcap, h + f.off[4] + (size_t)f.bcap * sizeof(cf), (size_t)l1 * sizeof(cf));
     }
-    r->pick[0] = hs.pick[0];
-    r->pick[1] = hs.pick[1];
-    r->pick_valid = hs.pick_valid;
-    r->shift = f.mode == MFB_BLOCK_SEARCH ? hs.shift : f.shift;
-    r->low = hs.low;
-    r->high = hs.high;
-    r->frac = hs.frac;
-    r->cr[0] = hs.cr[0];
-    r->cr[1] = hs.cr[1];
-    r->cr[2] = hs.cr[2];
-    r->spSym = hs.spSym;
-    r->codeOffset = hs.codeOffset;
-    r->count = hs.count;
-    r->rate_fallback = hs.rate_fallback;
-    r->band_len[0] = hs.band_len[0];
-    r->band_len[1] = hs.band_len[1];
+    fill_result(r, hs, f.mode, f.shift);
     return MFB_OK;
 }
 
@@ -1735,6 +1841,183 @@ extern "C" int mfb_receive_block(mfb_ctx *c, const mfb_block_params *p, mfb_bloc
     const int rc = block_begin(c, p, 0);
     if (rc) return rc;
     return block_end(c, 0, r, sym, cen, mag, bands_c64);
+}
+
+// ---- B consecutive blocks per call ---------------------------------------------------------------------------------------
+// The reference's own configurations use blocks of 2^15 ... 2^17 samples with 64 bins (config/base.json:13,33): one such block
+// is a few tens of microseconds of device work, and a loop that hands the device one block per turn (DP:284-338) leaves it idle
+// most of the time.  Here B consecutive blocks of the stream go to the device as ONE contiguous window of
+// B * stride + (N - stride) samples (stride = N - overlap: block b starts at b * stride -- the overlap between neighbours is
+// shared storage, nothing is copied twice) and through ONE set of launches: batched forward FFT, one search launch over
+// B x D (block, bin) streams, B picks in one launch, one matched-filter launch at the B shifts, batched envelope FFT, B rate
+// estimates, the centres of all blocks, one device-to-host copy of B result records.
+static int window_samples(const mfb_ctx *c, int nb) { return nb * c->win_stride + (c->N - c->win_stride); }
+
+static int batch_reserve(mfb_ctx *c, int nb, size_t rec) {
+    if (nb > c->bat_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        ++c->epoch;        // recorded graphs hold the old addresses
+        void **bufs[] = {(void **)&c->d_Xb, (void **)&c->d_xcb, (void **)&c->d_Pb, (void **)&c->d_envb, (void **)&c->d_sumb, (void **)&c->d_resb,
+                         (void **)&c->d_crb};
+        for (void **b : bufs) {
+            if (*b) HIPCHK(hipFree(*b));
+            *b = nullptr;
+        }
+        c->bat_cap = 0;
+        const size_t nbN = (size_t)nb * c->N;
+        HIPCHK(dev_alloc((void **)&c->d_Xb, nbN * sizeof(cf)));
+        HIPCHK(dev_alloc((void **)&c->d_xcb, nbN * c->M * sizeof(cf)));
+        HIPCHK(dev_alloc((void **)&c->d_Pb, nbN * sizeof(cf)));
+        HIPCHK(dev_alloc((void **)&c->d_envb, nbN * sizeof(float)));
+        HIPCHK(dev_alloc((void **)&c->d_sumb, (size_t)nb * c->Dtot * c->M * sizeof(float)));
+        HIPCHK(dev_alloc((void **)&c->d_resb, (size_t)nb * 2 * sizeof(float)));
+        HIPCHK(dev_alloc((void **)&c->d_crb, (size_t)nb * 3 * sizeof(float)));
+        c->bat_cap = nb;
+    }
+    if ((size_t)nb > c->z_rows) {       // the plain forward transforms of the batch take one row of the intermediate each
+        HIPCHK(hipStreamSynchronize(c->stream));
+        ++c->epoch;
+        if (c->d_Z) HIPCHK(hipFree(c->d_Z));
+        c->d_Z = nullptr;
+        c->z_rows = 0;
+        HIPCHK(dev_alloc((void **)&c->d_Z, (size_t)nb * c->N * sizeof(cf)));
+        c->z_rows = (size_t)nb;
+    }
+    if (rec * nb > c->batout_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        ++c->epoch;
+        if (c->d_batout) HIPCHK(hipFree(c->d_batout));
+        c->d_batout = nullptr;
+        c->batout_cap = 0;
+        HIPCHK(dev_alloc((void **)&c->d_batout, rec * nb));
+        c->batout_cap = rec * nb;
+    }
+    return MFB_OK;
+}
+
+extern "C" int mfb_window_buffer(mfb_ctx *c, int which, int max_blocks, int block_stride, float **host_c64) {
+    if (!c || !host_c64 || which < 0 || which > 1 || max_blocks < 1 || max_blocks > 1024 || block_stride < 1 || block_stride > c->N)
+        return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->win_blocks != max_blocks || c->win_stride != block_stride) {
+        for (int s = 0; s < 2; ++s)
+            if (c->flight[s].active && c->flight[s].nb) return MFB_ERR_STATE;      // a batch is reading the windows
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->in_stream) HIPCHK(hipStreamSynchronize(c->in_stream));
+        ++c->epoch;
+        for (int i = 0; i < 2; ++i) {
+            if (c->h_win[i]) HIPCHK(hipHostFree(c->h_win[i]));
+            if (c->d_win[i]) HIPCHK(hipFree(c->d_win[i]));
+            c->h_win[i] = nullptr;
+            c->d_win[i] = nullptr;
+        }
+        c->win_blocks = max_blocks;
+        c->win_stride = block_stride;
+    }
+    if (!c->h_win[which]) {
+        const size_t bytes = (size_t)window_samples(c, c->win_blocks) * sizeof(cf);
+        HIPCHK(hipHostMalloc((void **)&c->h_win[which], bytes, hipHostMallocDefault));
+        memset(c->h_win[which], 0, bytes);
+        HIPCHK(dev_alloc((void **)&c->d_win[which], bytes));
+    }
+    *host_c64 = (float *)c->h_win[which];
+    return MFB_OK;
+}
+
+extern "C" int mfb_receive_blocks_begin(mfb_ctx *c, const mfb_block_params *p, int nblocks, int slot) {
+    if (!c || !p || slot < 0 || slot > 1 || nblocks < 1) return MFB_ERR_ARG;
+    int rc = check_block_params(c, p);
+    if (rc) return rc;
+    const bool win_in = p->input == MFB_INPUT_WINDOW || p->input == MFB_INPUT_WINDOW2;
+    if (!win_in && p->input != MFB_INPUT_DEVICE) return MFB_ERR_ARG;
+    const int which = p->input == MFB_INPUT_WINDOW2 ? 1 : 0;
+    int stride = p->block_stride;
+    if (win_in) {
+        if (!c->h_win[which] || nblocks > c->win_blocks) return MFB_ERR_STATE;
+        if (stride == 0) stride = c->win_stride;
+        if (stride != c->win_stride) return MFB_ERR_ARG;
+    } else if (!p->device_block || stride < 1 || stride > c->N) {
+        return MFB_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    if (c->path != MFB_PATH_SEGMENT || (p->mode == MFB_BLOCK_SEARCH && c->search_mode != MFB_SEARCH_TRANSFORMS)) return MFB_ERR_UNSUPPORTED;
+    BlockFlight &f = c->flight[slot];
+    if (f.active) return MFB_ERR_STATE;
+    const int bcap = p->mode == MFB_BLOCK_SEARCH ? p->band_capacity : 0;
+    const int capacity = p->max_symbols < c->cap ? p->max_symbols : c->cap;
+    int nthreads = p->k_offset + p->k_len + 1;
+    if (nthreads > capacity) nthreads = capacity;
+    const size_t rec = blkout_bytes(bcap, nthreads);
+    if ((rc = batch_reserve(c, nblocks > c->win_blocks ? nblocks : (c->win_blocks > 0 ? c->win_blocks : nblocks), rec))) return rc;
+    if ((rc = staging_reserve(c, slot, rec * nblocks))) return rc;
+    if (!c->ev_blk[slot]) HIPCHK(hipEventCreateWithFlags(&c->ev_blk[slot], hipEventDisableTiming));
+    if (win_in && (rc = input_copy(c, c->h_win[which], c->d_win[which], (size_t)(nblocks * stride + (c->N - stride)), c->ev_wh2d, c->ev_wfree, which)))
+        return rc;
+    BlkBufs bb{nblocks, win_in ? (const cf *)c->d_win[which] : (const cf *)p->device_block, stride, c->d_Xb, c->d_sumb, c->d_resb, c->d_xcb,
+               c->d_envb, c->d_Pb, c->d_crb, c->d_batout, rec};
+    int shift = p->mode == MFB_BLOCK_FIXED_SHIFT ? ((p->fixed_shift % c->N) + c->N) % c->N : 0;
+    const bool allowed = win_in && graphs_allowed() && !c->prof;
+    mfb_block_params q = *p;
+    q.block_stride = stride;
+    rc = graph_or_launch(c, c->wgraph[which][slot], &q, nblocks, allowed,
+                         [&]() { return block_enqueue(c, &q, bb, c->h_blk[slot], nthreads, bcap, capacity, &shift); });
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev_blk[slot], c->stream));
+    if (win_in) HIPCHK(hipEventRecord(c->ev_wfree[which], c->stream));
+    const size_t sym_off = BLK_HEAD + align16((size_t)2 * bcap * sizeof(cf)), arr = align16((size_t)nthreads * sizeof(int));
+    f.off[0] = 0;
+    f.off[4] = BLK_HEAD;
+    f.off[1] = sym_off;
+    f.off[2] = sym_off + arr;
+    f.off[3] = sym_off + 2 * arr;
+    f.active = true;
+    f.mode = p->mode;
+    f.nthreads = nthreads;
+    f.bcap = bcap;
+    f.shift = shift;
+    f.seq = ++c->blk_seq;
+    f.op = p->op;
+    f.nb = nblocks;
+    f.rec = rec;
+    // the handle's one-block buffers (spectrum, matched-filter outputs) hold nothing of this batch
+    c->have_xc = false;
+    return MFB_OK;
+}
+
+extern "C" int mfb_receive_blocks_end(mfb_ctx *c, int slot, mfb_block_result *results, int32_t *sym, int32_t *cen, float *mag,
+                                      int symbol_stride, float *bands_c64) {
+    if (!c || slot < 0 || slot > 1 || !results || !sym || !cen || !mag || symbol_stride < 1) return MFB_ERR_ARG;
+    BlockFlight &f = c->flight[slot];
+    if (!f.active || !f.nb) return MFB_ERR_STATE;
+    if (f.bcap > 0 && f.mode == MFB_BLOCK_SEARCH && !bands_c64) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventSynchronize(c->ev_blk[slot]));
+    f.active = false;
+    int rc = MFB_OK;
+    for (int b = 0; b < f.nb; ++b) {
+        const uint8_t *h = c->h_blk[slot] + (size_t)b * f.rec;
+        BlockScalars hs;
+        memcpy(&hs, h + f.off[0], sizeof(hs));
+        int n = hs.count;
+        // (the rate fallback k* == 0 -> spSym = 10 could ask for more symbols than the rate window admits; it cannot occur while
+        // the window starts above bin 0, and a batch has no second pass to fetch them: the record's symbols are delivered)
+        if (n > f.nthreads) {
+            n = f.nthreads;
+            rc = MFB_ERR_UNSUPPORTED;
+        }
+        if (n > symbol_stride) return MFB_ERR_ARG;
+        memcpy(sym + (size_t)b * symbol_stride, h + f.off[1], (size_t)n * sizeof(int));
+        memcpy(cen + (size_t)b * symbol_stride, h + f.off[2], (size_t)n * sizeof(int));
+        memcpy(mag + (size_t)b * symbol_stride, h + f.off[3], (size_t)n * sizeof(float));
+        if (f.mode == MFB_BLOCK_SEARCH && f.bcap > 0) {
+            const int l0 = hs.band_len[0] < f.bcap ? hs.band_len[0] : f.bcap, l1 = hs.band_len[1] < f.bcap ? hs.band_len[1] : f.bcap;
+            float *dst = bands_c64 + (size_t)b * 4 * f.bcap;
+            memcpy(dst, h + f.off[4], (size_t)l0 * sizeof(cf));
+            memcpy(dst + (size_t)2 * f.bcap, h + f.off[4] + (size_t)f.bcap * sizeof(cf), (size_t)l1 * sizeof(cf));
+        }
+        fill_result(&results[b], hs, f.mode, f.shift);
+    }
+    return rc;
 }
 
 // Test seam of the one-call path (include/mfbank.h): block_pick_body / block_rate_body on injected device results.

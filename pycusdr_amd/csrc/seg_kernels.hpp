@@ -125,6 +125,12 @@ struct SegArgs {
     int out_off;         // STORE: (window start + T_eff - 1) mod N
     int part_row0, parts;   // REDUCE: row of bin 0, row stride (= slots of the block x waves per team)
     float scale;         // REDUCE: 1 / 2^18
+    // A batch of blocks in one launch (mfb_receive_blocks): stream jl of the launch is bin jl % dper of block jl / dper; that
+    // block's samples start xstride elements behind the previous block's (consecutive blocks of a stream share their overlap),
+    // its shift is shifts[j0 + jl % dper + (jl / dper) * sstride] and its STORE outputs go ostride (out) / N (env) elements on.
+    // dper = 0: one block (every stream reads x, shifts[j0 + jl]).  Partial-sum rows are part_row0 + jl either way.
+    int dper, xstride, sstride;
+    long long ostride;
 };
 
 template <int L>
@@ -250,7 +256,6 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
 
     const unsigned nmask = (unsigned)a.N - 1u;
     const unsigned lomask = (1u << a.lo) - 1u;
-    const auto xr = mk_rsrc(a.x, (unsigned)a.N * sizeof(cf));
     const auto lor = mk_rsrc(a.twLo, (unsigned)(1u << a.lo) * sizeof(cf));
     const auto hir = mk_rsrc(a.twHi, (unsigned)(a.N >> a.lo) * sizeof(cf));
     const auto gr = mk_rsrc(a.G, (unsigned)a.Grows * (unsigned)(L * sizeof(cf)));   // whole G; rows via the scalar offset
@@ -262,7 +267,11 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
     };
 
     for (int jl = bstream; jl < a.dc; jl += a.bsplit) {
-        const int shift = a.shifts ? a.shifts[a.j0 + jl] : a.fixed_shift;
+        // (wave-uniform: bstream comes from the workgroup index and the wave's team)
+        const int bk = a.dper ? jl / a.dper : 0;               // block of the batch
+        const int jb = jl - bk * a.dper;                       // = jl for a single block
+        const int shift = a.shifts ? a.shifts[a.j0 + jb + bk * a.sstride] : a.fixed_shift;
+        const auto xr = mk_rsrc(a.x + (size_t)bk * (size_t)a.xstride, (unsigned)a.N * sizeof(cf));
         [[maybe_unused]] cf pg = mkc(1.f, 0.f);
         if constexpr (PTAB) {
             // relative mixing phasors of all L positions of a segment, shared by the wave's columns
@@ -432,7 +441,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                     const cf rsum = (racc[0] + racc[1]) + (racc[2] + racc[3]);
                     lacc[mi * SEG_ACC_STRIDE + lane] = rsum.x + rsum.y;       // reduced over the lanes after the last filter
                 } else {
-                    const auto orr = mk_rsrc(a.out + (size_t)rm * a.N, (unsigned)a.N * sizeof(cf));
+                    const auto orr = mk_rsrc(a.out + (size_t)bk * (size_t)a.ostride + (size_t)rm * a.N, (unsigned)a.N * sizeof(cf));
                     const unsigned o0 = e0 + (unsigned)a.out_off;
                     const bool in_env = a.env && rm >= a.env_lo && rm < a.env_hi;      // team-uniform
                     auto put = [&](int, cf val, auto, auto nu) {
@@ -471,7 +480,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                     const unsigned o0 = e0 + (unsigned)a.out_off;
 #pragma unroll
                     for (int k = 0; k < PPL; ++k)
-                        if (k * NT < lim) a.env[(o0 + (unsigned)(k * NT)) & nmask] = envacc[k];
+                        if (k * NT < lim) a.env[(size_t)bk * (size_t)a.N + ((o0 + (unsigned)(k * NT)) & nmask)] = envacc[k];
                 }
             }
         }

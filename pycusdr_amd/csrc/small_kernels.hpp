@@ -237,7 +237,10 @@ __global__ void __launch_bounds__(64) k_pick(const float *in, float *res, int nu
 DEVI float abs2c(cf z) { return __fmaf_rn(z.x, z.x, __fmul_rn(z.y, z.y)); }
 
 // sumXCorrBuffMasks (cuda_kernels.cu:191-205)
+// (blockIdx.y = block of a batch: its M rows and its envelope follow the previous block's)
 __global__ void k_envelope(const cf *xc, float *env, int N, int M, int off) {
+    xc += (size_t)blockIdx.y * (size_t)M * (size_t)N;
+    env += (size_t)blockIdx.y * (size_t)N;
     for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < N; x += gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int m = off; m < M - off; ++m) s = __fadd_rn(s, abs2c(xc[(size_t)m * N + x]));
@@ -403,10 +406,21 @@ DEVI void block_pick_body(const float *res, const int *shifts, int Dtot, int N, 
 // Block path, search mode: findDopplerEst, then (one thread) the shift interpolation, then (all 64 threads) the two SNR
 // windows copied piece after piece into bands[band][cap] -- one launch instead of three; longer bands are flagged by
 // band_len > cap on the host.
+// A batch of blocks (mfb_receive_blocks): workgroup b takes block b -- its score table (num + offset rows on), its spectrum (N
+// elements on), its result record (rec_stride bytes on: scalars and bands live in the record).
 __global__ void __launch_bounds__(64) k_pick_block(const float *in, float *res, int num, int offset, int M, int sum_all, const int *shifts,
-                                                   int Dtot, int N, int w, const cf *X, BlockScalars *out, cf *bands, int cap) {
+                                                   int Dtot, int N, int w, const cf *X, BlockScalars *out, cf *bands, int cap,
+                                                   size_t rec_stride) {
     __shared__ float sIdx[64], sVal[64];
     __shared__ float scol[PICK_LDS];
+    {
+        const size_t b = blockIdx.x;
+        in += b * (size_t)(num + offset) * (size_t)M;
+        res += 2 * b;
+        X += b * (size_t)N;
+        out = reinterpret_cast<BlockScalars *>(reinterpret_cast<uint8_t *>(out) + b * rec_stride);
+        bands = reinterpret_cast<cf *>(reinterpret_cast<uint8_t *>(bands) + b * rec_stride);
+    }
     pick_body(in, res, num, offset, M, sum_all, sIdx, sVal, scol);
     __threadfence_block();
     __syncthreads();
@@ -424,8 +438,9 @@ __global__ void __launch_bounds__(64) k_pick_block(const float *in, float *res, 
     }
 }
 // Block path, fixed shift (STX): no pick -- the scalars of the search are cleared
-__global__ void k_block_clear(BlockScalars *out) {
-    if (threadIdx.x || blockIdx.x) return;
+__global__ void k_block_clear(BlockScalars *out, size_t rec_stride) {
+    if (threadIdx.x) return;
+    out = reinterpret_cast<BlockScalars *>(reinterpret_cast<uint8_t *>(out) + (size_t)blockIdx.x * rec_stride);
     out->pick[0] = out->pick[1] = 0.f;
     out->pick_valid = 0;
     out->shift = out->low = out->high = 0;
@@ -476,15 +491,29 @@ __global__ void k_block_scalars_debug(int n, const float *picks, const float *tr
 }
 
 // findCentres with its two float arguments taken from the block scalars
+// (blockIdx.y = block of a batch: record rec_stride bytes on, matched-filter outputs M * lenSig elements on)
 __global__ void k_centres_block(int *outSym, int *outIdx, float *mag, const cf *sig, const BlockScalars *sc, int lenSig, int M, int W,
-                                int op, int capacity) {
+                                int op, int capacity, size_t rec_stride) {
+    {
+        const size_t off = (size_t)blockIdx.y * rec_stride;
+        outSym = reinterpret_cast<int *>(reinterpret_cast<uint8_t *>(outSym) + off);
+        outIdx = reinterpret_cast<int *>(reinterpret_cast<uint8_t *>(outIdx) + off);
+        mag = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(mag) + off);
+        sc = reinterpret_cast<const BlockScalars *>(reinterpret_cast<const uint8_t *>(sc) + off);
+        sig += (size_t)blockIdx.y * (size_t)M * (size_t)lenSig;
+    }
     centres_body(outSym, outIdx, mag, sig, sc->spSymF, sc->offsetF, lenSig, M, W, op, capacity, (int)(blockIdx.x * blockDim.x + threadIdx.x));
 }
 
 // Block path: the same, and thread 0 goes on to the float64 rate/phase arithmetic (one launch instead of two)
-__global__ void k_code_rate_block(const cf *P, float *out, int offset, int len, int N, int spsym_min, int capacity, BlockScalars *sc) {
+// (blockIdx.x = block of a batch)
+__global__ void k_code_rate_block(const cf *P, float *out, int offset, int len, int N, int spsym_min, int capacity, BlockScalars *sc,
+                                  size_t rec_stride) {
     __shared__ float sv[1024];
     __shared__ int si[1024];
+    P += (size_t)blockIdx.x * (size_t)N;
+    out += 3 * (size_t)blockIdx.x;
+    sc = reinterpret_cast<BlockScalars *>(reinterpret_cast<uint8_t *>(sc) + (size_t)blockIdx.x * rec_stride);
     code_rate_body(P, out, offset, len, sv, si);
     if (threadIdx.x == 0) {
         __threadfence_block();

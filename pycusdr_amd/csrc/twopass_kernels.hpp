@@ -29,6 +29,7 @@ struct P1Args {
     int dc;       // Doppler bins in this chunk
     int ntiles, mgroups, jsplit;  // 1-D grid = ntiles * mgroups * jsplit workgroups
     int fixed_shift;  // used when shifts == nullptr
+    int in_stride;    // FWDC / FWDR with jsplit = rows > 1: elements between the inputs of consecutive rows (row r -> Z row r)
 };
 
 struct P2Args {
@@ -152,17 +153,18 @@ __global__ void __launch_bounds__((L1 / 16) * TILE, (L1 == 256 && KIND == KIND_B
     };
 
     if constexpr (KIND != KIND_BANK) {
+        // plain forward transforms: one row per value of zj (a batch of blocks: mfb_receive_blocks)
         cf v[16];
         if constexpr (KIND == KIND_FWDC) {
-            const auto xr = mk_rsrc(a.X, rowbytes);
+            const auto xr = mk_rsrc(a.X + (size_t)zj * (size_t)a.in_stride, rowbytes);
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = cconj(buf_load_cf(xr, vo_in, i * so_in));
         } else {
-            const auto xr = mk_rsrc(a.Xr, (unsigned)N * sizeof(float));
+            const auto xr = mk_rsrc(a.Xr + (size_t)zj * (size_t)a.in_stride, (unsigned)N * sizeof(float));
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = mkc(buf_load_f(xr, vo_in / 2, i * (so_in / 2)), 0.f);
         }
-        const auto zr = mk_rsrc(a.Z, rowbytes);
+        const auto zr = mk_rsrc(a.Z + (size_t)zj * (size_t)N, rowbytes);
         auto store = [&](int, cf val, auto slot, auto nu) { z_store(zr, val, slot, nu); };
         fft_passes<L1, TILE, 0, true, Cfg::PP, Cfg::HALF>(v, lds, ebuf, g, col, twr, a.tw1, store);
     } else {

@@ -312,6 +312,29 @@ class Demodulator:
         self.dopplerIdxlast = self.doppOffsetIdx
         return 0, 0, self.clippedPeakIPure, 0
 
+    # ---- B consecutive blocks per call ----------------------------------------------------------
+    def blockWindows(self, blocks_per_call):
+        """The two page-locked sample windows of the batched path: each takes ``blocks_per_call`` consecutive blocks of the
+        stream, block b at ``b * (N - overlap)`` (neighbours share their overlap samples)."""
+        return self.bank.windows(int(blocks_per_call), self.sigLen - self.sigOverlap)
+
+    def beginBlocks(self, slot, nblocks, source='window'):
+        """``beginBlock`` for the first ``nblocks`` blocks of window ``source`` ('window' / 'window2'): the device side of all of
+        them as one set of launches (mfb_receive_blocks_begin); ``endBlocks(slot)`` collects.  UHF back end, one-call path."""
+        self.bank.begin_blocks(slot, nblocks, self.codeRateAndPhaseOffsetHigh,
+                               self.codeRateAndPhaseOffsetLow - self.codeRateAndPhaseOffsetHigh, self.spsymMin,
+                               op=Operations.CENTRES_ABS.value, snr_window=5, source=source)
+
+    def endBlocks(self, slot):
+        """One ``((freqOffset_Hz, metric, clippedPeakIdx, SNR_dB), device record)`` per block of the batch begun in ``slot``,
+        in stream order: what ``endBlock`` + ``demodulateDevice`` return block by block."""
+        out = []
+        for blk in self.bank.end_blocks(slot):
+            self._pending = blk
+            est = self._estimate_from_block(blk)
+            out.append((est, self.demodulateDevice()))
+        return out
+
     def _estimate_from_block(self, blk):
         """The host half of __findUHF (reference DB:604-632) on what mfb_receive_block returned: Hz interpolation, SNR,
         the tuple the caller gets.  The shift interpolation itself ran on the device, same float64 operations."""

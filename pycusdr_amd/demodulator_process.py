@@ -175,13 +175,14 @@ class DemodulatorRunner:
             self.raw[ov - sps:ov] = new_samples
         self.count += 1
 
-    def feed_host(self, part, prev_tail=None):
+    def feed_host(self, part, prev_tail=None, timed=True):
         """Sequential half of one block (A12, A13): bits, alignment against the previous block, trust tagging, and the
         result dict that goes to the decoder.  Must be called in block order -- or with the previous block's
         ``Demodulator.overlapTail`` as ``prev_tail`` (time-chunk sharding: the owner of a block runs this stage itself)."""
         t0 = time.time()
         bits, centres, trust, spSym = self.demod.demodulateHost(part['rec'], prev_tail=prev_tail)
-        spent = part['time_device'] + (time.time() - t0)
+        # (timed = False: the caller measured the whole loop turn itself -- the overlapped loops)
+        spent = part['time_device'] + ((time.time() - t0) if timed else 0.0)
         return self.compose_result(part['count'], part['timestamp'], part['doppler'], part['doppler_std'], part['SNR'], bits, trust,
                                    spSym, spent)
 
@@ -204,7 +205,20 @@ class DemodulatorRunner:
         data['rate_ksps_avg'] = self.samplesPerSlice / self.timeMA / 1000
         return data
 
-    def run_stream(self, chunk_source, sink=None, decoder=None, pipelined=False, overlapped=True):
+    def report(self, d):
+        """The reference's rate line (DP:324-333), every 50th block."""
+        if d['count'] % 50 == 0:
+            log.info('[%s]: freq offset % 6.0f Hz, SNR % 2.1f dB, est spsym % 3.2f, time % 3.2f ms (avg % 3.2f ms), '
+                     'rate %5.0f ksamples/s (avg %5.0f)', self.radioName, d['doppler'], d['SNR'], d['spSymEst'],
+                     d['time_ms'], self.timeMA * 1e3, d['rate_ksps'], d['rate_ksps_avg'])
+
+    def blocks_per_call(self):
+        """``"HIP": {"blocks_per_call": B}`` of the radio's GPU settings (next to the reference's "CUDA" block): B > 1 makes
+        ``run_stream`` hand the device B consecutive blocks per call (mfb_receive_blocks_*).  Default 1."""
+        confGPU = self.conf['GPU'][self.confRadio['CUDA_settings']]
+        return max(1, int(confGPU.get('HIP', {}).get('blocks_per_call', 1)))
+
+    def run_stream(self, chunk_source, sink=None, decoder=None, pipelined=False, overlapped=True, blocks_per_call=None):
         """The reference's loop shape (DP:284-338): chunks of ANY size (GNU Radio ~4096 samples, the BER bench
         2^14); ends when the chunk source is exhausted.  Sequential form: every chunk is copied once, straight into the
         page-locked input buffer behind the carried overlap (sigFIFO.BlockAssembler), and each completed block is processed
@@ -225,6 +239,9 @@ class DemodulatorRunner:
         if not (overlapped and self.radioBackend == 'UHF' and getattr(self.demod, '_one_call', False)):
             asm = BlockAssembler(self.raw, self.overlap)
             return self.run((None for chunk in chunk_source for _ in asm.push(chunk)), sink=sink, decoder=decoder)
+        B = self.blocks_per_call() if blocks_per_call is None else max(1, int(blocks_per_call))
+        if B > 1:
+            return self._run_stream_batched(chunk_source, sink, decoder, B)
         # Overlapped form: block i is on the device while this thread runs the sequential host stages and the decoder of
         # block i-1 and assembles block i+1 in the other page-locked buffer.  Same calls in the same order on the same data
         # as the plain loop, so the same results; only the waiting moves.
@@ -253,13 +270,22 @@ class DemodulatorRunner:
                 packets.extend(pk)
                 deliver(d)
 
+        last = [None]                    # when the previous block was collected
+
         def collect(fl):
             slot, count, stamp = fl
             part = {'count': count, 'timestamp': stamp}
             part['doppler'], part['doppler_std'], _, part['SNR'] = self.demod.endBlock(slot)
             part['rec'] = self.demod.demodulateDevice()
-            part['time_device'] = time.time() - stamp
-            d = self.feed_host(part)
+            now = time.time()
+            # the loop's cost per block is the interval between two collects (the device side of block i overlaps the host stages
+            # of block i - 1): that is what time_ms / rate_ksps report here (DP:324-333 times a loop turn); begin -> collect is
+            # the block's latency
+            part['time_device'] = (now - last[0]) if last[0] is not None else (now - stamp)
+            last[0] = now
+            d = self.feed_host(part, timed=False)
+            d['latency_ms'] = (now - stamp) * 1e3
+            self.report(d)
             if split:
                 # the decoder's searches of this block run on the device while this thread goes on; their hits are
                 # collected, and the packet state machine run, right before the next block's bits go in
@@ -308,6 +334,108 @@ class DemodulatorRunner:
             self.raw = bufs[cur]         # where the next block would be assembled
         return results, packets
 
+    def _run_stream_batched(self, chunk_source, sink, decoder, B):
+        """``run_stream`` with B consecutive blocks per device call (``"HIP": {"blocks_per_call": B}``; mfb_receive_blocks_*).
+        The reference's loop hands the device one block per turn (DP:284-338); at its own block sizes (2^15 ... 2^17 samples,
+        64 bins: config/base.json:13,33) a block is a few tens of microseconds of device work and the turn is all host.  Here the
+        chunks are copied ONCE into a page-locked window of B blocks (block b at b * (N - overlap): the overlap between
+        neighbours is shared storage, the carry happens once per window), the window goes through one set of launches while the
+        host stages and the decoder of the previous window's blocks run, and the blocks come out one by one in stream order:
+        the same result dicts, bits and packets as the one-block loop.  At the end of the source the complete blocks of the
+        last, partly filled window are processed as a shorter batch."""
+        from .sigFIFO import WindowAssembler
+        wins = self.demod.blockWindows(B)
+        names = ('window', 'window2')
+        cur = 0
+        wins[cur][:self.overlap] = self.raw[:self.overlap]      # goes on behind the overlap the last call left
+        asm = WindowAssembler(wins[cur], self.overlap, self.samplesPerSlice, B)
+        results, packets = [], []
+        flying = None
+        searching = []
+        split = decoder is not None and hasattr(decoder, 'findFrames_begin')
+        if split and hasattr(decoder, 'prepare'):
+            decoder.prepare()
+        last = [None]
+
+        def deliver(d):
+            if sink is not None:
+                sink(d)
+            else:
+                results.append(d)
+
+        def finish_search():
+            if searching:
+                d = searching.pop()
+                pk, _, nsync = decoder.findFrames_end()
+                d['numSyncSig'] = nsync
+                packets.extend(pk)
+                deliver(d)
+
+        def collect(fl):
+            slot, count0, nb, stamp, arrived = fl
+            recs = self.demod.endBlocks(slot)
+            now = time.time()
+            per_block = ((now - last[0]) if last[0] is not None else (now - stamp)) / nb
+            last[0] = now
+            for i, ((doppler, doppler_std, _, snr), rec) in enumerate(recs):
+                part = {'count': count0 + i, 'timestamp': arrived[i], 'doppler': doppler, 'doppler_std': doppler_std, 'SNR': snr,
+                        'rec': rec, 'time_device': per_block}
+                d = self.feed_host(part, timed=False)
+                d['latency_ms'] = (now - arrived[i]) * 1e3
+                self.report(d)
+                if split:
+                    finish_search()
+                    decoder.findFrames_begin(d['data'], 0)
+                    searching.append(d)
+                    continue
+                if decoder is not None:
+                    pk, _, nsync = decoder.findFrames(d['data'], 0)
+                    d['numSyncSig'] = nsync
+                    packets.extend(pk)
+                deliver(d)
+
+        def launch(nb):
+            nonlocal cur, flying
+            self.demod.beginBlocks(cur, nb, source=names[cur])
+            started = (cur, self.count, nb, time.time(), list(asm.stamps[:nb]))
+            self.count += nb
+            cur = 1 - cur
+            # the previous batch lives in wins[cur]: collect it (its host-to-device copy is then certainly over) BEFORE the
+            # samples behind this batch are carried into that window
+            if flying is not None:
+                fl, flying = flying, None
+                collect(fl)
+            asm.retarget(wins[cur], nb)
+            flying = started
+
+        try:
+            for chunk in chunk_source:
+                for nb in asm.push(chunk):
+                    launch(nb)
+            if asm.complete_blocks():
+                launch(asm.complete_blocks())
+            if flying is not None:
+                fl, flying = flying, None
+                collect(fl)
+            finish_search()
+        except BaseException:
+            for slot in (0, 1):
+                try:
+                    self.demod.bank.end_blocks(slot)
+                except Exception:       # noqa: BLE001 -- nothing was in flight in this slot
+                    pass
+            if searching:
+                try:
+                    decoder.findFrames_end()
+                except Exception:       # noqa: BLE001
+                    pass
+            raise
+        finally:
+            # the overlap a later call (batched or not) goes on behind; samples of an incomplete block are dropped, as the
+            # one-block loop drops them
+            self.raw[:self.overlap] = asm.buf[:self.overlap]
+        return results, packets
+
     def run(self, sample_source, sink=None, decoder=None, pipelined=False):
         """Drive the loop over an iterable of new-sample slices.  With a ``decoder`` every block's
         bits go through ``findFrames`` and the packets are collected.
@@ -328,11 +456,7 @@ class DemodulatorRunner:
             else:
                 results.append(d)
 
-        def report(d):
-            if d['count'] % 50 == 0:
-                log.info('[%s]: freq offset % 6.0f Hz, SNR % 2.1f dB, est spsym % 3.2f, time % 3.2f ms (avg % 3.2f ms), '
-                         'rate %5.0f ksamples/s (avg %5.0f)', self.radioName, d['doppler'], d['SNR'], d['spSymEst'],
-                         d['time_ms'], self.timeMA * 1e3, d['rate_ksps'], d['rate_ksps_avg'])
+        report = self.report
 
         if not pipelined:
             for chunk in sample_source:       # None: the block sits in self.raw already (run_stream)

@@ -39,6 +39,7 @@ class MFBank:
         if getattr(self, '_h', None) is not None and self._h:
             self.input = None
             self._input2 = None
+            self._wins, self._win_key = None, None
             self._lib.mfb_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -206,10 +207,11 @@ class MFBank:
     BAND_CAPACITY = 1024       # complex64 elements per SNR window delivered with the block (longer ones: get_spectrum);
                                # an instance may set its own before the first block (Demodulator: from the bin spacing)
 
-    SOURCES = {'pinned': 0, 'device': 1, 'uploaded': 2, 'pinned2': 3}
+    SOURCES = {'pinned': 0, 'device': 1, 'uploaded': 2, 'pinned2': 3, 'window': 4, 'window2': 5}
 
-    def _block_params(self, k_offset, k_len, spsym_min, op, snr_window, fixed_shift, source, device_ptr):
+    def _block_params(self, k_offset, k_len, spsym_min, op, snr_window, fixed_shift, source, device_ptr, block_stride=0):
         P = _lib.BlockParams()
+        P.block_stride = int(block_stride)
         P.mode = 0 if fixed_shift is None else 1
         P.input = self.SOURCES[source]
         P.device_block = C.c_void_p(int(device_ptr)) if device_ptr else None
@@ -304,6 +306,68 @@ class MFBank:
         finally:            # collected, or failed: either way the slot holds no block any more
             self._flying = getattr(self, '_flying', set()) - {int(slot)}
         return self._block_result(R, self._searched.get(int(slot), True))
+
+    # -- B consecutive blocks per call -----------------------------------------------------------
+    def windows(self, max_blocks, block_stride):
+        """The two page-locked sample windows of the batched block path (mfb_window_buffer): each holds ``max_blocks``
+        consecutive blocks of the stream as ``max_blocks * block_stride + (N - block_stride)`` complex64 samples -- block b
+        starts at ``b * block_stride``, neighbours share their overlap.  Returns (window 0, window 1) as writable numpy
+        views; asking for another geometry re-allocates them."""
+        key = (int(max_blocks), int(block_stride))
+        if getattr(self, '_win_key', None) != key:
+            n = key[0] * key[1] + (self.N - key[1])
+            wins = []
+            for which in (0, 1):
+                buf = C.POINTER(C.c_float)()
+                _lib.check(self._lib.mfb_window_buffer(self._h, which, key[0], key[1], C.byref(buf)), 'mfb_window_buffer')
+                wins.append(np.ctypeslib.as_array(buf, shape=(2 * n,)).view(np.complex64))
+            self._wins, self._win_key = tuple(wins), key
+        return self._wins
+
+    def begin_blocks(self, slot, nblocks, k_offset, k_len, spsym_min, op=0, snr_window=5, fixed_shift=None, source='window',
+                     device_ptr=None, block_stride=0):
+        """``begin_block`` for ``nblocks`` consecutive blocks of a window (mfb_receive_blocks_begin): one set of launches, one
+        read-back; returns at once.  ``source``: 'window' / 'window2' (``windows()``) or 'device' (``device_ptr`` = the window in
+        device memory, ``block_stride`` required)."""
+        P = self._block_params(k_offset, k_len, spsym_min, op, snr_window, fixed_shift, source, device_ptr, block_stride)
+        _lib.check(self._lib.mfb_receive_blocks_begin(self._h, C.byref(P), int(nblocks), int(slot)), 'mfb_receive_blocks_begin')
+        self._searched = getattr(self, '_searched', {})
+        self._searched[int(slot)] = fixed_shift is None
+        self._batch = getattr(self, '_batch', {})
+        self._batch[int(slot)] = (int(nblocks), int(k_offset) + int(k_len) + 1)
+        self._flying = getattr(self, '_flying', set()) | {int(slot)}
+
+    def end_blocks(self, slot):
+        """Wait for the batch begun in ``slot``; one dict per block, each exactly what ``receive_block`` returns for that block
+        alone (the arrays are views into storage owned by the returned list's batch -- no further copies)."""
+        slot = int(slot)
+        nb, nsym = self._batch[slot]
+        nsym = min(nsym, self.N // 2)
+        cap = self.BAND_CAPACITY
+        R = (_lib.BlockResult * nb)()
+        sym = np.empty((nb, nsym), np.int32)
+        cen = np.empty((nb, nsym), np.int32)
+        mag = np.empty((nb, nsym), np.float32)
+        bands = np.empty((nb, 2, cap), np.complex64)
+        try:
+            _lib.check(self._lib.mfb_receive_blocks_end(self._h, slot, R, _ptr(sym), _ptr(cen), _ptr(mag), nsym, _ptr(bands)),
+                       'mfb_receive_blocks_end')
+        finally:
+            self._flying = getattr(self, '_flying', set()) - {slot}
+        searched = self._searched.get(slot, True)
+        out = []
+        for b in range(nb):
+            r = R[b]
+            n = r.count
+            d = {'pick': (np.float32(r.pick[0]), np.float32(r.pick[1])), 'pick_valid': bool(r.pick_valid), 'shift': int(r.shift),
+                 'low': int(r.low), 'high': int(r.high), 'frac': float(r.frac),
+                 'cr': (np.float32(r.cr[0]), np.float32(r.cr[1]), np.float32(r.cr[2])), 'spSym': float(r.spSym),
+                 'codeOffset': float(r.codeOffset), 'rate_fallback': bool(r.rate_fallback),
+                 'symbols': sym[b, :n], 'centres': cen[b, :n], 'magnitudes': mag[b, :n], 'bands': None}
+            if searched and r.band_len[0] <= cap and r.band_len[1] <= cap:
+                d['bands'] = (bands[b, 0, :r.band_len[0]], bands[b, 1, :r.band_len[1]])
+            out.append(d)
+        return out
 
     def get_xcorr(self):
         out = np.empty((self.M, self.N), dtype=np.complex64)

@@ -20,6 +20,7 @@ Three pieces:
   (``TimeoutError('Terminated')``, sigFIFO.py:167-169).
 """
 import logging
+import time
 
 import numpy as np
 
@@ -62,6 +63,55 @@ class BlockAssembler:
             raise IndexError('block buffers of unequal length')
         other[:self.ov] = self.buf[len(self.buf) - self.ov:]
         self.buf, self.fill, self._moved = other, self.ov, True
+
+
+class WindowAssembler:
+    """``BlockAssembler`` for a window of B consecutive blocks (the batched block path, mfb_receive_blocks_*): ``window`` holds
+    ``B * stride + overlap`` samples, block b at ``b * stride`` (stride = block length - overlap: neighbours share their overlap
+    as storage).  ``push(chunk)`` copies every sample once and yields B each time the window is complete; the consumer then calls
+    ``retarget(other, nblocks)`` -- everything behind the ``nblocks`` blocks it took (the carried overlap, and whatever has been
+    filled of the next block) moves to the front of ``other`` and filling goes on there, the completed window stays untouched for
+    the copy engine.  ``complete_blocks()``: whole blocks in a partly filled window (end of a stream)."""
+
+    def __init__(self, window, overlap, stride, blocks):
+        if len(window) != blocks * stride + overlap or overlap < 0 or stride < 1:
+            raise IndexError('window of %d samples does not hold %d blocks of stride %d + overlap %d' % (len(window), blocks, stride, overlap))
+        self.buf, self.ov, self.stride, self.B = window, int(overlap), int(stride), int(blocks)
+        self.fill = self.ov              # the first block starts behind whatever the caller left in window[:overlap]
+        self.stamps = []                 # time.time() at which each complete block of the window got its last sample
+
+    def complete_blocks(self):
+        return max(0, (self.fill - self.ov) // self.stride)
+
+    def push(self, chunk):
+        chunk = np.asarray(chunk)
+        n, pos, size = len(chunk), 0, len(self.buf)
+        while pos < n:
+            take = min(n - pos, size - self.fill)
+            self.buf[self.fill:self.fill + take] = chunk[pos:pos + take]
+            self.fill += take
+            pos += take
+            while len(self.stamps) < (self.fill - self.ov) // self.stride:
+                self.stamps.append(time.time())
+            if self.fill == size:
+                self._moved = False
+                yield self.B
+                if not self._moved:          # a consumer that is done with the window and keeps filling it
+                    self.retarget(self.buf, self.B)
+
+    def retarget(self, other, nblocks):
+        if len(other) != len(self.buf):
+            raise IndexError('windows of unequal length')
+        start = int(nblocks) * self.stride
+        rest = self.fill - start
+        if nblocks < 0 or rest < self.ov:
+            raise IndexError('the window does not hold %d complete blocks' % nblocks)
+        if other is self.buf:
+            other[:rest] = self.buf[start:self.fill].copy() if start < rest else self.buf[start:self.fill]
+        else:
+            other[:rest] = self.buf[start:self.fill]
+        self.buf, self.fill, self._moved = other, rest, True
+        del self.stamps[:int(nblocks)]
 
 
 class RingBuffer:

@@ -1,0 +1,209 @@
+"""mfb_receive_blocks_begin / _end -- B consecutive blocks of the stream per device call -- against the one-block call
+(mfb_receive_block): every number of every block must be identical, bit for bit, whatever B is, for all four modulations,
+with an all-zero (NaN pick) block inside a batch and a symbol slip at a batch edge.  Reference: the loop these calls batch is
+Demodulator_process.run, demodulator_process.py:284-338 (one block per turn); the per-block arithmetic is DB:548-632, 711-1009."""
+import copy
+
+import numpy as np
+import pytest
+
+from pycusdr_amd import config as cfg, signals as sg
+from pycusdr_amd.decoder import Decoder
+from pycusdr_amd.demodulator import UHF
+from pycusdr_amd.demodulator_process import DemodulatorRunner
+from pycusdr_amd.protocol import loadProtocol
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    return bool(np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True))
+
+
+def _blocks_one_by_one(demod, sig, nblocks, step, N):
+    out = []
+    for b in range(nblocks):
+        raw = demod.get_signalBufferHostPointer()
+        raw[:] = sig[b * step: b * step + N]
+        est = demod.uploadAndFindCarrier(raw)
+        scores = demod.bank.get_scores().copy()
+        out.append((est, demod.demodulateDevice(), scores))
+    return out
+
+
+def _check_block(tag, got, want):
+    (ea, ra), (eb, rb, _) = got, want
+    assert _same([ea[0], ea[1], ea[3]], [eb[0], eb[1], eb[3]]), (tag, ea, eb)
+    assert ra['spSym'] == rb['spSym'], tag
+    for k in ('symbols', 'centres', 'trust'):
+        assert _same(ra[k], rb[k]), (tag, k)
+
+
+@pytest.mark.parametrize('mod,pname,bs,D', [('GMSK', 'bench_GMSK', 15, 64), ('FSK', 'bench_FSK', 16, 33), ('GFSK', 'bench_GFSK', 14, 16),
+                                            ('BPSK', 'bench_BPSK', 15, 40)])
+def test_batches_equal_the_one_block_call(mod, pname, bs, D):
+    N, ov = 1 << bs, 1 << 10
+    step = N - ov
+    nblocks = 11
+    conf = cfg.bench_config(pname, blockSize=bs, doppCarrierSteps=D)
+    p = loadProtocol(pname)(conf=conf)
+    sig = sg.s1_stream(nblocks, N, ov, mod, snr_db=9.0, seed=11)
+    sig[3 * step: 4 * step + ov] = 0        # an all-zero block (NaN index, skipped: DB:625-630) inside every batch size below
+    one, bat = UHF.Demodulator(conf, p, 'UHF-H'), UHF.Demodulator(conf, p, 'UHF-H')
+    try:
+        want = _blocks_one_by_one(one, sig, nblocks, step, N)
+        assert want[3][0][0] == 0.0 and want[3][0][3] == 0.0       # the zero block was skipped
+        for B in (2, 5, 8):
+            wins = bat.blockWindows(B)
+            b0, turn = 0, 0
+            while b0 < nblocks:
+                nb = min(B, nblocks - b0)
+                w = wins[turn & 1]
+                w[:nb * step + ov] = sig[b0 * step: (b0 + nb) * step + ov]
+                bat.beginBlocks(turn & 1, nb, source=('window', 'window2')[turn & 1])
+                got = bat.endBlocks(turn & 1)
+                assert len(got) == nb
+                for i in range(nb):
+                    _check_block((B, b0 + i), got[i], want[b0 + i])
+                b0 += nb
+                turn += 1
+    finally:
+        one.close()
+        bat.close()
+
+
+def test_batch_scores_equal_one_block_scores_bit_for_bit():
+    """The score table of every block of a batch against the one-block search (the numbers behind the pick): read from the
+    batch's device table through a second batch of ONE block at each position."""
+    bs, D, ov = 15, 48, 1 << 10
+    N = 1 << bs
+    step = N - ov
+    conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=D)
+    p = loadProtocol('bench_GMSK')(conf=conf)
+    sig = sg.s1_stream(6, N, ov, 'GMSK', snr_db=6.0, seed=3)
+    one, bat = UHF.Demodulator(conf, p, 'UHF-H'), UHF.Demodulator(conf, p, 'UHF-H')
+    try:
+        want = _blocks_one_by_one(one, sig, 6, step, N)
+        w = bat.blockWindows(6)[0]
+        w[:] = sig[:6 * step + ov]
+        bat.beginBlocks(0, 6)
+        got = bat.endBlocks(0)
+        for i in range(6):
+            _check_block(i, got[i], want[i])
+            # the pick's two floats are functions of the whole table: equal picks on different tables would be a coincidence;
+            # the metric is the weighted score itself
+            assert got[i][0][1] == want[i][0][1]
+    finally:
+        one.close()
+        bat.close()
+
+
+def test_long_filters_and_noise_bin_in_a_batch():
+    """CC11xx geometry (384-tap filters: 2048-point segments, one wave per segment; IF offset; noise-reference bin)."""
+    from pycusdr_amd.protocol.CC11xx import frame_bits
+    bs, sps = 17, 128
+    N = 1 << bs
+    step = N - 1024
+    conf = cfg.cc11xx_config(blockSize=bs, doppCarrierSteps=48, samplesPerSym=sps)
+    conf['Radios']['Rx']['UHF-H']['noise_measure_offset_Hz'] = 300000
+    p = loadProtocol('CC11xx')(conf=conf)
+    rs = np.random.RandomState(4)
+    fs = 7416 * sps
+    bits = np.concatenate([frame_bits(rs.randint(0, 256, 60).astype(np.uint8), preamble=(0xAA,) * 10) for _ in range(6)])
+    sig = sg.modulateFSK(bits, sps)
+    sig = np.tile(sig, int(np.ceil((3 * step + 1024) / len(sig))))[:3 * step + 1024]
+    sig = sg.awgn(sig * np.exp(2j * np.pi * 148320 / fs * np.arange(len(sig))), 12.0, rng=np.random.RandomState(2)).astype(np.complex64)
+    one, bat = UHF.Demodulator(conf, p, 'UHF-H'), UHF.Demodulator(conf, p, 'UHF-H')
+    try:
+        want = _blocks_one_by_one(one, sig, 3, step, N)
+        w = bat.blockWindows(3)[1]
+        w[:] = sig
+        bat.beginBlocks(1, 3, source='window2')
+        got = bat.endBlocks(1)
+        for i in range(3):
+            _check_block(i, got[i], want[i])
+            assert len(got[i][1]['symbols']) > 900
+    finally:
+        one.close()
+        bat.close()
+
+
+@pytest.mark.parametrize('B', [2, 5, 8])
+def test_batched_stream_equals_one_block_stream(B):
+    """run_stream with "HIP": {"blocks_per_call": B}: result dicts, bits, trust and packets equal the one-block loop's, with a
+    symbol slip planted in the first block of a batch (the alignment against the last block of the previous batch, DB:863-988)
+    and chunks that do not divide the window."""
+    bs, ov = 15, 1 << 10
+    N = 1 << bs
+    step = N - ov
+    conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=32)
+    p = loadProtocol('bench_GMSK')(conf=conf)
+    nblocks = 2 * B + 3
+    sig = sg.s1_stream(nblocks, N, ov, 'GMSK', snr_db=10.0, seed=5)[ov:]
+    confB = copy.deepcopy(conf)
+    confB['GPU']['UHF'].setdefault('HIP', {})['blocks_per_call'] = B
+    a, b = DemodulatorRunner(conf, p, 'UHF-H'), DemodulatorRunner(confB, p, 'UHF-H')
+
+    def slipping(run):
+        """Drop one symbol decision at the front of block B (first block of the second batch) -- what a +1 slip of the
+        symbol clock at a block edge looks like to checkSymbolOverlap."""
+        inner = run.demod.demodulateHost
+
+        def host(rec, prev_tail=None):
+            if host.calls == B:
+                rec = dict(rec)
+                for k in ('symbols', 'centres', 'trust'):
+                    rec[k] = rec[k][1:]
+                rec.pop('_bits', None)
+            host.calls += 1
+            return inner(rec, prev_tail=prev_tail)
+        host.calls = 0
+        run.demod.demodulateHost = host
+    try:
+        slipping(a)
+        slipping(b)
+        da, db = Decoder(conf, p), Decoder(conf, p)
+        ra, pa = a.run_stream((sig[i:i + 16384] for i in range(0, len(sig), 16384)), decoder=da)
+        rb, pb = b.run_stream((sig[i:i + 5000] for i in range(0, len(sig), 5000)), decoder=db)
+        assert len(ra) == len(rb) == nblocks
+        for x, y in zip(ra, rb):
+            assert x['count'] == y['count']
+            for k in ('doppler', 'doppler_std', 'SNR', 'spSymEst', 'baudrate_est', 'rangerate', 'numSyncSig'):
+                assert _same(x[k], y[k]), (x['count'], k)
+            assert _same(x['data'], y['data']) and _same(x['trust'], y['trust']), x['count']
+            assert 'latency_ms' in y and y['rate_ksps'] > 0
+        assert len(pa) == len(pb) and all(_same(u.bits, v.bits) for u, v in zip(pa, pb))
+        assert _same(a.demod.poswinP, b.demod.poswinP) and _same(a.demod.posSymEnd, b.demod.posSymEnd)
+        # a second stream on the same runners goes on behind the overlap the first left
+        more = sg.s1_stream(B + 1, N, ov, 'GMSK', snr_db=10.0, seed=6)[ov:]
+        ra2, _ = a.run_stream([more], decoder=da)
+        rb2, _ = b.run_stream([more], decoder=db)
+        assert len(ra2) == len(rb2) == B + 1
+        assert all(_same(x['data'], y['data']) for x, y in zip(ra2, rb2))
+    finally:
+        a.close()
+        b.close()
+
+
+def test_batch_errors():
+    bs = 15
+    conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=8)
+    p = loadProtocol('bench_GMSK')(conf=conf)
+    d = UHF.Demodulator(conf, p, 'UHF-H')
+    try:
+        with pytest.raises(Exception):
+            d.beginBlocks(0, 2)                 # no window yet
+        d.blockWindows(3)
+        with pytest.raises(Exception):
+            d.beginBlocks(0, 4)                 # more blocks than the window holds
+        d.beginBlocks(0, 2)
+        with pytest.raises(Exception):
+            d.beginBlocks(0, 2)                 # the slot is in flight
+        with pytest.raises(Exception):
+            d.bank.end_block(0)                 # a batch is not a block
+        assert len(d.endBlocks(0)) == 2
+        d.bank.set_search_path('twopass')
+        with pytest.raises(ValueError):
+            d.beginBlocks(0, 2)                 # batches run on the segment path
+    finally:
+        d.close()

@@ -1,5 +1,7 @@
-"""Whole-chain rate (ring buffer -> H2D -> Doppler search -> demodulation -> decoder -> packets) at a block size and bin
-count, sequential and pipelined.  usage: chain_rate.py [log2N] [nRuns] [doppler bins] [modulation]"""
+"""Whole-chain rate (chunks -> page-locked buffer -> H2D -> Doppler search -> demodulation -> host stages [-> decoder -> packets])
+at a block size and bin count: the one-block loop, the loop with B blocks per device call, with and without the decoder (in the
+reference the decoder is another process: the receive loop proper, DP:284-338, ends at the send).
+usage: chain_rate.py [log2N] [nRuns] [doppler bins] [modulation] [B,B,...]"""
 import importlib.util
 import os
 import sys
@@ -13,9 +15,16 @@ log2N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 D = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 mod = sys.argv[4] if len(sys.argv) > 4 else 'GMSK'
+Bs = [int(x) for x in sys.argv[5].split(',')] if len(sys.argv) > 5 else [1, 4, 8, 16]
 bm.run_snr(mod, 2, 12.0, log2N, 'transforms', 1, D)
-for search in ('transforms', 'energy'):
-    for pipelined in (False, True):
-        r = bm.run_snr(mod, n, 12.0, log2N, search, 2, D, pipelined)
-        print(f"{mod} N=2^{log2N} D={D} search={search:10s} pipelined={pipelined!s:5s}: {r['ksamples_per_s'] / 1e3:8.1f} Msamples/s, "
+for B in Bs:
+    for decode in (True, False):
+        r = bm.run_snr(mod, n, 12.0, log2N, 'transforms', 2, D, False, blocks_per_call=B, decode=decode)
+        print(f"{mod} N=2^{log2N} D={D} blocks_per_call={B:2d} decoder={decode!s:5s}: {r['ksamples_per_s'] / 1e3:8.1f} Msamples/s, "
               f"{r['blocks']} blocks, packets {r['packets']}/{r['sent']}, BER {r['BER']:.2e}", flush=True)
+if len(sys.argv) > 6 and sys.argv[6] == 'all':
+    for search in ('energy',):
+        for pipelined in (False, True):
+            r = bm.run_snr(mod, n, 12.0, log2N, search, 2, D, pipelined)
+            print(f"{mod} N=2^{log2N} D={D} search={search:10s} pipelined={pipelined!s:5s}: {r['ksamples_per_s'] / 1e3:8.1f} Msamples/s, "
+                  f"{r['blocks']} blocks, packets {r['packets']}/{r['sent']}, BER {r['BER']:.2e}", flush=True)
