@@ -127,6 +127,10 @@ class Decoder:
         self._flight = None
         if hits is None:
             hits = self._multi.end()
+        return self._frames(rawBits_DS, bits_less_raw, frameStartIdx, hits)
+
+    def _frames(self, rawBits_DS, bits_less_raw, frameStartIdx, hits):
+        """The packet state machine of one call (DEC:101-293) on the stitched stream and the hits of its two searches."""
         (idxCand, candScore), (syncSigStartIdx, _) = hits
         packetIdx = idxCand - len(self.mask) + 1          # the peak sits on the template's last bit
         numSyncSig = len(syncSigStartIdx)
@@ -140,6 +144,93 @@ class Decoder:
             for _ in packetIdx:
                 self.protocol.packetDataProcessor()
         return packets, bits_less_raw, numSyncSig
+
+    # ---- several consecutive calls at once ---------------------------------------------------------
+    def _search_streams(self, streams):
+        """Both searches of every stream in ONE device round trip: [(mask hits, sync hits)] per stream."""
+        p = self.protocol
+        tmpls = (self.mask, self.syncSig)
+        thr = (p.numOnesHeader - p.headerTol, p.numOnesSyncSig - p.syncSigTol)
+        if self._finder is None:
+            return [tuple(self.hits(s, t, h) for t, h in zip(tmpls, thr)) for s in streams]
+        lens = [len(s) for s in streams]
+        buf = np.zeros((len(streams), max(lens)), dtype=np.uint8)       # zero padding adds nothing to a full convolution
+        for row, s in zip(buf, streams):
+            row[:len(s)] = s
+        res = _hip_finder_multi(buf, tmpls, thr, device=self.device)
+        out = []
+        for b, n in enumerate(lens):
+            per = []
+            for k, t in enumerate(tmpls):
+                idx, sc = res[k][b]
+                keep = idx < n + len(t) - 1                               # positions past this stream's own end: padding
+                per.append((idx[keep], sc[keep]))
+            out.append(tuple(per))
+        return out
+
+    def findFrames_batch(self, blocks_bits, frameStartIdx=0):
+        """``findFrames`` for several consecutive blocks: the same packets, returned bits and sync counts, call by call (a list
+        of ``findFrames`` results), from ONE device round trip for the searches of all blocks instead of one per block.
+
+        Every call's stream is a window [a, e) of the bit sequence so far: e the end of the block's bits, a either
+        ``numBitsOverlap`` bits before the block (DEC:89-90) or -- FIXED mode with a packet still incomplete -- where the
+        previous call stashed its candidate (DEC:254-263), which only the previous call's state machine can tell.  So the
+        searches run ahead on the windows without a stash (the first block's on its real stream), and a block whose window
+        turns out longer gets its hits put together, exactly: a full convolution's score at a position depends on the window
+        only through which taps hang over its two ends, so positions at least T - 1 behind the default start are those of the
+        default window, positions in front of that were positions of the previous call's stream (same bits, no overhang),
+        and the first T - 1 positions are the previous call's when the start did not move -- else they are searched."""
+        pre = [self.preprocessor(b) for b in blocks_bits]
+        nb, nOv = len(pre), self.numBitsOverlap
+        Ts = (len(self.mask), len(self.syncSig))
+        if nb < 2 or nOv < max(Ts) or len(self.bitsOverlapBuf) < nOv:
+            return [self.findFrames(b, frameStartIdx) for b in blocks_bits]
+        hist = np.concatenate([self.bitsOverlapBuf] + pre)
+        ends = np.cumsum([len(self.bitsOverlapBuf)] + [len(b) for b in pre])
+        starts = [0] + [int(ends[i]) - nOv for i in range(1, nb)]
+        ahead = self._search_streams([hist[starts[i]:ends[i + 1]] for i in range(nb)])
+        out = []
+        a, a_prev, prev = 0, 0, None
+        for i in range(nb):
+            e, d = int(ends[i + 1]), starts[i]
+            stream = hist[a:e]
+            if a == d:
+                hits = ahead[i]
+            else:
+                edge = None
+                if a != a_prev:       # a new stash: its first T - 1 positions have never been searched -- both templates in one call
+                    edge = self._search_streams([stream[:max(Ts) - 1]])[0]
+                hits = tuple(self._window_hits(Ts[k], prev[k], a_prev, a, d, ahead[i][k], edge[k] if edge else None) for k in range(2))
+            self.bitsOverlapBuf = stream[-nOv:]
+            out.append(self._frames(stream, pre[i], frameStartIdx, hits))
+            a_prev, prev = a, hits
+            a = e - len(self.bitsOverlapBuf)
+        return out
+
+    @staticmethod
+    def _window_hits(T, prev, a_prev, a, d, ahead, edge):
+        """Hits of a T-tap template on the window [a, e), a < d, from the hits ``ahead`` of [d, e), ``prev`` of the previous call's
+        window [a_prev, e_prev) (a_prev <= a, e_prev = d + numBitsOverlap) and -- when the start moved -- ``edge``, the hits of
+        the window's first T - 1 bits searched on their own."""
+        ai, asc = ahead
+        pi, ps = prev
+        if edge is None and not len(pi):
+            if not len(ai):
+                return ahead
+            m = ai >= T - 1
+            return ai[m] + (d - a), asc[m]
+        m = ai >= T - 1
+        new_i, new_s = ai[m] + (d - a), asc[m]
+        g = pi + a_prev                                        # previous hits in the sequence's coordinates
+        m = (g >= a + T - 1) & (g < d + T - 1)
+        old_i, old_s = g[m] - a, ps[m]
+        if edge is None:                                       # the start did not move: the same first T - 1 positions
+            m = pi < T - 1
+            edge_i, edge_s = pi[m], ps[m]
+        else:
+            m = edge[0] < T - 1
+            edge_i, edge_s = edge[0][m], edge[1][m]
+        return np.concatenate((edge_i, old_i, new_i)), np.concatenate((edge_s, old_s, new_s))
 
     # ---- FIXED: packets of protocol.packetLen bits (reference decoder.py:245-280) ---------------
     def _frames_fixed(self, stream, candScore, packetIdx):

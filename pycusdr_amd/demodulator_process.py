@@ -371,18 +371,30 @@ class DemodulatorRunner:
                 packets.extend(pk)
                 deliver(d)
 
+        batch_dec = decoder is not None and hasattr(decoder, 'findFrames_batch')
+
         def collect(fl):
             slot, count0, nb, stamp, arrived = fl
             recs = self.demod.endBlocks(slot)
             now = time.time()
             per_block = ((now - last[0]) if last[0] is not None else (now - stamp)) / nb
             last[0] = now
+            ds = []
             for i, ((doppler, doppler_std, _, snr), rec) in enumerate(recs):
                 part = {'count': count0 + i, 'timestamp': arrived[i], 'doppler': doppler, 'doppler_std': doppler_std, 'SNR': snr,
                         'rec': rec, 'time_device': per_block}
                 d = self.feed_host(part, timed=False)
                 d['latency_ms'] = (now - arrived[i]) * 1e3
                 self.report(d)
+                ds.append(d)
+            if batch_dec:
+                # the decoder's searches of all blocks of the batch in one device round trip (Decoder.findFrames_batch)
+                for d, (pk, _, nsync) in zip(ds, decoder.findFrames_batch([d['data'] for d in ds], 0)):
+                    d['numSyncSig'] = nsync
+                    packets.extend(pk)
+                    deliver(d)
+                return
+            for d in ds:
                 if split:
                     finish_search()
                     decoder.findFrames_begin(d['data'], 0)

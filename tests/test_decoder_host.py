@@ -90,3 +90,92 @@ def test_flags_mode_within_one_block_and_across_blocks():
     assert len(p2) == 1 and np.array_equal(p2[0].bits[:16], p.HDR) and p2[0].frameSplitIdx > 0
     assert d.headerFrameStartIdx is None
     del rs
+
+
+def _packets_equal(pa, pb):
+    assert len(pa) == len(pb)
+    for x, y in zip(pa, pb):
+        assert np.array_equal(np.asarray(x.bits), np.asarray(y.bits))
+        assert x.frameStartIdx == y.frameStartIdx and x.maskBitErrors == y.maskBitErrors
+        assert getattr(x, 'frameSplitIdx', None) == getattr(y, 'frameSplitIdx', None)
+
+
+def _bench_stream(rs, nblocks, blk, flips):
+    """Back-to-back seed-123 bench packets (10 000 bits: their first 128 bits are the header, a packet spans several blocks, so
+    the FIXED-mode stash DEC:254-263 is live in most calls), noise bits in between, a few bit errors in the headers."""
+    pkt = np.random.RandomState(123).randint(0, 2, 10000)
+    parts = []
+    while sum(len(x) for x in parts) < nblocks * (blk + 2):
+        q = pkt.copy()
+        q[rs.randint(0, 128, flips)] ^= 1
+        parts += [rs.randint(0, 2, rs.randint(0, 700)), q]
+    return np.concatenate(parts).astype(np.uint8)
+
+
+@pytest.mark.parametrize('blk,B,flips', [(1950, 8, 0), (1950, 5, 20), (2500, 3, 30), (700, 16, 26), (9000, 2, 0), (130, 16, 10)])
+def test_findframes_batch_equals_call_by_call_fixed(blk, B, flips):
+    """findFrames_batch (searches run ahead on the default windows, stashed windows put together from the previous call's hits)
+    against findFrames call by call: packets, returned bits, sync counts and the overlap buffer, block by block."""
+    p = loadProtocol('bench_GMSK')(conf=cfg.bench_config())
+    rs = np.random.RandomState(blk + B)
+    nblocks = 4 * B + 3
+    stream = _bench_stream(rs, nblocks, blk, flips)
+    cuts = np.cumsum([0] + [blk + int(rs.randint(-1, 2)) for _ in range(nblocks)])
+    blocks = [stream[cuts[i]:cuts[i + 1]] for i in range(nblocks)]
+    a, b = Decoder({}, p, correlator=orc.sync_correlate), Decoder({}, p, correlator=orc.sync_correlate)
+    direct = [0]
+    inner = b.hits
+
+    def counting(bits, template, threshold):
+        direct[0] += 1
+        return inner(bits, template, threshold)
+    want = [a.findFrames(x, 7) for x in blocks]
+    got = []
+    for i in range(0, nblocks, B):
+        group = blocks[i:i + B]
+        b.hits = counting
+        before = direct[0]
+        got += b.findFrames_batch(group, 7)
+        # searches: two per block for the run-ahead windows, plus two per NEW stash (once per packet, not once per block)
+        assert direct[0] - before <= 2 * len(group) + 2 * 3, (i, direct[0] - before)
+    found = 0
+    for (pw, bw, nw), (pg, bg, ng) in zip(want, got):
+        _packets_equal(pw, pg)
+        assert np.array_equal(bw, bg) and nw == ng
+        found += len(pw)
+    assert found >= 1 or blk * nblocks < 12000
+    assert np.array_equal(np.asarray(a.bitsOverlapBuf), np.asarray(b.bitsOverlapBuf))
+
+
+def test_findframes_batch_equals_call_by_call_flags_and_cc11xx():
+    rs = np.random.RandomState(8)
+    p = _FlagsProto()
+    frame = np.concatenate((p.FLAG, p.HDR, np.zeros(300), p.FLAG))
+    stream = np.concatenate([np.concatenate((rs.randint(0, 2, rs.randint(20, 200)) * 0, frame)) for _ in range(12)] + [np.zeros(300)])
+    cuts = np.cumsum([0] + [int(rs.randint(150, 400)) for _ in range(200)])
+    cuts = cuts[cuts < len(stream)]
+    blocks = [stream[cuts[i]:cuts[i + 1]] for i in range(len(cuts) - 1)]
+    a, b = Decoder({}, p, correlator=orc.sync_correlate), Decoder({}, p, correlator=orc.sync_correlate)
+    want = [a.findFrames(x, 5) for x in blocks]
+    got = []
+    for i in range(0, len(blocks), 6):
+        got += b.findFrames_batch(blocks[i:i + 6], 5)
+    assert sum(len(w[0]) for w in want) >= 8
+    for (pw, bw, nw), (pg, bg, ng) in zip(want, got):
+        _packets_equal(pw, pg)
+        assert nw == ng
+    assert a.headerFrameStartIdx == b.headerFrameStartIdx
+    # the reference's CC11xx KAT stream, cut as recorded, as one batch
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ref_goldens.npz'))
+    g = {k.replace('__', '/'): z[k] for k in z.files}
+    pc = loadProtocol('CC11xx')(conf=cfg.cc11xx_config())
+    s2 = g['g4/CC11xx/stream'].astype(np.float64)
+    c2 = g['g4/CC11xx/cuts']
+    a, b = Decoder({}, pc, correlator=orc.sync_correlate), Decoder({}, pc, correlator=orc.sync_correlate)
+    want = [a.findFrames(s2[c2[i]:c2[i + 1]], 0) for i in range(3)]
+    got = b.findFrames_batch([s2[c2[i]:c2[i + 1]] for i in range(3)], 0)
+    for (pw, bw, nw), (pg, bg, ng) in zip(want, got):
+        _packets_equal(pw, pg)
+        assert nw == ng
+    assert np.array_equal(np.asarray(a.bitsOverlapBuf), np.asarray(b.bitsOverlapBuf))
