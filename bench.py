@@ -76,11 +76,13 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(masks, shifts, x_block, N, ov, D, budget_bins=None):
-    """The oracle's Doppler search (numpy/scipy restatement) timed on this host's cores on a bounded
-    sample of the same workload: the first `nb` of the D Doppler bins of one block; the per-block figure
-    is scaled by D/nb.  Two modes: all cores (scipy.fft complex64, workers = cores) and one
-    thread (numpy pocketfft, complex128, row at a time).  Reported baseline, not a target."""
+def cpu_baseline(masks, shifts, x_blocks, N, ov, D, budget_s=26.0):
+    """The oracle's Doppler search (numpy/scipy restatement) timed on this host's cores on a bounded sample of the same
+    workload (C2 on >= 2 blocks): whole blocks -- all D bins -- of `x_blocks` while about `budget_s` seconds of CPU
+    work allow (two C2 blocks on the 16-CPU share of a GPU box), else the leading bins of ONE block with the per-block figure
+    scaled by D/nb (`blocks_timed` < 1 says so).  Two modes: all cores (scipy.fft complex64, workers = the CPU share) and one
+    thread (numpy pocketfft, complex128, row at a time, 8 bins).  Reported baseline, not a target.  Returns the figures, the
+    all-cores scores of every block timed (a list) and the single-thread scores of the first block's leading bins."""
     import scipy.fft as sfft
     from oracle import mfbank_oracle as orc
     from pycusdr_amd.hostcpu import cpu_share
@@ -88,10 +90,9 @@ def cpu_baseline(masks, shifts, x_block, N, ov, D, budget_bins=None):
     M = masks.shape[0]
     group = max(1, share // M)                             # bins per inverse-FFT call: group * M rows, one per worker
     cores = min(share, group * M)
-    X = orc.forward_fft(x_block)
     Mw = masks.astype(np.complex64)
 
-    def run(nb):
+    def run(X, nb):
         t0 = time.perf_counter()
         out = np.zeros(nb)
         for j0 in range(0, nb, group):
@@ -101,24 +102,79 @@ def cpu_baseline(masks, shifts, x_block, N, ov, D, budget_bins=None):
             e = (y.real.astype(np.float64) ** 2 + y.imag.astype(np.float64) ** 2).sum(axis=-1) / orc.SCALE_2_18
             out[j0:j0 + len(js)] = e.reshape(len(js), M).sum(axis=1)
         return time.perf_counter() - t0, out
-    t1, _ = run(group)                   # warm-up + calibration
-    nb = budget_bins or int(max(2, min(D, round(14.0 * group / max(t1, 1e-3)))))     # the whole block when it fits ~14 s
-    t, scores = run(nb)
-    t_block = t * D / nb
-    # single thread, numpy: two bins
-    ns = 2
+    X0 = orc.forward_fft(x_blocks[0])
+    t1, _ = run(X0, group)                   # warm-up + calibration
+    est_block = t1 * D / group
+    nblk = int(min(len(x_blocks), max(0, budget_s // max(est_block, 1e-3))))
+    scores, t = [], 0.0
+    if nblk >= 1:
+        for b in range(nblk):                # whole blocks: forward FFT included, as in the GPU step
+            t0 = time.perf_counter()
+            Xb = X0 if b == 0 else orc.forward_fft(x_blocks[b])
+            tb, sb = run(Xb, D)
+            t += (time.perf_counter() - t0) if b else tb
+            scores.append(sb)
+        nb, t_block, blocks_timed = D, t / nblk, float(nblk)
+        what = f'{nblk} whole block(s) of 2^{int(np.log2(N))} samples, all {D} Doppler bins each (M={M})'
+    else:
+        nb = int(max(2, min(D, round(0.55 * budget_s * group / max(t1, 1e-3)))))
+        t, sb = run(X0, nb)
+        scores.append(sb)
+        t_block, blocks_timed = t * D / nb, nb / D
+        what = f'{nb} of {D} Doppler bins of one 2^{int(np.log2(N))}-sample block (M={M}); per-block time scaled by D/{nb}'
+    # single thread, numpy complex128: 8 bins
+    ns = min(8, D)
     t0 = time.perf_counter()
-    single = orc.doppler_scores(X, masks, shifts[:ns], True)[:, 0]
+    single = orc.doppler_scores(X0, masks, shifts[:ns], True)[:, 0]
     ts = time.perf_counter() - t0
     return {
         'value': round((N - ov) / t_block / 1e6, 5), 'unit': 'Msamples/s', 'cores': cores, 'kind': 'port',
-        'cpu': cpu_model(),
-        'sample': f'{nb} of {D} Doppler bins of one 2^{int(np.log2(N))}-sample block (M={masks.shape[0]}), '
-                  f'{t:.1f} s of scipy.fft complex64 work, {group} bins x {M} filters per call, workers={cores} '
-                  f'(CPU share of this process {share} of {os.cpu_count()} host cores); per-block time scaled by D/{nb}',
+        'cpu': cpu_model(), 'blocks_timed': round(blocks_timed, 4),
+        'sample': f'{what}, {t:.1f} s of scipy.fft complex64 work, {group} bins x {M} filters per call, workers={cores} '
+                  f'(CPU share of this process {share} of {os.cpu_count()} host cores)',
         'single_thread': {'value': round((N - ov) / (ts * D / ns) / 1e6, 6), 'unit': 'Msamples/s', 'cores': 1,
                           'sample': f'{ns} of {D} bins, numpy.fft complex128, {ts:.1f} s; scaled by D/{ns}'},
     }, scores, single
+
+
+def kfd_gpu_count():
+    """GPUs of this node as the kernel driver lists them (/sys/class/kfd/kfd/topology/nodes: a node with SIMDs is a GPU), read
+    WITHOUT touching the HIP runtime -- the parent of the rank processes must never initialise the GPU.  None when the
+    topology is not readable."""
+    base = '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        n = 0
+        for node in os.listdir(base):
+            for line in open(os.path.join(base, node, 'properties')):
+                k, _, v = line.partition(' ')
+                if k == 'simd_count' and int(v) > 0:
+                    n += 1
+        return n
+    except (OSError, ValueError):
+        return None
+
+
+def chain_figures(local_rank, blocks_per_call=8, n_packets=90):
+    """The whole receive chain at the reference's own block geometry (config/base.json:13,33: blocks of 2^15 ... 2^17 samples, 64
+    bins): host chunks of 2^14 samples in (examples/benchmark/bench_modem.py:32), page-locked window, H2D, A3 ... A13, result
+    dicts out -- `recv_*`, the loop the reference's Demodulator_process runs (DP:284-338) -- and the same with the decoder in the
+    same thread, packets out -- `chain_*` (in the reference the decoder is another process).  B consecutive blocks per device
+    call (mfb_receive_blocks_*); `*_b1_*` is the one-block loop."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_modem', os.path.join(ROOT, 'examples', 'benchmark', 'bench_modem.py'))
+    bm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bm)
+    out = {}
+    for log2n in (15, 17):
+        bm.run_snr('GMSK', 2, 12.0, log2n, 'transforms', 1, 64, blocks_per_call=blocks_per_call)          # handles, code objects, clock
+        for B, tag in ((blocks_per_call, ''), (1, '_b1')):
+            for decode, name in ((True, 'chain'), (False, 'recv')):
+                r = bm.run_snr('GMSK', n_packets, 12.0, log2n, 'transforms', 2, 64, blocks_per_call=B, decode=decode)
+                out[f'{name}{tag}_n{log2n}_d64_msamples'] = round(r['ksamples_per_s'] / 1e3, 1)
+                if decode:
+                    out[f'{name}{tag}_n{log2n}_d64_packets'] = f"{r['packets']}/{r['sent']}"
+    out['chain_blocks_per_call'] = blocks_per_call
+    return out
 
 
 def segment_roofline_core(info, Dl, Mu, launches, kernel_ms_total):
@@ -280,6 +336,66 @@ def run_block_shard(args, dist, rank, G, local_rank, dev):
     dist.destroy_process_group()
 
 
+def run_blocks_leg(args, dist, rank, G, local_rank, dev, steps=6, warmup=2):
+    """After the bins-mode loop of an N > 1 job: a short leg of the OTHER sharding axis of SURVEY 8(e) in the same job -- every GPU
+    runs the full 256-bin bank on every G-th time block (pycusdr_amd.dist.BlockShard, no collective on the data path) -- and,
+    for scale, the same loop on rank 0 alone.  BASELINE's wording (256 bins at 1/2/4/8 GPUs) is this axis.  Returns flat keys
+    on rank 0, None elsewhere."""
+    import torch
+    from pycusdr_amd import config as cfg, signals as sg
+    from pycusdr_amd.decoder import Decoder
+    from pycusdr_amd.demodulator_process import DemodulatorRunner
+    from pycusdr_amd.dist import BlockShard
+    from pycusdr_amd.protocol import loadProtocol
+    log2N, ov = args.log2n, 1 << 10
+    N = 1 << log2N
+    conf = cfg.bench_config(args.protocol, blockSize=log2N, overlap=10, doppCarrierSteps=args.bins, device=local_rank)
+    rr, _ = widen_range_rate(conf, 'UHF-H', N, args.bins)
+    conf['Radios']['rangeRateMax'] = rr
+    proto = loadProtocol(args.protocol)(conf=conf)
+    runner = DemodulatorRunner(conf, proto, 'UHF-H')
+    group = dist.new_group(backend='gloo') if args.backend == 'nccl' else None     # the hand-back moves host arrays
+    solo = dist.new_group(ranks=[0], backend='gloo')                                # (collective: every rank calls it)
+    nblocks = 8
+    stream = sg.s1_stream(nblocks, N, ov, 'GMSK', 16, 153600, snr_db=10.0, seed=1)
+    host_blocks = np.stack([stream[b * (N - ov): b * (N - ov) + N] for b in range(nblocks)])
+    blocks = torch.from_numpy(host_blocks.view(np.float32).reshape(nblocks, 2 * N)).to(dev)
+    esz = blocks.element_size() * 2 * N
+    torch.cuda.synchronize(dev)
+    decoder = Decoder(conf, proto) if rank == 0 else None
+
+    def feed(i):
+        return runner.feed_resident(blocks.data_ptr() + (i % nblocks) * esz)
+
+    def feed_begin(i):
+        runner.feed_resident_begin(blocks.data_ptr() + (i % nblocks) * esz)
+
+    def skip(i):
+        runner.count += 1
+
+    def measure(shard, members, n):
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        if members:
+            shard.run(runner, range(n), decoder=decoder, feed=feed, skip=skip, feed_begin=feed_begin)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        return time.perf_counter() - t0
+    shard = BlockShard(group=group)
+    measure(shard, True, warmup * G)
+    t_all = measure(shard, True, steps * G)
+    one = BlockShard(rank=0, world=1, group=solo) if rank == 0 else None
+    measure(one, rank == 0, warmup)
+    t_one = measure(one, rank == 0, steps)
+    runner.close()
+    if rank != 0:
+        return None
+    all_ms, one_ms = steps * G * (N - ov) / t_all / 1e6, steps * (N - ov) / t_one / 1e6
+    return {'blocks_stream_msamples': round(all_ms, 2), 'blocks_1gpu_msamples': round(one_ms, 2),
+            'blocks_efficiency_vs_1gpu': round(all_ms / (G * one_ms), 4), 'blocks_leg_steps': steps}
+
+
 def free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -287,23 +403,84 @@ def free_port():
         return s.getsockname()[1]
 
 
-def spawn_ranks(n, backend):
+SAFE_MODE = ['--single-comm', '--no-prefetch']
+
+
+def _run_child(cmd, env):
+    """Start `cmd` as a child process, pass SIGTERM / SIGINT on to it, return its exit code."""
+    import signal
+    import subprocess
+    child = subprocess.Popen(cmd, env=env)
+
+    def forward(sig, _frame):
+        try:
+            child.send_signal(sig)
+        except OSError:
+            pass
+    old = {sg_: signal.signal(sg_, forward) for sg_ in (signal.SIGTERM, signal.SIGINT)}
+    try:
+        return child.wait()
+    finally:
+        for sg_, h in old.items():
+            signal.signal(sg_, h)
+
+
+def spawn_ranks(n, backend, argv):
     """`python bench.py --gpus N` without a launcher: run the documented launch line as a child process
     (python -m torch.distributed.run, one fresh rank per GPU) and return its exit code.  With the RCCL backend the
-    node must have N devices -- a smaller box is an error, never a smaller figure."""
-    import subprocess
-    import torch
-    have = torch.cuda.device_count()
+    node must have N devices -- a smaller box is an error, never a smaller figure.
+
+    One-shot safety: the first attempt runs the default mode (block broadcast on a communicator and stream of its own, one
+    block ahead) under a 60 s watchdog; if it leaves with a non-zero status -- a collective some rank never joined, named by
+    the watchdog -- a FRESH set of ranks is started in the conservative mode (--single-comm --no-prefetch: every collective of
+    the job in one program order on one stream).  This process never touches the GPU; no rank is ever re-executed.  The line
+    says which mode produced it (config.dist_mode, config.fallback_from)."""
+    have = kfd_gpu_count()
+    if have is None:
+        import torch
+        have = torch.cuda.device_count()
     if backend == 'nccl' and have < n:
         sys.stderr.write(f'bench.py: --gpus {n} needs {n} GPUs, this node has {have} (use --backend gloo to rehearse '
                          f'{n} ranks on fewer devices)\n')
         return 2
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
-           '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.stderr.write('bench.py: no launcher (WORLD_SIZE unset), starting ' + ' '.join(cmd) + '\n')
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    return subprocess.call(cmd, env=env)
+    env['BENCH_WORKER'] = '1'            # the ranks below are the workers themselves: no second layer of children
+
+    def launch(extra):
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+               '--master-port', str(free_port()), os.path.abspath(__file__)] + argv + extra
+        sys.stderr.write('bench.py: no launcher (WORLD_SIZE unset), starting ' + ' '.join(cmd) + '\n')
+        return _run_child(cmd, env)
+    conservative = all(a in argv for a in SAFE_MODE)
+    rc = launch([] if conservative or '--watchdog' in argv else ['--watchdog', '60'])
+    if rc == 0 or conservative or '--shard' in argv and argv[argv.index('--shard') + 1] == 'blocks':
+        return rc
+    sys.stderr.write(f'bench.py: the ranks left with status {rc} in the default mode; starting fresh ranks with {" ".join(SAFE_MODE)}\n')
+    env.pop('BENCH_FAIL_FIRST_ATTEMPT', None)           # (test knob: only the first attempt is made to fail)
+    return launch(SAFE_MODE + ['--fallback-from', f'default mode (concurrent broadcast, prefetch) exit {rc}'])
+
+
+def rank_supervisor(argv):
+    """Started BY a launcher (the driver's `python -m torch.distributed.run ... bench.py --gpus N`) with N > 1: this rank process
+    does not touch the GPU either -- it runs the real worker as a child (same environment, BENCH_WORKER=1) under a 60 s
+    watchdog and, if the worker leaves with a non-zero status in the default mode, starts a fresh worker in the conservative
+    mode on a rendezvous of its own (MASTER_PORT + 1, rank 0 hosts the store).  Every rank's worker fails together -- a hung
+    collective stops all of them, each watchdog fires -- so every supervisor takes the same decision."""
+    env = dict(os.environ)
+    env['BENCH_WORKER'] = '1'
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    me = [sys.executable, os.path.abspath(__file__)]
+    conservative = all(a in argv for a in SAFE_MODE)
+    rc = _run_child(me + argv + ([] if conservative or '--watchdog' in argv else ['--watchdog', '60']), env)
+    if rc == 0 or conservative or '--shard' in argv and argv[argv.index('--shard') + 1] == 'blocks':
+        return rc
+    sys.stderr.write(f'bench.py: rank {env.get("RANK")}: the worker left with status {rc} in the default mode; starting a fresh worker '
+                     f'with {" ".join(SAFE_MODE)}\n')
+    env['MASTER_PORT'] = str(int(env.get('MASTER_PORT', '29500')) + 1)
+    env.pop('TORCHELASTIC_USE_AGENT_STORE', None)        # the launcher's store holds the first attempt's keys: rendezvous afresh
+    env.pop('BENCH_FAIL_FIRST_ATTEMPT', None)
+    return _run_child(me + argv + SAFE_MODE + ['--fallback-from', f'default mode (concurrent broadcast, prefetch) exit {rc}'], env)
 
 
 def main():
@@ -340,6 +517,9 @@ def main():
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="process-group backend; 'gloo' lets several ranks share ONE GPU (rehearsal of the N>1 path on a 1-GPU box)")
     ap.add_argument('--force-dist', action='store_true', help='run the sharded/RCCL path even with one rank (rehearsal)')
+    ap.add_argument('--fallback-from', default=None, help='(set by the launcher ladder) the mode whose failure led to this run')
+    ap.add_argument('--no-blocks-leg', action='store_true', help='N>1: skip the short time-chunk-sharded leg after the bins-mode loop')
+    ap.add_argument('--no-chain', action='store_true', help='N=1: skip the receive-chain figures at the reference block sizes')
     ap.add_argument('--no-other-banks', action='store_true',
                     help='skip the untimed per-bank figures (CC11xx sps 128, BPSK M=32 at D=256; C3 D=1024) in config.other_banks / config.c3')
     args = ap.parse_args()
@@ -353,8 +533,11 @@ def main():
         sys.exit(2)
     if args.gpus > 1 and env_world is None:
         # started without a launcher: start one rank per GPU as FRESH child processes (nothing in this process has
-        # touched the GPU yet -- torch.cuda.device_count() does not initialise it) and leave with their exit code
-        sys.exit(spawn_ranks(args.gpus, args.backend))
+        # touched the GPU: the device count comes from the kernel driver's topology files) and leave with their exit code
+        sys.exit(spawn_ranks(args.gpus, args.backend, sys.argv[1:]))
+    if args.gpus > 1 and os.environ.get('BENCH_WORKER') != '1':
+        # started by a launcher: supervise the real worker from here (one-shot safety, see rank_supervisor)
+        sys.exit(rank_supervisor(sys.argv[1:]))
 
     import torch
     import __graft_entry__
@@ -461,6 +644,11 @@ def main():
             dog.beat(i)
             return out_
 
+    if os.environ.get('BENCH_FAIL_FIRST_ATTEMPT') and shard is not None and not args.single_comm and rank == G - 1:
+        # test knob: the last rank of the first (default-mode) attempt never joins the first collective -- the others sit in
+        # it until their watchdog names it and exits 3; this rank leaves the same way a little later
+        time.sleep(args.watchdog + 2.0)
+        os._exit(3)
     step(0)            # initialisation: first launches load the code objects and touch the workspaces
     torch.cuda.synchronize(dev)
     t_w = time.perf_counter()
@@ -661,6 +849,13 @@ def main():
                                  for p in ('CC11xx', 'bench_BPSK') if p != args.protocol]
         extras['c3'] = bank_figure(dev, local_rank, args.protocol, 1024, log2N, blocks, esz, nblocks, steps=4, warmup=1)
 
+    blocks_leg = None
+    if dist is not None and G > 1 and shard is not None and not args.no_blocks_leg:
+        blocks_leg = run_blocks_leg(args, dist, rank, G, local_rank, dev)
+    chain = None
+    if shard is None and G == 1 and not args.no_extras and not args.no_chain and rank == 0 and log2N == 20 and args.bins == 256:
+        chain = chain_figures(local_rank)           # (the default run only: C2's line carries the chain at the reference's own block sizes)
+
     # who took part: one entry per rank (process rank, device index, device uuid / name), gathered over the communicator
     props = torch.cuda.get_device_properties(dev)
     me = {'rank': rank, 'device': local_rank, 'uuid': str(getattr(props, 'uuid', '')), 'name': props.name}
@@ -726,7 +921,7 @@ def main():
                     'hbm_note': 'no length-N intermediate exists on this path: HBM traffic per launch is the 8 MiB block plus partial sums '
                                 '(see traffic); the two-pass algorithmic bytes below are context, not bytes moved',
                     'twopass_formulation_alg_bytes_per_block': b_alg(Dl_, Mu, N),
-                    'twopass_formulation_alg_bytes_over_time_GBps': round(b_alg(Dl_, Mu, N) / t_block_dev / 1e9, 1)}
+                    'twopass_alg_bytes_over_time_GBps': round(b_alg(Dl_, Mu, N) / t_block_dev / 1e9, 1)}
 
         if pinfo['path'] == 'segment':
             roof = segment_roofline(pinfo, Dl, counts, kms)
@@ -734,20 +929,16 @@ def main():
             roof = twopass_roofline(Dl, counts, kms, tun, timed_steps)
         roof['pipeline'] = {'device_ms_per_block': round(t_block_dev * 1e3, 4),
                             'B_alg_twopass_per_block': b_alg(Dl, Mu, N), 'B_ref_unfused_per_block': b_ref(Dl, M, N)}
+        pshort = pinfo['path'] + (f' L=2^{pinfo["log2L"]}, {pinfo["taps"]} taps' if pinfo['path'] == 'segment' else '')
+        # (<= 120 characters: the driver's record keeps that much of a string)
         if G == 1 and log2N == 20 and args.bins == 256 and args.protocol == 'bench_GMSK':
-            workload = ('C2: single MI355X, D=256 Doppler bins, M=8 GMSK matched filters (bench_GMSK), N=2^20 complex64 chunk, '
-                        f'ov=2^10; search path: {pinfo["path"]}'
-                        + (f' (L=2^{pinfo["log2L"]}, {pinfo["taps"]} taps)' if pinfo['path'] == 'segment' else ''))
+            workload = f'C2: 1 MI355X, D=256 Doppler bins, M=8 GMSK filters (bench_GMSK), N=2^20 complex64, ov=2^10; {pshort}'
         elif G == 1 and not args.force_dist:
-            workload = (f'single MI355X, D={D_total} Doppler bins, M={M} matched filters of {args.protocol} ({sps_bank} samples/symbol), '
-                        f'N=2^{log2N} complex64 chunk, ov=2^10; search path: {pinfo["path"]}'
-                        + (f' (L=2^{pinfo["log2L"]}, {pinfo["taps"]} taps)' if pinfo['path'] == 'segment' else ''))
+            workload = f'1 MI355X, D={D_total} Doppler bins, M={M} filters of {args.protocol} ({sps_bank} samples/symbol), N=2^{log2N}; {pshort}'
         elif by_blocks:
-            workload = (f'block round-robin: every one of {G} GPUs runs the full D={D_total} bank on different time blocks, M={M}, '
-                        f'N=2^{log2N}, no data-path collective; search path: {pinfo["path"]}')
+            workload = f'block round-robin: {G} GPUs, each the full D={D_total} bank on other time blocks, M={M}, N=2^{log2N}; {pshort}'
         else:
-            workload = (f'C4-style: D={D_total} Doppler bins sharded {Dl}/GPU over {G} GPUs, M={M}, N=2^{log2N}; rank 0 broadcasts the '
-                        f'block, one RCCL all-reduce of the per-bin scores per block; search path: {pinfo["path"]}')
+            workload = f'C4-style: D={D_total} bins, {Dl}/GPU over {G} GPUs, M={M}, N=2^{log2N}; block bcast + 1 RCCL score exchange/block; {pshort}'
         out = {
             'metric': 'IQ Msamples/sec through Doppler matched-filter bank (256 bins, 2^20 chunk)',
             'value': round(value, 3), 'unit': 'Msamples/s', 'n_gpus': G, 'steps': args.steps, 'warmup': args.warmup,
@@ -773,21 +964,21 @@ def main():
         out['config'].update(extras)
         # the same figures as flat scalars (a reader that keeps only scalar config keys still sees every single-GPU config)
         per_step = (N - ov) * G / 1e6
-        out['config'].update({
+        flat = {
             'repeats': args.repeats, 'untimed_steps_before': first - timed_steps,
             'ms_per_step_min': round(min(times) / args.steps * 1e3, 4), 'ms_per_step_max': round(max(times) / args.steps * 1e3, 4),
             'value_min': round(per_step / (max(times) / args.steps), 3), 'value_max': round(per_step / (min(times) / args.steps), 3),
-            'roofline_frac': roof.get('frac'), 'roofline_bound': roof.get('bound')})
+            'roofline_frac': roof.get('frac'), 'roofline_bound': roof.get('bound')}
         for key, fig in [(b['protocol'].replace('bench_', '').lower(), b) for b in extras.get('other_banks', [])] + \
                         ([('c3', extras['c3'])] if 'c3' in extras else []):
-            out['config'][f'{key}_msamples'] = fig['msamples']
-            out['config'][f'{key}_ms_per_step'] = fig['ms_per_step']
-            out['config'][f'{key}_roofline_frac'] = fig.get('roofline', {}).get('frac')
+            flat[f'{key}_msamples'] = fig['msamples']
+            flat[f'{key}_ms_per_step'] = fig['ms_per_step']
+            flat[f'{key}_roofline_frac'] = fig.get('roofline', {}).get('frac')
         if 'sync_correlator' in extras:
-            out['config']['sync_streams_per_s'] = extras['sync_correlator']['streams_per_s']
+            flat['sync_streams_per_s'] = extras['sync_correlator']['streams_per_s']
         for key in ('span_basis_search', 'energy_search'):
             if key in extras:
-                out['config'][f'{key}_msamples'] = extras[key]['msamples']
+                flat[f'{key}_msamples'] = extras[key]['msamples']
         if other is not None:
             o_info, o_t, o_counts, o_kms, o_tun, osteps = other
             o_roof = (segment_roofline(o_info, Dl, o_counts, o_kms) if o_info['path'] == 'segment'
@@ -795,15 +986,46 @@ def main():
             o_roof['ms_per_step'] = round(o_t * 1e3, 4)
             o_roof['msamples'] = round((N - ov) / o_t / 1e6, 2)
             out['roofline_other_path'] = {'path': o_info['path'], **o_roof}
-            out['config'][f"{o_info['path']}_msamples"] = o_roof['msamples']
-            out['config'][f"{o_info['path']}_{'hbm' if o_roof['bound'] == 'hbm' else 'valu'}_frac"] = o_roof['frac']
+            flat[f"{o_info['path']}_msamples"] = o_roof['msamples']
+            flat[f"{o_info['path']}_{'hbm' if o_roof['bound'] == 'hbm' else 'valu'}_frac"] = o_roof['frac']
             if o_roof.get('traffic') and o_roof.get('alg_bytes_per_launch'):
-                out['config'][f"{o_info['path']}_traffic_over_alg"] = round(o_roof['traffic'] / o_roof['alg_bytes_per_launch'], 3)
+                flat[f"{o_info['path']}_traffic_over_alg"] = round(o_roof['traffic'] / o_roof['alg_bytes_per_launch'], 3)
+        if chain:
+            flat.update(chain)
+        if blocks_leg:
+            flat.update(blocks_leg)
+        if shard is not None:
+            flat['dist_mode'] = ('single-comm' if args.single_comm else 'concurrent-broadcast') + ('' if not args.no_prefetch else ', no-prefetch')
+            if args.fallback_from:
+                flat['fallback_from'] = args.fallback_from[:110]
+        flat['stream_msamples'] = out['config']['stream_msamples']
+        # ORDER: `workload`, then the scalars a reader that keeps only the first twenty scalar keys must see (key names <= 40
+        # characters, strings <= 120), then everything else
+        LEAD = ['roofline_frac', 'dist_mode', 'fallback_from', 'blocks_stream_msamples', 'blocks_efficiency_vs_1gpu', 'c3_msamples',
+                'c3_roofline_frac', 'cc11xx_msamples', 'cc11xx_roofline_frac', 'bpsk_msamples', 'bpsk_roofline_frac', 'twopass_msamples',
+                'twopass_hbm_frac', 'twopass_traffic_over_alg', 'ms_per_step_min', 'ms_per_step_max', 'repeats', 'sync_streams_per_s',
+                'chain_n15_d64_msamples', 'chain_n17_d64_msamples', 'recv_n15_d64_msamples', 'recv_n17_d64_msamples', 'stream_msamples']
+        lead = {k: flat[k] for k in LEAD if flat.get(k) is not None}
+        rest = {k: v for k, v in out['config'].items() if k != 'workload' and k not in lead}
+        rest.update({k: v for k, v in flat.items() if k not in lead})
+        out['config'] = {'workload': out['config']['workload'], **lead, **rest}
+        # the roofline object the same way: the contract's scalars first
+        out['roofline'] = {**{k: roof[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic') if k in roof},
+                           **{k: v for k, v in roof.items() if k not in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')}}
         if not args.no_cpu_baseline and G == 1:
-            cb, cscores, single = cpu_baseline(masks, shifts[lo:hi], host_blocks[last_block], N, ov, Dl)
-            # the bounded CPU sample doubles as a full-size parity spot check of the last timed block
+            # C2 on two whole blocks when ~26 s of CPU work allow -- the last timed block and its successor
+            second = (last_block + 1) % nblocks
+            cb, cscores_all, single = cpu_baseline(masks, shifts[lo:hi], [host_blocks[last_block], host_blocks[second]], N, ov, Dl)
+            cscores = cscores_all[0]
+            # the bounded CPU sample doubles as a full-size parity spot check of the last timed block (and of the second one)
             rel = float(np.abs(gscores[:len(cscores)] - cscores).max() / cscores.max())
             rel1 = float(np.abs(gscores[:len(single)] - single).max() / single.max())
+            if len(cscores_all) > 1:
+                bank.upload_device(blocks.data_ptr() + second * esz)
+                bank.find_carrier()
+                g2 = bank.get_scores()[:, 0].astype(np.float64)
+                rel = max(rel, float(np.abs(g2 - cscores_all[1]).max() / cscores_all[1].max()))
+            out['config']['cpu_blocks_timed'] = cb['blocks_timed']
             cb['max_rel_diff_vs_gpu'] = rel
             cb['max_rel_diff_vs_gpu_fp64_oracle'] = rel1
             cb['parity_tolerance'] = PARITY_TOL
