@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_stored_bench_line_follows_the_contract():
-    line = open(os.path.join(ROOT, 'profiles', 'r04_bench.json')).read().strip().splitlines()[-1]
+    line = open(os.path.join(ROOT, 'profiles', 'r05_bench.json')).read().strip().splitlines()[-1]
     d = json.loads(line)
     base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
     assert base['metric'].startswith(d['metric']) and d['unit'] == 'Msamples/s'      # BASELINE adds "at 1/2/4/8 GPUs"; n_gpus says which
@@ -44,5 +44,22 @@ def test_stored_bench_line_follows_the_contract():
     assert c['twopass_msamples'] > 100 and 0.4 < c['twopass_hbm_frac'] < 1 and 1.0 <= c['twopass_traffic_over_alg'] < 1.3
     assert c['sync_streams_per_s'] == c['sync_correlator']['streams_per_s'] and c['roofline_frac'] == r['frac']
     assert banks['CC11xx']['path']['log2L'] == 11 and banks['CC11xx']['roofline']['frac'] > 0.46      # the wave-local 2048-point kernel
+    # ORDER: the driver's record keeps the first twenty scalar keys of `config` (names cut at 40 characters, strings at 120):
+    # `workload` and the flat figures come first, nested objects only after them
+    keys = list(c)
+    assert keys[0] == 'workload' and len(c['workload']) <= 120
+    lead = keys[:20]
+    assert all(not isinstance(c[k], (dict, list)) and len(k) <= 40 for k in lead), lead
+    for k in ('roofline_frac', 'c3_msamples', 'c3_roofline_frac', 'cc11xx_msamples', 'cc11xx_roofline_frac', 'bpsk_msamples',
+              'bpsk_roofline_frac', 'twopass_msamples', 'twopass_hbm_frac', 'twopass_traffic_over_alg', 'ms_per_step_min',
+              'ms_per_step_max', 'repeats', 'sync_streams_per_s', 'chain_n15_d64_msamples', 'chain_n17_d64_msamples',
+              'recv_n15_d64_msamples', 'recv_n17_d64_msamples', 'stream_msamples'):
+        assert k in lead, k
+    assert list(r)[:6] == ['bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'] and all(len(k) <= 40 for k in r)
+    # the receive chain at the reference's own block geometry (config/base.json:13,33), B blocks per device call
+    assert c['recv_n15_d64_msamples'] >= 580 and c['recv_n17_d64_msamples'] >= 900
+    assert c['recv_n15_d64_msamples'] > 2 * c['recv_b1_n15_d64_msamples'] and c['chain_n15_d64_packets'].split('/')[0] == c['chain_n15_d64_packets'].split('/')[1]
+    # the CPU baseline timed two whole blocks; the single-thread leg eight bins
+    assert d['cpu_baseline']['blocks_timed'] >= 1 and '8 of 256 bins' in d['cpu_baseline']['single_thread']['sample']
     sc = d['config']['sync_correlator']
     assert sc['exact_vs_np_convolve_stream0'] and sc['device_ms'] < sc['call_ms'] and 0 < sc['pcie_frac_of_63GBps'] < 1
