@@ -248,7 +248,11 @@ def code_rate_window(N, spsym):
 
 def code_rate_and_phase(env, offset, length):
     """[k*, arg(P[k*]), |P[k*]|^2] (CU:236-320): P = rfft(env); argmax of |P|^2 over
-    [offset, offset+length); ties -> lowest index."""
+    [offset, offset+length); ties -> lowest index.  float64: the true maximum.  The reference squares in fp32
+    (ComplexAbsSquared CU:1022-1026), which overflows to +inf for strong signals in long blocks with long filters
+    (|P|^2 ~ M^2 N^6 T^4 a^8: amplitude-1 samples, 384 taps, N = 2^20); what its warp butterfly returns among several +inf
+    is an artefact of the shuffle pattern and is NOT restated here.  Wherever the fp32 squares are finite the fp32 argmax
+    and this one pick the same bin (the HIP kernel compares exactly scaled fp32 squares: small_kernels.hpp)."""
     P = np.fft.rfft(np.asarray(env, dtype=np.float64))
     w = np.abs(P[offset:offset + length]) ** 2
     k = int(np.argmax(w)) + offset

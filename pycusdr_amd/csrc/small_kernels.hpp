@@ -250,12 +250,35 @@ __global__ void k_envelope(const cf *xc, float *env, int N, int M, int off) {
 
 // findCodeRateAndPhase (cuda_kernels.cu:236-320): argmax |P[k]|^2 over [offset, offset+len);
 // ties resolve to the lowest k (deterministic).  out = {k, atan2(im,re), |P|^2}
+// The reference squares in fp32 (ComplexAbsSquared, CU:1022-1026): for a strong signal in a long block with long filters
+// (|P| ~ M N^3 T^2 a^4: amplitude-1 samples, 384 taps, N = 2^20) |P[k]|^2 exceeds the fp32 range, every candidate near the
+// peak reads +inf, and which of them the reference's warp butterfly then returns is an artefact of its shuffle pattern.  Here
+// the comparison runs on P scaled by a power of two that brings the window's largest component to [1, 2): the scaling is exact,
+// so wherever the reference's squares are finite and normal the same k wins with the same ties, and where they overflow the
+// true maximum still wins (candidates 2^-63 below the largest flush to zero: they could not win either way).  out[2] stays
+// the reference's own fp32 square (+inf when it overflows; the host never reads it, DB:730-752).
 DEVI void code_rate_body(const cf *P, float *out, int offset, int len, float *sv, int *si) {
     const int tid = threadIdx.x;
+    unsigned emax = 0;             // largest finite |component| of the window, as its fp32 bit pattern (monotonic for >= 0)
+    for (int x = tid; x < len; x += blockDim.x) {
+        const cf z = P[x + offset];
+        const unsigned a = __float_as_uint(fabsf(z.x)), b = __float_as_uint(fabsf(z.y));
+        if (a < 0x7f800000u && a > emax) emax = a;
+        if (b < 0x7f800000u && b > emax) emax = b;
+    }
+    si[tid] = (int)emax;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if (tid < s && (unsigned)si[tid + s] > (unsigned)si[tid]) si[tid] = si[tid + s];
+        __syncthreads();
+    }
+    const int shift = 127 - (int)(((unsigned)si[0] >> 23) & 0xffu);      // 2^shift * largest component in [1, 2) (0 for a zero window)
+    __syncthreads();
     float best = -1.f;
     int bi = 0x7fffffff;
     for (int x = tid; x < len; x += blockDim.x) {
-        const float v = abs2c(P[x + offset]);
+        const cf z = P[x + offset];
+        const float v = abs2c(mkc(ldexpf(z.x, shift), ldexpf(z.y, shift)));
         if (v > best) {
             best = v;
             bi = x + offset;
@@ -280,7 +303,7 @@ DEVI void code_rate_body(const cf *P, float *out, int offset, int len, float *sv
         const cf z = P[k];
         out[0] = (float)k;
         out[1] = atan2f(z.y, z.x);
-        out[2] = sv[0];
+        out[2] = (len > 0) ? abs2c(z) : -1.f;
     }
 }
 __global__ void k_code_rate(const cf *P, float *out, int offset, int len) {

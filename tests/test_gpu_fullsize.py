@@ -124,7 +124,9 @@ def test_c2_demod_stage_fullsize(c2):
     xc = bank.get_xcorr()
     assert np.abs(env - orc.envelope(xc)).max() / env.max() < 1e-6
     ok, oarg, oval = orc.code_rate_and_phase(env, k_off, k_len)
-    assert ok == int(k) and abs(float(arg) - oarg) < 1e-3
+    # (measured at this size: 1.4e-5 rad against the fp64 oracle chain, tests/test_gpu_fullsize_decisions.py; here the oracle
+    # transforms the DEVICE's envelope, so only the last transform differs)
+    assert ok == int(k) and abs(float(arg) - oarg) < 5e-5
     spSym, codeOffset = orc.code_rate_host(k, arg, N)
     S = int(N / spSym)
     sym, cen, mag = bank.find_centres(np.float32(spSym), np.float32(codeOffset), 0, S)
