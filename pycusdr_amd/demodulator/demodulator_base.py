@@ -183,7 +183,13 @@ class Demodulator:
             # room for the two spectrum windows computeSNR reads (DB:635-667), whichever neighbouring pair of bins the pick
             # falls between: the block call then always delivers them, and nothing ever has to be fetched from a spectrum
             # that a later block may already have replaced
-            self.bank.BAND_CAPACITY = self._snr_band_capacity(5)
+            self.bank.BAND_CAPACITY, longest = self._snr_band_capacity(5)
+            log.info('[%s]: SNR windows of up to %d spectrum bins travel with every block (longest window of this bin table: %d)',
+                     radioName, self.bank.BAND_CAPACITY, longest)
+            if longest > self.bank.BAND_CAPACITY:
+                log.warning('[%s]: a pick between bins %d spectrum bins apart needs a longer SNR window than travels with the block: '
+                            'it is fetched afterwards when no later block is on the device yet, else that block reports SNR = nan',
+                            radioName, longest)
 
         # windowed argmax range of the symbol-rate estimate (reference DB:508-512)
         self.symsTolLow = 0.9 * spsym
@@ -387,8 +393,11 @@ class Demodulator:
         return freqOffset, sdev_Hz, self.clippedPeakIPure, SNR
 
     def _snr_band_capacity(self, windowWidth):
-        """Longest spectrum window ``computeSNR`` can ask for (reference DB:635-667), over every (low, high) the pick can
-        produce: high = low or low + 1.  Rounded up to a power of two, at least 256 elements."""
+        """(capacity, longest): the longest spectrum window ``computeSNR`` can ask for (reference DB:635-667), over every
+        (low, high) the pick can produce -- high = low or low + 1 --, and the capacity reserved for it in every block's result
+        record: rounded up to a power of two, at least 256 elements and at most 2^16 (two windows of 2^16 complex64 are 1 MiB
+        of page-locked staging and read-back per block; a sparse table over a wide range -- one neighbour gap or a wrap pair of
+        half a spectrum -- must not make every block ship 16 MiB)."""
         # (the noise-reference rows in front of the table never take part in a pick: its index starts behind them, CU:536)
         N, sh = self.Nfft, self.doppCyperSymNorm[self.doppIdxArrayOffset:].astype(np.int64)
         lo = np.concatenate((sh, sh[:-1]))
@@ -403,7 +412,7 @@ class Demodulator:
             w = windowWidth
             return np.where(a > b, sl(a - w, np.full_like(a, N)) + sl(np.zeros_like(b), b + w), sl(a - w, b + w))
         longest = int(max(lengths(lo, hi).max(), lengths((lo + N // 2) % N, (hi + N // 2) % N).max(), 1))
-        return int(min(N, max(256, 1 << int(np.ceil(np.log2(longest))))))
+        return int(min(N, 1 << 16, max(256, 1 << int(np.ceil(np.log2(longest)))))), longest
 
     def _spectrum_slice(self, a, b):
         """``X[a:b]`` with numpy slice semantics, fetching only that window from the device."""

@@ -21,8 +21,11 @@ the filter bank.  Per block:
 The exchange is latency-bound (<= 8 KiB), not link-bandwidth-bound.
 """
 import contextlib
+import logging
 
 import numpy as np
+
+log = logging.getLogger('pycusdr_amd.dist')
 
 
 def bin_slice(num_bins, rank, world):
@@ -64,16 +67,30 @@ class StepWatchdog:
 
     def beat(self, step=None):
         self._beats += 1
+        self._suspended = False
         self._last = self._time.monotonic()
         self.step = self.step + 1 if step is None else int(step)
 
     def stop(self):
         self._stop.set()
 
+    def suspend(self):
+        """Stop counting: the loop that beats has returned (``BlockShard.run`` / ``GridShard.run`` suspend the watchdog they were
+        given when they leave, so a caller that spends longer than ``timeout_s`` on its results, or idles before the next
+        ``run``, is not killed with a misleading 'no progress').  ``resume()`` / the next ``beat()`` re-arm it.  The caller
+        owns ``stop()``."""
+        self._suspended = True
+
+    def resume(self):
+        self._last = self._time.monotonic()
+        self._suspended = False
+
     def _watch(self):
         import os
         import sys
         while not self._stop.wait(min(0.25, self.timeout_s / 4)):
+            if getattr(self, '_suspended', False):
+                continue
             idle = self._time.monotonic() - self._last
             if idle > (self.timeout_s if self._beats else max(self.timeout_s, self.first_grace_s)):
                 what = ''
@@ -338,7 +355,7 @@ class BlockShard:
     ``torch.distributed.new_group(backend='gloo')``.
     """
     HEADER = 12         # float64: block index, doppler, doppler_std, SNR, spSym, kept symbols, device + host seconds, tail: post, end,
-    #                     dtype code, exact flag; one spare
+    #                     dtype code, exact flag; the owner's block stamp (epoch seconds)
     TAIL_HEADER = 5     # float64: block index, post, end, dtype code, exact flag
 
     def __init__(self, rank=None, world=None, group=None, comm=None, root=0, ranks=None):
@@ -388,8 +405,10 @@ class BlockShard:
         if len(bits) != len(trust):
             raise ValueError('bit and trust arrays of unequal length')
         th, tb = self.pack_tail(d['count'], tail)
+        # (head[11]: the owner's block stamp, epoch seconds -- the root's result dict must say when the samples arrived, not when
+        # the finished block was delivered 2 G - 1 blocks later)
         head = np.array([d['count'], d['doppler'], d['doppler_std'], d['SNR'], d['spSymEst'], len(bits), d['time_ms'] * 1e-3,
-                         th[1], th[2], th[3], th[4], time_device], dtype=np.float64)
+                         th[1], th[2], th[3], th[4], float(d['timestamp'])], dtype=np.float64)
         return head, np.concatenate((bits, trust, tb))
 
     @staticmethod
@@ -397,7 +416,8 @@ class BlockShard:
         S = int(head[5])
         _, tail = BlockShard.unpack_tail(np.array([head[0], head[7], head[8], head[9], head[10]]), body[2 * S:])
         return {'count': int(head[0]), 'doppler': float(head[1]), 'doppler_std': float(head[2]), 'SNR': float(head[3]),
-                'spSym': float(head[4]), 'spent': float(head[6]), 'bits': body[:S], 'trust': body[S:2 * S], 'tail': tail}
+                'spSym': float(head[4]), 'spent': float(head[6]), 'timestamp': float(head[11]), 'bits': body[:S],
+                'trust': body[S:2 * S], 'tail': tail}
 
     # -- transport -------------------------------------------------------------------------------------------------------
     TAG_TAIL, TAG_RESULT = 1, 2      # two message kinds may travel between one pair of ranks: matched by tag, not by order
@@ -454,7 +474,27 @@ class BlockShard:
     def recv_result(self, index):
         head, body = self._recv(self.owner(index), self.HEADER, lambda h: 2 * int(h[5]) + int(h[7]) + int(h[8]),
                                 f'the finished block {index}', self.TAG_RESULT)
+        if head[0] < 0:                    # (head[0] is the owner's running block counter) -1: the owner failed and says so
+            raise RuntimeError(f'rank {self.owner(index)} reported a failure where its finished block {index} was expected')
         return self.unpack(head, body)
+
+    def _poison(self, next_index):
+        """This rank is leaving ``run`` with an exception: tell the peers that would otherwise sit in a receive for ever -- the
+        owner of the next block (it waits for this rank's tail) and the root (it waits for this rank's finished blocks).  Empty
+        messages with block index -1; the receivers raise.  Best effort: nothing here may raise or wait."""
+        try:
+            torch = self.torch
+            if self.world > 1:
+                nxt = self.owner(next_index)
+                if nxt != self.rank:
+                    th = torch.from_numpy(np.array([-1.0, 0, 0, 0, 0]))
+                    self._poisoned = [(self.dist.isend(th, self.peers[nxt], group=self.group, tag=self.TAG_TAIL), th)]
+                if self.rank != self.root:
+                    hh = torch.from_numpy(np.concatenate(([-1.0], np.zeros(self.HEADER - 1))))
+                    self._poisoned = getattr(self, '_poisoned', []) + [(self.dist.isend(hh, self.peers[self.root], group=self.group,
+                                                                                     tag=self.TAG_RESULT), hh)]
+        except Exception:       # noqa: BLE001
+            pass
 
     # -- the loop ------------------------------------------------------------------------------------------------------
     def run(self, runner, sample_source, sink=None, decoder=None, feed=None, skip=None, watchdog=None, feed_begin=None):
@@ -515,7 +555,7 @@ class BlockShard:
                 r = self.recv_result(i)
                 self.stats['root_wait_s'] += time.perf_counter() - t_in
                 t_in = time.perf_counter()
-                d = runner.compose_result(r['count'], time.time(), r['doppler'], r['doppler_std'], r['SNR'], r['bits'], r['trust'],
+                d = runner.compose_result(r['count'], r['timestamp'], r['doppler'], r['doppler_std'], r['SNR'], r['bits'], r['trust'],
                                           r['spSym'], r['spent'])
                 tail = r['tail']
             else:
@@ -541,7 +581,10 @@ class BlockShard:
             t_in = time.perf_counter()
             tail = demod.overlapTail(part['rec'])
             if not tail['exact']:
-                raise ValueError('time-chunk sharding needs windows of at least overlapOffset + 2 symbols per block')
+                # a window shorter than overlapOffset + 2 symbols: the single-process loop logs its failed alignment and carries
+                # on (DB:965-967); so does this one -- the forwarded tail is then the un-adjusted one
+                log.error('block %d: window of fewer than overlapOffset + 2 symbols: its tail is forwarded without the +-1 '
+                          'adjustment the next block\'s alignment may have needed', i)
             if G > 1 and state['seen'] > i:
                 self.send_tail(i, tail)
             else:
@@ -571,57 +614,80 @@ class BlockShard:
                         backlog[k] = (j, fin)
 
         import time
-        for i, chunk in enumerate(sample_source):
-            if first[0] is None:
-                first[0] = i
-            state['seen'] = i
-            own = self.owner(i) == self.rank
-            # a tail that waited for this block to show up
-            if state['tail'] is not None and state['tail'][0] == i - 1 and G > 1:
-                self.send_tail(*state['tail'])
-                state['tail'] = None
-            if own:
-                collect_flying()                               # this rank's previous block: G blocks back
-                if use_async:
-                    feed_begin(chunk)
-                    state['flying'] = i
-                    if is_root:
-                        backlog.append((i, 'flying'))
+        try:
+            for i, chunk in enumerate(sample_source):
+                if first[0] is None:
+                    first[0] = i
+                state['seen'] = i
+                own = self.owner(i) == self.rank
+                # a tail that waited for this block to show up
+                if state['tail'] is not None and state['tail'][0] == i - 1 and G > 1:
+                    self.send_tail(*state['tail'])
+                    state['tail'] = None
+                if own:
+                    collect_flying()                               # this rank's previous block: G blocks back
+                    if use_async:
+                        feed_begin(chunk)
+                        state['flying'] = i
+                        if is_root:
+                            backlog.append((i, 'flying'))
+                    else:
+                        fin = finish_own(i, feed(chunk))
+                        if is_root:
+                            backlog.append((i, fin))
                 else:
-                    fin = finish_own(i, feed(chunk))
+                    skip(chunk)
                     if is_root:
-                        backlog.append((i, fin))
-            else:
-                skip(chunk)
+                        backlog.append((i, None))
                 if is_root:
-                    backlog.append((i, None))
+                    while len(backlog) > lag and backlog[0][1] != 'flying':
+                        deliver(backlog.pop(0))
+                if watchdog is not None:
+                    watchdog.beat(i)
+            collect_flying()
+            state['tail'] = None                                   # the stream's last block has no successor in this call ...
+            # ... but the NEXT call's first block (index 0 again: rank 0's) continues the stream: rank 0 must end up with the last
+            # block's tail as its alignment state.  The root gets it with the finished block; any other rank 0 gets it from the owner.
+            last = state['seen']
+            if G > 1 and last >= 0 and self.root != 0 and self.owner(last) != 0:
+                if self.owner(last) == self.rank:
+                    head, body = self.pack_tail(last, state['local_tail'][1])
+                    self._isend(head, body, 0, self.TAG_TAIL)
+                elif self.rank == 0:
+                    head, body = self._recv(self.owner(last), self.TAIL_HEADER, lambda h: int(h[1]) + int(h[2]),
+                                            f'the tail of the last block {last}', self.TAG_TAIL)
+                    tail = self.unpack_tail(head, body)[1]
+                    demod.poswinP, demod.posSymEnd = tail['post'], tail['end']
+            while backlog:
+                deliver(backlog.pop(0))
+                if watchdog is not None:
+                    watchdog.beat()         # (the drain is 2 G - 1 blocks of decoder work on the root)
             if is_root:
-                while len(backlog) > lag and backlog[0][1] != 'flying':
-                    deliver(backlog.pop(0))
+                t_in = time.perf_counter()
+                finish_search()
+                self.stats['root_s'] += time.perf_counter() - t_in
+            self.flush()
+            return results, packets
+
+        except BaseException:
+            # leave nothing behind a failure: no block in flight on this rank's device (the handle must be usable afterwards),
+            # no peer waiting for a message that will never come
+            if state['flying'] is not None:
+                state['flying'] = None
+                try:
+                    runner.feed_device_end()
+                except Exception:       # noqa: BLE001
+                    pass
+            if searching:
+                try:
+                    decoder.findFrames_end()
+                except Exception:       # noqa: BLE001
+                    pass
+            self._poison(state['seen'] + 1)
+            raise
+        finally:
             if watchdog is not None:
-                watchdog.beat(i)
-        collect_flying()
-        state['tail'] = None                                   # the stream's last block has no successor in this call ...
-        # ... but the NEXT call's first block (index 0 again: rank 0's) continues the stream: rank 0 must end up with the last
-        # block's tail as its alignment state.  The root gets it with the finished block; any other rank 0 gets it from the owner.
-        last = state['seen']
-        if G > 1 and last >= 0 and self.root != 0 and self.owner(last) != 0:
-            if self.owner(last) == self.rank:
-                head, body = self.pack_tail(last, state['local_tail'][1])
-                self._isend(head, body, 0, self.TAG_TAIL)
-            elif self.rank == 0:
-                head, body = self._recv(self.owner(last), self.TAIL_HEADER, lambda h: int(h[1]) + int(h[2]),
-                                        f'the tail of the last block {last}', self.TAG_TAIL)
-                tail = self.unpack_tail(head, body)[1]
-                demod.poswinP, demod.posSymEnd = tail['post'], tail['end']
-        while backlog:
-            deliver(backlog.pop(0))
-        if is_root:
-            t_in = time.perf_counter()
-            finish_search()
-            self.stats['root_s'] += time.perf_counter() - t_in
-        self.flush()
-        return results, packets
+                watchdog.suspend()      # the caller owns stop(); an idle or busy caller is not "no progress"
 
 
 # ---- Doppler bins x time chunks ----------------------------------------------------------------------------------------
@@ -670,11 +736,15 @@ class GridShard:
         them from its broadcast).  Returns (results, packets) on process 0, ([], []) elsewhere."""
         if self.blocks is not None:
             return self.blocks.run(runner, sample_source, sink=sink, decoder=decoder, watchdog=watchdog)
-        for i, chunk in enumerate(sample_source):
-            if self.owner_group(i) == self.g:
-                runner.feed_device(np.asarray(chunk, dtype=np.complex64))
-            else:
-                runner.skip_block(chunk)
+        try:
+            for i, chunk in enumerate(sample_source):
+                if self.owner_group(i) == self.g:
+                    runner.feed_device(np.asarray(chunk, dtype=np.complex64))
+                else:
+                    runner.skip_block(chunk)
+                if watchdog is not None:
+                    watchdog.beat(i)
+        finally:
             if watchdog is not None:
-                watchdog.beat(i)
+                watchdog.suspend()          # the caller owns stop()
         return [], []

@@ -442,6 +442,75 @@ def test_bins_by_blocks_grid_equals_single_process_stream(world, bin_ranks):
     assert res[0][2] == 27 and all(r[2] == 0 for r in res[1:])
 
 
+def _worker_blockshard_failure(rank, world, port, q):
+    """Rank 1 fails in the middle of the stream (its device call raises): it must leave ``run`` with that exception and
+    nothing in flight, and the other ranks must leave too -- with an exception that names the failed rank -- instead of
+    sitting in a receive for ever; a suspended watchdog does not kill a caller that idles afterwards."""
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    import torch.distributed as dist
+    from oracle_bank import OracleBank
+    import pycusdr_amd.demodulator.demodulator_base as dbm
+    from pycusdr_amd import config as cfg
+    from pycusdr_amd.demodulator_process import DemodulatorRunner
+    from pycusdr_amd.dist import BlockShard, StepWatchdog
+    from pycusdr_amd.protocol import loadProtocol
+    dbm.MFBank = OracleBank
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    bs, ov, D = 13, 1 << 10, 8
+    N = 1 << bs
+    nblocks = 12
+    conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=D)
+    p = loadProtocol('bench_GMSK')(conf=conf)
+    sig, _ = _hopping_stream(N, ov, nblocks, np.zeros(nblocks))
+    step = N - ov
+    chunks = [sig[ov + i * step: ov + (i + 1) * step] for i in range(nblocks)]
+    shard = BlockShard()
+    run = DemodulatorRunner(conf, p, 'UHF-H')
+    run.raw[:ov] = sig[:ov]
+    if rank == 1:
+        inner, calls = run.feed_device, [0]
+
+        def failing(x=None):
+            calls[0] += 1
+            if calls[0] == 3:
+                raise OSError('planted device failure')
+            return inner(x)
+        run.feed_device = failing
+    dog = StepWatchdog(1.5, rank=rank, describe=shard.describe, first_grace_s=60.0)
+    what = 'returned'
+    t0 = time.time()
+    try:
+        shard.run(run, chunks, watchdog=dog)
+    except OSError as e:
+        what = f'OSError: {e}'
+    except RuntimeError as e:
+        what = f'RuntimeError: {e}'
+    took = time.time() - t0
+    time.sleep(2.5)            # longer than the watchdog's limit: run() suspended it on the way out
+    dog.stop()
+    q.put((rank, what, took < 60.0))
+    try:
+        dist.destroy_process_group()
+    except Exception:       # noqa: BLE001
+        pass
+
+
+@pytest.mark.timeout(200)
+def test_block_round_robin_failure_leaves_no_rank_waiting():
+    res = _spawn(_worker_blockshard_failure, world=3, timeout=150)
+    by = {r[0]: r for r in res}
+    assert by[1][1].startswith('OSError: planted') and all(r[2] for r in res), res
+    # the root waits for rank 1's finished blocks, rank 2 for rank 1's tails: both are told
+    assert by[0][1].startswith('RuntimeError') and ('failure' in by[0][1] or 'arrived where' in by[0][1]), res
+    assert by[2][1].startswith('RuntimeError'), res
+
+
 def test_block_shard_wire_format_round_trip():
     """What travels under time-chunk sharding: the tail of a block (owner -> next owner) and the finished block (owner -> root);
     every array comes back with its dtype and values."""
@@ -457,6 +526,7 @@ def test_block_shard_wire_format_round_trip():
     with pytest.raises(TypeError):
         BlockShard.pack_tail(0, {'post': np.zeros(3, np.int32), 'end': np.zeros(3, np.int32), 'exact': True})
     d = {'count': 41, 'doppler': -123.456, 'doppler_std': 7.5, 'SNR': float('nan'), 'spSymEst': 15.987654321, 'time_ms': 2.5,
+         'timestamp': 1759560000.123456,        # the owner's block stamp travels with the block (epoch seconds, float64: exact to ~0.2 us)
          'data': rs.randint(0, 2, S).astype(np.uint8), 'trust': rs.randint(0, 256, S).astype(np.uint8)}
     sh = BlockShard.__new__(BlockShard)
     head, body = BlockShard.pack(sh, d, tail, 1e-3)
@@ -464,6 +534,7 @@ def test_block_shard_wire_format_round_trip():
     back = BlockShard.unpack(head, body)
     assert back['count'] == 41 and back['doppler'] == -123.456 and np.isnan(back['SNR']) and back['spSym'] == d['spSymEst']
     assert np.array_equal(back['bits'], d['data']) and np.array_equal(back['trust'], d['trust']) and back['spent'] == 2.5e-3
+    assert back['timestamp'] == d['timestamp']
     assert all(np.array_equal(back['tail'][k], tail[k]) and back['tail'][k].dtype == tail[k].dtype for k in ('post', 'end'))
     empty = dict(d, data=d['data'][:0], trust=d['trust'][:0])
     h2, b2 = BlockShard.pack(sh, empty, {'post': tail['post'][:0], 'end': tail['end'][:0], 'exact': True}, 0.0)

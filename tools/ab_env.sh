@@ -1,4 +1,5 @@
 #!/bin/bash
+mkdir -p gpurun_out
 # A/B of an environment switch of the library (e.g. MFB_NO_SIDE, MFB_NO_GRAPH) on ONE box, whole bench lines interleaved:
 #   tools/ab_env.sh MFB_NO_SIDE [reps]        (run on the GPU box; prints value / ms_per_step / chain figures per run)
 var=$1; reps=${2:-2}

@@ -1,3 +1,4 @@
+#!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/stall
 timeout -k 5 150 rocprofv3 --pmc SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL --output-format csv -d gpurun_out/stall/lds -- python3 bench.py --no-cpu-baseline --no-extras --steps 4 --warmup 1 --repeats 1 --protocol CC11xx > gpurun_out/stall/lds.log 2>&1 || echo "lds pass failed"
