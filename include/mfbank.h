@@ -51,7 +51,8 @@ const char *mfb_strerror(int status);
  * at run time, SourceModule DB:214). */
 int mfb_abi_version(void);   /* 2: search paths, mfb_xcorr; 3: mfb_set_search_mode, mfb_sync_find_multi; 4: mfb_receive_block,
                               * mfb_export_rows_async, mfb_sync_find_packed; 5: mfb_debug_block_scalars; 6: mfb_receive_blocks_*,
-                              * mfb_window_buffer, mfb_block_params.block_stride */
+                              * mfb_window_buffer, mfb_block_params.block_stride; 7: mfb_set_stream_stages, mfb_stream_seed,
+                              * mfb_receive_blocks_end_record */
 
 /* Create a handle on HIP device `device` for blocks of N = 2^log2N samples, `num_dopplers`
  * Doppler bins plus `doppler_offset` leading noise-reference bins (DB:150-159), M matched
@@ -278,6 +279,53 @@ int mfb_window_buffer(mfb_ctx *ctx, int which, int max_blocks, int block_stride,
 int mfb_receive_blocks_begin(mfb_ctx *ctx, const mfb_block_params *params, int nblocks, int slot);
 int mfb_receive_blocks_end(mfb_ctx *ctx, int slot, mfb_block_result *results, int32_t *sym, int32_t *centres, float *magnitude,
                            int symbol_stride, float *bands_c64);
+/* The integer stages behind the symbol decisions, on the device, for the blocks of a batch (mfb_receive_blocks_*; UHF search
+ * mode).  Replaces, block by block and bit for bit:
+ *   A12  extractBits (DB:1012-1023: bits = bitLUT[sym]) -- lut_mode 1, lut = uint8[lut_rows] of 0 / 1 -- or extractBitsNRZs
+ *        (DB:1026-1051) -- lut_mode 2, lut = int32[lut_rows][2][lut_successors] = symbolLUT[sym][is-one | is-zero][successors],
+ *        impossible transitions -> 0 and counted;
+ *   A13  checkSymbolOverlap (DB:863-988): the symbols whose centre lies in [overlap_samples / 2, N - overlap_samples / 2], the
+ *        +-1 repair against the previous block over overlap_offset symbols with match_threshold (DB:97-99, 938-957), skipped
+ *        above error_threshold impossible transitions (DB:925), and the uint8 casts of DB:859 (centres mod 256; trust = the raw
+ *        bytes of the leading fp32 magnitudes, DB:472,1005-1006);
+ *   A14  the decoder's two searches np.where(np.convolve(stream, template) >= threshold) (DEC:96-113) on the stream it stitches
+ *        when no candidate is stashed -- the last bits_overlap bits before the block + the block's bits (DEC:89-90) -- for up to
+ *        two templates of taps in {-1, 0, +1} (header mask, sync flag), thresholds numOnes - tolerance (DEC:101,113).
+ * A block whose case is irregular (a symbol index outside the LUT, no first / last centre, a window or a previous tail too
+ * short for the slices numpy would take) is flagged (a13_status 0) and left to the host path, which does whatever the
+ * reference does there; the sync hits are flagged invalid from such a block to the end of the batch (and until the caller
+ * seeds the state again).  The state a batch starts from -- the previous block's tail (bits behind its window: poswinP, last
+ * overlap_offset + 1 bits inside it: posSymEnd, DB:977-979) and the last bits_overlap bits of the stream -- stays on the device
+ * from batch to batch; mfb_stream_seed sets it from the host's (start of a stream, after an irregular block, after blocks
+ * that went another way).  p == NULL switches the stages off. */
+typedef struct mfb_stream_params {
+    int32_t overlap_samples;     /* 2^overlap (config GPU.overlap) */
+    int32_t overlap_offset;      /* symbol_check_overlap_offset (DB:19-26): 20 */
+    int32_t match_threshold;     /* overlap_offset - symbol_check_match_num_errors_allowed */
+    int32_t error_threshold;     /* symbol_check_error_threshold */
+    int32_t lut_mode, lut_rows, lut_successors;
+    const void *lut;
+    int32_t num_templates;       /* 0: no sync search */
+    int32_t bits_overlap;        /* protocol.numBitsOverlap */
+    int32_t template_taps[2], template_thresholds[2];
+    const int8_t *templates;     /* taps back to back, as np.convolve takes them (the flipped +-1 masks) */
+} mfb_stream_params;
+/* A12 / A13 / A14 on the device (DB:1012-1051, DB:863-988, DEC:89-113: the block comment above); mfb_stream_seed hands over what
+ * the host keeps between blocks: poswinP / posSymEnd (DB:977-979) and the tail of bitsOverlapBuf (DEC:90). */
+int mfb_set_stream_stages(mfb_ctx *ctx, const mfb_stream_params *params);
+int mfb_stream_seed(mfb_ctx *ctx, const uint8_t *post, int npost, const uint8_t *end, int nend, const uint8_t *ring, int ring_len);
+/* A finished batch as it came off the device: nblocks records of record_bytes each copied into dst (capacity bytes), and where
+ * things are inside a record -- the scalars (struct BlockScalars of csrc/small_kernels.hpp, scalars_bytes long, at offset 0),
+ * the two SNR windows, int32 symbols / centres and float32 magnitudes (`symbols` entries each; `count` of them valid), and
+ * with the stream stages on: kept bits / centres mod 256 / trust bytes (uint8, a13_nwin valid), the block's tail (post: a13_npost
+ * bytes, end: a13_nend), the sync hits (per template: int32 idx[max_hits] | score[max_hits]; sync_count valid).  One copy per
+ * batch instead of one call per array and block: what mfb_receive_blocks_end hands out, read in place (DB:1000-1006 reads
+ * three arrays per block with three memcpy_dtoh). */
+typedef struct mfb_record_layout {
+    int32_t nblocks, scalars_bytes, symbols, band_capacity, mode, fixed_shift, stream_stages, max_hits, templates, reserved;
+    int64_t record_bytes, off_bands, off_sym, off_cen, off_mag, off_bits, off_centres_u8, off_trust, off_post, off_end, off_hits;
+} mfb_record_layout;
+int mfb_receive_blocks_end_record(mfb_ctx *ctx, int slot, void *dst, size_t capacity, mfb_record_layout *layout);
 /* Test seam of the one-call path.  mfb_receive_block moved two pieces of the reference's float64 HOST arithmetic onto the
  * device: the shift interpolation and the bounds of computeSNR's spectrum windows behind the pick (DB:609-620, 635-667), and
  * samples per symbol / code phase / clamp / symbol count behind the rate argmax (DB:733-752, 994-999).  This call runs exactly

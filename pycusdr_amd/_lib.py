@@ -49,6 +49,22 @@ class BlockResult(C.Structure):
                 ('count', C.c_int32), ('rate_fallback', C.c_int32), ('band_len', C.c_int32 * 2)]
 
 
+class StreamParams(C.Structure):
+    """mfb_stream_params of include/mfbank.h."""
+    _fields_ = [('overlap_samples', C.c_int32), ('overlap_offset', C.c_int32), ('match_threshold', C.c_int32),
+                ('error_threshold', C.c_int32), ('lut_mode', C.c_int32), ('lut_rows', C.c_int32), ('lut_successors', C.c_int32),
+                ('lut', C.c_void_p), ('num_templates', C.c_int32), ('bits_overlap', C.c_int32), ('template_taps', C.c_int32 * 2),
+                ('template_thresholds', C.c_int32 * 2), ('templates', C.c_void_p)]
+
+
+class RecordLayout(C.Structure):
+    """mfb_record_layout of include/mfbank.h."""
+    _fields_ = [(k, C.c_int32) for k in ('nblocks', 'scalars_bytes', 'symbols', 'band_capacity', 'mode', 'fixed_shift', 'stream_stages',
+                                         'max_hits', 'templates', 'reserved')] + \
+               [(k, C.c_int64) for k in ('record_bytes', 'off_bands', 'off_sym', 'off_cen', 'off_mag', 'off_bits', 'off_centres_u8',
+                                         'off_trust', 'off_post', 'off_end', 'off_hits')]
+
+
 # name -> (restype, argtypes); exactly the prototypes of include/mfbank.h
 PROTOTYPES = {
     'mfb_strerror': (C.c_char_p, [_i]),
@@ -86,6 +102,9 @@ PROTOTYPES = {
     'mfb_window_buffer': (_i, [_vp, _i, _i, _i, C.POINTER(_fp)]),
     'mfb_receive_blocks_begin': (_i, [_vp, C.POINTER(BlockParams), _i, _i]),
     'mfb_receive_blocks_end': (_i, [_vp, _i, C.POINTER(BlockResult), _vp, _vp, _vp, _i, _vp]),
+    'mfb_receive_blocks_end_record': (_i, [_vp, _i, _vp, C.c_size_t, C.POINTER(RecordLayout)]),
+    'mfb_set_stream_stages': (_i, [_vp, C.POINTER(StreamParams)]),
+    'mfb_stream_seed': (_i, [_vp, _vp, _i, _vp, _i, _vp, _i]),
     'mfb_debug_block_scalars': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, C.POINTER(BlockResult), _vp, _vp]),
     'mfb_pick_column': (_i, [_vp, _vp, _i, _i, _fp]),
     'mfb_find_carrier': (_i, [_vp, _fp]),

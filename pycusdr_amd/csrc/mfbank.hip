@@ -48,6 +48,7 @@
 #include "small_kernels.hpp"
 #include "sync_kernels.hpp"
 #include "energy_kernels.hpp"
+#include "stream_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -57,6 +58,7 @@ struct BlockFlight {      // one block -- or one batch of nb blocks -- between m
     int mode, nthreads, bcap, shift, op;
     int nb;               // 0: a single block (mfb_receive_block_begin); > 0: a batch (mfb_receive_blocks_begin)
     size_t rec;           // bytes per block record in the staging buffer (batches)
+    size_t ext;           // offset of the stream-stage outputs inside a record (0: none)
     size_t off[5];
     unsigned long long seq;
 };
@@ -147,7 +149,17 @@ struct mfb_ctx {
     float *d_envb, *d_sumb, *d_resb, *d_crb;   // envelopes [B][N], doppSum [B][Dtot][M], picks [B][2], rate triples [B][3]
     uint8_t *d_batout;            // result records [B][rec]
     size_t batout_cap;
-    BlockGraph wgraph[2][2];      // [window][slot]
+    BlockGraph wgraph[2][2][2];   // [window][slot][carry parity]
+    // the integer stages behind the symbol decisions on the device (stream_kernels.hpp; mfb_set_stream_stages): A12 bit lookup,
+    // A13 block-overlap alignment, A14 sync search on the stream without a stash -- batches only
+    bool st_on;
+    StreamArgs st;                // constant part (LUTs, thresholds, templates); records, carries filled per batch
+    uint8_t *d_lut8;
+    int *d_lut3;
+    int8_t *d_sttmpl;
+    StreamCarry *d_carry[2];      // [parity]: the previous batch's tail and bit ring / this batch's
+    int carry_cur;                // buffer that holds the state the next batch starts from
+    StreamCarry *h_seed;          // page-locked staging of mfb_stream_seed
     std::vector<hipEvent_t> ev[2];
     std::vector<hipEvent_t> ev_pool;
 };
@@ -191,7 +203,7 @@ extern "C" const char *mfb_strerror(int s) {
         default: return "unknown status";
     }
 }
-extern "C" int mfb_abi_version(void) { return 6; }
+extern "C" int mfb_abi_version(void) { return 7; }
 
 static void make_twiddles(std::vector<cf> &v, int count, double denom, double stepmul) {
     v.resize(count);
@@ -484,7 +496,8 @@ extern "C" int mfb_destroy(mfb_ctx *c) {
     void *bufs[] = {c->d_uniq, c->d_rep, c->d_x,  c->d_X,    c->d_masks, c->d_Z,   c->d_xc,  c->d_P,   c->d_env, c->d_shifts, c->d_tw1,
                     c->d_tw2, c->d_twLo, c->d_twHi,  c->d_part, c->d_sum, c->d_res, c->d_cr,  c->d_sym,    c->d_cen, c->d_mag,
                     c->d_G, c->d_twL, c->d_Gb, c->d_pow, c->d_W, c->d_blkout, c->d_x2,
-                    c->d_win[0], c->d_win[1], c->d_Xb, c->d_xcb, c->d_Pb, c->d_envb, c->d_sumb, c->d_resb, c->d_crb, c->d_batout};
+                    c->d_win[0], c->d_win[1], c->d_Xb, c->d_xcb, c->d_Pb, c->d_envb, c->d_sumb, c->d_resb, c->d_crb, c->d_batout,
+                    c->d_lut8, c->d_lut3, c->d_sttmpl, c->d_carry[0], c->d_carry[1]};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (c->h_in) (void)hipHostFree(c->h_in);
@@ -497,12 +510,14 @@ extern "C" int mfb_destroy(mfb_ctx *c) {
     for (auto &row : c->bgraph)
         for (auto &g : row) graph_drop(g);
     for (auto &row : c->wgraph)
-        for (auto &g : row) graph_drop(g);
+        for (auto &col : row)
+            for (auto &g : col) graph_drop(g);
     for (int i = 0; i < 2; ++i) {
         if (c->h_blk[i]) (void)hipHostFree(c->h_blk[i]);
         if (c->ev_blk[i]) (void)hipEventDestroy(c->ev_blk[i]);
     }
     if (c->h_back) (void)hipHostFree(c->h_back);
+    if (c->h_seed) (void)hipHostFree(c->h_seed);
     if (c->h_X) (void)hipHostFree(c->h_X);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->in_stream) {
@@ -1442,9 +1457,11 @@ struct BlkBufs {
     float *cr;           // rate triples [nb][3]
     uint8_t *out;        // result records [nb][rec]
     size_t rec;
+    size_t ext;          // offset of the stream-stage outputs inside a record (0: the stages run on the host)
+    int parity;          // carry buffer the stream stages read
 };
 static BlkBufs single_bufs(mfb_ctx *c) {
-    return BlkBufs{1, c->d_in, 0, c->d_X, c->d_sum, c->d_res, c->d_xc, c->d_env, c->d_P, c->d_cr, c->d_blkout, 0};
+    return BlkBufs{1, c->d_in, 0, c->d_X, c->d_sum, c->d_res, c->d_xc, c->d_env, c->d_P, c->d_cr, c->d_blkout, 0, 0, 0};
 }
 
 // A9 + A10 enqueued on the handle's stream: matched filters at one shift per block (a value, or -- shift_dev != nullptr -- an
@@ -1596,6 +1613,35 @@ static int block_enqueue(mfb_ctx *c, const mfb_block_params *p, const BlkBufs &b
     hipLaunchKernelGGL(k_centres_block, dim3((nthreads + 255) / 256, nb), dim3(256), 0, c->stream, d_sym, d_cen, d_mag, (const cf *)bb.xc,
                        (const BlockScalars *)scal, c->N, c->M, c->W, p->op, nthreads, rec);
     HIPCHK(hipGetLastError());
+    if (batch && bb.ext) {
+        // A12 / A13 / A14 of every block of the batch on the device (stream_kernels.hpp); the state they chain on -- the previous
+        // batch's tail and bit ring -- sits in carry[cur], this batch leaves its own in carry[1 - cur]
+        StreamArgs sa = c->st;
+        sa.rec0 = d;
+        sa.rec = rec;
+        sa.off_sym = (size_t)((uint8_t *)d_sym - d);
+        sa.off_cen = (size_t)((uint8_t *)d_cen - d);
+        sa.off_mag = (size_t)((uint8_t *)d_mag - d);
+        const size_t a1 = align16((size_t)nthreads);
+        sa.off_bits = bb.ext;
+        sa.off_cenw = bb.ext + a1;
+        sa.off_trust = bb.ext + 2 * a1;
+        sa.off_post = bb.ext + 3 * a1;
+        sa.off_end = sa.off_post + STREAM_POST_MAX;
+        sa.off_hits = sa.off_end + STREAM_END_MAX;
+        sa.nb = nb;
+        sa.carry_in = c->d_carry[bb.parity];
+        sa.carry_out = c->d_carry[1 - bb.parity];
+        hipLaunchKernelGGL(k_stream_align, dim3(nb), dim3(256), 0, c->stream, sa);
+        HIPCHK(hipGetLastError());
+        if (sa.K > 0) {
+            int Tmax = 0;
+            for (int t = 0; t < sa.K; ++t) Tmax = sa.T[t] > Tmax ? sa.T[t] : Tmax;
+            hipLaunchKernelGGL(k_stream_sync, dim3(sa.K, nb), dim3(256), (size_t)Tmax + SYNC_SEG + Tmax - 1, c->stream, sa);
+            hipLaunchKernelGGL(k_stream_ring, dim3(1), dim3(256), 0, c->stream, sa);
+            HIPCHK(hipGetLastError());
+        }
+    }
     HIPCHK(hipMemcpyAsync(h_dst, d, rec * nb, hipMemcpyDeviceToHost, c->stream));
     *shift_out = shift;
     return MFB_OK;
@@ -1708,7 +1754,8 @@ static int check_block_params(const mfb_ctx *c, const mfb_block_params *p) {
 static int staging_reserve(mfb_ctx *c, int slot, size_t need) {
     if (need <= c->blk_cap[slot]) return MFB_OK;
     for (auto &row : c->bgraph) graph_drop(row[slot]);
-    for (auto &row : c->wgraph) graph_drop(row[slot]);
+    for (auto &row : c->wgraph)
+        for (auto &g : row[slot]) graph_drop(g);
     if (c->h_blk[slot]) HIPCHK(hipHostFree(c->h_blk[slot]));
     c->h_blk[slot] = nullptr;
     c->blk_cap[slot] = 0;
@@ -1947,21 +1994,29 @@ extern "C" int mfb_receive_blocks_begin(mfb_ctx *c, const mfb_block_params *p, i
     const int capacity = p->max_symbols < c->cap ? p->max_symbols : c->cap;
     int nthreads = p->k_offset + p->k_len + 1;
     if (nthreads > capacity) nthreads = capacity;
-    const size_t rec = blkout_bytes(bcap, nthreads);
+    const size_t core = blkout_bytes(bcap, nthreads);
+    const bool stages = c->st_on && p->mode == MFB_BLOCK_SEARCH && nblocks <= 64;
+    // stream-stage outputs behind the core record: kept bits | kept centres | trust bytes (uint8[nthreads] each), the block's
+    // tail (post, end), the sync hits (idx | score per template)
+    const size_t ext_bytes = 3 * align16((size_t)nthreads) + STREAM_POST_MAX + STREAM_END_MAX +
+                             (size_t)STREAM_MAX_TMPL * 2 * STREAM_MAX_HITS * sizeof(int32_t);
+    const size_t rec = core + (stages ? ext_bytes : 0);
     if ((rc = batch_reserve(c, nblocks > c->win_blocks ? nblocks : (c->win_blocks > 0 ? c->win_blocks : nblocks), rec))) return rc;
     if ((rc = staging_reserve(c, slot, rec * nblocks))) return rc;
     if (!c->ev_blk[slot]) HIPCHK(hipEventCreateWithFlags(&c->ev_blk[slot], hipEventDisableTiming));
     if (win_in && (rc = input_copy(c, c->h_win[which], c->d_win[which], (size_t)(nblocks * stride + (c->N - stride)), c->ev_wh2d, c->ev_wfree, which)))
         return rc;
+    const int parity = c->carry_cur;
     BlkBufs bb{nblocks, win_in ? (const cf *)c->d_win[which] : (const cf *)p->device_block, stride, c->d_Xb, c->d_sumb, c->d_resb, c->d_xcb,
-               c->d_envb, c->d_Pb, c->d_crb, c->d_batout, rec};
+               c->d_envb, c->d_Pb, c->d_crb, c->d_batout, rec, stages ? core : 0, parity};
     int shift = p->mode == MFB_BLOCK_FIXED_SHIFT ? ((p->fixed_shift % c->N) + c->N) % c->N : 0;
     const bool allowed = win_in && graphs_allowed() && !c->prof;
     mfb_block_params q = *p;
     q.block_stride = stride;
-    rc = graph_or_launch(c, c->wgraph[which][slot], &q, nblocks, allowed,
+    rc = graph_or_launch(c, c->wgraph[which][slot][parity], &q, nblocks, allowed,
                          [&]() { return block_enqueue(c, &q, bb, c->h_blk[slot], nthreads, bcap, capacity, &shift); });
     if (rc) return rc;
+    if (stages) c->carry_cur = 1 - parity;        // this batch's tail and ring are the next batch's start
     HIPCHK(hipEventRecord(c->ev_blk[slot], c->stream));
     if (win_in) HIPCHK(hipEventRecord(c->ev_wfree[which], c->stream));
     const size_t sym_off = BLK_HEAD + align16((size_t)2 * bcap * sizeof(cf)), arr = align16((size_t)nthreads * sizeof(int));
@@ -1979,6 +2034,7 @@ extern "C" int mfb_receive_blocks_begin(mfb_ctx *c, const mfb_block_params *p, i
     f.op = p->op;
     f.nb = nblocks;
     f.rec = rec;
+    f.ext = stages ? core : 0;
     // the handle's one-block buffers (spectrum, matched-filter outputs) hold nothing of this batch
     c->have_xc = false;
     return MFB_OK;
@@ -2018,6 +2074,129 @@ extern "C" int mfb_receive_blocks_end(mfb_ctx *c, int slot, mfb_block_result *re
         fill_result(&results[b], hs, f.mode, f.shift);
     }
     return rc;
+}
+
+// The whole batch as it came off the device: nb records of `rec` bytes copied into the caller's buffer, and where things are
+// inside a record.  The caller (the Python host) reads scalars and arrays in place -- one copy per batch instead of a dozen
+// small ones per block.
+extern "C" int mfb_receive_blocks_end_record(mfb_ctx *c, int slot, void *dst, size_t capacity, mfb_record_layout *lay) {
+    if (!c || slot < 0 || slot > 1 || !dst || !lay) return MFB_ERR_ARG;
+    BlockFlight &f = c->flight[slot];
+    if (!f.active || !f.nb) return MFB_ERR_STATE;
+    if (capacity < f.rec * (size_t)f.nb) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventSynchronize(c->ev_blk[slot]));
+    f.active = false;
+    memcpy(dst, c->h_blk[slot], f.rec * (size_t)f.nb);
+    memset(lay, 0, sizeof(*lay));
+    lay->nblocks = f.nb;
+    lay->record_bytes = (int64_t)f.rec;
+    lay->scalars_bytes = (int32_t)sizeof(BlockScalars);
+    lay->symbols = f.nthreads;
+    lay->band_capacity = f.bcap;
+    lay->mode = f.mode;
+    lay->fixed_shift = f.shift;
+    lay->off_bands = (int64_t)f.off[4];
+    lay->off_sym = (int64_t)f.off[1];
+    lay->off_cen = (int64_t)f.off[2];
+    lay->off_mag = (int64_t)f.off[3];
+    if (f.ext) {
+        const size_t a1 = align16((size_t)f.nthreads);
+        lay->stream_stages = 1;
+        lay->off_bits = (int64_t)f.ext;
+        lay->off_centres_u8 = (int64_t)(f.ext + a1);
+        lay->off_trust = (int64_t)(f.ext + 2 * a1);
+        lay->off_post = (int64_t)(f.ext + 3 * a1);
+        lay->off_end = lay->off_post + STREAM_POST_MAX;
+        lay->off_hits = lay->off_end + STREAM_END_MAX;
+        lay->max_hits = STREAM_MAX_HITS;
+        lay->templates = c->st.K;
+    }
+    return MFB_OK;
+}
+
+// The integer stages behind the symbol decisions on the device, for batches (stream_kernels.hpp).
+extern "C" int mfb_set_stream_stages(mfb_ctx *c, const mfb_stream_params *p) {
+    if (!c) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    ++c->epoch;
+    c->st_on = false;
+    if (!p) return MFB_OK;                 // switched off
+    if ((p->lut_mode != 1 && p->lut_mode != 2) || p->lut_rows < 1 || p->lut_rows > 4096 || !p->lut || p->overlap_samples < 2 ||
+        p->overlap_samples >= c->N || p->overlap_offset < 1 || p->overlap_offset + 1 > STREAM_END_MAX || p->num_templates < 0 ||
+        p->num_templates > STREAM_MAX_TMPL || (p->lut_mode == 2 && (p->lut_successors < 1 || p->lut_successors > 64)))
+        return MFB_ERR_ARG;
+    if (p->num_templates > 0 && (!p->templates || p->bits_overlap < 1 || p->bits_overlap > STREAM_NOV_MAX)) return MFB_ERR_ARG;
+    StreamArgs &a = c->st;
+    memset(&a, 0, sizeof(a));
+    a.N = c->N;
+    a.ovw = p->overlap_samples / 2;
+    a.o = p->overlap_offset;
+    a.thr = p->match_threshold;
+    a.err_thr = p->error_threshold;
+    a.mode = p->lut_mode;
+    a.rows = p->lut_rows;
+    a.succ = p->lut_mode == 2 ? p->lut_successors : 0;
+    void **olds[] = {(void **)&c->d_lut8, (void **)&c->d_lut3, (void **)&c->d_sttmpl};
+    for (void **q : olds) {
+        if (*q) HIPCHK(hipFree(*q));
+        *q = nullptr;
+    }
+    if (a.mode == 1) {
+        HIPCHK(dev_alloc((void **)&c->d_lut8, (size_t)a.rows));
+        HIPCHK(hipMemcpy(c->d_lut8, p->lut, (size_t)a.rows, hipMemcpyHostToDevice));
+    } else {
+        const size_t n = (size_t)a.rows * 2 * a.succ * sizeof(int);
+        HIPCHK(dev_alloc((void **)&c->d_lut3, n));
+        HIPCHK(hipMemcpy(c->d_lut3, p->lut, n, hipMemcpyHostToDevice));
+    }
+    a.lut8 = c->d_lut8;
+    a.lut3 = c->d_lut3;
+    a.K = p->num_templates;
+    a.nOv = p->bits_overlap;
+    a.max_hits = STREAM_MAX_HITS;
+    size_t taps = 0;
+    for (int t = 0; t < a.K; ++t) {
+        if (p->template_taps[t] < 1 || p->template_taps[t] > 4096) return MFB_ERR_ARG;
+        a.T[t] = p->template_taps[t];
+        a.thrs[t] = p->template_thresholds[t];
+        a.toff[t] = (int)taps;
+        taps += (size_t)a.T[t];
+    }
+    if (taps) {
+        HIPCHK(dev_alloc((void **)&c->d_sttmpl, taps));
+        HIPCHK(hipMemcpy(c->d_sttmpl, p->templates, taps, hipMemcpyHostToDevice));
+    }
+    a.tmpls = c->d_sttmpl;
+    for (int i = 0; i < 2; ++i) {
+        if (!c->d_carry[i]) HIPCHK(dev_alloc((void **)&c->d_carry[i], sizeof(StreamCarry)));
+        HIPCHK(hipMemset(c->d_carry[i], 0, sizeof(StreamCarry)));       // valid = 0: nothing known until mfb_stream_seed
+    }
+    if (!c->h_seed) HIPCHK(hipHostMalloc((void **)&c->h_seed, sizeof(StreamCarry), hipHostMallocDefault));
+    c->carry_cur = 0;
+    c->st_on = true;
+    return MFB_OK;
+}
+
+extern "C" int mfb_stream_seed(mfb_ctx *c, const uint8_t *post, int npost, const uint8_t *end, int nend, const uint8_t *ring, int ring_len) {
+    if (!c || npost < 0 || nend < 0 || ring_len < 0 || (npost && !post) || (nend && !end) || (ring_len && !ring)) return MFB_ERR_ARG;
+    if (!c->st_on) return MFB_ERR_STATE;
+    if (npost > STREAM_POST_MAX || nend > STREAM_END_MAX || ring_len > STREAM_NOV_MAX) return MFB_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));          // h_seed may still be on its way from the last seed
+    StreamCarry *h = c->h_seed;
+    memset(h, 0, sizeof(*h));
+    h->valid = 1;
+    h->npost = npost;
+    h->nend = nend;
+    if (npost) memcpy(h->post, post, (size_t)npost);
+    if (nend) memcpy(h->end, end, (size_t)nend);
+    h->ring_valid = ring_len > 0 && ring_len == c->st.nOv;
+    h->ring_len = ring_len;
+    if (ring_len) memcpy(h->ring, ring, (size_t)ring_len);
+    HIPCHK(hipMemcpyAsync(c->d_carry[c->carry_cur], h, sizeof(*h), hipMemcpyHostToDevice, c->stream));
+    return MFB_OK;
 }
 
 // Test seam of the one-call path (include/mfbank.h): block_pick_body / block_rate_body on injected device results.

@@ -373,7 +373,16 @@ struct BlockScalars {
     int rate_fallback;     // k* == 0 -> spSym = 10 (DB:737-740)
     int band[2][2][2];     // SNR windows (DB:635-667): [signal | noise][piece][start, length] in the spectrum
     int band_len[2];
+    // batches with the stream stages on the device (stream_kernels.hpp): A12 / A13 ...
+    int a13_status;        // 1: the record holds the block's kept bits / centres / trust bytes and its tail; 0: the host does it
+    int a13_start, a13_end, a13_nwin;      // the kept window [start, end) after the +-1 repair; its length
+    int a13_noerr;         // impossible NRZ-S transitions
+    int a13_npost, a13_nend;               // bits behind the window / the last offset + 1 bits inside it, as delivered
+    // ... and A14 on the stream without a stash
+    int sync_valid;        // 1: sync_count / the hit lists are those of the last numBitsOverlap bits before the block + its bits
+    int sync_count[2];
 };
+static_assert(sizeof(BlockScalars) == 160 && sizeof(BlockScalars) <= 256, "BlockScalars: the record head (the Python side mirrors this layout)");
 
 // Python's slice(a, b).indices(N) for step 1; has_a / has_b = 0 stand for None
 DEVI void slice_indices(int has_a, int a, int has_b, int b, int N, int *start, int *len) {

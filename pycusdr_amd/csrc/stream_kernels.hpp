@@ -1,0 +1,385 @@
+// stream_kernels.hpp -- the integer stages behind the symbol decisions, for batches of blocks (mfb_receive_blocks_*):
+//   A12  symbol -> bit            bit LUT (extractBits, demodulator_base.py:1012-1023) or NRZ-S transition decode with the 3-D
+//                                 LUT symbolLUT[sym][0|1][successors] (extractBitsNRZs, DB:1026-1051)
+//   A13  block-overlap alignment  checkSymbolOverlap (DB:863-988): keep the symbols whose centre lies in [ov/2, N - ov/2], repair
+//                                 a +-1 symbol slip against the previous block (20-symbol windows, match threshold), uint8 casts
+//                                 of the caller's three arrays (DB:859) incl. the trust bytes of quirk Q3 (DB:472,1005-1006)
+//   A14  sync / preamble search   np.convolve(stream, template) >= threshold of the decoder (decoder.py:96-113) on the stream the
+//                                 decoder stitches when no candidate is stashed: the last numBitsOverlap bits before the block +
+//                                 the block's bits (DEC:89-90)
+// All integer / byte work: results equal the host code's bit for bit, or the block is flagged and the host does it (every
+// irregular case -- a symbol index outside the LUT, a window or a previous tail too short for the comparisons numpy would make,
+// a first / last centre that does not exist -- is left to the host path, which reproduces whatever the reference does there).
+// The previous block's tail (the bits behind its window, the last offset + 1 bits inside it) is a function of that block's
+// DEVICE results alone (the +-1 repair moves a window's start, never its last bits), so every block of a batch is aligned in
+// parallel; the first block's predecessor comes from a device-resident carry the previous batch left (double-buffered).
+#pragma once
+#include <stdint.h>
+
+#include "small_kernels.hpp"
+
+#define STREAM_POST_MAX 512      // bits behind a block's window kept in its record (ov/2 / samples per symbol + a few)
+#define STREAM_END_MAX 32        // overlapOffset + 1 <= 32
+#define STREAM_MAX_HITS 64       // sync hits per (block, template) kept in the record
+#define STREAM_MAX_TMPL 2
+#define STREAM_NOV_MAX 4096      // numBitsOverlap <= 4096 (CC11xx: 2048)
+
+#define A13_DEVICE 1             // a13_status: the record holds the block's final arrays
+#define A13_HOST 0               //             the host runs A12 / A13 for this block (irregular case)
+
+struct StreamCarry {             // what the next batch's first block needs of this batch's last one
+    int valid;                   // 0: unknown (the last block was irregular, or nothing was seeded): the first block goes to the host
+    int npost, nend;
+    int ring_valid, ring_len;    // A14: the last numBitsOverlap bits of the stream so far
+    int pad[3];
+    uint8_t post[STREAM_POST_MAX];
+    uint8_t end[STREAM_END_MAX];
+    uint8_t ring[STREAM_NOV_MAX];
+};
+
+struct StreamArgs {
+    uint8_t *rec0;               // result records [nb][rec]
+    size_t rec;
+    size_t off_sym, off_cen, off_mag;        // int32[count] | int32[count] | float32[count] inside a record
+    size_t off_bits, off_cenw, off_trust;    // uint8[nwin] each (A13 outputs)
+    size_t off_post, off_end, off_hits;
+    int nb, N, ovw;              // blocks, block length, overlap / 2
+    int o, thr, err_thr;         // overlapOffset, match threshold, symbol_check_error_threshold
+    int mode;                    // 1: bit LUT (uint8[rows]); 2: NRZ-S LUT (int32[rows][2][succ])
+    int rows, succ;
+    const uint8_t *lut8;
+    const int *lut3;
+    const StreamCarry *carry_in;
+    StreamCarry *carry_out;
+    // A14
+    int K, nOv, max_hits;
+    int T[STREAM_MAX_TMPL], thrs[STREAM_MAX_TMPL], toff[STREAM_MAX_TMPL];
+    const int8_t *tmpls;
+};
+
+// A12 on the fly: dataBits[x] of a block from its symbol indices; *bad = the transition is impossible (NRZ-S) or the index is
+// outside the LUT (any mode: the host path then raises or wraps as numpy does)
+DEVI int stream_bit(const StreamArgs &a, const int *sym, int x, bool *irregular, bool *mismatch) {
+    const int s = sym[x];
+    if (s < 0 || s >= a.rows) {
+        *irregular = true;
+        return 0;
+    }
+    if (a.mode == 1) return a.lut8[s];
+    const int n = sym[x + 1];
+    if (n < 0 || n >= a.rows) {          // the successor indexes the LUT itself one symbol later
+        *irregular = true;
+        return 0;
+    }
+    bool one = false, zero = false;
+    for (int q = 0; q < a.succ; ++q) {
+        one = one || (n == a.lut3[(s * 2 + 0) * a.succ + q]);
+        zero = zero || (n == a.lut3[(s * 2 + 1) * a.succ + q]);
+    }
+    if (!one && !zero) {
+        *mismatch = true;
+        return 0;                         // SYMBOL_MISMATCHVAL
+    }
+    return one ? 1 : 0;
+}
+
+// first x < n with pred(x), n when there is none; all 256 threads of the workgroup
+template <class P>
+DEVI int first_true(int n, P pred, int *slot) {
+    if (threadIdx.x == 0) *slot = n;
+    __syncthreads();
+    int mine = n;
+    for (int x = threadIdx.x; x < n; x += blockDim.x)
+        if (pred(x)) {
+            mine = x;
+            break;
+        }
+    if (mine < n) atomicMin(slot, mine);
+    __syncthreads();
+    const int r = *slot;
+    __syncthreads();
+    return r;
+}
+
+struct BlockWindow {
+    int count, nbits;            // symbols decided; dataBits available (count, or count - 1 for NRZ-S)
+    int start, end;              // first centre >= ov/2, first centre > N - ov/2 (count: none)
+    bool ok;                     // both exist, every index inside the LUT, window >= o + 2 symbols, end <= nbits
+};
+
+// Workgroup of 256 threads = one block of the batch.
+__global__ void __launch_bounds__(256) k_stream_align(StreamArgs a) {
+    __shared__ int s_slot, s_flag, s_err;
+    __shared__ int s_start;
+    const int b = blockIdx.x;
+    uint8_t *rec = a.rec0 + (size_t)b * a.rec;
+    BlockScalars *sc = reinterpret_cast<BlockScalars *>(rec);
+    const int o = a.o;
+
+    auto window = [&](const uint8_t *r, BlockWindow &w, int *noerr) {
+        const BlockScalars *s = reinterpret_cast<const BlockScalars *>(r);
+        const int *sym = reinterpret_cast<const int *>(r + a.off_sym), *cen = reinterpret_cast<const int *>(r + a.off_cen);
+        w.count = s->count;
+        w.nbits = a.mode == 1 ? w.count : w.count - 1;
+        w.start = first_true(w.count, [&](int x) { return cen[x] >= a.ovw; }, &s_slot);
+        w.end = first_true(w.count, [&](int x) { return cen[x] > a.N - a.ovw; }, &s_slot);
+        if (threadIdx.x == 0) {
+            s_flag = 0;
+            s_err = 0;
+        }
+        __syncthreads();
+        bool irr = false;
+        int bad = 0;
+        for (int x = threadIdx.x; x < w.nbits; x += blockDim.x) {
+            bool m = false;
+            (void)stream_bit(a, sym, x, &irr, &m);
+            bad += m ? 1 : 0;
+        }
+        if (irr) atomicOr(&s_flag, 1);
+        if (bad) atomicAdd(&s_err, bad);
+        __syncthreads();
+        if (noerr) *noerr = s_err;
+        w.ok = s_flag == 0 && w.start < w.count && w.end < w.count && w.end - w.start >= o + 2 && w.end <= w.nbits && w.nbits > 0;
+        __syncthreads();
+    };
+
+    BlockWindow me;
+    int noerr = 0;
+    window(rec, me, &noerr);
+    const int *sym = reinterpret_cast<const int *>(rec + a.off_sym), *cen = reinterpret_cast<const int *>(rec + a.off_cen);
+    const uint8_t *magb = rec + a.off_mag;         // trust = the raw bytes of the leading fp32 magnitudes (quirk Q3)
+
+    // ---- the previous block's tail: first o + 1 bits behind its window, last o + 1 bits inside it ----
+    __shared__ uint8_t p_post[STREAM_END_MAX + 1], p_end[STREAM_END_MAX];
+    __shared__ int p_npost, p_nend, p_known;
+    if (b > 0) {
+        const uint8_t *pr = a.rec0 + (size_t)(b - 1) * a.rec;
+        BlockWindow pw;
+        window(pr, pw, nullptr);
+        const int *psym = reinterpret_cast<const int *>(pr + a.off_sym);
+        if (threadIdx.x == 0) {
+            p_known = pw.ok ? 1 : 0;
+            p_npost = pw.ok ? pw.nbits - pw.end : 0;
+            p_nend = pw.ok ? o + 1 : 0;
+        }
+        if (pw.ok) {
+            bool i1 = false, m1 = false;
+            for (int q = threadIdx.x; q < o + 1 && q < pw.nbits - pw.end; q += blockDim.x) p_post[q] = (uint8_t)stream_bit(a, psym, pw.end + q, &i1, &m1);
+            for (int q = threadIdx.x; q < o + 1; q += blockDim.x) p_end[q] = (uint8_t)stream_bit(a, psym, pw.end - (o + 1) + q, &i1, &m1);
+        }
+    } else {
+        const StreamCarry *c = a.carry_in;
+        if (threadIdx.x == 0) {
+            p_known = c->valid;
+            p_npost = c->npost;
+            p_nend = c->nend;
+        }
+        for (int q = threadIdx.x; q < o + 1 && q < c->npost; q += blockDim.x) p_post[q] = c->post[q];
+        for (int q = threadIdx.x; q < c->nend && q < STREAM_END_MAX; q += blockDim.x) p_end[q] = c->end[q];
+    }
+    __syncthreads();
+
+    // ---- alignment (one thread; a few dozen byte compares) ----
+    if (threadIdx.x == 0) {
+        int status = A13_DEVICE, start = me.start;
+        // regular case only: everything numpy would slice exists at full length
+        const bool have_prev = p_npost > 0;
+        if (!me.ok || !p_known) status = A13_HOST;
+        else if (noerr > a.err_thr) {
+            // "pass": no alignment (DB:925)
+        } else if (have_prev) {
+            if (p_npost < o + 1 || p_nend != o + 1 || me.start < o + 1 || me.count - me.end > STREAM_POST_MAX) status = A13_HOST;
+            else {
+                bool irr = false, mm = false;
+                auto bit = [&](int x) { return stream_bit(a, sym, x, &irr, &mm); };
+                // win[i] = bit(start + i), pre[-k] = bit(start - k); prev_end[-k] = p_end[o + 1 - k]
+                bool all_pre = true, all_pos = true;
+                int m_pre[3] = {0, 0, 0}, m_pos[3] = {0, 0, 0};
+                for (int i = 0; i < o; ++i) {
+                    const int w0 = bit(me.start + i), w1 = bit(me.start + i + 1);
+                    all_pre = all_pre && (p_post[i] == w0);
+                    m_pre[0] += p_post[i] == w0;
+                    m_pre[1] += p_post[i] == w1;
+                    m_pre[2] += p_post[i + 1] == w0;
+                    // pre[-o:][i] = bit(start - o + i); pre[-o-1:-1][i] = bit(start - o - 1 + i)
+                    const int q0 = bit(me.start - o + i), q1 = bit(me.start - o - 1 + i);
+                    const int e0 = p_end[1 + i], e1 = p_end[i];        // prev_end[-o:][i], prev_end[-o-1:-1][i]
+                    all_pos = all_pos && (e0 == q0);
+                    m_pos[0] += e0 == q0;
+                    m_pos[1] += e1 == q0;
+                    m_pos[2] += e0 == q1;
+                }
+                if (!(all_pre || all_pos)) {
+                    const int mx_pre = max(m_pre[0], max(m_pre[1], m_pre[2])), mx_pos = max(m_pos[0], max(m_pos[1], m_pos[2]));
+                    if (a.thr < m_pre[1] && m_pre[1] == mx_pre) {
+                        if (a.thr < m_pos[1] && m_pos[1] == mx_pos) start += 1;
+                    } else if (a.thr < m_pre[2] && m_pre[2] == mx_pre) {
+                        if (a.thr < m_pos[2] && m_pos[2] == mx_pos) start -= 1;
+                    }
+                }
+            }
+        }
+        if (status == A13_DEVICE && me.nbits - me.end > STREAM_POST_MAX) status = A13_HOST;
+        s_start = start;
+        sc->a13_status = status;
+        sc->a13_start = start;
+        sc->a13_end = me.end;
+        sc->a13_nwin = status == A13_DEVICE ? me.end - start : 0;
+        sc->a13_noerr = noerr;
+        sc->a13_npost = status == A13_DEVICE ? me.nbits - me.end : 0;
+        sc->a13_nend = status == A13_DEVICE ? o + 1 : 0;
+    }
+    __syncthreads();
+    const bool dev = sc->a13_status == A13_DEVICE;
+    const int start = s_start;
+    // ---- the caller's three arrays, the block's own tail ----
+    if (dev) {
+        uint8_t *ob = rec + a.off_bits, *oc = rec + a.off_cenw, *ot = rec + a.off_trust, *op = rec + a.off_post, *oe = rec + a.off_end;
+        bool i1 = false, m1 = false;
+        for (int x = start + threadIdx.x; x < me.end; x += blockDim.x) {
+            ob[x - start] = (uint8_t)stream_bit(a, sym, x, &i1, &m1);
+            oc[x - start] = (uint8_t)(cen[x] & 0xff);
+            ot[x - start] = magb[x];
+        }
+        for (int x = me.end + threadIdx.x; x < me.nbits; x += blockDim.x) op[x - me.end] = (uint8_t)stream_bit(a, sym, x, &i1, &m1);
+        for (int q = threadIdx.x; q < o + 1; q += blockDim.x) oe[q] = (uint8_t)stream_bit(a, sym, me.end - (o + 1) + q, &i1, &m1);
+    }
+    // ---- the carry for the next batch's first block ----
+    if (b == a.nb - 1) {
+        StreamCarry *c = a.carry_out;
+        if (threadIdx.x == 0) {
+            c->valid = dev ? 1 : 0;
+            c->npost = dev ? me.nbits - me.end : 0;
+            c->nend = dev ? o + 1 : 0;
+        }
+        if (dev) {
+            bool i1 = false, m1 = false;
+            for (int x = me.end + threadIdx.x; x < me.nbits; x += blockDim.x) c->post[x - me.end] = (uint8_t)stream_bit(a, sym, x, &i1, &m1);
+            for (int q = threadIdx.x; q < o + 1; q += blockDim.x) c->end[q] = (uint8_t)stream_bit(a, sym, me.end - (o + 1) + q, &i1, &m1);
+        }
+    }
+}
+
+// ---- A14 on the windows without a stash -----------------------------------------------------------------------------------
+// V = ring (the numBitsOverlap bits before the batch) ++ bitsWin_0 ++ bitsWin_1 ++ ...; block b's stream is
+// V[cum_b : cum_b + nOv + nwin_b] (cum_b = kept bits of the blocks before it).  Workgroup (template, block) walks over its stream
+// in segments with a running offset, so hits come out ordered without atomics (as k_sync_small does for the decoder's own call).
+// Valid only while every block up to b was aligned on the device and the ring is known; sync_valid says so per block.
+DEVI int stream_v(const StreamArgs &a, int p, const int *cum) {           // V[p]
+    if (p < a.nOv) return a.carry_in->ring[p];
+    p -= a.nOv;
+    int i = 0;
+    while (i + 1 < a.nb && p >= cum[i + 1]) ++i;
+    return (a.rec0 + (size_t)i * a.rec + a.off_bits)[p - cum[i]];
+}
+
+__global__ void __launch_bounds__(256) k_stream_sync(StreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) int8_t sm[];
+    __shared__ int wsum[4];
+    __shared__ int cum[65];
+    __shared__ int s_valid;
+    const int t = blockIdx.x, b = blockIdx.y;
+    uint8_t *rec = a.rec0 + (size_t)b * a.rec;
+    BlockScalars *sc = reinterpret_cast<BlockScalars *>(rec);
+    if (threadIdx.x == 0) {
+        int run = 0, ok = a.carry_in->ring_valid && a.carry_in->ring_len == a.nOv && a.nb <= 64;
+        for (int i = 0; i < a.nb && i < 64; ++i) {
+            cum[i] = run;
+            const BlockScalars *s = reinterpret_cast<const BlockScalars *>(a.rec0 + (size_t)i * a.rec);
+            if (i <= b) ok = ok && s->a13_status == A13_DEVICE;
+            run += s->a13_nwin;
+        }
+        cum[a.nb < 64 ? a.nb : 64] = run;
+        s_valid = ok;
+    }
+    __syncthreads();
+    const int T = a.T[t], thr = a.thrs[t];
+    int32_t *oi = reinterpret_cast<int32_t *>(rec + a.off_hits) + (size_t)t * 2 * a.max_hits, *os = oi + a.max_hits;
+    if (!s_valid) {
+        if (threadIdx.x == 0) {
+            sc->sync_valid = 0;
+            sc->sync_count[t] = 0;
+        }
+        return;
+    }
+    int8_t *st = sm, *sb = sm + T;
+    for (int q = threadIdx.x; q < T; q += 256) st[q] = a.tmpls[a.toff[t] + q];
+    const int L = a.nOv + sc->a13_nwin, base = cum[b];
+    const int outLen = L + T - 1;
+    const int nseg = (outLen + SYNC_SEG - 1) / SYNC_SEG;
+    int run = 0;
+    for (int seg = 0; seg < nseg; ++seg) {
+        const int i0 = seg * SYNC_SEG;
+        __syncthreads();
+        for (int q = threadIdx.x; q < SYNC_SEG + T - 1; q += 256) {
+            const int src = i0 - (T - 1) + q;
+            sb[q] = (src >= 0 && src < L) ? (int8_t)stream_v(a, base + src, cum) : (int8_t)0;
+        }
+        __syncthreads();
+        int scv[4];
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int li = threadIdx.x * 4 + u;
+            int acc = 0;
+            const int8_t *p = sb + li + T - 1;
+            for (int q = 0; q < T; ++q) acc += (int)st[q] * (int)p[-q];
+            scv[u] = acc;
+            cnt += (i0 + li < outLen && acc >= thr) ? 1 : 0;
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if ((int)(threadIdx.x & 63) >= o) incl += v;
+        }
+        const int wid = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 63) wsum[wid] = incl;
+        __syncthreads();
+        int wbase = 0, total = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wid) wbase += wsum[w];
+            total += wsum[w];
+        }
+        int pos = run + wbase + incl - cnt;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int li = threadIdx.x * 4 + u;
+            if (i0 + li < outLen && scv[u] >= thr) {
+                if (pos < a.max_hits) {
+                    oi[pos] = i0 + li;
+                    os[pos] = scv[u];
+                }
+                ++pos;
+            }
+        }
+        run += total;
+    }
+    if (threadIdx.x == 0) {
+        sc->sync_valid = 1;
+        sc->sync_count[t] = run;
+    }
+}
+
+// the ring for the next batch: the last numBitsOverlap bits of V (one workgroup)
+__global__ void __launch_bounds__(256) k_stream_ring(StreamArgs a) {
+    __shared__ int cum[65];
+    __shared__ int s_ok, s_total;
+    if (threadIdx.x == 0) {
+        int run = 0, ok = a.carry_in->ring_valid && a.carry_in->ring_len == a.nOv && a.nb <= 64;
+        for (int i = 0; i < a.nb && i < 64; ++i) {
+            cum[i] = run;
+            const BlockScalars *s = reinterpret_cast<const BlockScalars *>(a.rec0 + (size_t)i * a.rec);
+            ok = ok && s->a13_status == A13_DEVICE;
+            run += s->a13_nwin;
+        }
+        cum[a.nb < 64 ? a.nb : 64] = run;
+        s_ok = ok;
+        s_total = run;
+        a.carry_out->ring_valid = ok;
+        a.carry_out->ring_len = a.nOv;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    for (int q = threadIdx.x; q < a.nOv; q += blockDim.x) a.carry_out->ring[q] = (uint8_t)stream_v(a, s_total + q, cum);
+}

@@ -66,6 +66,7 @@ class Decoder:
         self.syncSig = protocol.get_syncFlag()
         self.numBitsOverlap = protocol.numBitsOverlap
         self.bitsOverlapBuf = np.zeros(self.numBitsOverlap)
+        self._prev = None              # (start of the last call's stream in the bit sequence, its hits): findFrames_batch
         # cross-block packet state (FLAGS mode)
         self.headerFrameStartIdx = None
         self.packetBuffer = None
@@ -127,6 +128,7 @@ class Decoder:
         self._flight = None
         if hits is None:
             hits = self._multi.end()
+        self._prev = None              # (a batch that follows searches its first block itself)
         return self._frames(rawBits_DS, bits_less_raw, frameStartIdx, hits)
 
     def _frames(self, rawBits_DS, bits_less_raw, frameStartIdx, hits):
@@ -168,33 +170,49 @@ class Decoder:
             out.append(tuple(per))
         return out
 
-    def findFrames_batch(self, blocks_bits, frameStartIdx=0):
+    def findFrames_batch(self, blocks_bits, frameStartIdx=0, ahead=None):
         """``findFrames`` for several consecutive blocks: the same packets, returned bits and sync counts, call by call (a list
-        of ``findFrames`` results), from ONE device round trip for the searches of all blocks instead of one per block.
+        of ``findFrames`` results), from ONE device round trip for the searches of all blocks instead of one per block -- or
+        none: ``ahead[i]`` = the hits of block i's stream without a stash (the last ``numBitsOverlap`` bits before the block +
+        its bits), as the batched block path delivers them with the block (None where it could not).
 
         Every call's stream is a window [a, e) of the bit sequence so far: e the end of the block's bits, a either
         ``numBitsOverlap`` bits before the block (DEC:89-90) or -- FIXED mode with a packet still incomplete -- where the
         previous call stashed its candidate (DEC:254-263), which only the previous call's state machine can tell.  So the
-        searches run ahead on the windows without a stash (the first block's on its real stream), and a block whose window
-        turns out longer gets its hits put together, exactly: a full convolution's score at a position depends on the window
-        only through which taps hang over its two ends, so positions at least T - 1 behind the default start are those of the
-        default window, positions in front of that were positions of the previous call's stream (same bits, no overhang),
-        and the first T - 1 positions are the previous call's when the start did not move -- else they are searched."""
+        searches run ahead on the windows without a stash, and a block whose window turns out longer gets its hits put
+        together, exactly: a full convolution's score at a position depends on the window only through which taps hang over
+        its two ends, so positions at least T - 1 behind the default start are those of the default window, positions in front
+        of that were positions of the previous call's stream (same bits, no overhang), and the first T - 1 positions are the
+        previous call's when the start did not move -- else they are searched."""
         pre = [self.preprocessor(b) for b in blocks_bits]
         nb, nOv = len(pre), self.numBitsOverlap
         Ts = (len(self.mask), len(self.syncSig))
-        if nb < 2 or nOv < max(Ts) or len(self.bitsOverlapBuf) < nOv:
+        if nOv < max(Ts) or len(self.bitsOverlapBuf) < nOv or (nb < 2 and ahead is None):
             return [self.findFrames(b, frameStartIdx) for b in blocks_bits]
         hist = np.concatenate([self.bitsOverlapBuf] + pre)
-        ends = np.cumsum([len(self.bitsOverlapBuf)] + [len(b) for b in pre])
-        starts = [0] + [int(ends[i]) - nOv for i in range(1, nb)]
-        ahead = self._search_streams([hist[starts[i]:ends[i + 1]] for i in range(nb)])
+        ends = np.cumsum([len(self.bitsOverlapBuf)] + [len(b) for b in pre]).tolist()
+        starts = [ends[i] - nOv for i in range(nb)]              # the windows without a stash, in hist's coordinates
+        a, a_prev, prev = 0, None, None
+        if self._prev is not None:                                # the previous call's window, in hist's coordinates (<= 0)
+            a_prev, prev = self._prev[0] - self._seq_end + ends[0], self._prev[1]
+        ahead = list(ahead) if ahead is not None else [None] * nb
+        self.ahead_blocks = getattr(self, 'ahead_blocks', 0) + sum(1 for h in ahead if h is not None)   # searches that came with the block
+        # blocks whose run-ahead hits did not come with them: one device round trip for all of them.  The first block's real
+        # stream is known: it is searched as it is when it cannot be put together from the previous call's hits
+        first_direct = a != starts[0] and prev is None
+        todo = [i for i in range(nb) if ahead[i] is None and not (i == 0 and first_direct)]
+        streams = [hist[starts[i]:ends[i + 1]] for i in todo] + ([hist[a:ends[1]]] if first_direct else [])
+        if streams:
+            found = self._search_streams(streams)
+            for i, h in zip(todo, found):
+                ahead[i] = h
         out = []
-        a, a_prev, prev = 0, 0, None
         for i in range(nb):
-            e, d = int(ends[i + 1]), starts[i]
+            e, d = ends[i + 1], starts[i]
             stream = hist[a:e]
-            if a == d:
+            if i == 0 and first_direct:
+                hits = found[-1]
+            elif a == d:
                 hits = ahead[i]
             else:
                 edge = None
@@ -205,6 +223,8 @@ class Decoder:
             out.append(self._frames(stream, pre[i], frameStartIdx, hits))
             a_prev, prev = a, hits
             a = e - len(self.bitsOverlapBuf)
+        self._seq_end = ends[nb]
+        self._prev = (a_prev, prev)
         return out
 
     @staticmethod

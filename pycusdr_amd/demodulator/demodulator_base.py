@@ -331,15 +331,128 @@ class Demodulator:
                                self.codeRateAndPhaseOffsetLow - self.codeRateAndPhaseOffsetHigh, self.spsymMin,
                                op=Operations.CENTRES_ABS.value, snr_window=5, source=source)
 
+    # ---- A12 / A13 / A14 of a batch on the device (stream_kernels.hpp) -----------------------------
+    def enableStreamStages(self, decoder=None):
+        """Let the device run the integer stages behind the symbol decisions for the blocks of a batch: the bit lookup
+        (DB:1012-1051), the block-overlap alignment with its uint8 casts (DB:863-988, 859) and -- with ``decoder`` -- its two
+        searches on the stream without a stash (DEC:89-113).  Returns False (and leaves them on the host) where a precondition
+        does not hold: a bit LUT that is not plain 0 / 1, a decoder preprocessor that is not the identity, templates with
+        other taps than -1 / 0 / +1, more overlap bits than the device keeps.  Results are the host code's, bit for bit; blocks
+        the device flags as irregular go through the host code."""
+        from ..protocol.protocolBase import ProtocolBase
+        self._stages = False
+        if not self._one_call or self.backend != 'UHF' or self.overlapOffset + 1 > 32:
+            return False
+        kw = {}
+        if self._bitLUT_u8 is not None:
+            kw['bit_lut'] = self._bitLUT_u8
+        elif self.bitLUT is None and self.symbolLUT is not None and len(self.symbolLUT.shape) == 3 and self.symbolLUT.shape[1] == 2:
+            kw['nrzs_lut'] = self.symbolLUT
+        else:
+            return False
+        self._stage_decoder = None
+        if decoder is not None and getattr(decoder, '_finder', None) is not None:
+            p = decoder.protocol
+            ok = (getattr(type(p), 'decoderPreprocessor', None) is ProtocolBase.decoderPreprocessor and decoder.numBitsOverlap <= 4096 and
+                  decoder.numBitsOverlap >= max(len(decoder.mask), len(decoder.syncSig)) and
+                  all(np.array_equal(np.asarray(t), np.asarray(t, dtype=np.int8)) and np.abs(np.asarray(t)).max() <= 1
+                      for t in (decoder.mask, decoder.syncSig)))
+            if ok:
+                kw.update(templates=(decoder.mask, decoder.syncSig), bits_overlap=decoder.numBitsOverlap,
+                          thresholds=(p.numOnesHeader - p.headerTol, p.numOnesSyncSig - p.syncSigTol))
+                self._stage_decoder = decoder
+        self.bank.set_stream_stages(self.sigOverlap, self.overlapOffset, self.symbol_check_match_threshold,
+                                    self.symbol_check_error_threshold, **kw)
+        self._stages = True
+        self._stream_dirty = True        # nothing is known on the device until seedStreamStages
+        return True
+
+    def seedStreamStages(self):
+        """Hand the device the state the next batch starts from -- this object's alignment state (``poswinP``, ``posSymEnd``) and
+        the decoder's last ``numBitsOverlap`` bits.  Nothing may be in flight."""
+        post = np.asarray(self.poswinP, dtype=np.uint8)
+        end = np.asarray(getattr(self, 'posSymEnd', []), dtype=np.uint8)
+        ring = None
+        if self._stage_decoder is not None:
+            ring = np.asarray(self._stage_decoder.bitsOverlapBuf[-self._stage_decoder.numBitsOverlap:], dtype=np.uint8)
+        if len(post) > 512 or len(end) > 32:
+            return False
+        self.bank.stream_seed(post, end, ring)
+        self._dev_tail = (self.poswinP, getattr(self, 'posSymEnd', None))      # what the device assumes in front of the next block
+        self._stream_dirty = False
+        return True
+
     def endBlocks(self, slot):
         """One ``((freqOffset_Hz, metric, clippedPeakIdx, SNR_dB), device record)`` per block of the batch begun in ``slot``,
         in stream order: what ``endBlock`` + ``demodulateDevice`` return block by block."""
+        R = self.bank.end_blocks_record(slot)
+        s, nb = R.s, R.nb
+        snr = self._batch_snr(R)
+        stages = R.stages and getattr(self, '_stages', False)
+        nrzs = self._bitLUT_u8 is None
         out = []
-        for blk in self.bank.end_blocks(slot):
-            self._pending = blk
-            est = self._estimate_from_block(blk)
-            out.append((est, self.demodulateDevice()))
+        prev_export = getattr(self, '_dev_tail', None)
+        empty = np.zeros(0, dtype=np.int64)
+        for b in range(nb):
+            if not s['pick_valid'][b]:       # NaN index (all-zero block): skip the block (reference DB:625-630)
+                log.error('Error occurred during find_UHF -- skipping block. Message: cannot convert float NaN to integer')
+                self.dopplerIdxlast = 0
+                est = (0., 0., self.clippedPeakIPure, 0.)
+            else:
+                lowIdx, highIdx = s['low'][b], s['high'][b]
+                self._pick_bin = lowIdx
+                lowVal, highVal = self.doppHzLUT[lowIdx], self.doppHzLUT[highIdx]
+                bestDopplerScaled = lowVal + (highVal - lowVal) * s['frac'][b]
+                self.dopplerIdxlast = np.int32(s['shift'][b])
+                if snr is not None:
+                    SNR = snr[b]
+                else:
+                    l0, l1 = s['band_len'][b]
+                    bands = (R.bands[b, 0, :l0], R.bands[b, 1, :l1]) if (R.bands is not None and l0 <= R.bcap and l1 <= R.bcap) else None
+                    SNR = self.computeSNR(lowIdx, highIdx, 5, bands=bands)
+                est = (bestDopplerScaled - self.centreFreqOffset, float(s['pick'][b][1]) / self.Nfft * self.sampleRate,
+                       self.clippedPeakIPure, SNR)
+            n = s['count'][b]
+            if s['rate_fallback'][b]:
+                log.error('Code rate result 0 should not happen but happened -- fixing it to 10')
+            self._codeRateResult = np.array(s['cr'][b], dtype=np.float32)
+            self.magnitudes = R.mag[b, :n]
+            rec = {'spSym': s['spSym'][b], 'symbols': R.sym[b, :n], 'centres': R.cen[b, :n],
+                   'trust': R.mag[b].view(TRUSTTYPE)[:n], 'clipped': empty}
+            if stages:
+                if s['a13_status'][b]:
+                    nw = s['a13_nwin'][b]
+                    post, end = R.post[b, :s['a13_npost'][b]], R.end[b, :s['a13_nend'][b]]
+                    if nrzs:
+                        post, end = post.view(np.bool_), end.view(np.bool_)
+                    # (the kept bits / centres mod 256 / trust bytes, the block's own tail, the tail the device assumed in front of it)
+                    rec['_a13'] = (R.bits[b, :nw], R.cen8[b, :nw], R.trust[b, :nw], post, end, prev_export)
+                    prev_export = (post, end)
+                else:
+                    prev_export = None
+                if s['sync_valid'][b] and max(s['sync_count'][b][:R.templates]) <= R.max_hits and R.templates == 2:
+                    c0, c1 = s['sync_count'][b]
+                    rec['_sync'] = ((R.hits[b, 0, 0, :c0], R.hits[b, 0, 1, :c0]), (R.hits[b, 1, 0, :c1], R.hits[b, 1, 1, :c1]))
+            out.append((est, rec))
+        if stages:
+            self._dev_tail = prev_export
         return out
+
+    def _batch_snr(self, R):
+        """computeSNR (DB:635-667) of every block of a batch in one go when their windows have the same two lengths (the usual
+        case: the pick sits between the same pair of bins) -- the same float32 operations element by element, so the same
+        values; None otherwise (the blocks are then done one by one)."""
+        s = R.s
+        if R.bands is None or not R.searched or not all(s['pick_valid']):
+            return None
+        lens = s['band_len']
+        l0, l1 = lens[0]
+        if any(x != lens[0] for x in lens) or l0 > R.bcap or l1 > R.bcap:
+            return None
+        with np.errstate(divide='ignore', invalid='ignore'):
+            sig = np.abs(R.bands[:, 0, :l0]).mean(axis=1) if l0 else np.full(R.nb, np.nan, np.float32)
+            noise = np.abs(R.bands[:, 1, :l1]).mean(axis=1) if l1 else np.full(R.nb, np.nan, np.float32)
+            return list(20 * np.log10(sig / noise - 1))
 
     def _estimate_from_block(self, blk):
         """The host half of __findUHF (reference DB:604-632) on what mfb_receive_block returned: Hz interpolation, SNR,
@@ -527,6 +640,20 @@ class Demodulator:
         """The sequential half (reference DB:1012-1051, 863-988, 817-859): bit lookup, alignment against the previous
         block (stateful: ``poswinP``, ``posSymEnd``), clipped-peak tagging, uint8 casts.  Must see the blocks in order --
         or be given the previous block's ``overlapTail`` as ``prev_tail`` (then any process may run any block)."""
+        a13 = rec.get('_a13')
+        if a13 is not None and prev_tail is None and not getattr(self, '_stream_dirty', True) and not len(rec['clipped']):
+            # the device ran A12 / A13 for this block (stream_kernels.hpp) in front of the tail a13[5]; that must be THIS object's
+            # state -- the arrays the previous device block left here, or equal ones
+            bits, cen8, trust8, post, end, assumed = a13
+            mine = (self.poswinP, getattr(self, 'posSymEnd', None))
+            if assumed is not None and ((mine[0] is assumed[0] and mine[1] is assumed[1]) or
+                                        (mine[1] is not None and assumed[1] is not None and np.array_equal(mine[0], assumed[0])
+                                         and np.array_equal(mine[1], assumed[1]))):
+                self.poswinP, self.posSymEnd = post, end
+                self.stage_blocks = getattr(self, 'stage_blocks', 0) + 1        # blocks whose A12 / A13 the device did
+                return bits, cen8, trust8, rec['spSym']
+        if getattr(self, '_stages', False):
+            self._stream_dirty = True        # this block goes through the host code: the device's chain is broken until it is seeded again
         spSym, idxSymbol, centres, trustSymbol = rec['spSym'], rec['symbols'], rec['centres'], rec['trust']
         dataBits, noError = self.hostBits(rec)
         if prev_tail is not None:

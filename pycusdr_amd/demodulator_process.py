@@ -347,6 +347,18 @@ class DemodulatorRunner:
         wins = self.demod.blockWindows(B)
         names = ('window', 'window2')
         cur = 0
+        # the integer stages behind the symbol decisions (bit lookup, block-overlap alignment, the decoder's searches on the
+        # stream without a stash) on the device too, unless "HIP": {"stream_stages": false}: same results, bit for bit; blocks
+        # the device flags as irregular go through the host code, and the device's state is then seeded again
+        confGPU = self.conf['GPU'][self.confRadio['CUDA_settings']]
+        stages = bool(confGPU.get('HIP', {}).get('stream_stages', True)) and hasattr(self.demod, 'enableStreamStages')
+        if stages:
+            key = id(decoder) if decoder is not None else None
+            if getattr(self, '_stages_for', ()) != (key,):
+                stages = self.demod.enableStreamStages(decoder if hasattr(decoder, 'findFrames_batch') else None)
+                self._stages_for = (key,) if stages else ()
+            if stages:
+                stages = self.demod.seedStreamStages()
         wins[cur][:self.overlap] = self.raw[:self.overlap]      # goes on behind the overlap the last call left
         asm = WindowAssembler(wins[cur], self.overlap, self.samplesPerSlice, B)
         results, packets = [], []
@@ -379,7 +391,7 @@ class DemodulatorRunner:
             now = time.time()
             per_block = ((now - last[0]) if last[0] is not None else (now - stamp)) / nb
             last[0] = now
-            ds = []
+            ds, ahead = [], []
             for i, ((doppler, doppler_std, _, snr), rec) in enumerate(recs):
                 part = {'count': count0 + i, 'timestamp': arrived[i], 'doppler': doppler, 'doppler_std': doppler_std, 'SNR': snr,
                         'rec': rec, 'time_device': per_block}
@@ -387,9 +399,13 @@ class DemodulatorRunner:
                 d['latency_ms'] = (now - arrived[i]) * 1e3
                 self.report(d)
                 ds.append(d)
+                # the hits of the decoder's searches came with the block -- valid while every block since the last seed took
+                # the device's bits
+                ahead.append(rec.get('_sync') if stages and not self.demod._stream_dirty else None)
             if batch_dec:
-                # the decoder's searches of all blocks of the batch in one device round trip (Decoder.findFrames_batch)
-                for d, (pk, _, nsync) in zip(ds, decoder.findFrames_batch([d['data'] for d in ds], 0)):
+                # the decoder's searches of all blocks of the batch: delivered with the blocks, or one device round trip for
+                # those that were not (Decoder.findFrames_batch)
+                for d, (pk, _, nsync) in zip(ds, decoder.findFrames_batch([d['data'] for d in ds], 0, ahead=ahead if stages else None)):
                     d['numSyncSig'] = nsync
                     packets.extend(pk)
                     deliver(d)
@@ -408,6 +424,13 @@ class DemodulatorRunner:
 
         def launch(nb):
             nonlocal cur, flying
+            if stages and self.demod._stream_dirty:
+                # a block went through the host code: everything in flight was enqueued behind the stale state -- collect it, hand
+                # the device this side's state, go on
+                if flying is not None:
+                    fl, flying = flying, None
+                    collect(fl)
+                self.demod.seedStreamStages()
             self.demod.beginBlocks(cur, nb, source=names[cur])
             started = (cur, self.count, nb, time.time(), list(asm.stamps[:nb]))
             self.count += nb

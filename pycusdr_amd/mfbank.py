@@ -15,6 +15,59 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+# struct BlockScalars of csrc/small_kernels.hpp (the head of every block record), field for field
+BLOCK_SCALARS = np.dtype({
+    'names': ['frac', 'spSym', 'codeOffset', 'pick', 'cr', 'spSymF', 'offsetF', 'shift', 'low', 'high', 'pick_valid', 'count',
+              'rate_fallback', 'band', 'band_len', 'a13_status', 'a13_start', 'a13_end', 'a13_nwin', 'a13_noerr', 'a13_npost',
+              'a13_nend', 'sync_valid', 'sync_count'],
+    'formats': ['<f8', '<f8', '<f8', ('<f4', 2), ('<f4', 3), '<f4', '<f4', '<i4', '<i4', '<i4', '<i4', '<i4', '<i4', ('<i4', (2, 2, 2)),
+                ('<i4', 2), '<i4', '<i4', '<i4', '<i4', '<i4', '<i4', '<i4', '<i4', ('<i4', 2)],
+    'offsets': [0, 8, 16, 24, 32, 44, 48, 52, 56, 60, 64, 68, 72, 76, 108, 116, 120, 124, 128, 132, 136, 140, 144, 148],
+    'itemsize': 160})
+
+
+class BatchRecord:
+    """A finished batch of blocks as it came off the device (mfb_receive_blocks_end_record): ``nb`` records in one buffer, read
+    in place.  Scalars come as one Python list per field (``s['count'][b]``); arrays as 2-D views, block b in row b."""
+
+    def __init__(self, buf, lay, searched):
+        nb, rec, n = lay.nblocks, lay.record_bytes, lay.symbols
+        self.nb, self.searched, self.bcap, self.mode = nb, searched, lay.band_capacity, lay.mode
+        if lay.scalars_bytes != BLOCK_SCALARS.itemsize:
+            raise RuntimeError('the library\'s BlockScalars layout differs from this binding\'s')
+        a = buf[:nb * rec].reshape(nb, rec)
+        heads = a[:, :BLOCK_SCALARS.itemsize].copy().view(BLOCK_SCALARS).reshape(nb)
+        self.s = {k: heads[k].tolist() for k in BLOCK_SCALARS.names}
+        if not searched:
+            self.s['shift'] = [int(lay.fixed_shift)] * nb
+
+        def arr(off, count, dt):
+            return a[:, off:off + count * np.dtype(dt).itemsize].view(dt)
+        self.sym, self.cen, self.mag = arr(lay.off_sym, n, np.int32), arr(lay.off_cen, n, np.int32), arr(lay.off_mag, n, np.float32)
+        self.bands = arr(lay.off_bands, 2 * lay.band_capacity, np.complex64).reshape(nb, 2, lay.band_capacity) if lay.band_capacity else None
+        self.stages = bool(lay.stream_stages)
+        if self.stages:
+            self.bits, self.cen8, self.trust = (arr(lay.off_bits, n, np.uint8), arr(lay.off_centres_u8, n, np.uint8),
+                                                arr(lay.off_trust, n, np.uint8))
+            self.post, self.end = a[:, lay.off_post:lay.off_post + 512], a[:, lay.off_end:lay.off_end + 32]
+            self.templates, mh = lay.templates, lay.max_hits
+            self.hits = arr(lay.off_hits, 2 * 2 * mh, np.int32).reshape(nb, 2, 2, mh)      # [block][template][idx | score][hit]
+            self.max_hits = mh
+
+    def block(self, b):
+        """Block b as the dict ``receive_block`` returns."""
+        s, n = self.s, self.s['count'][b]
+        d = {'pick': (np.float32(s['pick'][b][0]), np.float32(s['pick'][b][1])), 'pick_valid': bool(s['pick_valid'][b]),
+             'shift': int(s['shift'][b]), 'low': s['low'][b], 'high': s['high'][b], 'frac': s['frac'][b],
+             'cr': tuple(np.float32(v) for v in s['cr'][b]), 'spSym': s['spSym'][b], 'codeOffset': s['codeOffset'][b],
+             'rate_fallback': bool(s['rate_fallback'][b]), 'symbols': self.sym[b, :n], 'centres': self.cen[b, :n],
+             'magnitudes': self.mag[b, :n], 'bands': None}
+        l0, l1 = s['band_len'][b]
+        if self.searched and self.bands is not None and l0 <= self.bcap and l1 <= self.bcap:
+            d['bands'] = (self.bands[b, 0, :l0], self.bands[b, 1, :l1])
+        return d
+
+
 class MFBank:
     def __init__(self, log2N, num_dopplers, M, window_width=7, sum_all_masks=True,
                  code_search_mask_offset=0, doppler_offset=0, device=0):
@@ -337,37 +390,72 @@ class MFBank:
         self._batch[int(slot)] = (int(nblocks), int(k_offset) + int(k_len) + 1)
         self._flying = getattr(self, '_flying', set()) | {int(slot)}
 
-    def end_blocks(self, slot):
-        """Wait for the batch begun in ``slot``; one dict per block, each exactly what ``receive_block`` returns for that block
-        alone (the arrays are views into storage owned by the returned list's batch -- no further copies)."""
+    def end_blocks_record(self, slot):
+        """Wait for the batch begun in ``slot`` and return it as a ``BatchRecord`` (one copy, read in place)."""
         slot = int(slot)
-        nb, nsym = self._batch[slot]
-        nsym = min(nsym, self.N // 2)
-        cap = self.BAND_CAPACITY
-        R = (_lib.BlockResult * nb)()
-        sym = np.empty((nb, nsym), np.int32)
-        cen = np.empty((nb, nsym), np.int32)
-        mag = np.empty((nb, nsym), np.float32)
-        bands = np.empty((nb, 2, cap), np.complex64)
+        lay = _lib.RecordLayout()
+        buf = np.empty(getattr(self, '_recbuf_need', 1 << 16), np.uint8)      # a fresh buffer per batch: the views handed out keep it alive
         try:
-            _lib.check(self._lib.mfb_receive_blocks_end(self._h, slot, R, _ptr(sym), _ptr(cen), _ptr(mag), nsym, _ptr(bands)),
-                       'mfb_receive_blocks_end')
+            rc = self._lib.mfb_receive_blocks_end_record(self._h, slot, _ptr(buf), buf.size, C.byref(lay))
+            if rc == _lib.MFB_ERR_ARG and self._batch.get(slot):
+                # too small for this batch: size it from the geometry and take the batch (it is still in flight)
+                nb, nsym = self._batch[slot]
+                self._recbuf_need = nb * (8192 + 16 * self.BAND_CAPACITY + 16 * min(nsym, self.N // 2))
+                buf = np.empty(self._recbuf_need, np.uint8)
+                rc = self._lib.mfb_receive_blocks_end_record(self._h, slot, _ptr(buf), buf.size, C.byref(lay))
+            _lib.check(rc, 'mfb_receive_blocks_end_record')
         finally:
             self._flying = getattr(self, '_flying', set()) - {slot}
-        searched = self._searched.get(slot, True)
-        out = []
-        for b in range(nb):
-            r = R[b]
-            n = r.count
-            d = {'pick': (np.float32(r.pick[0]), np.float32(r.pick[1])), 'pick_valid': bool(r.pick_valid), 'shift': int(r.shift),
-                 'low': int(r.low), 'high': int(r.high), 'frac': float(r.frac),
-                 'cr': (np.float32(r.cr[0]), np.float32(r.cr[1]), np.float32(r.cr[2])), 'spSym': float(r.spSym),
-                 'codeOffset': float(r.codeOffset), 'rate_fallback': bool(r.rate_fallback),
-                 'symbols': sym[b, :n], 'centres': cen[b, :n], 'magnitudes': mag[b, :n], 'bands': None}
-            if searched and r.band_len[0] <= cap and r.band_len[1] <= cap:
-                d['bands'] = (bands[b, 0, :r.band_len[0]], bands[b, 1, :r.band_len[1]])
-            out.append(d)
-        return out
+        return BatchRecord(buf, lay, self._searched.get(slot, True))
+
+    def end_blocks(self, slot):
+        """Wait for the batch begun in ``slot``; one dict per block, each exactly what ``receive_block`` returns for that block
+        alone (the arrays are views into the batch's record -- no further copies)."""
+        rec = self.end_blocks_record(slot)
+        return [rec.block(b) for b in range(rec.nb)]
+
+    # -- the integer stages behind the symbol decisions, on the device (batches) ---------------------
+    def set_stream_stages(self, overlap_samples, overlap_offset, match_threshold, error_threshold, bit_lut=None, nrzs_lut=None,
+                          templates=(), thresholds=(), bits_overlap=0):
+        """A12 (bit LUT uint8[rows] of 0 / 1, or the 3-D NRZ-S LUT int[rows][2][successors]), A13 (block-overlap alignment) and --
+        with ``templates`` -- A14 (the decoder's searches on the stream without a stash) for the blocks of a batch
+        (mfb_set_stream_stages).  ``None`` for both LUTs switches the stages off."""
+        if bit_lut is None and nrzs_lut is None:
+            _lib.check(self._lib.mfb_set_stream_stages(self._h, None), 'mfb_set_stream_stages')
+            self._stages = False
+            return
+        P = _lib.StreamParams()
+        P.overlap_samples, P.overlap_offset, P.match_threshold, P.error_threshold = (int(overlap_samples), int(overlap_offset),
+                                                                                     int(match_threshold), int(error_threshold))
+        if bit_lut is not None:
+            lut = np.ascontiguousarray(bit_lut, dtype=np.uint8)
+            P.lut_mode, P.lut_rows, P.lut_successors = 1, lut.size, 0
+        else:
+            lut = np.ascontiguousarray(nrzs_lut, dtype=np.int32)
+            if lut.ndim != 3 or lut.shape[1] != 2:
+                raise ValueError('NRZ-S LUT: int[rows][2][successors]')
+            P.lut_mode, P.lut_rows, P.lut_successors = 2, lut.shape[0], lut.shape[2]
+        P.lut = lut.ctypes.data
+        tis = [np.ascontiguousarray(t, dtype=np.int8) for t in templates]
+        for t, ti in zip(templates, tis):
+            if not np.array_equal(ti, np.asarray(t)) or np.abs(ti).max(initial=0) > 1:
+                raise ValueError('templates: taps in {-1, 0, +1}')
+        P.num_templates, P.bits_overlap = len(tis), int(bits_overlap)
+        packed = np.concatenate(tis) if tis else np.zeros(0, np.int8)
+        for k, ti in enumerate(tis):
+            P.template_taps[k] = ti.size
+            P.template_thresholds[k] = int(np.ceil(thresholds[k]))
+        P.templates = packed.ctypes.data if tis else None
+        _lib.check(self._lib.mfb_set_stream_stages(self._h, C.byref(P)), 'mfb_set_stream_stages')
+        self._stages = True
+
+    def stream_seed(self, post, end, ring=None):
+        """The state the next batch starts from: the previous block's tail (``post``: the bits behind its window, ``end``: the last
+        overlap_offset + 1 bits inside it) and the last bits_overlap bits of the decoder's stream (``ring``; None: unknown)."""
+        post = np.ascontiguousarray(post, dtype=np.uint8)
+        end = np.ascontiguousarray(end, dtype=np.uint8)
+        ring = np.zeros(0, np.uint8) if ring is None else np.ascontiguousarray(ring, dtype=np.uint8)
+        _lib.check(self._lib.mfb_stream_seed(self._h, _ptr(post), post.size, _ptr(end), end.size, _ptr(ring), ring.size), 'mfb_stream_seed')
 
     def get_xcorr(self):
         out = np.empty((self.M, self.N), dtype=np.complex64)

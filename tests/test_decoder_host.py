@@ -112,8 +112,9 @@ def _bench_stream(rs, nblocks, blk, flips):
     return np.concatenate(parts).astype(np.uint8)
 
 
+@pytest.mark.parametrize('with_ahead', [False, True])
 @pytest.mark.parametrize('blk,B,flips', [(1950, 8, 0), (1950, 5, 20), (2500, 3, 30), (700, 16, 26), (9000, 2, 0), (130, 16, 10)])
-def test_findframes_batch_equals_call_by_call_fixed(blk, B, flips):
+def test_findframes_batch_equals_call_by_call_fixed(blk, B, flips, with_ahead):
     """findFrames_batch (searches run ahead on the default windows, stashed windows put together from the previous call's hits)
     against findFrames call by call: packets, returned bits, sync counts and the overlap buffer, block by block."""
     p = loadProtocol('bench_GMSK')(conf=cfg.bench_config())
@@ -131,11 +132,24 @@ def test_findframes_batch_equals_call_by_call_fixed(blk, B, flips):
         return inner(bits, template, threshold)
     want = [a.findFrames(x, 7) for x in blocks]
     got = []
+    # with_ahead: the hits of every block's stream without a stash come with the block, as the batched block path delivers them
+    # (here: the oracle's correlator on the bit sequence), some of them missing; no search but the new-stash edges is left
+    nOv = p.numBitsOverlap
+    seq = np.concatenate((np.zeros(nOv), stream[:cuts[-1]]))
+    thr = (p.numOnesHeader - p.headerTol, p.numOnesSyncSig - p.syncSigTol)
     for i in range(0, nblocks, B):
         group = blocks[i:i + B]
+        ahead = None
+        if with_ahead:
+            ahead = []
+            for j in range(i, min(i + B, nblocks)):
+                w = seq[cuts[j]:cuts[j + 1] + nOv]
+                ahead.append(None if (j % 7 == 3) else tuple(inner(w, t, h) for t, h in zip((b.mask, b.syncSig), thr)))
         b.hits = counting
         before = direct[0]
-        got += b.findFrames_batch(group, 7)
+        got += b.findFrames_batch(group, 7, ahead=ahead)
+        if with_ahead:
+            assert direct[0] - before <= 2 * sum(1 for x in ahead if x is None) + 2 * 3 + 2, (i, direct[0] - before)
         # searches: two per block for the run-ahead windows, plus two per NEW stash (once per packet, not once per block)
         assert direct[0] - before <= 2 * len(group) + 2 * 3, (i, direct[0] - before)
     found = 0

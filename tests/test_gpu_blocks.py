@@ -155,6 +155,7 @@ def test_batched_stream_equals_one_block_stream(B):
                 for k in ('symbols', 'centres', 'trust'):
                     rec[k] = rec[k][1:]
                 rec.pop('_bits', None)
+                rec.pop('_a13', None)          # (the device's own alignment of the unmodified block)
             host.calls += 1
             return inner(rec, prev_tail=prev_tail)
         host.calls = 0
@@ -174,6 +175,9 @@ def test_batched_stream_equals_one_block_stream(B):
             assert 'latency_ms' in y and y['rate_ksps'] > 0
         assert len(pa) == len(pb) and all(_same(u.bits, v.bits) for u, v in zip(pa, pb))
         assert _same(a.demod.poswinP, b.demod.poswinP) and _same(a.demod.posSymEnd, b.demod.posSymEnd)
+        # the device did the bit lookup and the alignment of (nearly) every block, and the decoder's searches came with them: all
+        # but the block with the planted slip -- which goes through the host code -- and what was in flight behind it
+        assert b.demod.stage_blocks >= nblocks - 2 * B - 1 and db.ahead_blocks >= nblocks - 2 * B - 1, (b.demod.stage_blocks, db.ahead_blocks)
         # a second stream on the same runners goes on behind the overlap the first left
         more = sg.s1_stream(B + 1, N, ov, 'GMSK', snr_db=10.0, seed=6)[ov:]
         ra2, _ = a.run_stream([more], decoder=da)
@@ -183,6 +187,44 @@ def test_batched_stream_equals_one_block_stream(B):
     finally:
         a.close()
         b.close()
+
+
+@pytest.mark.parametrize('mod,pname,bs,D,snr', [('GMSK', 'bench_GMSK', 15, 32, 8.0), ('FSK', 'bench_FSK', 15, 16, 12.0),
+                                                 ('GFSK', 'bench_GFSK', 14, 16, 12.0), ('BPSK', 'bench_BPSK', 15, 24, 10.0)])
+def test_device_stream_stages_equal_the_host_stages(mod, pname, bs, D, snr):
+    """The batched loop with A12 / A13 / A14 on the device (the default) against the same loop with them on the host
+    ("HIP": {"stream_stages": false}) and against the one-block loop: bits, trust, centres, packets, alignment state and the
+    decoder's overlap buffer -- for the bit-LUT modulations and for BPSK's NRZ-S decode; noiseless zero padding between the
+    packets makes some blocks irregular (symbol index -1: no sample above zero), which go through the host code."""
+    N, ov = 1 << bs, 1 << 10
+    step = N - ov
+    conf = cfg.bench_config(pname, blockSize=bs, doppCarrierSteps=D)
+    p = loadProtocol(pname)(conf=conf)
+    B, nblocks = 4, 19
+    sig = sg.s1_stream(nblocks, N, ov, mod, snr_db=snr, seed=9)[ov:]
+    confB, confH = copy.deepcopy(conf), copy.deepcopy(conf)
+    confB['GPU']['UHF'].setdefault('HIP', {})['blocks_per_call'] = B
+    confH['GPU']['UHF'].setdefault('HIP', {}).update(blocks_per_call=B, stream_stages=False)
+    runs = [DemodulatorRunner(c, p, 'UHF-H') for c in (conf, confB, confH)]
+    decs = [Decoder(conf, p) for _ in runs]
+    try:
+        outs = [r.run_stream((sig[i:i + 7000] for i in range(0, len(sig), 7000)), decoder=d) for r, d in zip(runs, decs)]
+        (r0, p0), (r1, p1), (r2, p2) = outs
+        assert len(r0) == len(r1) == len(r2) == nblocks
+        for x, y, z in zip(r0, r1, r2):
+            for k in ('doppler', 'doppler_std', 'SNR', 'spSymEst', 'numSyncSig'):
+                assert _same(x[k], y[k]) and _same(x[k], z[k]), (x['count'], k)
+            assert _same(x['data'], y['data']) and _same(x['trust'], y['trust']) and _same(x['data'], z['data']), x['count']
+            assert y['data'].dtype == np.uint8 and y['trust'].dtype == np.uint8
+        assert len(p0) == len(p1) == len(p2) >= 1 and all(_same(u.bits, v.bits) for u, v in zip(p0, p1))
+        for r in runs[1:]:
+            assert _same(runs[0].demod.poswinP, r.demod.poswinP) and _same(runs[0].demod.posSymEnd, r.demod.posSymEnd)
+        assert _same(decs[0].bitsOverlapBuf, decs[1].bitsOverlapBuf)
+        assert runs[1].demod.stage_blocks >= nblocks // 2 and getattr(runs[2].demod, 'stage_blocks', 0) == 0, runs[1].demod.stage_blocks
+        assert decs[1].ahead_blocks >= nblocks // 2
+    finally:
+        for r in runs:
+            r.close()
 
 
 def test_batch_errors():
