@@ -323,7 +323,11 @@ int mfb_stream_seed(mfb_ctx *ctx, const uint8_t *post, int npost, const uint8_t 
  * three arrays per block with three memcpy_dtoh). */
 typedef struct mfb_record_layout {
     int32_t nblocks, scalars_bytes, symbols, band_capacity, mode, fixed_shift, stream_stages, max_hits, templates, reserved;
-    int64_t record_bytes, off_bands, off_sym, off_cen, off_mag, off_bits, off_centres_u8, off_trust, off_post, off_end, off_hits;
+    int32_t edge_candidates, edge_hits;   /* per block: the leading T - 1 positions of the stream a FIXED-mode decoder would restart
+                                           * at for each of the first header hits (DEC:254-263): int32 {a_rel, valid, n[2],
+                                           * idx[2][edge_hits], score[2][edge_hits]} each, at off_edges */
+    int64_t record_bytes, off_bands, off_sym, off_cen, off_mag, off_bits, off_centres_u8, off_trust, off_post, off_end, off_hits,
+            off_edges;
 } mfb_record_layout;
 int mfb_receive_blocks_end_record(mfb_ctx *ctx, int slot, void *dst, size_t capacity, mfb_record_layout *layout);
 /* Test seam of the one-call path.  mfb_receive_block moved two pieces of the reference's float64 HOST arithmetic onto the

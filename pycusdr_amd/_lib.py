@@ -60,9 +60,9 @@ class StreamParams(C.Structure):
 class RecordLayout(C.Structure):
     """mfb_record_layout of include/mfbank.h."""
     _fields_ = [(k, C.c_int32) for k in ('nblocks', 'scalars_bytes', 'symbols', 'band_capacity', 'mode', 'fixed_shift', 'stream_stages',
-                                         'max_hits', 'templates', 'reserved')] + \
+                                         'max_hits', 'templates', 'reserved', 'edge_candidates', 'edge_hits')] + \
                [(k, C.c_int64) for k in ('record_bytes', 'off_bands', 'off_sym', 'off_cen', 'off_mag', 'off_bits', 'off_centres_u8',
-                                         'off_trust', 'off_post', 'off_end', 'off_hits')]
+                                         'off_trust', 'off_post', 'off_end', 'off_hits', 'off_edges')]
 
 
 # name -> (restype, argtypes); exactly the prototypes of include/mfbank.h

@@ -1629,6 +1629,7 @@ static int block_enqueue(mfb_ctx *c, const mfb_block_params *p, const BlkBufs &b
         sa.off_post = bb.ext + 3 * a1;
         sa.off_end = sa.off_post + STREAM_POST_MAX;
         sa.off_hits = sa.off_end + STREAM_END_MAX;
+        sa.off_edges = sa.off_hits + (size_t)STREAM_MAX_TMPL * 2 * STREAM_MAX_HITS * sizeof(int32_t);
         sa.nb = nb;
         sa.carry_in = c->d_carry[bb.parity];
         sa.carry_out = c->d_carry[1 - bb.parity];
@@ -1639,6 +1640,7 @@ static int block_enqueue(mfb_ctx *c, const mfb_block_params *p, const BlkBufs &b
             for (int t = 0; t < sa.K; ++t) Tmax = sa.T[t] > Tmax ? sa.T[t] : Tmax;
             hipLaunchKernelGGL(k_stream_sync, dim3(sa.K, nb), dim3(256), (size_t)Tmax + SYNC_SEG + Tmax - 1, c->stream, sa);
             hipLaunchKernelGGL(k_stream_ring, dim3(1), dim3(256), 0, c->stream, sa);
+            hipLaunchKernelGGL(k_stream_edges, dim3(nb), dim3(256), 0, c->stream, sa);
             HIPCHK(hipGetLastError());
         }
     }
@@ -1999,7 +2001,7 @@ extern "C" int mfb_receive_blocks_begin(mfb_ctx *c, const mfb_block_params *p, i
     // stream-stage outputs behind the core record: kept bits | kept centres | trust bytes (uint8[nthreads] each), the block's
     // tail (post, end), the sync hits (idx | score per template)
     const size_t ext_bytes = 3 * align16((size_t)nthreads) + STREAM_POST_MAX + STREAM_END_MAX +
-                             (size_t)STREAM_MAX_TMPL * 2 * STREAM_MAX_HITS * sizeof(int32_t);
+                             (size_t)STREAM_MAX_TMPL * 2 * STREAM_MAX_HITS * sizeof(int32_t) + align16(STREAM_EDGE_CANDS * sizeof(StreamEdge));
     const size_t rec = core + (stages ? ext_bytes : 0);
     if ((rc = batch_reserve(c, nblocks > c->win_blocks ? nblocks : (c->win_blocks > 0 ? c->win_blocks : nblocks), rec))) return rc;
     if ((rc = staging_reserve(c, slot, rec * nblocks))) return rc;
@@ -2109,6 +2111,9 @@ extern "C" int mfb_receive_blocks_end_record(mfb_ctx *c, int slot, void *dst, si
         lay->off_post = (int64_t)(f.ext + 3 * a1);
         lay->off_end = lay->off_post + STREAM_POST_MAX;
         lay->off_hits = lay->off_end + STREAM_END_MAX;
+        lay->off_edges = lay->off_hits + (int64_t)STREAM_MAX_TMPL * 2 * STREAM_MAX_HITS * (int64_t)sizeof(int32_t);
+        lay->edge_candidates = STREAM_EDGE_CANDS;
+        lay->edge_hits = STREAM_EDGE_HITS;
         lay->max_hits = STREAM_MAX_HITS;
         lay->templates = c->st.K;
     }

@@ -23,6 +23,15 @@
 #define STREAM_MAX_HITS 64       // sync hits per (block, template) kept in the record
 #define STREAM_MAX_TMPL 2
 #define STREAM_NOV_MAX 4096      // numBitsOverlap <= 4096 (CC11xx: 2048)
+#define STREAM_EDGE_CANDS 4      // header hits per block whose would-be stash start gets its first T - 1 positions searched
+#define STREAM_EDGE_HITS 8
+#define STREAM_EDGE_BACK 20      // the decoder keeps 20 bits in front of a stashed candidate (decoder.py:258)
+struct StreamEdge {              // the first T - 1 positions of the stream that would start at the stash of one header hit
+    int a_rel;                   // its start relative to the block's stream without a stash (may be negative)
+    int valid;                   // 0: not computed (outside what the device holds, template too long)
+    int n[2];
+    int idx[2][STREAM_EDGE_HITS], score[2][STREAM_EDGE_HITS];
+};
 
 #define A13_DEVICE 1             // a13_status: the record holds the block's final arrays
 #define A13_HOST 0               //             the host runs A12 / A13 for this block (irregular case)
@@ -42,7 +51,7 @@ struct StreamArgs {
     size_t rec;
     size_t off_sym, off_cen, off_mag;        // int32[count] | int32[count] | float32[count] inside a record
     size_t off_bits, off_cenw, off_trust;    // uint8[nwin] each (A13 outputs)
-    size_t off_post, off_end, off_hits;
+    size_t off_post, off_end, off_hits, off_edges;
     int nb, N, ovw;              // blocks, block length, overlap / 2
     int o, thr, err_thr;         // overlapOffset, match threshold, symbol_check_error_threshold
     int mode;                    // 1: bit LUT (uint8[rows]); 2: NRZ-S LUT (int32[rows][2][succ])
@@ -228,6 +237,8 @@ __global__ void __launch_bounds__(256) k_stream_align(StreamArgs a) {
         sc->a13_noerr = noerr;
         sc->a13_npost = status == A13_DEVICE ? me.nbits - me.end : 0;
         sc->a13_nend = status == A13_DEVICE ? o + 1 : 0;
+        sc->sync_valid = 0;              // (k_stream_sync, when it runs, says otherwise)
+        sc->sync_count[0] = sc->sync_count[1] = 0;
     }
     __syncthreads();
     const bool dev = sc->a13_status == A13_DEVICE;
@@ -382,4 +393,68 @@ __global__ void __launch_bounds__(256) k_stream_ring(StreamArgs a) {
     __syncthreads();
     if (!s_ok) return;
     for (int q = threadIdx.x; q < a.nOv; q += blockDim.x) a.carry_out->ring[q] = (uint8_t)stream_v(a, s_total + q, cum);
+}
+
+// A FIXED-mode decoder that finds a header whose packet is not complete yet restarts its next stream 20 bits in front of that
+// header (DEC:254-263).  The first T - 1 positions of such a stream are full-convolution positions whose window hangs over the
+// stream's start -- they belong to no other window and would cost the decoder a search of their own, once per packet.  Every
+// header hit of a block's stream is a possible restart: its T - 1 leading positions are searched here, for both templates.
+// Workgroup = block of the batch; hits of at most STREAM_EDGE_CANDS header hits, in order.
+__global__ void __launch_bounds__(256) k_stream_edges(StreamArgs a) {
+    __shared__ int cum[65];
+    __shared__ int s_flag[2][256];
+    const int b = blockIdx.x;
+    uint8_t *rec = a.rec0 + (size_t)b * a.rec;
+    const BlockScalars *sc = reinterpret_cast<const BlockScalars *>(rec);
+    StreamEdge *out = reinterpret_cast<StreamEdge *>(rec + a.off_edges);
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < a.nb && i < 64; ++i) {
+            cum[i] = run;
+            run += reinterpret_cast<const BlockScalars *>(a.rec0 + (size_t)i * a.rec)->a13_nwin;
+        }
+        cum[a.nb < 64 ? a.nb : 64] = run;
+    }
+    __syncthreads();
+    const bool usable = sc->sync_valid && a.K == 2 && a.T[0] <= 256 && a.T[1] <= 256;
+    const int nh = usable ? min(sc->sync_count[0], a.max_hits) : 0;
+    const int32_t *hidx = reinterpret_cast<const int32_t *>(rec + a.off_hits);
+    const int vend = a.nOv + cum[b] + sc->a13_nwin;              // end of block b's stream in V
+    for (int c = 0; c < STREAM_EDGE_CANDS; ++c) {
+        StreamEdge *e = out + c;
+        const bool have = c < nh;
+        const int a_rel = have ? hidx[c] - a.T[0] + 1 - STREAM_EDGE_BACK : 0;
+        const int av = cum[b] + a_rel;                           // start in V
+        const int Tm = max(a.T[0], a.T[1]);
+        const bool ok = have && av >= 0 && av + Tm - 1 <= vend;
+        __syncthreads();
+        for (int k = 0; k < 2; ++k) {
+            const int i = threadIdx.x;
+            int score = 0;
+            bool hit = false;
+            if (ok && i < a.T[k] - 1) {
+                for (int q = 0; q <= i; ++q) score += (int)a.tmpls[a.toff[k] + q] * stream_v(a, av + i - q, cum);
+                hit = score >= a.thrs[k];
+            }
+            s_flag[k][i] = hit ? score : INT32_MIN;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            e->a_rel = a_rel;
+            e->valid = ok ? 1 : 0;
+            for (int k = 0; k < 2; ++k) {
+                int n = 0;
+                for (int i = 0; ok && i < a.T[k] - 1; ++i)
+                    if (s_flag[k][i] != INT32_MIN) {
+                        if (n < STREAM_EDGE_HITS) {
+                            e->idx[k][n] = i;
+                            e->score[k][n] = s_flag[k][i];
+                        }
+                        ++n;
+                    }
+                e->n[k] = n;
+            }
+            if (e->n[0] > STREAM_EDGE_HITS || e->n[1] > STREAM_EDGE_HITS) e->valid = 0;
+        }
+    }
 }

@@ -67,6 +67,8 @@ class Decoder:
         self.numBitsOverlap = protocol.numBitsOverlap
         self.bitsOverlapBuf = np.zeros(self.numBitsOverlap)
         self._prev = None              # (start of the last call's stream in the bit sequence, its hits): findFrames_batch
+        self._abs_end = 0              # bits taken so far: position of the next block's first bit in the whole sequence
+        self._edge_map = {}            # sequence position of a would-be stash start -> hits of its first T - 1 positions
         # cross-block packet state (FLAGS mode)
         self.headerFrameStartIdx = None
         self.packetBuffer = None
@@ -110,6 +112,7 @@ class Decoder:
         _begin: the state machine of block i decides what block i + 1 is stitched to (DEC:254-263)."""
         p = self.protocol
         bits_less_raw = self.preprocessor(bits_raw)
+        self._abs_end += len(bits_less_raw)
         rawBits_DS = np.concatenate((self.bitsOverlapBuf, bits_less_raw))
         self.bitsOverlapBuf = rawBits_DS[-self.numBitsOverlap:]
         hits = None
@@ -170,11 +173,13 @@ class Decoder:
             out.append(tuple(per))
         return out
 
-    def findFrames_batch(self, blocks_bits, frameStartIdx=0, ahead=None):
+    def findFrames_batch(self, blocks_bits, frameStartIdx=0, ahead=None, edges=None):
         """``findFrames`` for several consecutive blocks: the same packets, returned bits and sync counts, call by call (a list
         of ``findFrames`` results), from ONE device round trip for the searches of all blocks instead of one per block -- or
         none: ``ahead[i]`` = the hits of block i's stream without a stash (the last ``numBitsOverlap`` bits before the block +
-        its bits), as the batched block path delivers them with the block (None where it could not).
+        its bits), as the batched block path delivers them with the block (None where it could not); ``edges[i]`` = for the first
+        header hits of that stream, the hits among the first T - 1 positions of the stream a FIXED-mode decoder would restart at
+        (20 bits in front of the header, DEC:254-263): ``(start relative to the stream, mask hits, sync hits)``.
 
         Every call's stream is a window [a, e) of the bit sequence so far: e the end of the block's bits, a either
         ``numBitsOverlap`` bits before the block (DEC:89-90) or -- FIXED mode with a packet still incomplete -- where the
@@ -196,6 +201,13 @@ class Decoder:
         if self._prev is not None:                                # the previous call's window, in hist's coordinates (<= 0)
             a_prev, prev = self._prev[0] - self._seq_end + ends[0], self._prev[1]
         ahead = list(ahead) if ahead is not None else [None] * nb
+        base = self._abs_end - ends[0]                            # sequence position of hist[0]
+        if edges is not None:
+            if len(self._edge_map) > 64:
+                self._edge_map = {k: v for k, v in self._edge_map.items() if k >= base}
+            for i, cands in enumerate(edges):
+                for a_rel, h0, h1 in cands or ():
+                    self._edge_map[base + starts[i] + a_rel] = (h0, h1)
         self.ahead_blocks = getattr(self, 'ahead_blocks', 0) + sum(1 for h in ahead if h is not None)   # searches that came with the block
         # blocks whose run-ahead hits did not come with them: one device round trip for all of them.  The first block's real
         # stream is known: it is searched as it is when it cannot be put together from the previous call's hits
@@ -216,14 +228,17 @@ class Decoder:
                 hits = ahead[i]
             else:
                 edge = None
-                if a != a_prev:       # a new stash: its first T - 1 positions have never been searched -- both templates in one call
-                    edge = self._search_streams([stream[:max(Ts) - 1]])[0]
+                if a != a_prev:       # a new stash: its first T - 1 positions belong to no other window: delivered, or searched now
+                    edge = self._edge_map.get(base + a)
+                    if edge is None:
+                        edge = self._search_streams([stream[:max(Ts) - 1]])[0]
                 hits = tuple(self._window_hits(Ts[k], prev[k], a_prev, a, d, ahead[i][k], edge[k] if edge else None) for k in range(2))
             self.bitsOverlapBuf = stream[-nOv:]
             out.append(self._frames(stream, pre[i], frameStartIdx, hits))
             a_prev, prev = a, hits
             a = e - len(self.bitsOverlapBuf)
         self._seq_end = ends[nb]
+        self._abs_end += ends[nb] - ends[0]
         self._prev = (a_prev, prev)
         return out
 
@@ -234,23 +249,25 @@ class Decoder:
         the window's first T - 1 bits searched on their own."""
         ai, asc = ahead
         pi, ps = prev
-        if edge is None and not len(pi):
+        if edge is None:
+            # the start did not move: every previous hit in front of the default window's own positions stays where it is (the
+            # first T - 1 positions included); behind them the default window's hits, shifted
+            if len(pi):
+                keep = pi < d - a_prev + T - 1
+                pi, ps = pi[keep], ps[keep]
             if not len(ai):
-                return ahead
+                return pi, ps
             m = ai >= T - 1
-            return ai[m] + (d - a), asc[m]
+            if not len(pi):
+                return ai[m] + (d - a), asc[m]
+            return np.concatenate((pi, ai[m] + (d - a))), np.concatenate((ps, asc[m]))
         m = ai >= T - 1
         new_i, new_s = ai[m] + (d - a), asc[m]
         g = pi + a_prev                                        # previous hits in the sequence's coordinates
         m = (g >= a + T - 1) & (g < d + T - 1)
         old_i, old_s = g[m] - a, ps[m]
-        if edge is None:                                       # the start did not move: the same first T - 1 positions
-            m = pi < T - 1
-            edge_i, edge_s = pi[m], ps[m]
-        else:
-            m = edge[0] < T - 1
-            edge_i, edge_s = edge[0][m], edge[1][m]
-        return np.concatenate((edge_i, old_i, new_i)), np.concatenate((edge_s, old_s, new_s))
+        m = edge[0] < T - 1
+        return np.concatenate((edge[0][m], old_i, new_i)), np.concatenate((edge[1][m], old_s, new_s))
 
     # ---- FIXED: packets of protocol.packetLen bits (reference decoder.py:245-280) ---------------
     def _frames_fixed(self, stream, candScore, packetIdx):

@@ -430,9 +430,18 @@ class Demodulator:
                     prev_export = (post, end)
                 else:
                     prev_export = None
-                if s['sync_valid'][b] and max(s['sync_count'][b][:R.templates]) <= R.max_hits and R.templates == 2:
+                if R.templates == 2 and s['sync_valid'][b] and max(s['sync_count'][b]) <= R.max_hits:
                     c0, c1 = s['sync_count'][b]
                     rec['_sync'] = ((R.hits[b, 0, 0, :c0], R.hits[b, 0, 1, :c0]), (R.hits[b, 1, 0, :c1], R.hits[b, 1, 1, :c1]))
+                    if c0 and R.edges is not None:
+                        # the leading positions of the streams the decoder would restart at for the first header hits
+                        eh, cands = R.edge_hits, []
+                        for E in R.edges[b].tolist():
+                            if E[1]:
+                                n0, n1 = E[2], E[3]
+                                cands.append((E[0], (np.array(E[4:4 + n0], np.int32), np.array(E[4 + 2 * eh:4 + 2 * eh + n0], np.int32)),
+                                              (np.array(E[4 + eh:4 + eh + n1], np.int32), np.array(E[4 + 3 * eh:4 + 3 * eh + n1], np.int32))))
+                        rec['_edges'] = cands
             out.append((est, rec))
         if stages:
             self._dev_tail = prev_export

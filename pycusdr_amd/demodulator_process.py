@@ -391,7 +391,7 @@ class DemodulatorRunner:
             now = time.time()
             per_block = ((now - last[0]) if last[0] is not None else (now - stamp)) / nb
             last[0] = now
-            ds, ahead = [], []
+            ds, ahead, edges = [], [], []
             for i, ((doppler, doppler_std, _, snr), rec) in enumerate(recs):
                 part = {'count': count0 + i, 'timestamp': arrived[i], 'doppler': doppler, 'doppler_std': doppler_std, 'SNR': snr,
                         'rec': rec, 'time_device': per_block}
@@ -402,10 +402,12 @@ class DemodulatorRunner:
                 # the hits of the decoder's searches came with the block -- valid while every block since the last seed took
                 # the device's bits
                 ahead.append(rec.get('_sync') if stages and not self.demod._stream_dirty else None)
+                edges.append(rec.get('_edges') if ahead[-1] is not None else None)
             if batch_dec:
                 # the decoder's searches of all blocks of the batch: delivered with the blocks, or one device round trip for
                 # those that were not (Decoder.findFrames_batch)
-                for d, (pk, _, nsync) in zip(ds, decoder.findFrames_batch([d['data'] for d in ds], 0, ahead=ahead if stages else None)):
+                for d, (pk, _, nsync) in zip(ds, decoder.findFrames_batch([d['data'] for d in ds], 0, ahead=ahead if stages else None,
+                                                                         edges=edges if stages else None)):
                     d['numSyncSig'] = nsync
                     packets.extend(pk)
                     deliver(d)

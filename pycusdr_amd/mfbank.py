@@ -53,6 +53,10 @@ class BatchRecord:
             self.templates, mh = lay.templates, lay.max_hits
             self.hits = arr(lay.off_hits, 2 * 2 * mh, np.int32).reshape(nb, 2, 2, mh)      # [block][template][idx | score][hit]
             self.max_hits = mh
+            # [block][candidate]{a_rel, valid, n[2], idx[2][eh], score[2][eh]}: the leading positions of would-be stash streams
+            ec, eh = lay.edge_candidates, lay.edge_hits
+            self.edges = arr(lay.off_edges, ec * (4 + 4 * eh), np.int32).reshape(nb, ec, 4 + 4 * eh) if ec else None
+            self.edge_hits = eh
 
     def block(self, b):
         """Block b as the dict ``receive_block`` returns."""
