@@ -154,7 +154,7 @@ def kfd_gpu_count():
         return None
 
 
-def chain_figures(local_rank, blocks_per_call=8, n_packets=90):
+def chain_figures(local_rank, blocks_per_call=None, n_packets=120):
     """The whole receive chain at the reference's own block geometry (config/base.json:13,33: blocks of 2^15 ... 2^17 samples, 64
     bins): host chunks of 2^14 samples in (examples/benchmark/bench_modem.py:32), page-locked window, H2D, A3 ... A13, result
     dicts out -- `recv_*`, the loop the reference's Demodulator_process runs (DP:284-338) -- and the same with the decoder in the
@@ -165,15 +165,17 @@ def chain_figures(local_rank, blocks_per_call=8, n_packets=90):
     bm = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bm)
     out = {}
+    per_call = blocks_per_call or {15: 16, 17: 8}             # about a millisecond of samples per device call at either size
     for log2n in (15, 17):
-        bm.run_snr('GMSK', 2, 12.0, log2n, 'transforms', 1, 64, blocks_per_call=blocks_per_call)          # handles, code objects, clock
-        for B, tag in ((blocks_per_call, ''), (1, '_b1')):
+        Bn = per_call[log2n] if isinstance(per_call, dict) else per_call
+        bm.run_snr('GMSK', 2, 12.0, log2n, 'transforms', 1, 64, blocks_per_call=Bn)          # handles, code objects, clock
+        out[f'chain_n{log2n}_blocks_per_call'] = Bn
+        for B, tag in ((Bn, ''), (1, '_b1')):
             for decode, name in ((True, 'chain'), (False, 'recv')):
                 r = bm.run_snr('GMSK', n_packets, 12.0, log2n, 'transforms', 2, 64, blocks_per_call=B, decode=decode)
                 out[f'{name}{tag}_n{log2n}_d64_msamples'] = round(r['ksamples_per_s'] / 1e3, 1)
                 if decode:
                     out[f'{name}{tag}_n{log2n}_d64_packets'] = f"{r['packets']}/{r['sent']}"
-    out['chain_blocks_per_call'] = blocks_per_call
     return out
 
 
