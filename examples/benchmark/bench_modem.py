@@ -32,28 +32,35 @@ def bandwidth(modulation, baud):
     return {'GMSK': baud / 0.7, 'BPSK': baud * 1.5, 'FSK': 2 * baud + 2 * (baud / 2), 'GFSK': 2 * baud + 2 * (baud / 2)}[modulation]
 
 
-def run_snr(modulation, n_runs, snr, block_size, search, seed, doppler_bins=64, pipelined=False, blocks_per_call=1, decode=True):
+def make_stream(modulation, n_runs, snr, block_size, seed):
+    """The stimulus of one SNR row: the bench packet sent ``n_runs`` times, each copy with fresh noise, and a noise-floor tail
+    that pushes the last packet through the overlap buffers.  Returns (samples complex64, payload bits, bandwidth)."""
     spSym, baud = 16, 9600
     fs = spSym * baud
+    sig, bit_data = sg.get_padded_packet(modulation, spSym, fs)
+    bw = bandwidth(modulation, baud)
+    snr_r = snr + 10 * np.log10(bw / fs)
+    rng = np.random.RandomState(seed)
+    N = 1 << block_size
+    parts = [sg.awgn(sig, snr_r, rng=rng).astype(np.complex64) for _ in range(n_runs)]
+    # push the last packet through the overlap buffers (noise floor only: an all-zero block has no Doppler pick)
+    parts.append((1e-3 * (rng.standard_normal(2 * N) + 1j * rng.standard_normal(2 * N))).astype(np.complex64))
+    return np.concatenate(parts), bit_data, bw
+
+
+def run_snr(modulation, n_runs, snr, block_size, search, seed, doppler_bins=64, pipelined=False, blocks_per_call=1, decode=True,
+            stimulus=None):
+    spSym, baud = 16, 9600
     pname = 'bench_' + modulation
     conf = cfg.bench_config(pname, blockSize=block_size, doppCarrierSteps=doppler_bins)
     if blocks_per_call > 1:         # B consecutive blocks per device call (mfb_receive_blocks_*)
         conf['GPU']['UHF'].setdefault('HIP', {})['blocks_per_call'] = int(blocks_per_call)
     proto = loadProtocol(pname)(conf=conf)
-    sig, bit_data = sg.get_padded_packet(modulation, spSym, fs)
-    bw = bandwidth(modulation, baud)
-    snr_r = snr + 10 * np.log10(bw / fs)
-    rng = np.random.RandomState(seed)
+    # the stimulus is made before the clock starts: the rate below is the receive chain's, not the noise generator's
+    stream, bit_data, bw = stimulus if stimulus is not None else make_stream(modulation, n_runs, snr, block_size, seed)
     run = DemodulatorRunner(conf, proto, 'UHF-H')
     if search != 'transforms':
         run.demod.bank.set_search_mode(search)
-    N = 1 << block_size
-
-    # the stimulus is made before the clock starts: the rate below is the receive chain's, not the noise generator's
-    parts = [sg.awgn(sig, snr_r, rng=rng).astype(np.complex64) for _ in range(n_runs)]
-    # push the last packet through the overlap buffers (noise floor only: an all-zero block has no Doppler pick)
-    parts.append((1e-3 * (rng.standard_normal(2 * N) + 1j * rng.standard_normal(2 * N))).astype(np.complex64))
-    stream = np.concatenate(parts)
     # the receive chain is long-lived in the reference (one Demodulator_process and one decoder process per run): what a new
     # decoder sets up once -- its device-side finder, page-locked staging -- is not part of the per-sample rate
     dec = Decoder(conf, proto)

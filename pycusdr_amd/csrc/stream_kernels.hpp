@@ -420,40 +420,51 @@ __global__ void __launch_bounds__(256) k_stream_edges(StreamArgs a) {
     const int nh = usable ? min(sc->sync_count[0], a.max_hits) : 0;
     const int32_t *hidx = reinterpret_cast<const int32_t *>(rec + a.off_hits);
     const int vend = a.nOv + cum[b] + sc->a13_nwin;              // end of block b's stream in V
+    __shared__ int8_t lead[256];          // the first Tmax - 1 bits of the would-be stream
+    __shared__ int8_t taps[2][256];
+    if (usable)
+        for (int k = 0; k < 2; ++k)
+            if ((int)threadIdx.x < a.T[k]) taps[k][threadIdx.x] = a.tmpls[a.toff[k] + threadIdx.x];
     for (int c = 0; c < STREAM_EDGE_CANDS; ++c) {
         StreamEdge *e = out + c;
         const bool have = c < nh;
+        if (!have) {                     // (uniform over the workgroup)
+            if (threadIdx.x == 0) e->valid = 0;
+            continue;
+        }
         const int a_rel = have ? hidx[c] - a.T[0] + 1 - STREAM_EDGE_BACK : 0;
         const int av = cum[b] + a_rel;                           // start in V
         const int Tm = max(a.T[0], a.T[1]);
         const bool ok = have && av >= 0 && av + Tm - 1 <= vend;
+        __syncthreads();
+        if (ok && (int)threadIdx.x < Tm - 1) lead[threadIdx.x] = (int8_t)stream_v(a, av + (int)threadIdx.x, cum);
         __syncthreads();
         for (int k = 0; k < 2; ++k) {
             const int i = threadIdx.x;
             int score = 0;
             bool hit = false;
             if (ok && i < a.T[k] - 1) {
-                for (int q = 0; q <= i; ++q) score += (int)a.tmpls[a.toff[k] + q] * stream_v(a, av + i - q, cum);
+                const int8_t *tp = taps[k];
+                for (int q = 0; q <= i; ++q) score += (int)tp[q] * (int)lead[i - q];
                 hit = score >= a.thrs[k];
             }
-            s_flag[k][i] = hit ? score : INT32_MIN;
+            // ordered compaction: position = hits in the lower lanes of the wave + hits of the lower waves
+            const unsigned long long bal = __ballot(hit);
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+            if (lane == 0) s_flag[k][wv] = __popcll(bal);
+            __syncthreads();
+            int pos = __popcll(bal & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wv; ++w) pos += s_flag[k][w];
+            if (hit && pos < STREAM_EDGE_HITS) {
+                e->idx[k][pos] = i;
+                e->score[k][pos] = score;
+            }
+            if (threadIdx.x == 0) e->n[k] = s_flag[k][0] + s_flag[k][1] + s_flag[k][2] + s_flag[k][3];
         }
         __syncthreads();
         if (threadIdx.x == 0) {
             e->a_rel = a_rel;
             e->valid = ok ? 1 : 0;
-            for (int k = 0; k < 2; ++k) {
-                int n = 0;
-                for (int i = 0; ok && i < a.T[k] - 1; ++i)
-                    if (s_flag[k][i] != INT32_MIN) {
-                        if (n < STREAM_EDGE_HITS) {
-                            e->idx[k][n] = i;
-                            e->score[k][n] = s_flag[k][i];
-                        }
-                        ++n;
-                    }
-                e->n[k] = n;
-            }
             if (e->n[0] > STREAM_EDGE_HITS || e->n[1] > STREAM_EDGE_HITS) e->valid = 0;
         }
     }
