@@ -185,6 +185,165 @@ def chain_figures(local_rank, blocks_per_call=None, n_packets=240):
     return out
 
 
+def segment_roofline_core(info, Dl, Mu, launches, kernel_ms_total):
+    """fp32-vector roofline of the segment kernel from its own launch durations (HIP events on the library's stream)."""
+    L, V, Q = 1 << info['log2L'], info['valid_per_segment'], info['segments']
+    fl = seg_flops(Dl, Q, Mu, L, V)
+    launches = max(launches, 1)
+    k_avg_s = kernel_ms_total / launches * 1e-3
+    return {'bound': 'valu_fp32', 'kernel': f'{info.get("kernel", "k_seg")}<{L},REDUCE> ({V} valid outputs of {L}, {Q} segments per bin)',
+            'achieved': round(fl / k_avg_s / 1e12, 2), 'peak': VALU_FP32_PEAK / 1e12, 'unit': 'TFLOP/s',
+            'frac': round(fl / k_avg_s / VALU_FP32_PEAK, 4), 'launches': launches, 'avg_launch_ms': round(k_avg_s * 1e3, 4),
+            'flops_per_launch': fl}
+
+
+def bank_figure(dev, local_rank, protocol, D, log2N, blocks, esz, nblocks, steps=10, warmup=2):
+    """Untimed-region figure of another BASELINE bank on the same device: its own handle, the same step as the headline
+    (forward FFT, search over D bins, pick, 8-byte read-back), HIP-event kernel time, the same flop formula."""
+    import torch
+    from pycusdr_amd import config as cfg
+    from pycusdr_amd.mfbank import MFBank
+    from pycusdr_amd.protocol import loadProtocol
+    N, ov = 1 << log2N, 1 << 10
+    if protocol == 'CC11xx':
+        conf, sps, msz = cfg.cc11xx_config(blockSize=log2N, doppCarrierSteps=D, device=local_rank), 128, 3
+    else:
+        conf, sps, msz = cfg.bench_config(protocol, blockSize=log2N, doppCarrierSteps=D, device=local_rank), 16, (5 if protocol == 'bench_BPSK' else 3)
+    rr, shifts = widen_range_rate(conf, 'UHF-H', N, D)
+    conf['Radios']['rangeRateMax'] = rr
+    proto = loadProtocol(protocol)(conf=conf)
+    t0 = time.perf_counter()
+    M, masks = proto.get_filter(N, sps, msz)
+    t_gen = time.perf_counter() - t0
+    bank = MFBank(log2N, D, M, window_width=7, sum_all_masks=True, device=local_rank)
+    try:
+        t0 = time.perf_counter()
+        bank.set_filters(masks)
+        t_set = time.perf_counter() - t0
+        bank.set_shifts(shifts)
+        info = bank.get_search_path()
+        Mu = bank.get_info()[2]
+
+        def one(i):
+            bank.upload_device(blocks.data_ptr() + (i % nblocks) * esz)
+            return bank.find_carrier()
+        # untimed: at least `warmup` steps and at least 50 ms of them -- building the handle (filter generation and analysis on
+        # the host) left the device idle, and it needs ~30 ms of work to settle its clock again (tools/ramp_probe.py)
+        t_w, i = time.perf_counter(), 0
+        while i < 1 + warmup or time.perf_counter() - t_w < 0.05:
+            one(i)
+            i += 1
+        settle = i
+        torch.cuda.synchronize(dev)
+        bank.profile_enable(True)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one(i)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        counts, kms = bank.profile_read()
+        bank.profile_enable(False)
+        out = {'protocol': protocol, 'D': D, 'M': M, 'M_unique': Mu, 'samplesPerSym': sps, 'taps': info['taps'], 'path': info,
+               'steps': steps, 'untimed_steps_before': settle, 'ms_per_step': round(dt * 1e3, 4), 'msamples': round((N - ov) / dt / 1e6, 2),
+               'filter_generation_s': round(t_gen, 2), 'mfb_set_filters_s': round(t_set, 2),
+               'rangeRateMax_used': rr, 'signal': 'S1 blocks of the headline (throughput only: the stimulus does not match this bank)'}
+        if info['path'] == 'segment':
+            out['roofline'] = segment_roofline_core(info, D, Mu, counts[0], kms[0])
+        return out
+    finally:
+        bank.close()
+
+
+def run_block_shard(args, dist, rank, G, local_rank, dev):
+    """--shard blocks: the time-chunk sharding product path (pycusdr_amd.dist.BlockShard).  Every GPU holds the full D-bin
+    bank; rank r runs the device stages (A3..A11) of blocks r, r + G, ...; rank 0 runs the sequential host stages (A12, A13)
+    and the decoder (A14) in block order on what the owners hand back (one point-to-point message per block, no
+    collective).  One step = G blocks, one per rank; value = samples of all blocks / wall time of the ordered chain."""
+    import torch
+    from pycusdr_amd import config as cfg, signals as sg
+    from pycusdr_amd.decoder import Decoder
+    from pycusdr_amd.demodulator_process import DemodulatorRunner
+    from pycusdr_amd.dist import BlockShard
+    from pycusdr_amd.protocol import loadProtocol
+    log2N, ov = args.log2n, 1 << 10
+    N = 1 << log2N
+    conf = cfg.bench_config(args.protocol, blockSize=log2N, overlap=10, doppCarrierSteps=args.bins, device=local_rank)
+    rr, shifts = widen_range_rate(conf, 'UHF-H', N, args.bins)
+    conf['Radios']['rangeRateMax'] = rr
+    proto = loadProtocol(args.protocol)(conf=conf)
+    runner = DemodulatorRunner(conf, proto, 'UHF-H')
+    group = dist.new_group(backend='gloo') if args.backend == 'nccl' else None     # the hand-back moves host arrays
+    shard = BlockShard(group=group)
+    nblocks = 16
+    stream = sg.s1_stream(nblocks, N, ov, 'GMSK', 16, 153600, snr_db=10.0, seed=1)
+    host_blocks = np.stack([stream[b * (N - ov): b * (N - ov) + N] for b in range(nblocks)])
+    blocks = torch.from_numpy(host_blocks.view(np.float32).reshape(nblocks, 2 * N)).to(dev)
+    esz = blocks.element_size() * 2 * N
+    torch.cuda.synchronize(dev)
+    decoder = Decoder(conf, proto) if rank == 0 else None
+
+    def feed(i):
+        return runner.feed_resident(blocks.data_ptr() + (i % nblocks) * esz)
+
+    def feed_begin(i):
+        runner.feed_resident_begin(blocks.data_ptr() + (i % nblocks) * esz)
+
+    def skip(i):
+        runner.count += 1
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    from pycusdr_amd.dist import StepWatchdog
+    dog = StepWatchdog(args.watchdog, rank=rank, describe=shard.describe) if args.watchdog > 0 else None
+    shard.run(runner, range((1 + args.warmup) * G), decoder=decoder, feed=feed, skip=skip, watchdog=dog, feed_begin=feed_begin)
+    barrier()
+    runner.demod.bank.profile_enable(True)
+    t0 = time.perf_counter()
+    res, packets = shard.run(runner, range(args.steps * G), decoder=decoder, feed=feed, skip=skip, watchdog=dog, feed_begin=feed_begin)
+    barrier()
+    if dog is not None:
+        dog.stop()
+    elapsed = time.perf_counter() - t0
+    counts, kms = runner.demod.bank.profile_read()
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    pinfo = runner.demod.bank.get_search_path()
+    Mu = runner.demod.bank.get_info()[2]
+    props = torch.cuda.get_device_properties(dev)
+    rank_devices = [None] * G
+    dist.all_gather_object(rank_devices, {'rank': rank, 'device': local_rank, 'uuid': str(getattr(props, 'uuid', '')), 'name': props.name})
+    if rank == 0:
+        nb = args.steps * G
+        host_ms = float(np.mean([d['time_ms'] for d in res])) if res else None
+        out = {'metric': 'IQ Msamples/sec through Doppler matched-filter bank (256 bins, 2^20 chunk)',
+               'value': round(nb * (N - ov) / elapsed / 1e6, 3), 'unit': 'Msamples/s', 'n_gpus': G, 'steps': args.steps,
+               'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': f'block round-robin (BlockShard): each of {G} GPUs runs the full D={args.bins} bank of {args.protocol} '
+                                      f'(N=2^{log2N}) on every {G}th block -- search, pick, matched filters at the found shift, symbol '
+                                      f'decisions, bit lookup and alignment (the previous block\'s tail comes from its owner) --, rank 0 '
+                                      f'runs the decoder in block order; blocks resident in HBM, two point-to-point messages per block, no collective',
+                          'shard': 'blocks', 'world_size': G, 'backend': args.backend, 'blocks_timed': nb, 'path': pinfo,
+                          'rccl_world': dist.get_world_size() if args.backend == 'nccl' else None, 'rank_devices': rank_devices,
+                          'distinct_devices': len({(d['device'], d['uuid']) for d in rank_devices}),
+                          'packets_found': len(packets), 'mean_block_ms_device_plus_host_on_root': host_ms,
+                          'root_ms_per_block': round(shard.stats['root_s'] / max(shard.stats['root_blocks'], 1) * 1e3, 4),
+                          'root_wait_ms_per_block': round(shard.stats['root_wait_s'] / max(shard.stats['root_blocks'], 1) * 1e3, 4),
+                          'owner_host_ms_per_own_block': round(shard.stats['host_s'] / max(shard.stats['own_blocks'], 1) * 1e3, 4),
+                          'root_note': 'root_ms_per_block: result dict + decoder, the only work the root does for EVERY block (root_wait_ms_per_block: '
+                                       'time it sat in the receive of a block that had not arrived yet); '
+                                       'owner_host_ms_per_own_block: tail exchange + bit lookup + alignment + hand-over, done by each owner for its own blocks',
+                          'units': 'samples of the one physical stream (every block is processed once)'},
+               'roofline': segment_roofline_core(pinfo, args.bins, Mu, counts[0], kms[0]) if pinfo['path'] == 'segment' else None,
+               'cpu_baseline': None}
+        print(json.dumps(out), flush=True)
+    runner.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def run_blocks_leg(args, dist, rank, G, local_rank, dev, steps=6, warmup=2):
     """After the bins-mode loop of an N > 1 job: a short leg of the OTHER sharding axis of SURVEY 8(e) in the same job -- every GPU
     runs the full 256-bin bank on every G-th time block (pycusdr_amd.dist.BlockShard, no collective on the data path) -- and,
