@@ -80,8 +80,8 @@ with open(f'profiles/{rnd}_pmc_summary.md', 'w') as f:
     f.write("\nAll three are compute-bound kernels (`roofline.bound = valu_fp32`); their HBM-side traffic is three orders below the two-pass formulation's\n"
             "34.45 GB per block (SURVEY 8d) because no length-N intermediate exists on this path: the 8.39 MB block once, one float per (bin, filter,\n"
             "slot) of partial sums, the segment spectra from L2.  `profiles/pmc_traffic.json` carries these traffic figures into `roofline.traffic` of\n"
-            "the bench line (labelled as stored from this profile).  The two-pass fallback has a file of its own (`r04_pmc_twopass.md`); the\n"
-            "2048-point kernel's cost table, A/B runs and taps sweeps are in `r04_long_filter.md`.\n")
+            f"the bench line (labelled as stored from this profile).  The two-pass fallback has a file of its own (`{rnd}_pmc_twopass.md`); the\n"
+            f"2048-point kernel's cost table, A/B runs and taps sweeps are in `r04_long_filter.md`, the costed LDS-DMA variant in `r05_long_filter.md`.\n")
 p = 'profiles/pmc_traffic.json'
 d = json.load(open(p))
 keys = {'': ('segment_D256_M8_N20_L8', 'k_seg<256,REDUCE,13> + masked tail'), '_cc': ('segment_D256_M8_N20_L11', 'bench.py --protocol CC11xx: k_seg<2048,REDUCE,26> (wave-local) + masked tail'),
