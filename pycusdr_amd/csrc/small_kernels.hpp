@@ -381,8 +381,10 @@ struct BlockScalars {
     // ... and A14 on the stream without a stash
     int sync_valid;        // 1: sync_count / the hit lists are those of the last numBitsOverlap bits before the block + its bits
     int sync_count[2];
+    int a13_prev_npost;    // bits the previous block left behind its window (a13_status 2: the operand numpy could not broadcast)
+    int pad_;
 };
-static_assert(sizeof(BlockScalars) == 160 && sizeof(BlockScalars) <= 256, "BlockScalars: the record head (the Python side mirrors this layout)");
+static_assert(sizeof(BlockScalars) == 168 && sizeof(BlockScalars) <= 256, "BlockScalars: the record head (the Python side mirrors this layout)");
 
 // Python's slice(a, b).indices(N) for step 1; has_a / has_b = 0 stand for None
 DEVI void slice_indices(int has_a, int a, int has_b, int b, int N, int *start, int *len) {

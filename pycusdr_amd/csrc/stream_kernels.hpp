@@ -35,6 +35,9 @@ struct StreamEdge {              // the first T - 1 positions of the stream that
 
 #define A13_DEVICE 1             // a13_status: the record holds the block's final arrays
 #define A13_HOST 0               //             the host runs A12 / A13 for this block (irregular case)
+#define A13_RAISED 2             //             final arrays too; the alignment's first comparison has operands of unequal length
+                                 //             (fewer than `offset` bits behind the previous window: 128 samples per symbol with a 2^10-sample
+                                 //             overlap, config/CC11xx.json) -- numpy raises, the reference logs and carries on (DB:965-967)
 
 struct StreamCarry {             // what the next batch's first block needs of this batch's last one
     int valid;                   // 0: unknown (the last block was irregular, or nothing was seeded): the first block goes to the host
@@ -196,6 +199,8 @@ __global__ void __launch_bounds__(256) k_stream_align(StreamArgs a) {
         if (!me.ok || !p_known) status = A13_HOST;
         else if (noerr > a.err_thr) {
             // "pass": no alignment (DB:925)
+        } else if (have_prev && min(o, p_npost) != min(o, me.end - me.start)) {
+            status = A13_RAISED;          // prev_post[:o] == win[:o] cannot be formed: exception, nothing is adjusted
         } else if (have_prev) {
             if (p_npost < o + 1 || p_nend != o + 1 || me.start < o + 1 || me.count - me.end > STREAM_POST_MAX) status = A13_HOST;
             else {
@@ -228,20 +233,21 @@ __global__ void __launch_bounds__(256) k_stream_align(StreamArgs a) {
                 }
             }
         }
-        if (status == A13_DEVICE && me.nbits - me.end > STREAM_POST_MAX) status = A13_HOST;
+        if (status != A13_HOST && me.nbits - me.end > STREAM_POST_MAX) status = A13_HOST;
         s_start = start;
         sc->a13_status = status;
         sc->a13_start = start;
         sc->a13_end = me.end;
-        sc->a13_nwin = status == A13_DEVICE ? me.end - start : 0;
+        sc->a13_nwin = status != A13_HOST ? me.end - start : 0;
         sc->a13_noerr = noerr;
-        sc->a13_npost = status == A13_DEVICE ? me.nbits - me.end : 0;
-        sc->a13_nend = status == A13_DEVICE ? o + 1 : 0;
+        sc->a13_npost = status != A13_HOST ? me.nbits - me.end : 0;
+        sc->a13_nend = status != A13_HOST ? o + 1 : 0;
+        sc->a13_prev_npost = p_npost;
         sc->sync_valid = 0;              // (k_stream_sync, when it runs, says otherwise)
         sc->sync_count[0] = sc->sync_count[1] = 0;
     }
     __syncthreads();
-    const bool dev = sc->a13_status == A13_DEVICE;
+    const bool dev = sc->a13_status != A13_HOST;
     const int start = s_start;
     // ---- the caller's three arrays, the block's own tail ----
     if (dev) {
@@ -297,7 +303,7 @@ __global__ void __launch_bounds__(256) k_stream_sync(StreamArgs a) {
         for (int i = 0; i < a.nb && i < 64; ++i) {
             cum[i] = run;
             const BlockScalars *s = reinterpret_cast<const BlockScalars *>(a.rec0 + (size_t)i * a.rec);
-            if (i <= b) ok = ok && s->a13_status == A13_DEVICE;
+            if (i <= b) ok = ok && s->a13_status != A13_HOST;
             run += s->a13_nwin;
         }
         cum[a.nb < 64 ? a.nb : 64] = run;
@@ -381,7 +387,7 @@ __global__ void __launch_bounds__(256) k_stream_ring(StreamArgs a) {
         for (int i = 0; i < a.nb && i < 64; ++i) {
             cum[i] = run;
             const BlockScalars *s = reinterpret_cast<const BlockScalars *>(a.rec0 + (size_t)i * a.rec);
-            ok = ok && s->a13_status == A13_DEVICE;
+            ok = ok && s->a13_status != A13_HOST;
             run += s->a13_nwin;
         }
         cum[a.nb < 64 ? a.nb : 64] = run;

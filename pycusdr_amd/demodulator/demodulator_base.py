@@ -426,7 +426,9 @@ class Demodulator:
                     if nrzs:
                         post, end = post.view(np.bool_), end.view(np.bool_)
                     # (the kept bits / centres mod 256 / trust bytes, the block's own tail, the tail the device assumed in front of it)
-                    rec['_a13'] = (R.bits[b, :nw], R.cen8[b, :nw], R.trust[b, :nw], post, end, prev_export)
+                    # (status 2: numpy could not form the alignment's first comparison -- the reference's log line goes out with the block)
+                    raised = (min(self.overlapOffset, s['a13_prev_npost'][b]), min(self.overlapOffset, nw)) if s['a13_status'][b] == 2 else None
+                    rec['_a13'] = (R.bits[b, :nw], R.cen8[b, :nw], R.trust[b, :nw], post, end, prev_export, raised)
                     prev_export = (post, end)
                 else:
                     prev_export = None
@@ -653,14 +655,18 @@ class Demodulator:
         if a13 is not None and prev_tail is None and not getattr(self, '_stream_dirty', True) and not len(rec['clipped']):
             # the device ran A12 / A13 for this block (stream_kernels.hpp) in front of the tail a13[5]; that must be THIS object's
             # state -- the arrays the previous device block left here, or equal ones
-            bits, cen8, trust8, post, end, assumed = a13
+            bits, cen8, trust8, post, end, assumed, raised = a13
             mine = (self.poswinP, getattr(self, 'posSymEnd', None))
             if assumed is not None and ((mine[0] is assumed[0] and mine[1] is assumed[1]) or
                                         (mine[1] is not None and assumed[1] is not None and np.array_equal(mine[0], assumed[0])
                                          and np.array_equal(mine[1], assumed[1]))):
+                if raised is not None:      # the reference logs the failed comparison and carries on (DB:965-967)
+                    log.error('symbol overlap failed. reason: %s',
+                              'operands could not be broadcast together with shapes (%d,) (%d,) ' % raised)
                 self.poswinP, self.posSymEnd = post, end
                 self.stage_blocks = getattr(self, 'stage_blocks', 0) + 1        # blocks whose A12 / A13 the device did
-                return bits, cen8, trust8, rec['spSym']
+                # (copies: what the caller keeps must not keep the whole batch's record alive)
+                return bits.copy(), cen8.copy(), trust8.copy(), rec['spSym']
         if getattr(self, '_stages', False):
             self._stream_dirty = True        # this block goes through the host code: the device's chain is broken until it is seeded again
         spSym, idxSymbol, centres, trustSymbol = rec['spSym'], rec['symbols'], rec['centres'], rec['trust']

@@ -19,11 +19,11 @@ def _ptr(a):
 BLOCK_SCALARS = np.dtype({
     'names': ['frac', 'spSym', 'codeOffset', 'pick', 'cr', 'spSymF', 'offsetF', 'shift', 'low', 'high', 'pick_valid', 'count',
               'rate_fallback', 'band', 'band_len', 'a13_status', 'a13_start', 'a13_end', 'a13_nwin', 'a13_noerr', 'a13_npost',
-              'a13_nend', 'sync_valid', 'sync_count'],
+              'a13_nend', 'sync_valid', 'sync_count', 'a13_prev_npost'],
     'formats': ['<f8', '<f8', '<f8', ('<f4', 2), ('<f4', 3), '<f4', '<f4', '<i4', '<i4', '<i4', '<i4', '<i4', '<i4', ('<i4', (2, 2, 2)),
-                ('<i4', 2), '<i4', '<i4', '<i4', '<i4', '<i4', '<i4', '<i4', '<i4', ('<i4', 2)],
-    'offsets': [0, 8, 16, 24, 32, 44, 48, 52, 56, 60, 64, 68, 72, 76, 108, 116, 120, 124, 128, 132, 136, 140, 144, 148],
-    'itemsize': 160})
+                ('<i4', 2), '<i4', '<i4', '<i4', '<i4', '<i4', '<i4', '<i4', '<i4', ('<i4', 2), '<i4'],
+    'offsets': [0, 8, 16, 24, 32, 44, 48, 52, 56, 60, 64, 68, 72, 76, 108, 116, 120, 124, 128, 132, 136, 140, 144, 148, 156],
+    'itemsize': 168})
 
 
 class BatchRecord:

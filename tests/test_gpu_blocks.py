@@ -249,3 +249,43 @@ def test_batch_errors():
             d.beginBlocks(0, 2)                 # batches run on the segment path
     finally:
         d.close()
+
+
+def test_cc11xx_stream_with_blocks_per_call():
+    """The production protocol (config/CC11xx.json: FSK-2 at 128 samples per symbol, 384-tap filters -> 2048-point segments, IF offset,
+    numBitsOverlap 2048, a 64-tap header mask and a 32-tap sync flag, FIXED packets of 2136 bits) through the batched loop with the
+    stream stages on the device, against the one-block loop: result dicts, bits, trust, packets (with their CRC flags), alignment state."""
+    from pycusdr_amd.protocol.CC11xx import frame_bits
+    bs, sps, B = 17, 128, 3
+    N, ov = 1 << bs, 1 << 10
+    step = N - ov
+    conf = cfg.cc11xx_config(blockSize=bs, doppCarrierSteps=48, samplesPerSym=sps)
+    p = loadProtocol('CC11xx')(conf=conf)
+    rs = np.random.RandomState(4)
+    fs = 7416 * sps
+    nblocks = 10
+    frames = [frame_bits(rs.randint(0, 256, 200).astype(np.uint8), preamble=(0xAA,) * 10) for _ in range(8)]
+    bits = np.concatenate([np.concatenate((f, rs.randint(0, 2, 300).astype(f.dtype))) for f in frames])
+    sig = sg.modulateFSK(bits, sps)
+    sig = np.tile(sig, -(-(nblocks * step) // len(sig)))[:nblocks * step]
+    sig = sg.awgn(sig * np.exp(2j * np.pi * 148320 / fs * np.arange(len(sig))), 12.0, rng=np.random.RandomState(2)).astype(np.complex64)
+    confB = copy.deepcopy(conf)
+    confB['GPU']['UHF'].setdefault('HIP', {})['blocks_per_call'] = B
+    a, b = DemodulatorRunner(conf, p, 'UHF-H'), DemodulatorRunner(confB, p, 'UHF-H')
+    da, db = Decoder(conf, p), Decoder(conf, p)
+    try:
+        ra, pa = a.run_stream((sig[i:i + 30000] for i in range(0, len(sig), 30000)), decoder=da)
+        rb, pb = b.run_stream((sig[i:i + 30000] for i in range(0, len(sig), 30000)), decoder=db)
+        assert len(ra) == len(rb) == nblocks
+        for x, y in zip(ra, rb):
+            for k in ('doppler', 'doppler_std', 'SNR', 'spSymEst', 'numSyncSig'):
+                assert _same(x[k], y[k]), (x['count'], k)
+            assert _same(x['data'], y['data']) and _same(x['trust'], y['trust']), x['count']
+        assert len(pa) == len(pb) >= 3
+        for u, v in zip(pa, pb):
+            assert _same(u.bits, v.bits) and u.frameStartIdx == v.frameStartIdx
+        assert _same(a.demod.poswinP, b.demod.poswinP) and _same(da.bitsOverlapBuf, db.bitsOverlapBuf)
+        assert b.demod.stage_blocks >= nblocks - 2 and db.ahead_blocks >= nblocks - 2
+    finally:
+        a.close()
+        b.close()

@@ -57,6 +57,8 @@ def soak(cycles=40, per=30, long_blocks=4000, budget_s=None, min_cycles=12, log=
     for c in range(cycles):
         pname = protos[c % len(protos)]
         conf = cfg.bench_config(pname, blockSize=bs, doppCarrierSteps=32 + 16 * (c % 3))
+        if c % 4 >= 2:              # every other pair of cycles: several blocks per device call, the stream stages on the device
+            conf['GPU']['UHF'].setdefault('HIP', {})['blocks_per_call'] = 3 + c % 5
         proto = loadProtocol(pname)(conf=conf)
         run = DemodulatorRunner(conf, proto, 'UHF-H')
         dec = Decoder(conf, proto)
@@ -93,10 +95,29 @@ def soak(cycles=40, per=30, long_blocks=4000, budget_s=None, min_cycles=12, log=
     log(f'long stream: {len(res)} blocks, {len(pk)} packets, {len(res) * step / dt / 1e6:.0f} Msamples/s; device {a[0] - b[0]:+.1f} MiB, '
         f'rss {b[1] - a[1]:+.1f} MiB, fds {b[2] - a[2]:+d}')
     run.close()
-    out = {'cycles': done, 'device_mib_per_cycle': d_dev, 'rss_mib_per_cycle': d_rss, 'fds_per_cycle': d_fd,
+    # ... and the same with 16 blocks per device call (windows, batch buffers, block graphs per window / slot / parity, carries)
+    confB = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=64)
+    confB['GPU']['UHF'].setdefault('HIP', {})['blocks_per_call'] = 16
+    runB = DemodulatorRunner(confB, proto, 'UHF-H')
+    decB = Decoder(confB, proto)
+    decB.prepare()
+    runB.run_stream(stream(51), decoder=decB)
+    aB = snapshot()
+    t0 = time.perf_counter()
+    resB, pkB = runB.run_stream(stream(long_blocks), decoder=decB)
+    dtB = time.perf_counter() - t0
+    bB = snapshot()
+    log(f'long stream, 16 blocks per call: {len(resB)} blocks, {len(pkB)} packets, {len(resB) * step / dtB / 1e6:.0f} Msamples/s; '
+        f'device {aB[0] - bB[0]:+.1f} MiB, rss {bB[1] - aB[1]:+.1f} MiB, fds {bB[2] - aB[2]:+d}; stage blocks {getattr(runB.demod, "stage_blocks", 0)}')
+    runB.close()
+    same = len(resB) == len(res) and len(pkB) == len(pk) and all(np.array_equal(x['data'], y['data']) for x, y in zip(res[::97], resB[::97]))
+    out = {'batched_blocks': len(resB), 'batched_packets': len(pkB), 'batched_device_mib': aB[0] - bB[0], 'batched_fds': bB[2] - aB[2],
+           'batched_rss_mib': bB[1] - aB[1], 'batched_equals_one_block_loop': bool(same), 'batched_msamples': len(resB) * step / dtB / 1e6,
+           'cycles': done, 'device_mib_per_cycle': d_dev, 'rss_mib_per_cycle': d_rss, 'fds_per_cycle': d_fd,
            'long_blocks': len(res), 'long_packets': len(pk), 'long_device_mib': a[0] - b[0], 'long_rss_mib': b[1] - a[1],
            'long_fds': b[2] - a[2], 'long_msamples': len(res) * step / dt / 1e6}
-    out['ok'] = bool(abs(d_dev) < 0.5 and d_rss < 1.0 and d_fd < 0.5 and abs(out['long_device_mib']) < 8 and out['long_fds'] == 0)
+    out['ok'] = bool(abs(d_dev) < 0.5 and d_rss < 1.0 and d_fd < 0.5 and abs(out['long_device_mib']) < 8 and out['long_fds'] == 0
+                     and abs(out['batched_device_mib']) < 8 and out['batched_fds'] == 0 and same)
     return out
 
 
