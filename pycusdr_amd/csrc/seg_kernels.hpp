@@ -495,9 +495,12 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
 // critical path: they get the 2-wave budget (no spills).
 // (the masked forms of the wave-local 2048-point kernel hold 32 points, the spectrum, 31 twiddles AND the per-lane limits:
 // they get the whole register file -- one wave per SIMD -- instead of spilling 50 registers at the two-wave budget)
+// (so do the masked forms of the 4096-point kernel -- four-wave teams, one wave per SIMD is enough: STORE needed 260 registers and
+// spilled four of them to scratch at the two-wave budget; the 8192-point kernel's eight-wave team needs two waves per SIMD to
+// fit a CU at all, its masked REDUCE form keeps 26 registers in scratch)
 template <int L, int PV>
 struct SegWaves {
-    static constexpr int value = PV < 0 ? (SegCfg<L>::W32 ? 1 : 2) : SegCfg<L>::WAVES;
+    static constexpr int value = PV < 0 ? ((SegCfg<L>::W32 || L == 4096) ? 1 : 2) : SegCfg<L>::WAVES;
 };
 #define SEG_KERNEL_ATTRS(L_, PV_) \
     __launch_bounds__(SegCfg<L_>::BLOCK) __attribute__((amdgpu_waves_per_eu(SegWaves<L_, PV_>::value, SegWaves<L_, PV_>::value)))
