@@ -330,6 +330,13 @@ typedef struct mfb_record_layout {
             off_edges;
 } mfb_record_layout;
 int mfb_receive_blocks_end_record(mfb_ctx *ctx, int slot, void *dst, size_t capacity, mfb_record_layout *layout);
+/* Test seam of the stream stages: the same kernels on INJECTED symbol decisions -- counts[nb], and per block `symbols` entries of
+ * symbol index / centre / magnitude, as findCentres writes them (DB:996-1006) -- in front of the state the last mfb_stream_seed (or
+ * batch) left; the records come back as mfb_receive_blocks_end_record delivers them.  Lets a test drive the alignment through
+ * planted +-1 slips, impossible transitions and irregular blocks and compare with the host's checkSymbolOverlap / extractBits*
+ * (DB:863-1051) bit for bit (tests/test_gpu_stream_stages.py).  Advances the device-side state like a batch. */
+int mfb_debug_stream_stages(mfb_ctx *ctx, int nb, int symbols, const int32_t *counts, const int32_t *sym, const int32_t *centres,
+                            const float *magnitude, void *dst, size_t capacity, mfb_record_layout *layout);
 /* Test seam of the one-call path.  mfb_receive_block moved two pieces of the reference's float64 HOST arithmetic onto the
  * device: the shift interpolation and the bounds of computeSNR's spectrum windows behind the pick (DB:609-620, 635-667), and
  * samples per symbol / code phase / clamp / symbol count behind the rate argmax (DB:733-752, 994-999).  This call runs exactly

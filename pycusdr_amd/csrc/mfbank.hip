@@ -2204,6 +2204,89 @@ extern "C" int mfb_stream_seed(mfb_ctx *c, const uint8_t *post, int npost, const
     return MFB_OK;
 }
 
+// Test seam of the stream stages (include/mfbank.h): k_stream_align / _sync / _ring / _edges on INJECTED symbol decisions.
+extern "C" int mfb_debug_stream_stages(mfb_ctx *c, int nb, int symbols, const int32_t *counts, const int32_t *sym, const int32_t *cen,
+                                       const float *mag, void *dst, size_t capacity, mfb_record_layout *lay) {
+    if (!c || nb < 1 || nb > 64 || symbols < 1 || !counts || !sym || !cen || !mag || !dst || !lay) return MFB_ERR_ARG;
+    if (!c->st_on) return MFB_ERR_STATE;
+    for (int s = 0; s < 2; ++s)
+        if (c->flight[s].active) return MFB_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t core = blkout_bytes(0, symbols), a1 = align16((size_t)symbols);
+    const size_t ext_bytes = 3 * a1 + STREAM_POST_MAX + STREAM_END_MAX + (size_t)STREAM_MAX_TMPL * 2 * STREAM_MAX_HITS * sizeof(int32_t) +
+                             align16(STREAM_EDGE_CANDS * sizeof(StreamEdge));
+    const size_t rec = core + ext_bytes;
+    if (capacity < rec * (size_t)nb) return MFB_ERR_ARG;
+    int rc = batch_reserve(c, nb > c->bat_cap ? nb : (c->bat_cap > 0 ? c->bat_cap : nb), rec);
+    if (rc) return rc;
+    if (rec * nb > c->batout_cap) return MFB_ERR_ALLOC;
+    std::vector<uint8_t> h(rec * (size_t)nb, 0);
+    const size_t off_sym = BLK_HEAD, arr = align16((size_t)symbols * sizeof(int));
+    for (int b = 0; b < nb; ++b) {
+        if (counts[b] < 0 || counts[b] > symbols) return MFB_ERR_ARG;
+        uint8_t *r = h.data() + (size_t)b * rec;
+        BlockScalars sc;
+        memset(&sc, 0, sizeof(sc));
+        sc.count = counts[b];
+        memcpy(r, &sc, sizeof(sc));
+        memcpy(r + off_sym, sym + (size_t)b * symbols, (size_t)symbols * sizeof(int));
+        memcpy(r + off_sym + arr, cen + (size_t)b * symbols, (size_t)symbols * sizeof(int));
+        memcpy(r + off_sym + 2 * arr, mag + (size_t)b * symbols, (size_t)symbols * sizeof(float));
+    }
+    HIPCHK(hipMemcpyAsync(c->d_batout, h.data(), h.size(), hipMemcpyHostToDevice, c->stream));
+    StreamArgs sa = c->st;
+    sa.rec0 = c->d_batout;
+    sa.rec = rec;
+    sa.off_sym = off_sym;
+    sa.off_cen = off_sym + arr;
+    sa.off_mag = off_sym + 2 * arr;
+    sa.off_bits = core;
+    sa.off_cenw = core + a1;
+    sa.off_trust = core + 2 * a1;
+    sa.off_post = core + 3 * a1;
+    sa.off_end = sa.off_post + STREAM_POST_MAX;
+    sa.off_hits = sa.off_end + STREAM_END_MAX;
+    sa.off_edges = sa.off_hits + (size_t)STREAM_MAX_TMPL * 2 * STREAM_MAX_HITS * sizeof(int32_t);
+    sa.nb = nb;
+    sa.carry_in = c->d_carry[c->carry_cur];
+    sa.carry_out = c->d_carry[1 - c->carry_cur];
+    hipLaunchKernelGGL(k_stream_align, dim3(nb), dim3(256), 0, c->stream, sa);
+    if (sa.K > 0) {
+        int Tmax = 0;
+        for (int t = 0; t < sa.K; ++t) Tmax = sa.T[t] > Tmax ? sa.T[t] : Tmax;
+        hipLaunchKernelGGL(k_stream_sync, dim3(sa.K, nb), dim3(256), (size_t)Tmax + SYNC_SEG + Tmax - 1, c->stream, sa);
+        hipLaunchKernelGGL(k_stream_ring, dim3(1), dim3(256), 0, c->stream, sa);
+        hipLaunchKernelGGL(k_stream_edges, dim3(nb), dim3(256), 0, c->stream, sa);
+    }
+    HIPCHK(hipGetLastError());
+    c->carry_cur = 1 - c->carry_cur;
+    HIPCHK(hipMemcpyAsync(dst, c->d_batout, rec * (size_t)nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memset(lay, 0, sizeof(*lay));
+    lay->nblocks = nb;
+    lay->record_bytes = (int64_t)rec;
+    lay->scalars_bytes = (int32_t)sizeof(BlockScalars);
+    lay->symbols = symbols;
+    lay->mode = MFB_BLOCK_SEARCH;
+    lay->off_bands = BLK_HEAD;
+    lay->off_sym = (int64_t)sa.off_sym;
+    lay->off_cen = (int64_t)sa.off_cen;
+    lay->off_mag = (int64_t)sa.off_mag;
+    lay->stream_stages = 1;
+    lay->off_bits = (int64_t)sa.off_bits;
+    lay->off_centres_u8 = (int64_t)sa.off_cenw;
+    lay->off_trust = (int64_t)sa.off_trust;
+    lay->off_post = (int64_t)sa.off_post;
+    lay->off_end = (int64_t)sa.off_end;
+    lay->off_hits = (int64_t)sa.off_hits;
+    lay->off_edges = (int64_t)sa.off_edges;
+    lay->edge_candidates = STREAM_EDGE_CANDS;
+    lay->edge_hits = STREAM_EDGE_HITS;
+    lay->max_hits = STREAM_MAX_HITS;
+    lay->templates = c->st.K;
+    return MFB_OK;
+}
+
 // Test seam of the one-call path (include/mfbank.h): block_pick_body / block_rate_body on injected device results.
 extern "C" int mfb_debug_block_scalars(mfb_ctx *c, int n, const float *picks, const float *triples, int spsym_min, int snr_window,
                                        int max_symbols, mfb_block_result *results, float *launch_args, int32_t *band_pieces) {

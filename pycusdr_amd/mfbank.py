@@ -453,6 +453,20 @@ class MFBank:
         _lib.check(self._lib.mfb_set_stream_stages(self._h, C.byref(P)), 'mfb_set_stream_stages')
         self._stages = True
 
+    def debug_stream_stages(self, counts, sym, cen, mag):
+        """Test seam (mfb_debug_stream_stages): the stream-stage kernels on injected symbol decisions int32 [nb][symbols] (centres,
+        float32 magnitudes alike; ``counts[b]`` valid entries) in front of the seeded state.  Returns a ``BatchRecord``."""
+        sym = np.ascontiguousarray(sym, dtype=np.int32)
+        cen = np.ascontiguousarray(cen, dtype=np.int32)
+        mag = np.ascontiguousarray(mag, dtype=np.float32)
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        nb, n = sym.shape
+        lay = _lib.RecordLayout()
+        buf = np.empty(nb * (8192 + 16 * n), np.uint8)
+        _lib.check(self._lib.mfb_debug_stream_stages(self._h, nb, n, _ptr(counts), _ptr(sym), _ptr(cen), _ptr(mag), _ptr(buf), buf.size,
+                                                     C.byref(lay)), 'mfb_debug_stream_stages')
+        return BatchRecord(buf, lay, True)
+
     def stream_seed(self, post, end, ring=None):
         """The state the next batch starts from: the previous block's tail (``post``: the bits behind its window, ``end``: the last
         overlap_offset + 1 bits inside it) and the last bits_overlap bits of the decoder's stream (``ring``; None: unknown)."""
