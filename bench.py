@@ -381,14 +381,23 @@ def run_blocks_leg(args, dist, rank, G, local_rank, dev, steps=6, warmup=2):
     def skip(i):
         runner.count += 1
 
+    # a hang in this leg must not cost the job its line: the watchdog turns it into exit status 3, and the fallback attempt of the
+    # launcher ladder runs without the leg (SAFE_MODE carries --no-blocks-leg)
+    from pycusdr_amd.dist import StepWatchdog
+    dog = StepWatchdog(args.watchdog, rank=rank, describe=lambda: 'time-chunk-sharded leg (run_blocks_leg)') if args.watchdog > 0 else None
+
     def measure(shard, members, n):
         dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         if members:
-            shard.run(runner, range(n), decoder=decoder, feed=feed, skip=skip, feed_begin=feed_begin)
+            shard.run(runner, range(n), decoder=decoder, feed=feed, skip=skip, feed_begin=feed_begin, watchdog=dog)
+        if dog is not None:
+            dog.beat()
         torch.cuda.synchronize(dev)
         dist.barrier()
+        if dog is not None:
+            dog.beat()
         return time.perf_counter() - t0
     shard = BlockShard(group=group)
     measure(shard, True, warmup * G)
@@ -397,6 +406,8 @@ def run_blocks_leg(args, dist, rank, G, local_rank, dev, steps=6, warmup=2):
     measure(one, rank == 0, warmup)
     t_one = measure(one, rank == 0, steps)
     runner.close()
+    if dog is not None:
+        dog.stop()
     if rank != 0:
         return None
     all_ms, one_ms = steps * G * (N - ov) / t_all / 1e6, steps * (N - ov) / t_one / 1e6
@@ -411,7 +422,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-SAFE_MODE = ['--single-comm', '--no-prefetch']
+SAFE_MODE = ['--single-comm', '--no-prefetch', '--no-blocks-leg']
 
 
 def _run_child(cmd, env):
@@ -460,7 +471,7 @@ def spawn_ranks(n, backend, argv):
                '--master-port', str(free_port()), os.path.abspath(__file__)] + argv + extra
         sys.stderr.write('bench.py: no launcher (WORLD_SIZE unset), starting ' + ' '.join(cmd) + '\n')
         return _run_child(cmd, env)
-    conservative = all(a in argv for a in SAFE_MODE)
+    conservative = all(a in argv for a in SAFE_MODE[:2])
     rc = launch([] if conservative or '--watchdog' in argv else ['--watchdog', '60'])
     if rc == 0 or conservative or '--shard' in argv and argv[argv.index('--shard') + 1] == 'blocks':
         return rc
@@ -479,7 +490,7 @@ def rank_supervisor(argv):
     env['BENCH_WORKER'] = '1'
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     me = [sys.executable, os.path.abspath(__file__)]
-    conservative = all(a in argv for a in SAFE_MODE)
+    conservative = all(a in argv for a in SAFE_MODE[:2])
     rc = _run_child(me + argv + ([] if conservative or '--watchdog' in argv else ['--watchdog', '60']), env)
     if rc == 0 or conservative or '--shard' in argv and argv[argv.index('--shard') + 1] == 'blocks':
         return rc

@@ -71,7 +71,7 @@ def test_bench_two_ranks_fall_back_to_the_conservative_mode(launcher):
     own) is made to fail -- the last rank never joins the first collective, the other rank's watchdog names it and exits 3 --,
     fresh ranks are started with --single-comm --no-prefetch, the run ends with status 0 and the line says which mode produced
     it.  Two gloo ranks on one GPU; once started by bench.py itself, once by the launcher the driver uses (then every rank
-    process supervises its own worker).  The same job reports the time-chunk-sharded leg."""
+    process supervises its own worker)."""
     args = ['--gpus', '2', '--backend', 'gloo', '--steps', '3', '--warmup', '1', '--log2n', '16', '--bins', '32', '--repeats', '2',
             '--watchdog', '8', '--no-cpu-baseline']
     bench = os.path.join(ROOT, 'bench.py')
@@ -97,8 +97,28 @@ def test_bench_two_ranks_fall_back_to_the_conservative_mode(launcher):
     assert d['n_gpus'] == 2 and d['value'] > 0 and c['world_size'] == 2
     assert c['dist_mode'].startswith('single-comm') and 'no-prefetch' in c['dist_mode']
     assert c['fallback_from'].startswith('default mode') and 'exit' in c['fallback_from']
-    assert c['blocks_stream_msamples'] > 0 and 0 < c['blocks_efficiency_vs_1gpu'] < 1.5
+    assert 'blocks_stream_msamples' not in c          # the fallback attempt runs without the time-chunk-sharded leg
     lead = _lead_is_flat(c)
-    for k in ('roofline_frac', 'dist_mode', 'fallback_from', 'blocks_stream_msamples', 'stream_msamples'):
+    for k in ('roofline_frac', 'dist_mode', 'fallback_from', 'stream_msamples'):
         assert k in lead[:20], (k, lead)
     assert 'fresh' in r.stderr          # the supervisor's notice that the default-mode ranks had left with a non-zero status
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_report_both_sharding_axes():
+    """An undisturbed two-rank job (gloo on one GPU): the default mode produces the line, and the same job carries the
+    time-chunk-sharded leg (SURVEY 8e's other axis) as flat keys among the first twenty."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '3', '--warmup', '1', '--log2n', '16',
+           '--bins', '32', '--repeats', '2', '--watchdog', '60', '--no-cpu-baseline']
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR', 'BENCH_WORKER', 'BENCH_FAIL_FIRST_ATTEMPT'):
+        env.pop(k, None)
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    c = d['config']
+    assert d['n_gpus'] == 2 and c['dist_mode'].startswith('concurrent-broadcast') and 'fallback_from' not in c
+    assert c['blocks_stream_msamples'] > 0 and 0 < c['blocks_efficiency_vs_1gpu'] < 1.5
+    lead = _lead_is_flat(c)
+    for k in ('roofline_frac', 'dist_mode', 'blocks_stream_msamples', 'blocks_efficiency_vs_1gpu', 'stream_msamples'):
+        assert k in lead[:20], (k, lead)
