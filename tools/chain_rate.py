@@ -12,7 +12,7 @@ bm = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(bm)
 bm.quiet_blas()          # numpy's BLAS workers must not spend the container's CPU quota (pycusdr_amd/hostcpu.py)
 log2N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 240
 D = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 mod = sys.argv[4] if len(sys.argv) > 4 else 'GMSK'
 Bs = [int(x) for x in sys.argv[5].split(',')] if len(sys.argv) > 5 else [1, 4, 8, 16]
