@@ -1631,6 +1631,7 @@ static int block_enqueue(mfb_ctx *c, const mfb_block_params *p, const BlkBufs &b
         sa.off_hits = sa.off_end + STREAM_END_MAX;
         sa.off_edges = sa.off_hits + (size_t)STREAM_MAX_TMPL * 2 * STREAM_MAX_HITS * sizeof(int32_t);
         sa.nb = nb;
+        sa.nsym = nthreads;
         sa.carry_in = c->d_carry[bb.parity];
         sa.carry_out = c->d_carry[1 - bb.parity];
         hipLaunchKernelGGL(k_stream_align, dim3(nb), dim3(256), 0, c->stream, sa);
@@ -2248,6 +2249,7 @@ extern "C" int mfb_debug_stream_stages(mfb_ctx *c, int nb, int symbols, const in
     sa.off_hits = sa.off_end + STREAM_END_MAX;
     sa.off_edges = sa.off_hits + (size_t)STREAM_MAX_TMPL * 2 * STREAM_MAX_HITS * sizeof(int32_t);
     sa.nb = nb;
+    sa.nsym = symbols;
     sa.carry_in = c->d_carry[c->carry_cur];
     sa.carry_out = c->d_carry[1 - c->carry_cur];
     hipLaunchKernelGGL(k_stream_align, dim3(nb), dim3(256), 0, c->stream, sa);

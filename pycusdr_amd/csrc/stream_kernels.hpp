@@ -56,6 +56,7 @@ struct StreamArgs {
     size_t off_bits, off_cenw, off_trust;    // uint8[nwin] each (A13 outputs)
     size_t off_post, off_end, off_hits, off_edges;
     int nb, N, ovw;              // blocks, block length, overlap / 2
+    int nsym;                    // entries the symbol / centre / magnitude arrays of a record hold
     int o, thr, err_thr;         // overlapOffset, match threshold, symbol_check_error_threshold
     int mode;                    // 1: bit LUT (uint8[rows]); 2: NRZ-S LUT (int32[rows][2][succ])
     int rows, succ;
@@ -131,7 +132,9 @@ __global__ void __launch_bounds__(256) k_stream_align(StreamArgs a) {
     auto window = [&](const uint8_t *r, BlockWindow &w, int *noerr) {
         const BlockScalars *s = reinterpret_cast<const BlockScalars *>(r);
         const int *sym = reinterpret_cast<const int *>(r + a.off_sym), *cen = reinterpret_cast<const int *>(r + a.off_cen);
-        w.count = s->count;
+        // (a count beyond what the record holds -- the rate fallback k* = 0, DB:737-740 -- is the host's business)
+        const bool fits = s->count <= a.nsym;
+        w.count = fits ? s->count : 0;
         w.nbits = a.mode == 1 ? w.count : w.count - 1;
         w.start = first_true(w.count, [&](int x) { return cen[x] >= a.ovw; }, &s_slot);
         w.end = first_true(w.count, [&](int x) { return cen[x] > a.N - a.ovw; }, &s_slot);
