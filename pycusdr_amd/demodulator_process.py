@@ -241,7 +241,12 @@ class DemodulatorRunner:
             return self.run((None for chunk in chunk_source for _ in asm.push(chunk)), sink=sink, decoder=decoder)
         B = self.blocks_per_call() if blocks_per_call is None else max(1, int(blocks_per_call))
         if B > 1:       # (a batch of ONE block is slower than the one-block loop below: 211 against 254 Msamples/s at 2^15 x 64 -- more launches)
-            return self._run_stream_batched(chunk_source, sink, decoder, B)
+            bank = self.demod.bank
+            if bank.get_search_path()['path'] == 'segment' and bank.get_search_mode() == 'transforms':
+                return self._run_stream_batched(chunk_source, sink, decoder, B)
+            # batches run on the segment search path (filters with a short impulse response: every shipped protocol) and the
+            # default search mode: anything else takes the one-block loop
+            log.warning('[%s]: blocks_per_call = %d ignored: the filter bank / search mode of this handle runs one block per call', self.radioName, B)
         # Overlapped form: block i is on the device while this thread runs the sequential host stages and the decoder of
         # block i-1 and assembles block i+1 in the other page-locked buffer.  Same calls in the same order on the same data
         # as the plain loop, so the same results; only the waiting moves.

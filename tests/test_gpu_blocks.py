@@ -227,6 +227,28 @@ def test_device_stream_stages_equal_the_host_stages(mod, pname, bs, D, snr):
             r.close()
 
 
+def test_batches_fall_back_to_the_one_block_loop_where_they_do_not_apply():
+    """A handle on the two-pass search path (filters without a short impulse response) or in the opt-in energy search mode runs
+    one block per call whatever ``blocks_per_call`` says: same results, a warning."""
+    bs, ov = 14, 1 << 10
+    N = 1 << bs
+    conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=16)
+    confB = copy.deepcopy(conf)
+    confB['GPU']['UHF'].setdefault('HIP', {}).update(blocks_per_call=4, search_path='twopass')
+    conf['GPU']['UHF'].setdefault('HIP', {}).update(search_path='twopass')
+    p = loadProtocol('bench_GMSK')(conf=conf)
+    sig = sg.s1_stream(7, N, ov, 'GMSK', snr_db=10.0, seed=2)[ov:]
+    a, b = DemodulatorRunner(conf, p, 'UHF-H'), DemodulatorRunner(confB, p, 'UHF-H')
+    try:
+        ra, _ = a.run_stream([sig])
+        rb, _ = b.run_stream([sig])
+        assert len(ra) == len(rb) == 7 and all(_same(x['data'], y['data']) and _same(x['SNR'], y['SNR']) for x, y in zip(ra, rb))
+        assert getattr(b.demod, 'stage_blocks', 0) == 0
+    finally:
+        a.close()
+        b.close()
+
+
 def test_batch_errors():
     bs = 15
     conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=8)

@@ -110,7 +110,6 @@ def test_alignment_and_bits_equal_the_host_code_on_planted_slips(mode, pname, se
             s = R.s
             for i, blk in enumerate(group):
                 b = b0 + i
-                start_before = None
                 got, err = _host_block(host, blk)
                 st = s['a13_status'][i]
                 if b in irregular:
@@ -130,7 +129,6 @@ def test_alignment_and_bits_equal_the_host_code_on_planted_slips(mode, pname, se
                 cnt, _, cen, _ = blk
                 first = int(np.argmax(cen[:cnt] >= OV // 2))
                 moved += int(s['a13_start'][i] != first)
-                del start_before
         # the planted slips were really repaired on the device (a slip right behind an irregular block goes to the host with it)
         assert moved >= 4, moved
         assert device_blocks >= nblocks - 2 * len(irregular) - 2 and host_blocks >= len(irregular), (device_blocks, host_blocks)
@@ -184,7 +182,6 @@ def test_sync_hits_ring_and_edges_equal_np_convolve():
                     a_rel = int(hdr[cidx]) - len(t0) + 1 - 20
                     assert E[cidx, 0] == a_rel
                     start = base + a_rel
-                    ok = start >= len(seq) - nOv - (len(seq) - nOv) * 0 and start + len(t0) - 1 <= len(full)
                     if not E[cidx, 1]:
                         continue
                     assert start >= 0
@@ -197,7 +194,6 @@ def test_sync_hits_ring_and_edges_equal_np_convolve():
                         assert np.array_equal(E[cidx, 4 + k * eh:4 + k * eh + n], want)
                         assert np.array_equal(E[cidx, 4 + 2 * eh + k * eh:4 + 2 * eh + k * eh + n], sc[want])
                     checked_edges += 1
-                    del ok
                 seq = full
         assert checked_edges >= 8
     finally:
