@@ -78,6 +78,51 @@ def run_snr(modulation, n_runs, snr, block_size, search, seed, doppler_bins=64, 
                 ksamples_per_s=nsamp / dt / 1e3, blocks=len(results))
 
 
+def make_cc11xx_stream(n_frames, snr, block_size, seed, payload_bytes=200):
+    """A stream for the reference's production protocol (config/CC11xx.json): ``n_frames`` CC11xx frames (preamble, sync word,
+    whitened length | payload | CRC, as its TX framer builds them) of random payloads, 2-FSK at 128 samples per symbol on the
+    148.32 kHz IF offset, gaps of random bits between them, AWGN; a noise-floor tail pushes the last frame through the overlap."""
+    from pycusdr_amd.protocol.CC11xx import frame_bits
+    sps, fs = 128, 7416 * 128
+    rs = np.random.RandomState(seed)
+    payloads = [rs.randint(0, 256, payload_bytes).astype(np.uint8) for _ in range(n_frames)]
+    bits = np.concatenate([np.concatenate((rs.randint(0, 2, 64).astype(np.uint8), frame_bits(pl, preamble=(0xAA,) * 10)))
+                           for pl in payloads])
+    sig = sg.modulateFSK(bits, sps)
+    sig = sig * np.exp(2j * np.pi * 148320 / fs * np.arange(len(sig)))
+    N = 1 << block_size
+    sig = sg.awgn(sig, snr, rng=rs).astype(np.complex64)
+    tail = (1e-3 * (rs.standard_normal(2 * N) + 1j * rs.standard_normal(2 * N))).astype(np.complex64)
+    return np.concatenate((sig, tail)), payloads
+
+
+def run_cc11xx(n_frames, snr, block_size, doppler_bins=64, blocks_per_call=1, decode=True, stimulus=None, seed=3):
+    """The receive chain on the CC11xx geometry of config/CC11xx.json (FSK-2, 128 samples per symbol -> 384-tap filters, IF offset,
+    64 bins): samples in, frames out; a frame counts when its de-whitened payload equals one that was sent."""
+    conf = cfg.cc11xx_config(blockSize=block_size, doppCarrierSteps=doppler_bins, samplesPerSym=128)
+    if blocks_per_call > 1:
+        conf['GPU']['UHF'].setdefault('HIP', {})['blocks_per_call'] = int(blocks_per_call)
+    proto = loadProtocol('CC11xx')(conf=conf)
+    proto.CRC_CHECK = 'framer'        # the stimulus is a TX-framer frame: its CRC sits inside the length-counted bytes
+    stream, payloads = stimulus if stimulus is not None else make_cc11xx_stream(n_frames, snr, block_size, seed)
+    run = DemodulatorRunner(conf, proto, 'UHF-H')
+    dec = Decoder(conf, proto)
+    dec.prepare()
+    t0 = time.perf_counter()
+    results, packets = run.run_stream((stream[i:i + CHUNK] for i in range(0, len(stream), CHUNK)), decoder=dec if decode else None)
+    dt = time.perf_counter() - t0
+    run.close()
+    sent = {pl.tobytes() for pl in payloads}
+    good = 0
+    for pk in packets:
+        try:
+            data, crc_err, _ = pk.getBinaryData()
+        except Exception:       # noqa: BLE001 -- a false header on noise: not a frame
+            continue
+        good += (not crc_err) and np.asarray(data[:-2], dtype=np.uint8).tobytes() in sent
+    return dict(frames=int(good), sent=len(payloads), packets=len(packets), ksamples_per_s=len(stream) / dt / 1e3, blocks=len(results))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('modulation', choices=['GMSK', 'FSK', 'BPSK', 'GFSK'])
