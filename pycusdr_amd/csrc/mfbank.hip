@@ -63,6 +63,7 @@ struct BlockFlight {      // one block -- or one batch of nb blocks -- between m
     unsigned long long seq;
 };
 
+constexpr int WG_NB = 32;
 struct BlockGraph {
     hipGraph_t graph;
     hipGraphExec_t exec;
@@ -149,7 +150,9 @@ struct mfb_ctx {
     float *d_envb, *d_sumb, *d_resb, *d_crb;   // envelopes [B][N], doppSum [B][Dtot][M], picks [B][2], rate triples [B][3]
     uint8_t *d_batout;            // result records [B][rec]
     size_t batout_cap;
-    BlockGraph wgraph[2][2][2];   // [window][slot][carry parity]
+    // [window][slot][carry parity][blocks of the batch]: a receive loop that takes whatever is complete (1 ... B blocks per call)
+    // keeps one recorded graph per batch size it has met twice; sizes above WG_NB share entry 0 (recorded again when the size changes)
+    BlockGraph wgraph[2][2][2][WG_NB + 1];
     // the integer stages behind the symbol decisions on the device (stream_kernels.hpp; mfb_set_stream_stages): A12 bit lookup,
     // A13 block-overlap alignment, A14 sync search on the stream without a stash -- batches only
     bool st_on;
@@ -511,7 +514,8 @@ extern "C" int mfb_destroy(mfb_ctx *c) {
         for (auto &g : row) graph_drop(g);
     for (auto &row : c->wgraph)
         for (auto &col : row)
-            for (auto &g : col) graph_drop(g);
+            for (auto &par : col)
+                for (auto &g : par) graph_drop(g);
     for (int i = 0; i < 2; ++i) {
         if (c->h_blk[i]) (void)hipHostFree(c->h_blk[i]);
         if (c->ev_blk[i]) (void)hipEventDestroy(c->ev_blk[i]);
@@ -1758,7 +1762,8 @@ static int staging_reserve(mfb_ctx *c, int slot, size_t need) {
     if (need <= c->blk_cap[slot]) return MFB_OK;
     for (auto &row : c->bgraph) graph_drop(row[slot]);
     for (auto &row : c->wgraph)
-        for (auto &g : row[slot]) graph_drop(g);
+        for (auto &par : row[slot])
+            for (auto &g : par) graph_drop(g);
     if (c->h_blk[slot]) HIPCHK(hipHostFree(c->h_blk[slot]));
     c->h_blk[slot] = nullptr;
     c->blk_cap[slot] = 0;
@@ -2016,7 +2021,7 @@ extern "C" int mfb_receive_blocks_begin(mfb_ctx *c, const mfb_block_params *p, i
     const bool allowed = win_in && graphs_allowed() && !c->prof;
     mfb_block_params q = *p;
     q.block_stride = stride;
-    rc = graph_or_launch(c, c->wgraph[which][slot][parity], &q, nblocks, allowed,
+    rc = graph_or_launch(c, c->wgraph[which][slot][parity][nblocks <= WG_NB ? nblocks : 0], &q, nblocks, allowed,
                          [&]() { return block_enqueue(c, &q, bb, c->h_blk[slot], nthreads, bcap, capacity, &shift); });
     if (rc) return rc;
     if (stages) c->carry_cur = 1 - parity;        // this batch's tail and ring are the next batch's start

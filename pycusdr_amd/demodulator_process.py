@@ -226,7 +226,7 @@ class DemodulatorRunner:
         Pipelined form: the stages run in threads, so blocks travel as copies through a SigFIFO."""
         if pipelined:
             from .sigFIFO import SigFIFO
-            fifo = SigFIFO(chunk_source, self.samplesPerSlice)
+            fifo = SigFIFO((c for c in chunk_source if c is not None), self.samplesPerSlice)
 
             def blocks():
                 while True:
@@ -238,7 +238,7 @@ class DemodulatorRunner:
         from .sigFIFO import BlockAssembler
         if not (overlapped and self.radioBackend == 'UHF' and getattr(self.demod, '_one_call', False)):
             asm = BlockAssembler(self.raw, self.overlap)
-            return self.run((None for chunk in chunk_source for _ in asm.push(chunk)), sink=sink, decoder=decoder)
+            return self.run((None for chunk in chunk_source if chunk is not None for _ in asm.push(chunk)), sink=sink, decoder=decoder)
         B = self.blocks_per_call() if blocks_per_call is None else max(1, int(blocks_per_call))
         if B > 1:       # (a batch of ONE block is slower than the one-block loop below: 211 against 254 Msamples/s at 2^15 x 64 -- more launches)
             bank = self.demod.bank
@@ -306,6 +306,13 @@ class DemodulatorRunner:
 
         try:
             for chunk in chunk_source:
+                if chunk is None:
+                    # "nothing more right now" (see _run_stream_batched): the block in flight does not wait for the next one
+                    if flying is not None:
+                        fl, flying = flying, None
+                        collect(fl)
+                    finish_search()
+                    continue
                 for _ in asm.push(chunk):
                     self.demod.beginBlock(cur, source=names[cur])
                     started = (cur, self.count, time.time())
@@ -339,6 +346,21 @@ class DemodulatorRunner:
             self.raw = bufs[cur]         # where the next block would be assembled
         return results, packets
 
+    @staticmethod
+    def drain_marked(poll, wait):
+        """A chunk source for ``run_stream`` from a live transport: ``poll()`` returns the next chunk or None at once, ``wait()``
+        blocks for the next chunk and returns None when the stream has ended.  Yields every chunk that is there, then a ``None``
+        marker ("nothing more right now") before it blocks -- so a backlog goes through in batches of up to blocks_per_call
+        blocks and a quiet source gets each block out as soon as it is complete."""
+        while True:
+            chunk = poll()
+            if chunk is None:
+                yield None
+                chunk = wait()
+                if chunk is None:
+                    return
+            yield chunk
+
     def _run_stream_batched(self, chunk_source, sink, decoder, B):
         """``run_stream`` with B consecutive blocks per device call (``"HIP": {"blocks_per_call": B}``; mfb_receive_blocks_*).
         The reference's loop hands the device one block per turn (DP:284-338); at its own block sizes (2^15 ... 2^17 samples,
@@ -347,7 +369,10 @@ class DemodulatorRunner:
         neighbours is shared storage, the carry happens once per window), the window goes through one set of launches while the
         host stages and the decoder of the previous window's blocks run, and the blocks come out one by one in stream order:
         the same result dicts, bits and packets as the one-block loop.  At the end of the source the complete blocks of the
-        last, partly filled window are processed as a shorter batch."""
+        last, partly filled window are processed as a shorter batch -- and so they are whenever the source yields ``None``
+        ("nothing more right now"): a live source that puts a ``None`` where it would block gets B blocks per call while it has
+        a backlog and every block out as soon as it is complete while it has not (``drain_marked`` builds such a source from
+        a poll function)."""
         from .sigFIFO import WindowAssembler
         wins = self.demod.blockWindows(B)
         names = ('window', 'window2')
@@ -452,6 +477,18 @@ class DemodulatorRunner:
 
         try:
             for chunk in chunk_source:
+                if chunk is None:
+                    # the source has nothing more RIGHT NOW (a live radio between two chunks): do not wait for a full window --
+                    # the complete blocks go out as a shorter batch, the batch in flight is collected, and a source that is
+                    # slower than the device sees the one-block latency of the reference's loop (DP:284-338) again
+                    if asm.complete_blocks():
+                        launch(asm.complete_blocks())
+                    if flying is not None:
+                        fl, flying = flying, None
+                        collect(fl)
+                    if not batch_dec:
+                        finish_search()
+                    continue
                 for nb in asm.push(chunk):
                     launch(nb)
             if asm.complete_blocks():

@@ -189,6 +189,85 @@ def test_batched_stream_equals_one_block_stream(B):
         b.close()
 
 
+@pytest.mark.parametrize('with_decoder', [True, False])
+def test_a_live_source_gets_every_complete_block_out_at_its_markers(with_decoder):
+    """A source that yields ``None`` where it would block ("nothing more right now", ``DemodulatorRunner.drain_marked``): the
+    complete blocks go out as a shorter batch at every marker -- batches of 0 ... B blocks in one stream, one recorded graph per
+    batch size -- and nothing waits for a full window.  Same dicts, bits and packets as the one-block loop; the one-block loop
+    and the pipelined form skip the markers."""
+    bs, ov, B = 15, 1 << 10, 6
+    N = 1 << bs
+    conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=32)
+    p = loadProtocol('bench_GMSK')(conf=conf)
+    nblocks = 31
+    sig = sg.s1_stream(nblocks, N, ov, 'GMSK', snr_db=10.0, seed=8)[ov:]
+    rs = np.random.RandomState(4)
+    cuts = np.sort(rs.choice(np.arange(1, len(sig) // 4096), 14, replace=False)) * 4096
+    chunks = [sig[i:i + 4096] for i in range(0, len(sig), 4096)]
+
+    def live():
+        """The stream in 4096-sample chunks through drain_marked: the transport runs dry at 14 random places."""
+        DRY = object()
+        items = []
+        for i, c in enumerate(chunks):
+            if i * 4096 in cuts:
+                items.append(DRY)
+            items.append(c)
+        items.reverse()
+
+        def wait():
+            while items and items[-1] is DRY:
+                items.pop()
+            return items.pop() if items else None
+
+        def poll():
+            if items and items[-1] is DRY:
+                items.pop()
+                return None
+            return wait()
+        return DemodulatorRunner.drain_marked(poll, wait)
+
+    confB = copy.deepcopy(conf)
+    confB['GPU']['UHF'].setdefault('HIP', {})['blocks_per_call'] = B
+    a, b = DemodulatorRunner(conf, p, 'UHF-H'), DemodulatorRunner(confB, p, 'UHF-H')
+    try:
+        da, db = (Decoder(conf, p), Decoder(conf, p)) if with_decoder else (None, None)
+        ra, pa = a.run_stream(live(), decoder=da)                       # one-block loop: markers collect the block in flight
+        sizes = []
+        inner = b.demod.beginBlocks
+        b.demod.beginBlocks = lambda which, nb, **kw: (sizes.append(nb), inner(which, nb, **kw))[1]
+        delivered_at_marker = []
+        out = []
+
+        def marked():
+            for c in live():
+                if c is None:
+                    yield None
+                    delivered_at_marker.append(len(out))               # what had been delivered when the loop came back for more
+                else:
+                    yield c
+        rb, pb = b.run_stream(marked(), decoder=db, sink=out.append)
+        rb = out
+        assert len(ra) == len(rb) == nblocks
+        for x, y in zip(ra, rb):
+            assert x['count'] == y['count']
+            for k in ('doppler', 'doppler_std', 'SNR', 'spSymEst', 'baudrate_est', 'rangerate') + (('numSyncSig',) if with_decoder else ()):
+                assert _same(x[k], y[k]), (x['count'], k)
+            assert _same(x['data'], y['data']) and _same(x['trust'], y['trust']), x['count']
+        assert len(pa) == len(pb) and all(_same(u.bits, v.bits) for u, v in zip(pa, pb))
+        assert sum(sizes) == nblocks and max(sizes) <= B and len(set(sizes)) >= 3, sizes
+        # at every marker every block that was complete had been delivered: nothing is held back for a fuller window
+        step = N - ov
+        for cut, n in zip(cuts, delivered_at_marker):
+            assert n == cut // step, (cut, n)
+        # the pipelined form takes the same source
+        rc, _ = a.run_stream(live(), pipelined=True)
+        assert len(rc) == nblocks
+    finally:
+        a.close()
+        b.close()
+
+
 @pytest.mark.parametrize('mod,pname,bs,D,snr', [('GMSK', 'bench_GMSK', 15, 32, 8.0), ('FSK', 'bench_FSK', 15, 16, 12.0),
                                                  ('GFSK', 'bench_GFSK', 14, 16, 12.0), ('BPSK', 'bench_BPSK', 15, 24, 10.0)])
 def test_device_stream_stages_equal_the_host_stages(mod, pname, bs, D, snr):
