@@ -1568,6 +1568,18 @@ extern "C" int mfb_demodulate(mfb_ctx *c, int shift, int k_offset, int k_len, fl
 // The same launches take a BATCH of bb.nb consecutive blocks of one window of samples (mfb_receive_blocks_*): every kernel
 // gets a block index in its grid, nothing else changes -- a block's numbers are those of the one-block call, bit for bit.
 // The launches of one block / batch, from the forward FFT to the ONE device-to-host copy of the result record(s).
+// A14 for the blocks of a batch: one packed launch (search + would-be stash edges + ring) where the templates allow it
+static void stream_search_launch(mfb_ctx *c, const StreamArgs &sa, int nb, int Tmax) {
+    const size_t words = (size_t)((STREAM_PACK_TAPS + sa.T[0] - 1 + STREAM_EDGE_BACK + sa.nOv + sa.nsym + 31) >> 5) + STREAM_PACK_TAPS / 32 + 4;
+    static const bool unpacked = getenv("MFB_STREAM_UNPACKED") != nullptr;       // (A/B switch of tools/chain_kernels.sh)
+    if (sa.packed && words * 4 <= 60 * 1024 && !unpacked) {
+        hipLaunchKernelGGL(k_stream_search, dim3(nb), dim3(256), words * 4, c->stream, sa);
+        return;
+    }
+    hipLaunchKernelGGL(k_stream_sync, dim3(sa.K, nb), dim3(256), (size_t)Tmax + SYNC_SEG + Tmax - 1, c->stream, sa);
+    hipLaunchKernelGGL(k_stream_ring, dim3(1), dim3(256), 0, c->stream, sa);
+    hipLaunchKernelGGL(k_stream_edges, dim3(nb), dim3(256), 0, c->stream, sa);
+}
 static int block_enqueue(mfb_ctx *c, const mfb_block_params *p, const BlkBufs &bb, uint8_t *h_dst, int nthreads, int bcap, int capacity,
                          int *shift_out) {
     int rc;
@@ -1643,9 +1655,7 @@ static int block_enqueue(mfb_ctx *c, const mfb_block_params *p, const BlkBufs &b
         if (sa.K > 0) {
             int Tmax = 0;
             for (int t = 0; t < sa.K; ++t) Tmax = sa.T[t] > Tmax ? sa.T[t] : Tmax;
-            hipLaunchKernelGGL(k_stream_sync, dim3(sa.K, nb), dim3(256), (size_t)Tmax + SYNC_SEG + Tmax - 1, c->stream, sa);
-            hipLaunchKernelGGL(k_stream_ring, dim3(1), dim3(256), 0, c->stream, sa);
-            hipLaunchKernelGGL(k_stream_edges, dim3(nb), dim3(256), 0, c->stream, sa);
+            stream_search_launch(c, sa, nb, Tmax);
             HIPCHK(hipGetLastError());
         }
     }
@@ -2175,6 +2185,20 @@ extern "C" int mfb_set_stream_stages(mfb_ctx *c, const mfb_stream_params *p) {
         a.toff[t] = (int)taps;
         taps += (size_t)a.T[t];
     }
+    // the packed search (k_stream_search) takes templates of up to STREAM_PACK_TAPS taps in {-1, 0, +1}
+    a.packed = a.K > 0;
+    memset(a.P, 0, sizeof(a.P));
+    memset(a.Q, 0, sizeof(a.Q));
+    for (int t = 0; t < a.K && a.packed; ++t) {
+        const int8_t *tp = p->templates + a.toff[t];
+        if (a.T[t] > STREAM_PACK_TAPS) a.packed = 0;
+        for (int q = 0; q < a.T[t] && a.packed; ++q) {
+            const int j = a.T[t] - 1 - q;                   // window element the tap multiplies
+            if (tp[q] == 1) a.P[t][j >> 5] |= 1u << (j & 31);
+            else if (tp[q] == -1) a.Q[t][j >> 5] |= 1u << (j & 31);
+            else if (tp[q] != 0) a.packed = 0;
+        }
+    }
     if (taps) {
         HIPCHK(dev_alloc((void **)&c->d_sttmpl, taps));
         HIPCHK(hipMemcpy(c->d_sttmpl, p->templates, taps, hipMemcpyHostToDevice));
@@ -2261,9 +2285,7 @@ extern "C" int mfb_debug_stream_stages(mfb_ctx *c, int nb, int symbols, const in
     if (sa.K > 0) {
         int Tmax = 0;
         for (int t = 0; t < sa.K; ++t) Tmax = sa.T[t] > Tmax ? sa.T[t] : Tmax;
-        hipLaunchKernelGGL(k_stream_sync, dim3(sa.K, nb), dim3(256), (size_t)Tmax + SYNC_SEG + Tmax - 1, c->stream, sa);
-        hipLaunchKernelGGL(k_stream_ring, dim3(1), dim3(256), 0, c->stream, sa);
-        hipLaunchKernelGGL(k_stream_edges, dim3(nb), dim3(256), 0, c->stream, sa);
+        stream_search_launch(c, sa, nb, Tmax);
     }
     HIPCHK(hipGetLastError());
     c->carry_cur = 1 - c->carry_cur;

@@ -25,6 +25,7 @@
 #define STREAM_NOV_MAX 4096      // numBitsOverlap <= 4096 (CC11xx: 2048)
 #define STREAM_EDGE_CANDS 4      // header hits per block whose would-be stash start gets its first T - 1 positions searched
 #define STREAM_EDGE_HITS 8
+#define STREAM_PACK_TAPS 256    // longest template the packed search takes (bench: 128 / 16 taps, CC11xx: 64 / 32)
 #define STREAM_EDGE_BACK 20      // the decoder keeps 20 bits in front of a stashed candidate (decoder.py:258)
 struct StreamEdge {              // the first T - 1 positions of the stream that would start at the stash of one header hit
     int a_rel;                   // its start relative to the block's stream without a stash (may be negative)
@@ -68,6 +69,10 @@ struct StreamArgs {
     int K, nOv, max_hits;
     int T[STREAM_MAX_TMPL], thrs[STREAM_MAX_TMPL], toff[STREAM_MAX_TMPL];
     const int8_t *tmpls;
+    // templates of at most STREAM_PACK_TAPS taps in {-1, 0, +1} (every shipped decoder: 2 * bits - 1): bit masks of the +1 / -1
+    // taps in WINDOW order (bit j of word k = tap T - 1 - (32 k + j)), for k_stream_search
+    int packed;
+    uint32_t P[STREAM_MAX_TMPL][STREAM_PACK_TAPS / 32], Q[STREAM_MAX_TMPL][STREAM_PACK_TAPS / 32];
 };
 
 // A12 on the fly: dataBits[x] of a block from its symbol indices; *bad = the transition is impossible (NRZ-S) or the index is
@@ -475,6 +480,174 @@ __global__ void __launch_bounds__(256) k_stream_edges(StreamArgs a) {
             e->a_rel = a_rel;
             e->valid = ok ? 1 : 0;
             if (e->n[0] > STREAM_EDGE_HITS || e->n[1] > STREAM_EDGE_HITS) e->valid = 0;
+        }
+    }
+}
+
+// ---- A14, packed: search, would-be stash edges and ring of a block in ONE workgroup -------------------------------------------
+// The block's stream (with the T0 - 1 + 20 bits in front of it that a would-be stash may start in) is packed into LDS, one bit per
+// bit, by wave ballots; a score is then popcount(window & P) - popcount(window & Q) over ceil(T / 32) words (exact for taps in
+// {-1, 0, +1}) instead of T multiply-adds on bytes.  Every thread owns a contiguous run of positions: one count pass, one
+// workgroup scan, one write pass -- hits in order, no atomics, no segment loop.  Same records as k_stream_sync + k_stream_ring +
+// k_stream_edges (which stay for templates the packing does not take).
+DEVI int packed_score(const uint32_t *zw, int s, const uint32_t *P, const uint32_t *Q, int K, int valid_from) {
+    const int w0 = s >> 5, sh = s & 31;
+    int acc = 0;
+    uint32_t lo = zw[w0];
+    for (int k = 0; k < K; ++k) {
+        const uint32_t hi = zw[w0 + k + 1];
+        uint32_t w = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
+        const int m = valid_from - 32 * k;            // window elements below valid_from lie in front of the stream's first bit: absent
+        if (m > 0) w &= m >= 32 ? 0u : (~0u << m);
+        acc += __popc(w & P[k]) - __popc(w & Q[k]);
+        lo = hi;
+    }
+    return acc;
+}
+
+__global__ void __launch_bounds__(256) k_stream_search(StreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t zw[];
+    __shared__ int cum[65];
+    __shared__ int s_valid, s_nh, s_h0[STREAM_EDGE_CANDS];
+    __shared__ int wsum[4];
+    __shared__ uint32_t s_P[STREAM_MAX_TMPL][STREAM_PACK_TAPS / 32], s_Q[STREAM_MAX_TMPL][STREAM_PACK_TAPS / 32];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < STREAM_MAX_TMPL * (STREAM_PACK_TAPS / 32)) {
+        s_P[tid / (STREAM_PACK_TAPS / 32)][tid % (STREAM_PACK_TAPS / 32)] = a.P[tid / (STREAM_PACK_TAPS / 32)][tid % (STREAM_PACK_TAPS / 32)];
+        s_Q[tid / (STREAM_PACK_TAPS / 32)][tid % (STREAM_PACK_TAPS / 32)] = a.Q[tid / (STREAM_PACK_TAPS / 32)][tid % (STREAM_PACK_TAPS / 32)];
+    }
+    uint8_t *rec = a.rec0 + (size_t)b * a.rec;
+    BlockScalars *sc = reinterpret_cast<BlockScalars *>(rec);
+    StreamEdge *edges = reinterpret_cast<StreamEdge *>(rec + a.off_edges);
+    if (tid == 0) {
+        int run = 0, ok = a.carry_in->ring_valid && a.carry_in->ring_len == a.nOv && a.nb <= 64;
+        for (int i = 0; i < a.nb && i < 64; ++i) {
+            cum[i] = run;
+            const BlockScalars *s = reinterpret_cast<const BlockScalars *>(a.rec0 + (size_t)i * a.rec);
+            if (i <= b) ok = ok && s->a13_status != A13_HOST;
+            run += s->a13_nwin;
+        }
+        cum[a.nb < 64 ? a.nb : 64] = run;
+        s_valid = ok;
+    }
+    __syncthreads();
+    if (!s_valid) {
+        if (tid == 0) {
+            sc->sync_valid = 0;
+            for (int t = 0; t < a.K; ++t) sc->sync_count[t] = 0;
+            if (b == a.nb - 1) {
+                a.carry_out->ring_valid = 0;
+                a.carry_out->ring_len = a.nOv;
+            }
+        }
+        if (tid < STREAM_EDGE_CANDS) edges[tid].valid = 0;
+        return;
+    }
+    const int nwin = sc->a13_nwin, L = a.nOv + nwin, base = cum[b];
+    const int back = a.T[0] - 1 + STREAM_EDGE_BACK;
+    const int exb = base < back ? base : back;                   // bits in front of the stream that exist in V
+    const int org = STREAM_PACK_TAPS + exb;                      // packed index of the stream's position 0
+    const int nwords = ((org + L + 31) >> 5) + STREAM_PACK_TAPS / 32 + 2;
+    for (int g = wv; 2 * g < nwords; g += 4) {
+        const int x = 64 * g + lane - org;
+        const int v = (x >= -exb && x < L) ? stream_v(a, base + x, cum) : 0;
+        const unsigned long long bal = __ballot(v != 0);
+        if (lane == 0) {
+            zw[2 * g] = (uint32_t)bal;
+            zw[2 * g + 1] = (uint32_t)(bal >> 32);
+        }
+    }
+    __syncthreads();
+    for (int t = 0; t < a.K; ++t) {
+        const int T = a.T[t], thr = a.thrs[t], K = (T + 31) >> 5;
+        int32_t *oi = reinterpret_cast<int32_t *>(rec + a.off_hits) + (size_t)t * 2 * a.max_hits, *os = oi + a.max_hits;
+        const int outLen = L + T - 1, ppt = (outLen + 255) >> 8;
+        const int i0 = tid * ppt, i1 = min(i0 + ppt, outLen);
+        int cnt = 0;
+        for (int i = i0; i < i1; ++i) cnt += packed_score(zw, org + i - (T - 1), s_P[t], s_Q[t], K, T - 1 - i) >= thr ? 1 : 0;
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        __syncthreads();                                          // (wsum of the previous template has been read)
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int pos = incl - cnt, total = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wv) pos += wsum[w];
+            total += wsum[w];
+        }
+        if (cnt)
+            for (int i = i0; i < i1; ++i) {
+                const int v = packed_score(zw, org + i - (T - 1), s_P[t], s_Q[t], K, T - 1 - i);
+                if (v >= thr) {
+                    if (pos < a.max_hits) {
+                        oi[pos] = i;
+                        os[pos] = v;
+                    }
+                    if (t == 0 && pos < STREAM_EDGE_CANDS) s_h0[pos] = i;
+                    ++pos;
+                }
+            }
+        if (tid == 0) {
+            sc->sync_valid = 1;
+            sc->sync_count[t] = total;
+        }
+        if (t == 0 && tid == 0) s_nh = total;                         // header hits, for the edges below
+        __syncthreads();
+    }
+    // ---- the leading T - 1 positions of the streams a FIXED-mode decoder would restart at (see k_stream_edges) ----
+    const bool usable = a.K == 2;
+    const int nh = usable ? min(s_nh, a.max_hits) : 0;
+    const int Tm = max(a.T[0], a.K == 2 ? a.T[1] : 0);
+    for (int c = 0; c < STREAM_EDGE_CANDS; ++c) {
+        StreamEdge *e = edges + c;
+        if (c >= nh) {                   // (uniform over the workgroup)
+            if (tid == 0) e->valid = 0;
+            continue;
+        }
+        const int a_rel = s_h0[c] - a.T[0] + 1 - STREAM_EDGE_BACK;
+        const bool ok = base + a_rel >= 0 && a_rel + Tm - 1 <= L;
+        int n[2];
+        for (int k = 0; k < 2; ++k) {
+            const int T = a.T[k];
+            int score = 0;
+            bool hit = false;
+            if (ok && tid < T - 1) {
+                // position tid of the stream that starts at a_rel: its window ends at a_rel + tid and has tid + 1 elements
+                score = packed_score(zw, org + a_rel + tid - (T - 1), s_P[k], s_Q[k], (T + 31) >> 5, T - 1 - tid);
+                hit = score >= a.thrs[k];
+            }
+            const unsigned long long bal = __ballot(hit);
+            __syncthreads();
+            if (lane == 0) wsum[wv] = __popcll(bal);
+            __syncthreads();
+            int pos = __popcll(bal & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wv; ++w) pos += wsum[w];
+            if (hit && pos < STREAM_EDGE_HITS) {
+                e->idx[k][pos] = tid;
+                e->score[k][pos] = score;
+            }
+            n[k] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        }
+        if (tid == 0) {
+            e->a_rel = a_rel;
+            e->n[0] = n[0];
+            e->n[1] = n[1];
+            e->valid = ok && n[0] <= STREAM_EDGE_HITS && n[1] <= STREAM_EDGE_HITS ? 1 : 0;
+        }
+    }
+    // ---- the ring for the next batch: the last numBitsOverlap bits of the stream so far = of the last block's stream ----
+    if (b == a.nb - 1) {
+        if (tid == 0) {
+            a.carry_out->ring_valid = 1;
+            a.carry_out->ring_len = a.nOv;
+        }
+        for (int q = tid; q < a.nOv; q += 256) {
+            const int idx = org + nwin + q;
+            a.carry_out->ring[q] = (uint8_t)((zw[idx >> 5] >> (idx & 31)) & 1u);
         }
     }
 }

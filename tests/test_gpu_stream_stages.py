@@ -137,19 +137,22 @@ def test_alignment_and_bits_equal_the_host_code_on_planted_slips(mode, pname, se
         host.close()
 
 
-def test_sync_hits_ring_and_edges_equal_np_convolve():
+@pytest.mark.parametrize('taps,thr,seed', [((40, 12), (9, 5), 5), ((128, 16), (20, 7), 6), ((33, 64), (8, 11), 7), ((256, 31), (23, 8), 8),
+                                           ((300, 12), (30, 5), 9)])
+def test_sync_hits_ring_and_edges_equal_np_convolve(taps, thr, seed):
     """A14 on injected decisions with templates that fire often: every block's hits on the stream without a stash, the ring carried
     from batch to batch on the device, and the leading positions of the would-be stash streams -- against np.convolve on the bit
-    sequence the host code produces."""
-    rs = np.random.RandomState(5)
+    sequence the host code produces.  Templates of up to 256 taps take the packed kernel (k_stream_search: popcounts on a
+    bit-packed stream, word boundaries at 32 / 33 / 64 / 256 taps); 300 taps the byte kernels (no edges there)."""
+    rs = np.random.RandomState(seed)
     conf = cfg.bench_config('bench_GMSK', blockSize=BS, doppCarrierSteps=8)
     p = loadProtocol('bench_GMSK')(conf=conf)
     dev, host = UHF.Demodulator(conf, p, 'UHF-H'), UHF.Demodulator(conf, p, 'UHF-H')
     try:
-        t0 = (2 * rs.randint(0, 2, 40) - 1).astype(np.int8)
-        t1 = (2 * rs.randint(0, 2, 12) - 1).astype(np.int8)
-        thr = (9, 5)
-        nOv = 96
+        t0 = (2 * rs.randint(0, 2, taps[0]) - 1).astype(np.int8)
+        t1 = (2 * rs.randint(0, 2, taps[1]) - 1).astype(np.int8)
+        t1[rs.randint(0, taps[1])] = 0                   # a tap of 0 belongs to neither mask
+        nOv = 96 if taps[0] < 100 else 320
         dev._stages, dev._stage_decoder = True, None
         dev.bank.set_stream_stages(dev.sigOverlap, dev.overlapOffset, dev.symbol_check_match_threshold, dev.symbol_check_error_threshold,
                                    bit_lut=dev._bitLUT_u8, templates=(t0, t1), thresholds=thr, bits_overlap=nOv)
@@ -160,6 +163,7 @@ def test_sync_hits_ring_and_edges_equal_np_convolve():
         checked_edges = 0
         for b0 in range(0, nblocks, B):
             group = blocks[b0:b0 + B]
+            vstart = len(seq) - nOv              # the oldest bit the device holds for this batch (its ring)
             R = dev.bank.debug_stream_stages([g[0] for g in group], np.stack([g[1] for g in group]), np.stack([g[2] for g in group]),
                                              np.stack([g[3] for g in group]))
             for i, blk in enumerate(group):
@@ -171,8 +175,9 @@ def test_sync_hits_ring_and_edges_equal_np_convolve():
                     score = np.convolve(window, t.astype(np.int64))
                     want = np.where(score >= h)[0]
                     c = R.s['sync_count'][i][k]
-                    assert c == len(want) and c <= R.max_hits, (b0 + i, k, c, len(want))
-                    assert np.array_equal(R.hits[i, k, 0, :c], want) and np.array_equal(R.hits[i, k, 1, :c], score[want]), (b0 + i, k)
+                    assert c == len(want), (b0 + i, k, c, len(want), R.hits[i, k, 0, :min(c, R.max_hits)].tolist(), want.tolist(), len(window))
+                    c = min(c, R.max_hits)               # (a count beyond what the record holds is reported, the first max_hits kept)
+                    assert np.array_equal(R.hits[i, k, 0, :c], want[:c]) and np.array_equal(R.hits[i, k, 1, :c], score[want[:c]]), (b0 + i, k)
                 # the leading positions of the stream a FIXED-mode decoder would restart at, for the first header hits
                 base = len(seq) - nOv                     # position of the window's first bit in `full`
                 full = np.concatenate((seq, bits))
@@ -183,9 +188,13 @@ def test_sync_hits_ring_and_edges_equal_np_convolve():
                     assert E[cidx, 0] == a_rel
                     start = base + a_rel
                     if not E[cidx, 1]:
+                        n_lead = [int((np.convolve(full[max(start, 0):max(start, 0) + max(len(t0), len(t1)) - 1], t.astype(np.int64))[:len(t) - 1] >= h).sum())
+                                  for t, h in ((t0, thr[0]), (t1, thr[1]))]
+                        # not computed only where it cannot be: outside what the device holds, too many hits, templates too long
+                        assert start < vstart or start + max(len(t0), len(t1)) - 1 > len(full) or max(n_lead) > eh or max(taps) > 256, (b0 + i, cidx)
                         continue
                     assert start >= 0
-                    lead = full[start:start + len(t0) - 1]
+                    lead = full[start:start + max(len(t0), len(t1)) - 1]
                     for k, (t, h) in enumerate(((t0, thr[0]), (t1, thr[1]))):
                         sc = np.convolve(lead, t.astype(np.int64))[:len(t) - 1]
                         want = np.where(sc >= h)[0]
@@ -195,7 +204,7 @@ def test_sync_hits_ring_and_edges_equal_np_convolve():
                         assert np.array_equal(E[cidx, 4 + 2 * eh + k * eh:4 + 2 * eh + k * eh + n], sc[want])
                     checked_edges += 1
                 seq = full
-        assert checked_edges >= 8
+        assert checked_edges >= (8 if max(taps) < 200 else 4) or max(taps) > 256
     finally:
         dev.close()
         host.close()
