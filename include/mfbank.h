@@ -283,7 +283,7 @@ int mfb_receive_blocks_end(mfb_ctx *ctx, int slot, mfb_block_result *results, in
  * mode).  Replaces, block by block and bit for bit:
  *   A12  extractBits (DB:1012-1023: bits = bitLUT[sym]) -- lut_mode 1, lut = uint8[lut_rows] of 0 / 1 -- or extractBitsNRZs
  *        (DB:1026-1051) -- lut_mode 2, lut = int32[lut_rows][2][lut_successors] = symbolLUT[sym][is-one | is-zero][successors],
- *        impossible transitions -> 0 and counted;
+ *        impossible transitions -> 0 and counted (lut_rows <= 256 resp. lut_rows * 2 * lut_successors <= 2048: MFB_ERR_ARG beyond);
  *   A13  checkSymbolOverlap (DB:863-988): the symbols whose centre lies in [overlap_samples / 2, N - overlap_samples / 2], the
  *        +-1 repair against the previous block over overlap_offset symbols with match_threshold (DB:97-99, 938-957), skipped
  *        above error_threshold impossible transitions (DB:925), and the uint8 casts of DB:859 (centres mod 256; trust = the raw

@@ -1650,7 +1650,7 @@ static int block_enqueue(mfb_ctx *c, const mfb_block_params *p, const BlkBufs &b
         sa.nsym = nthreads;
         sa.carry_in = c->d_carry[bb.parity];
         sa.carry_out = c->d_carry[1 - bb.parity];
-        hipLaunchKernelGGL(k_stream_align, dim3(nb), dim3(256), 0, c->stream, sa);
+        hipLaunchKernelGGL(k_stream_align, dim3(nb), dim3(STREAM_ALIGN_THREADS), 0, c->stream, sa);
         HIPCHK(hipGetLastError());
         if (sa.K > 0) {
             int Tmax = 0;
@@ -2144,7 +2144,9 @@ extern "C" int mfb_set_stream_stages(mfb_ctx *c, const mfb_stream_params *p) {
     ++c->epoch;
     c->st_on = false;
     if (!p) return MFB_OK;                 // switched off
-    if ((p->lut_mode != 1 && p->lut_mode != 2) || p->lut_rows < 1 || p->lut_rows > 4096 || !p->lut || p->overlap_samples < 2 ||
+    // (the LUTs live in the LDS of k_stream_align: 256 rows of a bit LUT, 2048 entries of an NRZ-S LUT -- 2^xcorrMaskSize is 8 ... 32)
+    if ((p->lut_mode != 1 && p->lut_mode != 2) || p->lut_rows < 1 || (p->lut_mode == 1 && p->lut_rows > STREAM_LUT8_MAX) ||
+        (p->lut_mode == 2 && (p->lut_successors < 1 || (long long)p->lut_rows * 2 * p->lut_successors > STREAM_LUT3_MAX)) || !p->lut || p->overlap_samples < 2 ||
         p->overlap_samples >= c->N || p->overlap_offset < 1 || p->overlap_offset + 1 > STREAM_END_MAX || p->num_templates < 0 ||
         p->num_templates > STREAM_MAX_TMPL || (p->lut_mode == 2 && (p->lut_successors < 1 || p->lut_successors > 64)))
         return MFB_ERR_ARG;
@@ -2281,7 +2283,7 @@ extern "C" int mfb_debug_stream_stages(mfb_ctx *c, int nb, int symbols, const in
     sa.nsym = symbols;
     sa.carry_in = c->d_carry[c->carry_cur];
     sa.carry_out = c->d_carry[1 - c->carry_cur];
-    hipLaunchKernelGGL(k_stream_align, dim3(nb), dim3(256), 0, c->stream, sa);
+    hipLaunchKernelGGL(k_stream_align, dim3(nb), dim3(STREAM_ALIGN_THREADS), 0, c->stream, sa);
     if (sa.K > 0) {
         int Tmax = 0;
         for (int t = 0; t < sa.K; ++t) Tmax = sa.T[t] > Tmax ? sa.T[t] : Tmax;

@@ -75,24 +75,23 @@ struct StreamArgs {
     uint32_t P[STREAM_MAX_TMPL][STREAM_PACK_TAPS / 32], Q[STREAM_MAX_TMPL][STREAM_PACK_TAPS / 32];
 };
 
-// A12 on the fly: dataBits[x] of a block from its symbol indices; *bad = the transition is impossible (NRZ-S) or the index is
-// outside the LUT (any mode: the host path then raises or wraps as numpy does)
-DEVI int stream_bit(const StreamArgs &a, const int *sym, int x, bool *irregular, bool *mismatch) {
-    const int s = sym[x];
+// A12 on the fly: dataBits[x] of a block from its symbol index s = sym[x] (and, NRZ-S, its successor n = sym[x + 1]); the LUTs are
+// the workgroup's LDS copies.  *irregular = an index is outside the LUT (the host path then raises or wraps as numpy does);
+// *mismatch = the transition is impossible (NRZ-S).
+DEVI int stream_bit(const StreamArgs &a, const uint8_t *l8, const int *l3, int s, int n, bool *irregular, bool *mismatch) {
     if (s < 0 || s >= a.rows) {
         *irregular = true;
         return 0;
     }
-    if (a.mode == 1) return a.lut8[s];
-    const int n = sym[x + 1];
+    if (a.mode == 1) return l8[s];
     if (n < 0 || n >= a.rows) {          // the successor indexes the LUT itself one symbol later
         *irregular = true;
         return 0;
     }
     bool one = false, zero = false;
     for (int q = 0; q < a.succ; ++q) {
-        one = one || (n == a.lut3[(s * 2 + 0) * a.succ + q]);
-        zero = zero || (n == a.lut3[(s * 2 + 1) * a.succ + q]);
+        one = one || (n == l3[(s * 2 + 0) * a.succ + q]);
+        zero = zero || (n == l3[(s * 2 + 1) * a.succ + q]);
     }
     if (!one && !zero) {
         *mismatch = true;
@@ -101,106 +100,132 @@ DEVI int stream_bit(const StreamArgs &a, const int *sym, int x, bool *irregular,
     return one ? 1 : 0;
 }
 
-// first x < n with pred(x), n when there is none; all 256 threads of the workgroup
-template <class P>
-DEVI int first_true(int n, P pred, int *slot) {
-    if (threadIdx.x == 0) *slot = n;
-    __syncthreads();
-    int mine = n;
-    for (int x = threadIdx.x; x < n; x += blockDim.x)
-        if (pred(x)) {
-            mine = x;
-            break;
-        }
-    if (mine < n) atomicMin(slot, mine);
-    __syncthreads();
-    const int r = *slot;
-    __syncthreads();
-    return r;
-}
-
 struct BlockWindow {
     int count, nbits;            // symbols decided; dataBits available (count, or count - 1 for NRZ-S)
     int start, end;              // first centre >= ov/2, first centre > N - ov/2 (count: none)
+    int noerr;                   // impossible transitions (NRZ-S)
     bool ok;                     // both exist, every index inside the LUT, window >= o + 2 symbols, end <= nbits
 };
 
-// Workgroup of 256 threads = one block of the batch.
-__global__ void __launch_bounds__(256) k_stream_align(StreamArgs a) {
-    __shared__ int s_slot, s_flag, s_err;
+#define STREAM_ALIGN_THREADS 1024
+#define STREAM_LUT8_MAX 256      // rows of a bit LUT (2^xcorrMaskSize: 8 ... 32 in the shipped protocols)
+#define STREAM_LUT3_MAX 2048     // rows * 2 * successors of an NRZ-S LUT (bench_BPSK: 16 * 2 * 4)
+
+// Workgroup of 1024 threads = one block of the batch.  The symbol / centre arrays are swept ONCE per window (16-byte loads,
+// four symbols per thread and step; the LUTs sit in LDS), for the block and for its predecessor at the same time; the bits the
+// +-1 comparison looks at are staged in LDS by 2 o + 3 threads before one thread compares them.
+__global__ void __launch_bounds__(STREAM_ALIGN_THREADS) k_stream_align(StreamArgs a) {
+    __shared__ int s_w[2][4];            // [me | previous block][first start, first end, irregular, impossible transitions]
     __shared__ int s_start;
-    const int b = blockIdx.x;
-    uint8_t *rec = a.rec0 + (size_t)b * a.rec;
-    BlockScalars *sc = reinterpret_cast<BlockScalars *>(rec);
-    const int o = a.o;
-
-    auto window = [&](const uint8_t *r, BlockWindow &w, int *noerr) {
-        const BlockScalars *s = reinterpret_cast<const BlockScalars *>(r);
-        const int *sym = reinterpret_cast<const int *>(r + a.off_sym), *cen = reinterpret_cast<const int *>(r + a.off_cen);
-        // (a count beyond what the record holds -- the rate fallback k* = 0, DB:737-740 -- is the host's business)
-        const bool fits = s->count <= a.nsym;
-        w.count = fits ? s->count : 0;
-        w.nbits = a.mode == 1 ? w.count : w.count - 1;
-        w.start = first_true(w.count, [&](int x) { return cen[x] >= a.ovw; }, &s_slot);
-        w.end = first_true(w.count, [&](int x) { return cen[x] > a.N - a.ovw; }, &s_slot);
-        if (threadIdx.x == 0) {
-            s_flag = 0;
-            s_err = 0;
-        }
-        __syncthreads();
-        bool irr = false;
-        int bad = 0;
-        for (int x = threadIdx.x; x < w.nbits; x += blockDim.x) {
-            bool m = false;
-            (void)stream_bit(a, sym, x, &irr, &m);
-            bad += m ? 1 : 0;
-        }
-        if (irr) atomicOr(&s_flag, 1);
-        if (bad) atomicAdd(&s_err, bad);
-        __syncthreads();
-        if (noerr) *noerr = s_err;
-        w.ok = s_flag == 0 && w.start < w.count && w.end < w.count && w.end - w.start >= o + 2 && w.end <= w.nbits && w.nbits > 0;
-        __syncthreads();
-    };
-
-    BlockWindow me;
-    int noerr = 0;
-    window(rec, me, &noerr);
-    const int *sym = reinterpret_cast<const int *>(rec + a.off_sym), *cen = reinterpret_cast<const int *>(rec + a.off_cen);
-    const uint8_t *magb = rec + a.off_mag;         // trust = the raw bytes of the leading fp32 magnitudes (quirk Q3)
-
-    // ---- the previous block's tail: first o + 1 bits behind its window, last o + 1 bits inside it ----
+    __shared__ uint8_t s_l8[STREAM_LUT8_MAX];
+    __shared__ int s_l3[STREAM_LUT3_MAX];
+    __shared__ uint8_t s_near[2 * STREAM_END_MAX + 4];
     __shared__ uint8_t p_post[STREAM_END_MAX + 1], p_end[STREAM_END_MAX];
     __shared__ int p_npost, p_nend, p_known;
+    const int b = blockIdx.x, tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
+    uint8_t *rec = a.rec0 + (size_t)b * a.rec;
+    const uint8_t *prec = a.rec0 + (size_t)(b > 0 ? b - 1 : 0) * a.rec;
+    BlockScalars *sc = reinterpret_cast<BlockScalars *>(rec);
+    const int o = a.o;
+    if (a.mode == 1)
+        for (int q = tid; q < a.rows; q += nth) s_l8[q] = a.lut8[q];
+    else
+        for (int q = tid; q < a.rows * 2 * a.succ; q += nth) s_l3[q] = a.lut3[q];
+    auto counts = [&](const uint8_t *r, BlockWindow &w) {
+        // (a count beyond what the record holds -- the rate fallback k* = 0, DB:737-740 -- is the host's business)
+        const int n = reinterpret_cast<const BlockScalars *>(r)->count;
+        w.count = n <= a.nsym ? n : 0;
+        w.nbits = a.mode == 1 ? w.count : w.count - 1;
+    };
+    BlockWindow me, pw;
+    counts(rec, me);
+    counts(prec, pw);
+    if (tid < 8) s_w[tid >> 2][tid & 3] = (tid & 3) < 2 ? ((tid >> 2) ? pw.count : me.count) : 0;
+    __syncthreads();
+
+    auto sweep = [&](const uint8_t *r, const BlockWindow &w, int *slot) {
+        const int *sym = reinterpret_cast<const int *>(r + a.off_sym), *cen = reinterpret_cast<const int *>(r + a.off_cen);
+        int lstart = w.count, lend = w.count, lbad = 0;
+        bool lirr = false;
+        for (int g = tid; 4 * g < w.count; g += nth) {
+            const int x0 = 4 * g;
+            const int4 c4 = *reinterpret_cast<const int4 *>(cen + x0), s4 = *reinterpret_cast<const int4 *>(sym + x0);
+            const int nx = (a.mode == 2 && x0 + 4 < w.count) ? sym[x0 + 4] : 0;
+            const int cs[4] = {c4.x, c4.y, c4.z, c4.w}, ss[5] = {s4.x, s4.y, s4.z, s4.w, nx};
+#pragma unroll
+            for (int u = 3; u >= 0; --u) {
+                const int x = x0 + u;
+                if (x < w.count && cs[u] >= a.ovw) lstart = x < lstart ? x : lstart;
+                if (x < w.count && cs[u] > a.N - a.ovw) lend = x < lend ? x : lend;
+                if (x < w.nbits) {
+                    bool m = false;
+                    (void)stream_bit(a, s_l8, s_l3, ss[u], ss[u + 1], &lirr, &m);
+                    lbad += m ? 1 : 0;
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            lstart = min(lstart, __shfl_xor(lstart, d, 64));
+            lend = min(lend, __shfl_xor(lend, d, 64));
+            lbad += __shfl_xor(lbad, d, 64);
+        }
+        const bool anyirr = __ballot(lirr) != 0ull;
+        if (lane == 0) {
+            if (lstart < w.count) atomicMin(&slot[0], lstart);
+            if (lend < w.count) atomicMin(&slot[1], lend);
+            if (anyirr) atomicOr(&slot[2], 1);
+            if (lbad) atomicAdd(&slot[3], lbad);
+        }
+    };
+    sweep(rec, me, s_w[0]);
+    if (b > 0) sweep(prec, pw, s_w[1]);
+    __syncthreads();
+    auto finish = [&](BlockWindow &w, const int *slot) {
+        w.start = slot[0];
+        w.end = slot[1];
+        w.noerr = slot[3];
+        w.ok = slot[2] == 0 && w.start < w.count && w.end < w.count && w.end - w.start >= o + 2 && w.end <= w.nbits && w.nbits > 0;
+    };
+    finish(me, s_w[0]);
+    finish(pw, s_w[1]);
+    const int noerr = me.noerr;
+    const int *sym = reinterpret_cast<const int *>(rec + a.off_sym), *cen = reinterpret_cast<const int *>(rec + a.off_cen);
+    const uint8_t *magb = rec + a.off_mag;         // trust = the raw bytes of the leading fp32 magnitudes (quirk Q3)
+    bool i1 = false, m1 = false;                  // (irregular indices were found by the sweep; a window with one is not ok)
+    auto bit = [&](const int *sy, int x) { return stream_bit(a, s_l8, s_l3, sy[x], a.mode == 2 ? sy[x + 1] : 0, &i1, &m1); };
+
+    // ---- the previous block's tail: first o + 1 bits behind its window, last o + 1 bits inside it ----
     if (b > 0) {
-        const uint8_t *pr = a.rec0 + (size_t)(b - 1) * a.rec;
-        BlockWindow pw;
-        window(pr, pw, nullptr);
-        const int *psym = reinterpret_cast<const int *>(pr + a.off_sym);
-        if (threadIdx.x == 0) {
+        const int *psym = reinterpret_cast<const int *>(prec + a.off_sym);
+        if (tid == 0) {
             p_known = pw.ok ? 1 : 0;
             p_npost = pw.ok ? pw.nbits - pw.end : 0;
             p_nend = pw.ok ? o + 1 : 0;
         }
         if (pw.ok) {
-            bool i1 = false, m1 = false;
-            for (int q = threadIdx.x; q < o + 1 && q < pw.nbits - pw.end; q += blockDim.x) p_post[q] = (uint8_t)stream_bit(a, psym, pw.end + q, &i1, &m1);
-            for (int q = threadIdx.x; q < o + 1; q += blockDim.x) p_end[q] = (uint8_t)stream_bit(a, psym, pw.end - (o + 1) + q, &i1, &m1);
+            if (tid < o + 1 && tid < pw.nbits - pw.end) p_post[tid] = (uint8_t)bit(psym, pw.end + tid);
+            if (tid >= 64 && tid - 64 < o + 1) p_end[tid - 64] = (uint8_t)bit(psym, pw.end - (o + 1) + tid - 64);
         }
     } else {
         const StreamCarry *c = a.carry_in;
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             p_known = c->valid;
             p_npost = c->npost;
             p_nend = c->nend;
         }
-        for (int q = threadIdx.x; q < o + 1 && q < c->npost; q += blockDim.x) p_post[q] = c->post[q];
-        for (int q = threadIdx.x; q < c->nend && q < STREAM_END_MAX; q += blockDim.x) p_end[q] = c->end[q];
+        if (tid < o + 1 && tid < c->npost) p_post[tid] = c->post[tid];
+        if (tid >= 64 && tid - 64 < c->nend && tid - 64 < STREAM_END_MAX) p_end[tid - 64] = c->end[tid - 64];
+    }
+    // ---- the bits the comparison looks at: dataBits[start - o - 1 ... start + o + 1] ----
+    if (me.ok && tid >= 128 && tid - 128 < 2 * o + 3) {
+        const int x = me.start - o - 1 + tid - 128;
+        s_near[tid - 128] = (x >= 0 && x < me.nbits) ? (uint8_t)bit(sym, x) : (uint8_t)0;
     }
     __syncthreads();
 
-    // ---- alignment (one thread; a few dozen byte compares) ----
-    if (threadIdx.x == 0) {
+    // ---- alignment (one thread; a few dozen byte compares in LDS) ----
+    if (tid == 0) {
         int status = A13_DEVICE, start = me.start;
         // regular case only: everything numpy would slice exists at full length
         const bool have_prev = p_npost > 0;
@@ -212,19 +237,16 @@ __global__ void __launch_bounds__(256) k_stream_align(StreamArgs a) {
         } else if (have_prev) {
             if (p_npost < o + 1 || p_nend != o + 1 || me.start < o + 1 || me.count - me.end > STREAM_POST_MAX) status = A13_HOST;
             else {
-                bool irr = false, mm = false;
-                auto bit = [&](int x) { return stream_bit(a, sym, x, &irr, &mm); };
-                // win[i] = bit(start + i), pre[-k] = bit(start - k); prev_end[-k] = p_end[o + 1 - k]
+                // win[i] = near[o + 1 + i]; pre[-o:][i] = near[1 + i]; pre[-o-1:-1][i] = near[i]; prev_end[-k] = p_end[o + 1 - k]
                 bool all_pre = true, all_pos = true;
                 int m_pre[3] = {0, 0, 0}, m_pos[3] = {0, 0, 0};
                 for (int i = 0; i < o; ++i) {
-                    const int w0 = bit(me.start + i), w1 = bit(me.start + i + 1);
+                    const int w0 = s_near[o + 1 + i], w1 = s_near[o + 2 + i];
                     all_pre = all_pre && (p_post[i] == w0);
                     m_pre[0] += p_post[i] == w0;
                     m_pre[1] += p_post[i] == w1;
                     m_pre[2] += p_post[i + 1] == w0;
-                    // pre[-o:][i] = bit(start - o + i); pre[-o-1:-1][i] = bit(start - o - 1 + i)
-                    const int q0 = bit(me.start - o + i), q1 = bit(me.start - o - 1 + i);
+                    const int q0 = s_near[1 + i], q1 = s_near[i];
                     const int e0 = p_end[1 + i], e1 = p_end[i];        // prev_end[-o:][i], prev_end[-o-1:-1][i]
                     all_pos = all_pos && (e0 == q0);
                     m_pos[0] += e0 == q0;
@@ -251,36 +273,35 @@ __global__ void __launch_bounds__(256) k_stream_align(StreamArgs a) {
         sc->a13_npost = status != A13_HOST ? me.nbits - me.end : 0;
         sc->a13_nend = status != A13_HOST ? o + 1 : 0;
         sc->a13_prev_npost = p_npost;
-        sc->sync_valid = 0;              // (k_stream_sync, when it runs, says otherwise)
+        sc->sync_valid = 0;              // (the search kernel, when it runs, says otherwise)
         sc->sync_count[0] = sc->sync_count[1] = 0;
+        p_known = status != A13_HOST;    // (reused: does the record get the block's arrays?)
     }
     __syncthreads();
-    const bool dev = sc->a13_status != A13_HOST;
+    const bool dev = p_known != 0;
     const int start = s_start;
     // ---- the caller's three arrays, the block's own tail ----
     if (dev) {
         uint8_t *ob = rec + a.off_bits, *oc = rec + a.off_cenw, *ot = rec + a.off_trust, *op = rec + a.off_post, *oe = rec + a.off_end;
-        bool i1 = false, m1 = false;
-        for (int x = start + threadIdx.x; x < me.end; x += blockDim.x) {
-            ob[x - start] = (uint8_t)stream_bit(a, sym, x, &i1, &m1);
+        for (int x = start + tid; x < me.end; x += nth) {
+            ob[x - start] = (uint8_t)bit(sym, x);
             oc[x - start] = (uint8_t)(cen[x] & 0xff);
             ot[x - start] = magb[x];
         }
-        for (int x = me.end + threadIdx.x; x < me.nbits; x += blockDim.x) op[x - me.end] = (uint8_t)stream_bit(a, sym, x, &i1, &m1);
-        for (int q = threadIdx.x; q < o + 1; q += blockDim.x) oe[q] = (uint8_t)stream_bit(a, sym, me.end - (o + 1) + q, &i1, &m1);
+        for (int x = me.end + tid; x < me.nbits; x += nth) op[x - me.end] = (uint8_t)bit(sym, x);
+        if (tid < o + 1) oe[tid] = (uint8_t)bit(sym, me.end - (o + 1) + tid);
     }
     // ---- the carry for the next batch's first block ----
     if (b == a.nb - 1) {
         StreamCarry *c = a.carry_out;
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             c->valid = dev ? 1 : 0;
             c->npost = dev ? me.nbits - me.end : 0;
             c->nend = dev ? o + 1 : 0;
         }
         if (dev) {
-            bool i1 = false, m1 = false;
-            for (int x = me.end + threadIdx.x; x < me.nbits; x += blockDim.x) c->post[x - me.end] = (uint8_t)stream_bit(a, sym, x, &i1, &m1);
-            for (int q = threadIdx.x; q < o + 1; q += blockDim.x) c->end[q] = (uint8_t)stream_bit(a, sym, me.end - (o + 1) + q, &i1, &m1);
+            for (int x = me.end + tid; x < me.nbits; x += nth) c->post[x - me.end] = (uint8_t)bit(sym, x);
+            if (tid < o + 1) c->end[tid] = (uint8_t)bit(sym, me.end - (o + 1) + tid);
         }
     }
 }
@@ -548,13 +569,21 @@ __global__ void __launch_bounds__(256) k_stream_search(StreamArgs a) {
     const int exb = base < back ? base : back;                   // bits in front of the stream that exist in V
     const int org = STREAM_PACK_TAPS + exb;                      // packed index of the stream's position 0
     const int nwords = ((org + L + 31) >> 5) + STREAM_PACK_TAPS / 32 + 2;
-    for (int g = wv; 2 * g < nwords; g += 4) {
-        const int x = 64 * g + lane - org;
-        const int v = (x >= -exb && x < L) ? stream_v(a, base + x, cum) : 0;
-        const unsigned long long bal = __ballot(v != 0);
-        if (lane == 0) {
-            zw[2 * g] = (uint32_t)bal;
-            zw[2 * g + 1] = (uint32_t)(bal >> 32);
+    for (int g0 = wv; 2 * g0 < nwords; g0 += 4 * 8) {              // eight loads in flight per lane before the first ballot
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int x = 64 * (g0 + 4 * u) + lane - org;
+            v[u] = (x >= -exb && x < L) ? stream_v(a, base + x, cum) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int g = g0 + 4 * u;
+            const unsigned long long bal = __ballot(v[u] != 0);
+            if (lane == 0 && 2 * g < nwords) {
+                zw[2 * g] = (uint32_t)bal;
+                zw[2 * g + 1] = (uint32_t)(bal >> 32);
+            }
         }
     }
     __syncthreads();

@@ -344,9 +344,10 @@ class Demodulator:
         if not self._one_call or self.backend != 'UHF' or self.overlapOffset + 1 > 32:
             return False
         kw = {}
-        if self._bitLUT_u8 is not None:
+        if self._bitLUT_u8 is not None and len(self._bitLUT_u8) <= 256:
             kw['bit_lut'] = self._bitLUT_u8
-        elif self.bitLUT is None and self.symbolLUT is not None and len(self.symbolLUT.shape) == 3 and self.symbolLUT.shape[1] == 2:
+        elif (self._bitLUT_u8 is None and self.bitLUT is None and self.symbolLUT is not None and len(self.symbolLUT.shape) == 3 and
+              self.symbolLUT.shape[1] == 2 and self.symbolLUT.size <= 2048):
             kw['nrzs_lut'] = self.symbolLUT
         else:
             return False
