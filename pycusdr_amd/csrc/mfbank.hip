@@ -1573,7 +1573,7 @@ static void stream_search_launch(mfb_ctx *c, const StreamArgs &sa, int nb, int T
     const size_t words = (size_t)((STREAM_PACK_TAPS + sa.T[0] - 1 + STREAM_EDGE_BACK + sa.nOv + sa.nsym + 31) >> 5) + STREAM_PACK_TAPS / 32 + 4;
     static const bool unpacked = getenv("MFB_STREAM_UNPACKED") != nullptr;       // (A/B switch of tools/chain_kernels.sh)
     if (sa.packed && words * 4 <= 60 * 1024 && !unpacked) {
-        hipLaunchKernelGGL(k_stream_search, dim3(nb), dim3(256), words * 4, c->stream, sa);
+        hipLaunchKernelGGL(k_stream_search, dim3(nb), dim3(STREAM_SEARCH_THREADS), words * 4, c->stream, sa);
         return;
     }
     hipLaunchKernelGGL(k_stream_sync, dim3(sa.K, nb), dim3(256), (size_t)Tmax + SYNC_SEG + Tmax - 1, c->stream, sa);

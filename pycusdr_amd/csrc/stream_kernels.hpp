@@ -511,28 +511,42 @@ __global__ void __launch_bounds__(256) k_stream_edges(StreamArgs a) {
 // {-1, 0, +1}) instead of T multiply-adds on bytes.  Every thread owns a contiguous run of positions: one count pass, one
 // workgroup scan, one write pass -- hits in order, no atomics, no segment loop.  Same records as k_stream_sync + k_stream_ring +
 // k_stream_edges (which stay for templates the packing does not take).
+// position x of block b's stream (x < 0: the bits in front of it): the block's own kept bits behind the first numBitsOverlap
+// positions, else the tail of the blocks before it (normally of block b - 1 alone) or the ring
+DEVI int stream_at(const StreamArgs &a, int b, int base, int x, const int *cum) {
+    if (x >= a.nOv) return (a.rec0 + (size_t)b * a.rec + a.off_bits)[x - a.nOv];
+    int p = base + x;
+    if (p < a.nOv) return a.carry_in->ring[p];
+    p -= a.nOv;
+    int i = b - 1;                        // (p < cum[b]: there is a block in front)
+    while (i > 0 && p < cum[i]) --i;
+    return (a.rec0 + (size_t)i * a.rec + a.off_bits)[p - cum[i]];
+}
+
 DEVI int packed_score(const uint32_t *zw, int s, const uint32_t *P, const uint32_t *Q, int K, int valid_from) {
     const int w0 = s >> 5, sh = s & 31;
-    int acc = 0;
+    int plus = 0, minus = 0;
     uint32_t lo = zw[w0];
     for (int k = 0; k < K; ++k) {
         const uint32_t hi = zw[w0 + k + 1];
-        uint32_t w = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
+        uint32_t w = __builtin_amdgcn_alignbit(hi, lo, sh);          // bits s + 32 k ... s + 32 k + 31 of the packed stream
         const int m = valid_from - 32 * k;            // window elements below valid_from lie in front of the stream's first bit: absent
         if (m > 0) w &= m >= 32 ? 0u : (~0u << m);
-        acc += __popc(w & P[k]) - __popc(w & Q[k]);
+        plus += __popc(w & P[k]);
+        minus += __popc(w & Q[k]);
         lo = hi;
     }
-    return acc;
+    return plus - minus;
 }
 
-__global__ void __launch_bounds__(256) k_stream_search(StreamArgs a) {
+#define STREAM_SEARCH_THREADS 1024
+__global__ void __launch_bounds__(STREAM_SEARCH_THREADS) k_stream_search(StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t zw[];
     __shared__ int cum[65];
     __shared__ int s_valid, s_nh, s_h0[STREAM_EDGE_CANDS];
-    __shared__ int wsum[4];
+    __shared__ int wsum[STREAM_SEARCH_THREADS / 64];
     __shared__ uint32_t s_P[STREAM_MAX_TMPL][STREAM_PACK_TAPS / 32], s_Q[STREAM_MAX_TMPL][STREAM_PACK_TAPS / 32];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nth = blockDim.x, nwv = nth >> 6;
     if (tid < STREAM_MAX_TMPL * (STREAM_PACK_TAPS / 32)) {
         s_P[tid / (STREAM_PACK_TAPS / 32)][tid % (STREAM_PACK_TAPS / 32)] = a.P[tid / (STREAM_PACK_TAPS / 32)][tid % (STREAM_PACK_TAPS / 32)];
         s_Q[tid / (STREAM_PACK_TAPS / 32)][tid % (STREAM_PACK_TAPS / 32)] = a.Q[tid / (STREAM_PACK_TAPS / 32)][tid % (STREAM_PACK_TAPS / 32)];
@@ -540,16 +554,25 @@ __global__ void __launch_bounds__(256) k_stream_search(StreamArgs a) {
     uint8_t *rec = a.rec0 + (size_t)b * a.rec;
     BlockScalars *sc = reinterpret_cast<BlockScalars *>(rec);
     StreamEdge *edges = reinterpret_cast<StreamEdge *>(rec + a.off_edges);
-    if (tid == 0) {
-        int run = 0, ok = a.carry_in->ring_valid && a.carry_in->ring_len == a.nOv && a.nb <= 64;
-        for (int i = 0; i < a.nb && i < 64; ++i) {
-            cum[i] = run;
-            const BlockScalars *s = reinterpret_cast<const BlockScalars *>(a.rec0 + (size_t)i * a.rec);
-            if (i <= b) ok = ok && s->a13_status != A13_HOST;
-            run += s->a13_nwin;
+    // kept bits in front of every block (64 loads side by side, one short prefix in LDS), and: was every block up to this one
+    // aligned on the device?
+    if (tid < 64) {
+        int nw = 0, host = 0;
+        if (tid < a.nb) {
+            const BlockScalars *s = reinterpret_cast<const BlockScalars *>(a.rec0 + (size_t)tid * a.rec);
+            nw = s->a13_nwin;
+            host = (tid <= b && s->a13_status == A13_HOST) ? 1 : 0;
         }
-        cum[a.nb < 64 ? a.nb : 64] = run;
-        s_valid = ok;
+        int incl = nw;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        cum[tid] = incl - nw;
+        if (tid == 63) cum[64] = incl;
+        const bool anyhost = __ballot(host != 0) != 0ull;
+        if (tid == 0) s_valid = a.carry_in->ring_valid && a.carry_in->ring_len == a.nOv && a.nb <= 64 && !anyhost;
     }
     __syncthreads();
     if (!s_valid) {
@@ -569,16 +592,16 @@ __global__ void __launch_bounds__(256) k_stream_search(StreamArgs a) {
     const int exb = base < back ? base : back;                   // bits in front of the stream that exist in V
     const int org = STREAM_PACK_TAPS + exb;                      // packed index of the stream's position 0
     const int nwords = ((org + L + 31) >> 5) + STREAM_PACK_TAPS / 32 + 2;
-    for (int g0 = wv; 2 * g0 < nwords; g0 += 4 * 8) {              // eight loads in flight per lane before the first ballot
-        int v[8];
+    for (int g0 = wv; 2 * g0 < nwords; g0 += nwv * 4) {            // four loads in flight per lane before the first ballot
+        int v[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int x = 64 * (g0 + 4 * u) + lane - org;
-            v[u] = (x >= -exb && x < L) ? stream_v(a, base + x, cum) : 0;
+        for (int u = 0; u < 4; ++u) {
+            const int x = 64 * (g0 + nwv * u) + lane - org;
+            v[u] = (x >= -exb && x < L) ? stream_at(a, b, base, x, cum) : 0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int g = g0 + 4 * u;
+        for (int u = 0; u < 4; ++u) {
+            const int g = g0 + nwv * u;
             const unsigned long long bal = __ballot(v[u] != 0);
             if (lane == 0 && 2 * g < nwords) {
                 zw[2 * g] = (uint32_t)bal;
@@ -590,7 +613,7 @@ __global__ void __launch_bounds__(256) k_stream_search(StreamArgs a) {
     for (int t = 0; t < a.K; ++t) {
         const int T = a.T[t], thr = a.thrs[t], K = (T + 31) >> 5;
         int32_t *oi = reinterpret_cast<int32_t *>(rec + a.off_hits) + (size_t)t * 2 * a.max_hits, *os = oi + a.max_hits;
-        const int outLen = L + T - 1, ppt = (outLen + 255) >> 8;
+        const int outLen = L + T - 1, ppt = (outLen + nth - 1) / nth;
         const int i0 = tid * ppt, i1 = min(i0 + ppt, outLen);
         int cnt = 0;
         for (int i = i0; i < i1; ++i) cnt += packed_score(zw, org + i - (T - 1), s_P[t], s_Q[t], K, T - 1 - i) >= thr ? 1 : 0;
@@ -604,7 +627,7 @@ __global__ void __launch_bounds__(256) k_stream_search(StreamArgs a) {
         if (lane == 63) wsum[wv] = incl;
         __syncthreads();
         int pos = incl - cnt, total = 0;
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < nwv; ++w) {
             if (w < wv) pos += wsum[w];
             total += wsum[w];
         }
@@ -649,12 +672,12 @@ __global__ void __launch_bounds__(256) k_stream_search(StreamArgs a) {
                 score = packed_score(zw, org + a_rel + tid - (T - 1), s_P[k], s_Q[k], (T + 31) >> 5, T - 1 - tid);
                 hit = score >= a.thrs[k];
             }
-            const unsigned long long bal = __ballot(hit);
+            const unsigned long long bal = __ballot(hit);            // (threads 0 ... T - 2: the first four waves)
             __syncthreads();
             if (lane == 0) wsum[wv] = __popcll(bal);
             __syncthreads();
             int pos = __popcll(bal & ((1ull << lane) - 1ull));
-            for (int w = 0; w < wv; ++w) pos += wsum[w];
+            for (int w = 0; w < wv && w < 4; ++w) pos += wsum[w];
             if (hit && pos < STREAM_EDGE_HITS) {
                 e->idx[k][pos] = tid;
                 e->score[k][pos] = score;
@@ -674,7 +697,7 @@ __global__ void __launch_bounds__(256) k_stream_search(StreamArgs a) {
             a.carry_out->ring_valid = 1;
             a.carry_out->ring_len = a.nOv;
         }
-        for (int q = tid; q < a.nOv; q += 256) {
+        for (int q = tid; q < a.nOv; q += nth) {
             const int idx = org + nwin + q;
             a.carry_out->ring[q] = (uint8_t)((zw[idx >> 5] >> (idx & 31)) & 1u);
         }
