@@ -1,6 +1,7 @@
 """Randomised equality sweep: run_stream with B blocks per device call (stream stages on the device or on the host) against the
 one-block loop -- block size, bins, modulation, SNR (down to where packets are lost), B, chunk size, zero stretches (skipped blocks,
-irregular blocks that go through the host code and force a re-seed of the device's state), two calls per runner.
+irregular blocks that go through the host code and force a re-seed of the device's state), "nothing more right now" markers of a live
+source at random places (batches of 0 ... B blocks in one stream), two calls per runner.
 usage: python tests/tools/fuzz_batches.py [cases] [seed]"""
 import copy
 import os
@@ -34,19 +35,26 @@ def one_case(rs, log=print):
         a = int(rs.randint(0, len(sig)))
         sig[a:a + int(rs.randint(step // 3, 3 * step))] = 0
     chunk = int(rs.choice([1000, 4096, 16384, step, 3 * step + 17]))
+    p_dry = float(rs.choice([0.0, 0.0, 0.05, 0.3]))      # how often the source says "nothing more right now" between two chunks
     conf = cfg.bench_config(pname, blockSize=bs, doppCarrierSteps=D)
     confB = copy.deepcopy(conf)
     confB['GPU']['UHF'].setdefault('HIP', {}).update(blocks_per_call=B, stream_stages=stages)
     p = loadProtocol(pname)(conf=conf)
     a, b = DemodulatorRunner(conf, p, 'UHF-H'), DemodulatorRunner(confB, p, 'UHF-H')
     da, db = Decoder(conf, p), Decoder(conf, p)
-    tag = f'{mod} N=2^{bs} D={D} B={B} snr={snr} stages={stages} blocks={nblocks} chunk={chunk}'
+    tag = f'{mod} N=2^{bs} D={D} B={B} snr={snr} stages={stages} blocks={nblocks} chunk={chunk} dry={p_dry}'
+
+    def chunks(part, size):
+        for i in range(0, len(part), size):
+            yield part[i:i + size]
+            if p_dry and rs.rand() < p_dry:
+                yield None
     try:
         cut = int(rs.randint(1, nblocks)) * step
         ok = True
         for part in (sig[:cut], sig[cut:]):              # two calls per runner: the second goes on where the first stopped
-            ra, pa = a.run_stream((part[i:i + 16384] for i in range(0, len(part), 16384)), decoder=da)
-            rb, pb = b.run_stream((part[i:i + chunk] for i in range(0, len(part), chunk)), decoder=db)
+            ra, pa = a.run_stream(chunks(part, 16384), decoder=da)
+            rb, pb = b.run_stream(chunks(part, chunk), decoder=db)
             ok = ok and len(ra) == len(rb) and len(pa) == len(pb)
             for x, y in zip(ra, rb):
                 ok = ok and x['count'] == y['count'] and _same(x['data'], y['data']) and _same(x['trust'], y['trust'])
