@@ -26,6 +26,23 @@ def radioBackendVoteGroupIDX(radioBackend):
     return groups[radioBackend]
 
 
+class MarkedSource:
+    """Chunks of a live transport with ``None`` where it would block (``DemodulatorRunner.drain_marked``)."""
+
+    def __init__(self, poll, wait):
+        self.poll, self.wait = poll, wait
+
+    def __iter__(self):
+        while True:
+            chunk = self.poll()
+            if chunk is None:
+                yield None
+                chunk = self.wait()
+                if chunk is None:
+                    return
+            yield chunk
+
+
 class DemodulatorRunner:
     """One receive channel, in-process.  ``feed(new_samples)`` takes exactly
     ``blockSize - overlap`` new complex64 samples and returns the result dict of that block."""
@@ -239,7 +256,12 @@ class DemodulatorRunner:
         if not (overlapped and self.radioBackend == 'UHF' and getattr(self.demod, '_one_call', False)):
             asm = BlockAssembler(self.raw, self.overlap)
             return self.run((None for chunk in chunk_source if chunk is not None for _ in asm.push(chunk)), sink=sink, decoder=decoder)
-        B = self.blocks_per_call() if blocks_per_call is None else max(1, int(blocks_per_call))
+        if blocks_per_call is None:
+            confGPU = self.conf['GPU'][self.confRadio['CUDA_settings']]
+            marked = isinstance(chunk_source, MarkedSource) and 'blocks_per_call' not in confGPU.get('HIP', {})
+            B = self.auto_blocks_per_call() if marked else self.blocks_per_call()
+        else:
+            B = max(1, int(blocks_per_call))
         if B > 1:       # (a batch of ONE block is slower than the one-block loop below: 211 against 254 Msamples/s at 2^15 x 64 -- more launches)
             bank = self.demod.bank
             if bank.get_search_path()['path'] == 'segment' and bank.get_search_mode() == 'transforms':
@@ -351,15 +373,14 @@ class DemodulatorRunner:
         """A chunk source for ``run_stream`` from a live transport: ``poll()`` returns the next chunk or None at once, ``wait()``
         blocks for the next chunk and returns None when the stream has ended.  Yields every chunk that is there, then a ``None``
         marker ("nothing more right now") before it blocks -- so a backlog goes through in batches of up to blocks_per_call
-        blocks and a quiet source gets each block out as soon as it is complete."""
-        while True:
-            chunk = poll()
-            if chunk is None:
-                yield None
-                chunk = wait()
-                if chunk is None:
-                    return
-            yield chunk
+        blocks and a quiet source gets each block out as soon as it is complete.  With such a source batches cost no latency, so
+        ``run_stream`` takes them without being asked (``auto_blocks_per_call``) unless the configuration says otherwise."""
+        return MarkedSource(poll, wait)
+
+    def auto_blocks_per_call(self):
+        """Blocks per device call for a source that marks where it would block: windows of about 2^19 samples, at most 16 blocks
+        (2^15-sample blocks: 16, 2^17: 4, 2^19 and above: one block per call)."""
+        return max(1, min(16, (1 << 19) // self.blockSize))
 
     def _run_stream_batched(self, chunk_source, sink, decoder, B):
         """``run_stream`` with B consecutive blocks per device call (``"HIP": {"blocks_per_call": B}``; mfb_receive_blocks_*).

@@ -232,7 +232,7 @@ def test_a_live_source_gets_every_complete_block_out_at_its_markers(with_decoder
     a, b = DemodulatorRunner(conf, p, 'UHF-H'), DemodulatorRunner(confB, p, 'UHF-H')
     try:
         da, db = (Decoder(conf, p), Decoder(conf, p)) if with_decoder else (None, None)
-        ra, pa = a.run_stream(live(), decoder=da)                       # one-block loop: markers collect the block in flight
+        ra, pa = a.run_stream(live(), decoder=da, blocks_per_call=1)    # one-block loop: markers collect the block in flight
         sizes = []
         inner = b.demod.beginBlocks
         b.demod.beginBlocks = lambda which, nb, **kw: (sizes.append(nb), inner(which, nb, **kw))[1]
@@ -263,6 +263,17 @@ def test_a_live_source_gets_every_complete_block_out_at_its_markers(with_decoder
         # the pipelined form takes the same source
         rc, _ = a.run_stream(live(), pipelined=True)
         assert len(rc) == nblocks
+        # a marked source gets batches without being configured (they cost it no latency): 2^15-sample blocks -> up to 16 per call
+        assert a.auto_blocks_per_call() == 16 and a.blocks_per_call() == 1
+        seen = []
+        inner_a = a.demod.beginBlocks
+        a.demod.beginBlocks = lambda which, nb, **kw: (seen.append(nb), inner_a(which, nb, **kw))[1]
+        rd, _ = a.run_stream(live())
+        assert len(rd) == nblocks and sum(seen) == nblocks and max(seen) > 1
+        # ... and a plain iterator does not
+        del seen[:]
+        re_, _ = a.run_stream(iter(chunks))
+        assert len(re_) == nblocks and not seen
     finally:
         a.close()
         b.close()
