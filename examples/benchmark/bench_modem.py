@@ -45,7 +45,9 @@ def make_stream(modulation, n_runs, snr, block_size, seed):
     parts = [sg.awgn(sig, snr_r, rng=rng).astype(np.complex64) for _ in range(n_runs)]
     # push the last packet through the overlap buffers (noise floor only: an all-zero block has no Doppler pick)
     parts.append((1e-3 * (rng.standard_normal(2 * N) + 1j * rng.standard_normal(2 * N))).astype(np.complex64))
-    return np.concatenate(parts), bit_data, bw
+    stream = np.concatenate(parts)
+    stream.flags.writeable = False       # a recording: the chunks cut from it cannot change (the batched loop copies them on its copy thread)
+    return stream, bit_data, bw
 
 
 def run_snr(modulation, n_runs, snr, block_size, search, seed, doppler_bins=64, pipelined=False, blocks_per_call=1, decode=True,
@@ -93,7 +95,9 @@ def make_cc11xx_stream(n_frames, snr, block_size, seed, payload_bytes=200):
     N = 1 << block_size
     sig = sg.awgn(sig, snr, rng=rs).astype(np.complex64)
     tail = (1e-3 * (rs.standard_normal(2 * N) + 1j * rs.standard_normal(2 * N))).astype(np.complex64)
-    return np.concatenate((sig, tail)), payloads
+    stream = np.concatenate((sig, tail))
+    stream.flags.writeable = False       # (a recording, as in make_stream)
+    return stream, payloads
 
 
 def run_cc11xx(n_frames, snr, block_size, doppler_bins=64, blocks_per_call=1, decode=True, stimulus=None, seed=3):

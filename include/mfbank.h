@@ -52,7 +52,7 @@ const char *mfb_strerror(int status);
 int mfb_abi_version(void);   /* 2: search paths, mfb_xcorr; 3: mfb_set_search_mode, mfb_sync_find_multi; 4: mfb_receive_block,
                               * mfb_export_rows_async, mfb_sync_find_packed; 5: mfb_debug_block_scalars; 6: mfb_receive_blocks_*,
                               * mfb_window_buffer, mfb_block_params.block_stride; 7: mfb_set_stream_stages, mfb_stream_seed,
-                              * mfb_receive_blocks_end_record */
+                              * mfb_receive_blocks_end_record; 8: mfb_hostcopy_* */
 
 /* Create a handle on HIP device `device` for blocks of N = 2^log2N samples, `num_dopplers`
  * Doppler bins plus `doppler_offset` leading noise-reference bins (DB:150-159), M matched
@@ -434,6 +434,18 @@ int mfb_profile_enable(mfb_ctx *ctx, int on);
 int mfb_profile_read(mfb_ctx *ctx, int counts[2], float total_ms[2]);
 /* Block until all work enqueued on the handle's stream has finished (the reference: cuda.Context.synchronize(), DB:651). */
 int mfb_sync(mfb_ctx *ctx);
+
+/* A host copy worker for the receive loop: the reference's loop copies every chunk of samples twice on its one thread, into the
+ * ring buffer (sigFIFO.py:62-84) and from there into the page-locked input buffer (`raw[ov:] = sigIn.getBlock()`, DP:287,337).
+ * Here a chunk is copied once, into the sample window of its batch (mfb_window_buffer) -- and with this worker that copy runs on a
+ * thread of its own while the caller's thread does the host stages of the previous batch.  No GPU involved (plain memory; usable
+ * before any handle exists).  mfb_hostcopy_submit returns at once; copies run in submission order; source and destination must
+ * stay valid and untouched until mfb_hostcopy_drain has returned.  One submitting thread per worker. */
+typedef struct mfb_hostcopy mfb_hostcopy;
+int mfb_hostcopy_create(mfb_hostcopy **out);
+int mfb_hostcopy_submit(mfb_hostcopy *q, void *dst, const void *src, size_t bytes);
+int mfb_hostcopy_drain(mfb_hostcopy *q);           /* returns when every submitted copy has been made (before the batch is begun; DP:287) */
+void mfb_hostcopy_destroy(mfb_hostcopy *q);        /* finishes what was submitted, then stops the thread (no reference counterpart) */
 
 #ifdef __cplusplus
 }

@@ -130,6 +130,10 @@ PROTOTYPES = {
     'mfb_profile_enable': (_i, [_vp, _i]),
     'mfb_profile_read': (_i, [_vp, C.POINTER(_i), _fp]),
     'mfb_sync': (_i, [_vp]),
+    'mfb_hostcopy_create': (_i, [C.POINTER(_vp)]),
+    'mfb_hostcopy_submit': (_i, [_vp, _vp, _vp, C.c_size_t]),
+    'mfb_hostcopy_drain': (_i, [_vp]),
+    'mfb_hostcopy_destroy': (None, [_vp]),
 }
 
 _lib = None

@@ -37,7 +37,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/mfbank.h"
@@ -206,7 +210,7 @@ extern "C" const char *mfb_strerror(int s) {
         default: return "unknown status";
     }
 }
-extern "C" int mfb_abi_version(void) { return 7; }
+extern "C" int mfb_abi_version(void) { return 8; }
 
 static void make_twiddles(std::vector<cf> &v, int count, double denom, double stepmul) {
     v.resize(count);
@@ -2994,4 +2998,92 @@ extern "C" int mfb_sync(mfb_ctx *c) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     return MFB_OK;
+}
+
+// ---- host copy worker (include/mfbank.h: mfb_hostcopy_*) ------------------------------------------------------------------------
+// One thread, one queue: the receive loop hands it the chunk -> window copies of the next batch and runs the host stages of the
+// previous batch meanwhile.  The worker spins for a few microseconds before it sleeps (chunks arrive in bursts; a futex wake costs
+// more than a 128 KiB copy).
+struct mfb_hostcopy {
+    struct Job {
+        void *dst;
+        const void *src;
+        size_t bytes;
+    };
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<Job> jobs;
+    std::atomic<long long> submitted{0}, done{0};
+    bool stop = false;
+    std::thread worker;
+
+    void run() {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                if (jobs.empty() && !stop) {
+                    lk.unlock();
+                    for (int spin = 0; spin < 4000 && submitted.load(std::memory_order_acquire) == done.load(std::memory_order_relaxed); ++spin)
+                        __builtin_ia32_pause();
+                    lk.lock();
+                }
+                cv_work.wait(lk, [&] { return stop || !jobs.empty(); });
+                if (jobs.empty()) return;              // stop, nothing left
+                j = jobs.front();
+                jobs.pop_front();
+            }
+            memcpy(j.dst, j.src, j.bytes);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                done.fetch_add(1, std::memory_order_release);
+            }
+            cv_done.notify_all();
+        }
+    }
+};
+
+extern "C" int mfb_hostcopy_create(mfb_hostcopy **out) {
+    if (!out) return MFB_ERR_ARG;
+    *out = nullptr;
+    mfb_hostcopy *q = new (std::nothrow) mfb_hostcopy();
+    if (!q) return MFB_ERR_ALLOC;
+    try {
+        q->worker = std::thread([q] { q->run(); });
+    } catch (...) {
+        delete q;
+        return MFB_ERR_ALLOC;
+    }
+    *out = q;
+    return MFB_OK;
+}
+
+extern "C" int mfb_hostcopy_submit(mfb_hostcopy *q, void *dst, const void *src, size_t bytes) {
+    if (!q || (bytes && (!dst || !src))) return MFB_ERR_ARG;
+    if (!bytes) return MFB_OK;
+    {
+        std::lock_guard<std::mutex> lk(q->mu);
+        q->jobs.push_back({dst, src, bytes});
+        q->submitted.fetch_add(1, std::memory_order_release);
+    }
+    q->cv_work.notify_one();
+    return MFB_OK;
+}
+
+extern "C" int mfb_hostcopy_drain(mfb_hostcopy *q) {
+    if (!q) return MFB_ERR_ARG;
+    std::unique_lock<std::mutex> lk(q->mu);
+    q->cv_done.wait(lk, [&] { return q->done.load(std::memory_order_acquire) == q->submitted.load(std::memory_order_acquire); });
+    return MFB_OK;
+}
+
+extern "C" void mfb_hostcopy_destroy(mfb_hostcopy *q) {
+    if (!q) return;
+    {
+        std::lock_guard<std::mutex> lk(q->mu);
+        q->stop = true;
+    }
+    q->cv_work.notify_all();
+    if (q->worker.joinable()) q->worker.join();
+    delete q;
 }

@@ -383,10 +383,15 @@ class Demodulator:
         self._stream_dirty = False
         return True
 
-    def endBlocks(self, slot):
+    def waitBlocks(self, slot):
+        """Wait for the batch begun in ``slot`` and take its records off the device (``endBlocks(slot, record)`` turns them into
+        the per-block results later: the receive loop queues the next window's copies in between)."""
+        return self.bank.end_blocks_record(slot)
+
+    def endBlocks(self, slot, record=None):
         """One ``((freqOffset_Hz, metric, clippedPeakIdx, SNR_dB), device record)`` per block of the batch begun in ``slot``,
         in stream order: what ``endBlock`` + ``demodulateDevice`` return block by block."""
-        R = self.bank.end_blocks_record(slot)
+        R = self.bank.end_blocks_record(slot) if record is None else record
         s, nb = R.s, R.nb
         snr = self._batch_snr(R)
         stages = R.stages and getattr(self, '_stages', False)

@@ -26,6 +26,13 @@ def radioBackendVoteGroupIDX(radioBackend):
     return groups[radioBackend]
 
 
+class _NoCopier:
+    """Stands in for mfbank.HostCopy when the chunk copies are made on the spot."""
+    @staticmethod
+    def drain():
+        pass
+
+
 class MarkedSource:
     """Chunks of a live transport with ``None`` where it would block (``DemodulatorRunner.drain_marked``)."""
 
@@ -75,6 +82,10 @@ class DemodulatorRunner:
         self.raw[:] = 0
 
     def close(self):
+        hc = getattr(self, '_copier', None)
+        if hc is not None:
+            hc.close()
+            self._copier = None
         self.demod.close()
 
     def computeMATime(self, t):
@@ -411,9 +422,21 @@ class DemodulatorRunner:
             if stages:
                 stages = self.demod.seedStreamStages()
         wins[cur][:self.overlap] = self.raw[:self.overlap]      # goes on behind the overlap the last call left
-        asm = WindowAssembler(wins[cur], self.overlap, self.samplesPerSlice, B)
+        # the chunk -> window copies run on the library's copy thread (mfb_hostcopy_*) while this thread does the host stages of
+        # the previous batch -- for chunks that cannot change under it: read-only arrays (np.frombuffer of a received message; a
+        # replay marks its samples flags.writeable = False).  A writable chunk may be storage the source fills again: it is copied
+        # on the spot.  "HIP": {"async_copies": true} queues every chunk (the source then keeps a window's worth of chunks
+        # untouched), false none.
+        mode = confGPU.get('HIP', {}).get('async_copies', 'auto')
+        copier = _NoCopier
+        if mode is not False:
+            if getattr(self, '_copier', None) is None:
+                from .mfbank import HostCopy
+                self._copier = HostCopy()
+            copier = self._copier
+        asm = WindowAssembler(wins[cur], self.overlap, self.samplesPerSlice, B, copier=None if copier is _NoCopier else copier,
+                              copy_all_async=mode is True)
         results, packets = [], []
-        flying = None
         searching = []
         split = decoder is not None and hasattr(decoder, 'findFrames_begin')
         if split and hasattr(decoder, 'prepare'):
@@ -436,9 +459,11 @@ class DemodulatorRunner:
 
         batch_dec = decoder is not None and hasattr(decoder, 'findFrames_batch')
 
-        def collect(fl):
+        def host_stages(fl, record):
+            """The host side of a finished batch: per-block estimates, A12 / A13 (the device's, or the host code for irregular
+            blocks), the result dicts, the decoder."""
             slot, count0, nb, stamp, arrived = fl
-            recs = self.demod.endBlocks(slot)
+            recs = self.demod.endBlocks(slot, record)
             now = time.time()
             per_block = ((now - last[0]) if last[0] is not None else (now - stamp)) / nb
             last[0] = now
@@ -475,49 +500,79 @@ class DemodulatorRunner:
                     packets.extend(pk)
                 deliver(d)
 
-        def launch(nb):
-            nonlocal cur, flying
-            if stages and self.demod._stream_dirty:
-                # a block went through the host code: everything in flight was enqueued behind the stale state -- collect it, hand
-                # the device this side's state, go on
+        END = object()
+        it = iter(chunk_source)
+        rest = [None]                    # what is left of a chunk that straddles two windows
+        fill_s = [0.0]                   # how long the last fill() took: a source that is slower than the device is not kept waiting
+
+        def fill():
+            """Chunks from the source into the window (copies queued, not waited for) until it is complete ('full'), the source
+            says it has nothing more right now ('dry') or ends ('end')."""
+            t0 = time.time()
+            try:
+                while True:
+                    if rest[0] is None:
+                        chunk = next(it, END)
+                        if chunk is END:
+                            return 'end'
+                        if chunk is None:
+                            return 'dry'
+                        rest[0] = chunk if isinstance(chunk, np.ndarray) else np.asarray(chunk)
+                    n = asm.take(rest[0])
+                    rest[0] = rest[0][n:] if n < len(rest[0]) else None
+                    if asm.full():
+                        return 'full'
+            finally:
+                fill_s[0] = time.time() - t0
+
+        flying = None                    # the batch on the device: (slot, first count, blocks, begin time, arrival stamps)
+        waiting = None                   # a batch whose records are here and whose host stages have not run yet: (flight, record)
+        try:
+            state = fill()
+            while True:
+                # (host stages of the batch before last: beside the copies fill() has just queued)
+                if waiting is not None:
+                    w, waiting = waiting, None
+                    host_stages(*w)
+                copier.drain()
+                nb = B if state == 'full' else asm.complete_blocks()
+                if nb:
+                    if stages and self.demod._stream_dirty:
+                        # a block went through the host code: everything in flight was enqueued behind the stale state -- collect it,
+                        # hand the device this side's state, go on
+                        if flying is not None:
+                            fl, flying = flying, None
+                            host_stages(fl, self.demod.waitBlocks(fl[0]))
+                        self.demod.seedStreamStages()
+                    self.demod.beginBlocks(cur, nb, source=names[cur])
+                    started = (cur, self.count, nb, time.time(), list(asm.stamps[:nb]))
+                    self.count += nb
+                    cur = 1 - cur
+                    # the previous batch lives in wins[cur]: take its records (the device is then done with that window) BEFORE the
+                    # samples behind this batch are carried into it
+                    if flying is not None:
+                        waiting = (flying, self.demod.waitBlocks(flying[0]))
+                    asm.retarget(wins[cur], nb)
+                    flying = started
+                if state == 'full':
+                    if fill_s[0] > 5e-3 and waiting is not None:
+                        # a source slower than the device (a live radio): its results first, then wait for more samples
+                        w, waiting = waiting, None
+                        host_stages(*w)
+                    state = fill()       # the next window's copies are on their way while the loop turns to `waiting`
+                    continue
+                # nothing more right now, or the end of the source: everything that is complete goes out
+                if waiting is not None:
+                    w, waiting = waiting, None
+                    host_stages(*w)
                 if flying is not None:
                     fl, flying = flying, None
-                    collect(fl)
-                self.demod.seedStreamStages()
-            self.demod.beginBlocks(cur, nb, source=names[cur])
-            started = (cur, self.count, nb, time.time(), list(asm.stamps[:nb]))
-            self.count += nb
-            cur = 1 - cur
-            # the previous batch lives in wins[cur]: collect it (its host-to-device copy is then certainly over) BEFORE the
-            # samples behind this batch are carried into that window
-            if flying is not None:
-                fl, flying = flying, None
-                collect(fl)
-            asm.retarget(wins[cur], nb)
-            flying = started
-
-        try:
-            for chunk in chunk_source:
-                if chunk is None:
-                    # the source has nothing more RIGHT NOW (a live radio between two chunks): do not wait for a full window --
-                    # the complete blocks go out as a shorter batch, the batch in flight is collected, and a source that is
-                    # slower than the device sees the one-block latency of the reference's loop (DP:284-338) again
-                    if asm.complete_blocks():
-                        launch(asm.complete_blocks())
-                    if flying is not None:
-                        fl, flying = flying, None
-                        collect(fl)
-                    if not batch_dec:
-                        finish_search()
-                    continue
-                for nb in asm.push(chunk):
-                    launch(nb)
-            if asm.complete_blocks():
-                launch(asm.complete_blocks())
-            if flying is not None:
-                fl, flying = flying, None
-                collect(fl)
-            finish_search()
+                    host_stages(fl, self.demod.waitBlocks(fl[0]))
+                if not batch_dec:
+                    finish_search()
+                if state == 'end':
+                    break
+                state = fill()
         except BaseException:
             for slot in (0, 1):
                 try:
@@ -533,7 +588,10 @@ class DemodulatorRunner:
         finally:
             # the overlap a later call (batched or not) goes on behind; samples of an incomplete block are dropped, as the
             # one-block loop drops them
-            self.raw[:self.overlap] = asm.buf[:self.overlap]
+            try:
+                copier.drain()
+            finally:
+                self.raw[:self.overlap] = asm.buf[:self.overlap]
         return results, packets
 
     def run(self, sample_source, sink=None, decoder=None, pipelined=False):

@@ -26,6 +26,56 @@ BLOCK_SCALARS = np.dtype({
     'itemsize': 168})
 
 
+class HostCopy:
+    """The library's host copy worker (mfb_hostcopy_*): ``submit(dst, dst_off, src)`` queues ``dst[dst_off:dst_off + len(src)] = src``
+    for a thread of its own and returns at once; ``drain()`` returns when every queued copy has been made.  Arrays handed to
+    ``submit`` are kept alive until then.  Plain host memory: no GPU involved."""
+
+    def __init__(self):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.mfb_hostcopy_create(C.byref(h)), 'mfb_hostcopy_create')
+        self._h = h
+        self._held = []
+        self._base = {}              # id(dst) -> (address, itemsize): asking numpy for it costs as much as a small copy
+
+    def submit(self, dst, dst_off, src):
+        n = len(src)
+        if not n:
+            return
+        key = id(dst)
+        base = self._base.get(key)
+        if base is None or base[2] is not dst:
+            if not dst.flags.c_contiguous or not dst.flags.writeable:
+                raise ValueError('destination must be a writable contiguous array')
+            base = self._base[key] = (dst.ctypes.data, dst.itemsize, dst)
+        if src.dtype != dst.dtype or not src.flags.c_contiguous:
+            src = np.ascontiguousarray(src, dtype=dst.dtype)
+        if dst_off < 0 or dst_off + n > len(dst):
+            raise IndexError('copy outside the destination')
+        self._held.append(src)
+        rc = self._lib.mfb_hostcopy_submit(self._h, base[0] + dst_off * base[1], src.__array_interface__['data'][0], n * base[1])
+        _lib.check(rc, 'mfb_hostcopy_submit')
+
+    def drain(self):
+        if self._held:
+            _lib.check(self._lib.mfb_hostcopy_drain(self._h), 'mfb_hostcopy_drain')
+            del self._held[:]
+
+    def close(self):
+        if self._h is not None:
+            self._lib.mfb_hostcopy_destroy(self._h)
+            self._h = None
+            del self._held[:]
+            self._base.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:        # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
 class BatchRecord:
     """A finished batch of blocks as it came off the device (mfb_receive_blocks_end_record): ``nb`` records in one buffer, read
     in place.  Scalars come as one Python list per field (``s['count'][b]``); arrays as 2-D views, block b in row b."""

@@ -39,6 +39,23 @@ class BlockAssembler:
         self.fill = self.ov              # the first block starts behind whatever the caller left in buffer[:overlap]
         self.blocks = 0
 
+    def full(self):
+        return self.fill == len(self.buf)
+
+    def take(self, chunk):
+        take = min(len(chunk), len(self.buf) - self.fill)
+        if take:
+            if self.copier is not None and (self.copy_all_async or not chunk.flags.writeable):
+                self.copier.submit(self.buf, self.fill, chunk[:take])
+            else:
+                self.buf[self.fill:self.fill + take] = chunk[:take]
+            self.fill += take
+            done = (self.fill - self.ov) // self.stride
+            if len(self.stamps) < done:
+                now = time.time()
+                self.stamps.extend([now] * (done - len(self.stamps)))
+        return take
+
     def push(self, chunk):
         chunk = np.asarray(chunk)
         n, pos, size = len(chunk), 0, len(self.buf)
@@ -71,17 +88,42 @@ class WindowAssembler:
     as storage).  ``push(chunk)`` copies every sample once and yields B each time the window is complete; the consumer then calls
     ``retarget(other, nblocks)`` -- everything behind the ``nblocks`` blocks it took (the carried overlap, and whatever has been
     filled of the next block) moves to the front of ``other`` and filling goes on there, the completed window stays untouched for
-    the copy engine.  ``complete_blocks()``: whole blocks in a partly filled window (end of a stream)."""
+    the copy engine.  ``complete_blocks()``: whole blocks in a partly filled window (end of a stream).
 
-    def __init__(self, window, overlap, stride, blocks):
+    Pull form: ``take(chunk)`` puts as much of the chunk as fits into the window and returns that count; ``full()``.  With a
+    ``copier`` (``mfbank.HostCopy``) ``take`` only QUEUES the copy of a READ-ONLY chunk (``np.frombuffer`` of a received message
+    is one; a replay marks its array ``flags.writeable = False``) for the library's copy thread -- the caller goes on (the host
+    stages of the previous batch) and calls ``copier.drain()`` before it hands the window to the device.  A writable chunk may be
+    storage its source fills again for the next chunk: it is copied on the spot (``copy_all_async``: queue those too)."""
+
+    def __init__(self, window, overlap, stride, blocks, copier=None, copy_all_async=False):
         if len(window) != blocks * stride + overlap or overlap < 0 or stride < 1:
             raise IndexError('window of %d samples does not hold %d blocks of stride %d + overlap %d' % (len(window), blocks, stride, overlap))
         self.buf, self.ov, self.stride, self.B = window, int(overlap), int(stride), int(blocks)
         self.fill = self.ov              # the first block starts behind whatever the caller left in window[:overlap]
         self.stamps = []                 # time.time() at which each complete block of the window got its last sample
+        self.copier = copier
+        self.copy_all_async = bool(copy_all_async)
 
     def complete_blocks(self):
         return max(0, (self.fill - self.ov) // self.stride)
+
+    def full(self):
+        return self.fill == len(self.buf)
+
+    def take(self, chunk):
+        take = min(len(chunk), len(self.buf) - self.fill)
+        if take:
+            if self.copier is not None and (self.copy_all_async or not chunk.flags.writeable):
+                self.copier.submit(self.buf, self.fill, chunk[:take])
+            else:
+                self.buf[self.fill:self.fill + take] = chunk[:take]
+            self.fill += take
+            done = (self.fill - self.ov) // self.stride
+            if len(self.stamps) < done:
+                now = time.time()
+                self.stamps.extend([now] * (done - len(self.stamps)))
+        return take
 
     def push(self, chunk):
         chunk = np.asarray(chunk)

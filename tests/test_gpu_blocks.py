@@ -142,6 +142,12 @@ def test_batched_stream_equals_one_block_stream(B):
     sig = sg.s1_stream(nblocks, N, ov, 'GMSK', snr_db=10.0, seed=5)[ov:]
     confB = copy.deepcopy(conf)
     confB['GPU']['UHF'].setdefault('HIP', {})['blocks_per_call'] = B
+    # the chunk -> window copies: on the spot for writable chunks (B = 2), on the library's copy thread for read-only ones
+    # (B = 5: a recording) or for all of them when the configuration says so (B = 8)
+    if B == 5:
+        sig.flags.writeable = False
+    elif B == 8:
+        confB['GPU']['UHF']['HIP']['async_copies'] = True
     a, b = DemodulatorRunner(conf, p, 'UHF-H'), DemodulatorRunner(confB, p, 'UHF-H')
 
     def slipping(run):
@@ -175,6 +181,7 @@ def test_batched_stream_equals_one_block_stream(B):
             assert 'latency_ms' in y and y['rate_ksps'] > 0
         assert len(pa) == len(pb) and all(_same(u.bits, v.bits) for u, v in zip(pa, pb))
         assert _same(a.demod.poswinP, b.demod.poswinP) and _same(a.demod.posSymEnd, b.demod.posSymEnd)
+        assert (getattr(b, '_copier', None) is not None) and not b._copier._held            # the copy thread exists and holds nothing back
         # the device did the bit lookup and the alignment of (nearly) every block, and the decoder's searches came with them: all
         # but the block with the planted slip -- which goes through the host code -- and what was in flight behind it
         assert b.demod.stage_blocks >= nblocks - 2 * B - 1 and db.ahead_blocks >= nblocks - 2 * B - 1, (b.demod.stage_blocks, db.ahead_blocks)

@@ -38,11 +38,14 @@ def one_case(rs, log=print):
     p_dry = float(rs.choice([0.0, 0.0, 0.05, 0.3]))      # how often the source says "nothing more right now" between two chunks
     conf = cfg.bench_config(pname, blockSize=bs, doppCarrierSteps=D)
     confB = copy.deepcopy(conf)
-    confB['GPU']['UHF'].setdefault('HIP', {}).update(blocks_per_call=B, stream_stages=stages)
+    copies = [True, False, 'auto', 'read-only'][rs.randint(0, 4)]      # chunk -> window copies: all queued for the copy thread / none / read-only chunks only
+    confB['GPU']['UHF'].setdefault('HIP', {}).update(blocks_per_call=B, stream_stages=stages, async_copies='auto' if copies == 'read-only' else copies)
+    if copies == 'read-only':
+        sig.flags.writeable = False
     p = loadProtocol(pname)(conf=conf)
     a, b = DemodulatorRunner(conf, p, 'UHF-H'), DemodulatorRunner(confB, p, 'UHF-H')
     da, db = Decoder(conf, p), Decoder(conf, p)
-    tag = f'{mod} N=2^{bs} D={D} B={B} snr={snr} stages={stages} blocks={nblocks} chunk={chunk} dry={p_dry}'
+    tag = f'{mod} N=2^{bs} D={D} B={B} snr={snr} stages={stages} blocks={nblocks} chunk={chunk} dry={p_dry} copies={copies}'
 
     def chunks(part, size):
         for i in range(0, len(part), size):
