@@ -76,10 +76,10 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(masks, shifts, x_blocks, N, ov, D, budget_s=26.0):
+def cpu_baseline(masks, shifts, x_blocks, N, ov, D, budget_s=34.0):
     """The oracle's Doppler search (numpy/scipy restatement) timed on this host's cores on a bounded sample of the same
     workload (C2 on >= 2 blocks): whole blocks -- all D bins -- of `x_blocks` while about `budget_s` seconds of CPU
-    work allow (two C2 blocks on the 16-CPU share of a GPU box), else the leading bins of ONE block with the per-block figure
+    work allow (two C2 blocks on the 16-CPU share of a GPU box: 12.5 ... 14 s each on the round's hosts), else the leading bins of ONE block with the per-block figure
     scaled by D/nb (`blocks_timed` < 1 says so).  Two modes: all cores (scipy.fft complex64, workers = the CPU share) and one
     thread (numpy pocketfft, complex128, row at a time, 8 bins).  Reported baseline, not a target.  Returns the figures, the
     all-cores scores of every block timed (a list) and the single-thread scores of the first block's leading bins."""
