@@ -137,7 +137,16 @@ class Decoder:
     def _frames(self, rawBits_DS, bits_less_raw, frameStartIdx, hits):
         """The packet state machine of one call (DEC:101-293) on the stitched stream and the hits of its two searches."""
         (idxCand, candScore), (syncSigStartIdx, _) = hits
-        packetIdx = idxCand - len(self.mask) + 1          # the peak sits on the template's last bit
+        back = len(self.mask) - 1                         # the peak sits on the template's last bit
+        if isinstance(idxCand, list):                     # (findFrames_batch keeps its few hits per block in plain lists)
+            if self.packetEndDetectMode == PacketEndDetect.FLAGS:
+                idxCand, candScore, syncSigStartIdx = (np.asarray(idxCand, dtype=np.int64), np.asarray(candScore, dtype=np.int64),
+                                                       np.asarray(syncSigStartIdx, dtype=np.int64))
+                packetIdx = idxCand - back
+            else:
+                packetIdx = [i - back for i in idxCand]
+        else:
+            packetIdx = idxCand - back
         numSyncSig = len(syncSigStartIdx)
 
         if self.packetEndDetectMode == PacketEndDetect.FLAGS:
@@ -200,7 +209,8 @@ class Decoder:
         a, a_prev, prev = 0, None, None
         if self._prev is not None:                                # the previous call's window, in hist's coordinates (<= 0)
             a_prev, prev = self._prev[0] - self._seq_end + ends[0], self._prev[1]
-        ahead = list(ahead) if ahead is not None else [None] * nb
+        # a block has a handful of hits: plain lists from here on (a numpy call costs more than the whole list)
+        ahead = [None if h is None else self._hit_lists(h) for h in ahead] if ahead is not None else [None] * nb
         base = self._abs_end - ends[0]                            # sequence position of hist[0]
         if edges is not None:
             if len(self._edge_map) > 64:
@@ -216,6 +226,7 @@ class Decoder:
         streams = [hist[starts[i]:ends[i + 1]] for i in todo] + ([hist[a:ends[1]]] if first_direct else [])
         if streams:
             found = self._search_streams(streams)
+            found = [self._hit_lists(h) for h in found]
             for i, h in zip(todo, found):
                 ahead[i] = h
         out = []
@@ -232,6 +243,7 @@ class Decoder:
                     edge = self._edge_map.get(base + a)
                     if edge is None:
                         edge = self._search_streams([stream[:max(Ts) - 1]])[0]
+                    edge = self._hit_lists(edge)
                 hits = tuple(self._window_hits(Ts[k], prev[k], a_prev, a, d, ahead[i][k], edge[k] if edge else None) for k in range(2))
             self.bitsOverlapBuf = stream[-nOv:]
             out.append(self._frames(stream, pre[i], frameStartIdx, hits))
@@ -243,31 +255,47 @@ class Decoder:
         return out
 
     @staticmethod
+    def _hit_lists(h):
+        """((idx, score), (idx, score)) of the two templates as plain lists of ints."""
+        if isinstance(h[0][0], list) and isinstance(h[1][0], list) and isinstance(h[0][1], list) and isinstance(h[1][1], list):
+            return h
+        return tuple((i if isinstance(i, list) else np.asarray(i).tolist(), s if isinstance(s, list) else np.asarray(s).tolist())
+                     for i, s in h)
+
+    @staticmethod
     def _window_hits(T, prev, a_prev, a, d, ahead, edge):
         """Hits of a T-tap template on the window [a, e), a < d, from the hits ``ahead`` of [d, e), ``prev`` of the previous call's
         window [a_prev, e_prev) (a_prev <= a, e_prev = d + numBitsOverlap) and -- when the start moved -- ``edge``, the hits of
-        the window's first T - 1 bits searched on their own."""
+        the window's first T - 1 bits searched on their own.  Lists in, lists out (index list, score list)."""
         ai, asc = ahead
         pi, ps = prev
+        lim, shift = T - 1, d - a
         if edge is None:
             # the start did not move: every previous hit in front of the default window's own positions stays where it is (the
             # first T - 1 positions included); behind them the default window's hits, shifted
-            if len(pi):
-                keep = pi < d - a_prev + T - 1
-                pi, ps = pi[keep], ps[keep]
-            if not len(ai):
-                return pi, ps
-            m = ai >= T - 1
-            if not len(pi):
-                return ai[m] + (d - a), asc[m]
-            return np.concatenate((pi, ai[m] + (d - a))), np.concatenate((ps, asc[m]))
-        m = ai >= T - 1
-        new_i, new_s = ai[m] + (d - a), asc[m]
-        g = pi + a_prev                                        # previous hits in the sequence's coordinates
-        m = (g >= a + T - 1) & (g < d + T - 1)
-        old_i, old_s = g[m] - a, ps[m]
-        m = edge[0] < T - 1
-        return np.concatenate((edge[0][m], old_i, new_i)), np.concatenate((edge[1][m], old_s, new_s))
+            cut = d - a_prev + lim
+            oi, os_ = [], []
+            for i, v in zip(pi, ps):
+                if i < cut:
+                    oi.append(i)
+                    os_.append(v)
+        else:
+            oi, os_ = [], []
+            for i, v in zip(edge[0], edge[1]):
+                if i < lim:
+                    oi.append(i)
+                    os_.append(v)
+            lo, hi = a + lim, d + lim                          # previous hits between the edge and the default window's own positions
+            for i, v in zip(pi, ps):
+                g = i + a_prev                                 # in the sequence's coordinates
+                if lo <= g < hi:
+                    oi.append(g - a)
+                    os_.append(v)
+        for i, v in zip(ai, asc):
+            if i >= lim:
+                oi.append(i + shift)
+                os_.append(v)
+        return oi, os_
 
     # ---- FIXED: packets of protocol.packetLen bits (reference decoder.py:245-280) ---------------
     def _frames_fixed(self, stream, candScore, packetIdx):

@@ -399,30 +399,28 @@ class Demodulator:
         out = []
         prev_export = getattr(self, '_dev_tail', None)
         empty = np.zeros(0, dtype=np.int64)
+        # (per-block Python is what bounds the loop with the decoder in the thread: the columns once, the object's "last block"
+        # attributes once behind the loop)
+        pick_valid, low, high, frac, picks, counts = s['pick_valid'], s['low'], s['high'], s['frac'], s['pick'], s['count']
+        hz, hz_off, clipped = self.doppHzLUT, self.centreFreqOffset, self.clippedPeakIPure
         for b in range(nb):
-            if not s['pick_valid'][b]:       # NaN index (all-zero block): skip the block (reference DB:625-630)
+            if not pick_valid[b]:       # NaN index (all-zero block): skip the block (reference DB:625-630)
                 log.error('Error occurred during find_UHF -- skipping block. Message: cannot convert float NaN to integer')
-                self.dopplerIdxlast = 0
-                est = (0., 0., self.clippedPeakIPure, 0.)
+                est = (0., 0., clipped, 0.)
             else:
-                lowIdx, highIdx = s['low'][b], s['high'][b]
-                self._pick_bin = lowIdx
-                lowVal, highVal = self.doppHzLUT[lowIdx], self.doppHzLUT[highIdx]
-                bestDopplerScaled = lowVal + (highVal - lowVal) * s['frac'][b]
-                self.dopplerIdxlast = np.int32(s['shift'][b])
+                lowIdx, highIdx = low[b], high[b]
+                lowVal, highVal = hz[lowIdx], hz[highIdx]
+                bestDopplerScaled = lowVal + (highVal - lowVal) * frac[b]
                 if snr is not None:
                     SNR = snr[b]
                 else:
                     l0, l1 = s['band_len'][b]
                     bands = (R.bands[b, 0, :l0], R.bands[b, 1, :l1]) if (R.bands is not None and l0 <= R.bcap and l1 <= R.bcap) else None
                     SNR = self.computeSNR(lowIdx, highIdx, 5, bands=bands)
-                est = (bestDopplerScaled - self.centreFreqOffset, float(s['pick'][b][1]) / self.Nfft * self.sampleRate,
-                       self.clippedPeakIPure, SNR)
-            n = s['count'][b]
+                est = (bestDopplerScaled - hz_off, float(picks[b][1]) / self.Nfft * self.sampleRate, clipped, SNR)
+            n = counts[b]
             if s['rate_fallback'][b]:
                 log.error('Code rate result 0 should not happen but happened -- fixing it to 10')
-            self._codeRateResult = np.array(s['cr'][b], dtype=np.float32)
-            self.magnitudes = R.mag[b, :n]
             rec = {'spSym': s['spSym'][b], 'symbols': R.sym[b, :n], 'centres': R.cen[b, :n],
                    'trust': R.mag[b].view(TRUSTTYPE)[:n], 'clipped': empty}
             if stages:
@@ -440,17 +438,28 @@ class Demodulator:
                     prev_export = None
                 if R.templates == 2 and s['sync_valid'][b] and max(s['sync_count'][b]) <= R.max_hits:
                     c0, c1 = s['sync_count'][b]
-                    rec['_sync'] = ((R.hits[b, 0, 0, :c0], R.hits[b, 0, 1, :c0]), (R.hits[b, 1, 0, :c1], R.hits[b, 1, 1, :c1]))
+                    # (plain lists: a block has a handful of hits, and the decoder composes them element by element)
+                    hb = R.hits[b]
+                    rec['_sync'] = ((hb[0, 0, :c0].tolist(), hb[0, 1, :c0].tolist()), (hb[1, 0, :c1].tolist(), hb[1, 1, :c1].tolist()))
                     if c0 and R.edges is not None:
                         # the leading positions of the streams the decoder would restart at for the first header hits
                         eh, cands = R.edge_hits, []
                         for E in R.edges[b].tolist():
                             if E[1]:
                                 n0, n1 = E[2], E[3]
-                                cands.append((E[0], (np.array(E[4:4 + n0], np.int32), np.array(E[4 + 2 * eh:4 + 2 * eh + n0], np.int32)),
-                                              (np.array(E[4 + eh:4 + eh + n1], np.int32), np.array(E[4 + 3 * eh:4 + 3 * eh + n1], np.int32))))
+                                cands.append((E[0], (E[4:4 + n0], E[4 + 2 * eh:4 + 2 * eh + n0]), (E[4 + eh:4 + eh + n1], E[4 + 3 * eh:4 + 3 * eh + n1])))
                         rec['_edges'] = cands
             out.append((est, rec))
+        if nb:
+            # what the object remembers of its last block (DB:612-632, 730-752)
+            last = nb - 1
+            if pick_valid[last]:
+                self._pick_bin = low[last]
+                self.dopplerIdxlast = np.int32(s['shift'][last])
+            else:
+                self.dopplerIdxlast = 0
+            self._codeRateResult = np.array(s['cr'][last], dtype=np.float32)
+            self.magnitudes = R.mag[last, :counts[last]]
         if stages:
             self._dev_tail = prev_export
         return out

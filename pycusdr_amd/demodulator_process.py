@@ -74,6 +74,7 @@ class DemodulatorRunner:
             self.demodulator, self.voteGroup = radioBackendVoteGroupIDX(self.radioBackend)
         self.decoderProtocol = confRadio.get('Protocol', 'None')
         self.frequencyOffset_Hz = confRadio['frequencyOffset_Hz']
+        self._fc = float(int(confRadio['frequency_Hz'] - confRadio['frequencyOffset_Hz']))    # the carrier the receiver is tuned to (DP:146)
         self.timeMA = 0.0
         self.iterCount = 0
         self.count = 0
@@ -225,7 +226,7 @@ class DemodulatorRunner:
         data['baudrate_est'] = self.Fs / data['spSymEst'] if data['spSymEst'] else 0.0
         # range rate implied by the measured frequency offset (reference computeTxFreqOffset, DP:359-379): against the carrier the
         # receiver is really tuned to, frequency_Hz minus the IF offset, as an integer (DP:146) -- pinned by fixture G19
-        fc = float(int(self.confRadio['frequency_Hz'] - self.confRadio['frequencyOffset_Hz']))
+        fc = self._fc
         data['rangerate'] = -data['doppler'] / fc * 299792458.0
         self.computeMATime(spent)
         data['time_ms'] = spent * 1e3
