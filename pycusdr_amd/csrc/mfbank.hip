@@ -53,6 +53,7 @@
 #include "sync_kernels.hpp"
 #include "energy_kernels.hpp"
 #include "stream_kernels.hpp"
+#include "hostcopy.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -3000,57 +3001,13 @@ extern "C" int mfb_sync(mfb_ctx *c) {
     return MFB_OK;
 }
 
-// ---- host copy worker (include/mfbank.h: mfb_hostcopy_*) ------------------------------------------------------------------------
-// One thread, one queue: the receive loop hands it the chunk -> window copies of the next batch and runs the host stages of the
-// previous batch meanwhile.  The worker spins for a few microseconds before it sleeps (chunks arrive in bursts; a futex wake costs
-// more than a 128 KiB copy).
-struct mfb_hostcopy {
-    struct Job {
-        void *dst;
-        const void *src;
-        size_t bytes;
-    };
-    std::mutex mu;
-    std::condition_variable cv_work, cv_done;
-    std::deque<Job> jobs;
-    std::atomic<long long> submitted{0}, done{0};
-    bool stop = false;
-    std::thread worker;
-
-    void run() {
-        for (;;) {
-            Job j;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                if (jobs.empty() && !stop) {
-                    lk.unlock();
-                    for (int spin = 0; spin < 4000 && submitted.load(std::memory_order_acquire) == done.load(std::memory_order_relaxed); ++spin)
-                        __builtin_ia32_pause();
-                    lk.lock();
-                }
-                cv_work.wait(lk, [&] { return stop || !jobs.empty(); });
-                if (jobs.empty()) return;              // stop, nothing left
-                j = jobs.front();
-                jobs.pop_front();
-            }
-            memcpy(j.dst, j.src, j.bytes);
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                done.fetch_add(1, std::memory_order_release);
-            }
-            cv_done.notify_all();
-        }
-    }
-};
-
+// ---- host copy worker (include/mfbank.h: mfb_hostcopy_*; the worker itself: hostcopy.hpp, plain C++) ----------------------------
 extern "C" int mfb_hostcopy_create(mfb_hostcopy **out) {
     if (!out) return MFB_ERR_ARG;
     *out = nullptr;
     mfb_hostcopy *q = new (std::nothrow) mfb_hostcopy();
     if (!q) return MFB_ERR_ALLOC;
-    try {
-        q->worker = std::thread([q] { q->run(); });
-    } catch (...) {
+    if (!q->start()) {
         delete q;
         return MFB_ERR_ALLOC;
     }
@@ -3060,30 +3017,18 @@ extern "C" int mfb_hostcopy_create(mfb_hostcopy **out) {
 
 extern "C" int mfb_hostcopy_submit(mfb_hostcopy *q, void *dst, const void *src, size_t bytes) {
     if (!q || (bytes && (!dst || !src))) return MFB_ERR_ARG;
-    if (!bytes) return MFB_OK;
-    {
-        std::lock_guard<std::mutex> lk(q->mu);
-        q->jobs.push_back({dst, src, bytes});
-        q->submitted.fetch_add(1, std::memory_order_release);
-    }
-    q->cv_work.notify_one();
+    if (bytes) q->submit(dst, src, bytes);
     return MFB_OK;
 }
 
 extern "C" int mfb_hostcopy_drain(mfb_hostcopy *q) {
     if (!q) return MFB_ERR_ARG;
-    std::unique_lock<std::mutex> lk(q->mu);
-    q->cv_done.wait(lk, [&] { return q->done.load(std::memory_order_acquire) == q->submitted.load(std::memory_order_acquire); });
+    q->drain();
     return MFB_OK;
 }
 
 extern "C" void mfb_hostcopy_destroy(mfb_hostcopy *q) {
     if (!q) return;
-    {
-        std::lock_guard<std::mutex> lk(q->mu);
-        q->stop = true;
-    }
-    q->cv_work.notify_all();
-    if (q->worker.joinable()) q->worker.join();
+    q->shutdown();
     delete q;
 }
