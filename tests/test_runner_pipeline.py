@@ -71,3 +71,31 @@ def test_pipelined_run_surfaces_failures_without_hanging(where, exc):
         run.run(_blocks(30, fail_at=9 if where == 'source' else None), decoder=_Decoder(fail_at=5 if where == 'decoder' else None),
                 pipelined=True)
     assert threading.active_count() <= 2          # the stage threads have ended
+
+
+def test_marked_source_puts_a_marker_where_the_transport_would_block():
+    """DemodulatorRunner.drain_marked(poll, wait): every chunk that is there, a ``None`` before each blocking wait, the end of the
+    stream when ``wait`` returns None; the object is re-iterable state-free glue (no device)."""
+    from pycusdr_amd.demodulator_process import MarkedSource
+    ready = [[1, 2], [], [3], [], []]          # what poll() finds before each time it comes back empty
+    waits = iter([10, 20, 30, None])           # what the blocking receive returns
+    batches = iter(ready)
+    cur = list(next(batches))
+    calls = []
+
+    def poll():
+        calls.append('poll')
+        return cur.pop(0) if cur else None
+
+    def wait():
+        calls.append('wait')
+        nonlocal cur
+        v = next(waits)
+        cur = list(next(batches, []))
+        return v
+    src = DemodulatorRunner.drain_marked(poll, wait)
+    assert isinstance(src, MarkedSource)
+    assert list(src) == [1, 2, None, 10, None, 20, 3, None, 30, None]
+    # every wait() is preceded by a poll() that came back empty: the loop has flushed before it blocks
+    for i, c in enumerate(calls):
+        assert c != 'wait' or calls[i - 1] == 'poll'
