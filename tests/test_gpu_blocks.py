@@ -196,6 +196,34 @@ def test_batched_stream_equals_one_block_stream(B):
         b.close()
 
 
+def test_more_blocks_per_call_than_the_device_stages_take():
+    """70 blocks per call (the device's stream stages chain at most 64 blocks, a recorded graph is kept per size up to 32): the
+    batch runs, the integer stages fall to the host code, everything equals the one-block loop."""
+    bs, ov, B = 13, 1 << 10, 70
+    N = 1 << bs
+    conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=16)
+    p = loadProtocol('bench_GMSK')(conf=conf)
+    nblocks = 2 * B + 9
+    sig = sg.s1_stream(nblocks, N, ov, 'GMSK', snr_db=12.0, seed=9)[ov:]
+    confB = copy.deepcopy(conf)
+    confB['GPU']['UHF'].setdefault('HIP', {})['blocks_per_call'] = B
+    a, b = DemodulatorRunner(conf, p, 'UHF-H'), DemodulatorRunner(confB, p, 'UHF-H')
+    try:
+        da, db = Decoder(conf, p), Decoder(conf, p)
+        ra, pa = a.run_stream([sig], decoder=da)
+        rb, pb = b.run_stream((sig[i:i + 30000] for i in range(0, len(sig), 30000)), decoder=db)
+        assert len(ra) == len(rb) == nblocks
+        for x, y in zip(ra, rb):
+            for k in ('count', 'doppler', 'doppler_std', 'SNR', 'spSymEst', 'numSyncSig'):
+                assert _same(x[k], y[k]), (x['count'], k)
+            assert _same(x['data'], y['data']) and _same(x['trust'], y['trust']), x['count']
+        assert len(pa) == len(pb) and all(_same(u.bits, v.bits) for u, v in zip(pa, pb))
+        assert getattr(b.demod, 'stage_blocks', 0) <= 9        # only the short last batch could run its stages on the device
+    finally:
+        a.close()
+        b.close()
+
+
 @pytest.mark.parametrize('with_decoder', [True, False])
 def test_a_live_source_gets_every_complete_block_out_at_its_markers(with_decoder):
     """A source that yields ``None`` where it would block ("nothing more right now", ``DemodulatorRunner.drain_marked``): the
