@@ -297,7 +297,8 @@ int mfb_receive_blocks_end(mfb_ctx *ctx, int slot, mfb_block_result *results, in
  * seeds the state again).  The state a batch starts from -- the previous block's tail (bits behind its window: poswinP, last
  * overlap_offset + 1 bits inside it: posSymEnd, DB:977-979) and the last bits_overlap bits of the stream -- stays on the device
  * from batch to batch; mfb_stream_seed sets it from the host's (start of a stream, after an irregular block, after blocks
- * that went another way).  p == NULL switches the stages off. */
+ * that went another way).  Batches of more than 64 blocks run without the stages (their records carry layout.stream_stages = 0: the
+ * host does A12 ... A14 for them).  p == NULL switches the stages off. */
 typedef struct mfb_stream_params {
     int32_t overlap_samples;     /* 2^overlap (config GPU.overlap) */
     int32_t overlap_offset;      /* symbol_check_overlap_offset (DB:19-26): 20 */
