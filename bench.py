@@ -165,7 +165,7 @@ def chain_figures(local_rank, blocks_per_call=None, n_packets=240):
     bm = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bm)
     out = {}
-    per_call = blocks_per_call or {15: 16, 17: 8}             # about a millisecond of samples per device call at either size
+    per_call = blocks_per_call or {15: 32, 17: 8}             # windows of 2^20 samples (DemodulatorRunner.auto_blocks_per_call)
     for log2n in (15, 17):
         Bn = per_call[log2n] if isinstance(per_call, dict) else per_call
         stim = bm.make_stream('GMSK', n_packets, 12.0, log2n, 2)          # one stimulus for every run at this size

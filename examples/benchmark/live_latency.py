@@ -1,6 +1,6 @@
 """What a live source pays for batches: a producer thread hands the receive loop 4096-sample chunks at a set pace through a queue
 (the reference's ZeroMQ subscriber in miniature, sigFIFO.py:156-163), the loop runs ``run_stream(drain_marked(poll, wait))`` --
-up to 16 blocks per device call while there is a backlog, every complete block at once while there is none.  Printed per pace: the
+up to 32 blocks (2^20 samples) per device call while there is a backlog, every complete block at once while there is none.  Printed per pace: the
 mean number of blocks per device call and the latency from a block's last sample to its result dict.
 usage: python examples/benchmark/live_latency.py [log2N] [blocks per pace]"""
 import os

@@ -390,9 +390,10 @@ class DemodulatorRunner:
         return MarkedSource(poll, wait)
 
     def auto_blocks_per_call(self):
-        """Blocks per device call for a source that marks where it would block: windows of about 2^19 samples, at most 16 blocks
-        (2^15-sample blocks: 16, 2^17: 4, 2^19 and above: one block per call)."""
-        return max(1, min(16, (1 << 19) // self.blockSize))
+        """Blocks per device call for a source that marks where it would block: windows of about 2^20 samples, at most 32 blocks
+        (2^15-sample blocks: 32, 2^17: 8, 2^20 and above: one block per call) -- the sizes the sweep in profiles/r05_chain.md
+        found best."""
+        return max(1, min(32, (1 << 20) // self.blockSize))
 
     def _run_stream_batched(self, chunk_source, sink, decoder, B):
         """``run_stream`` with B consecutive blocks per device call (``"HIP": {"blocks_per_call": B}``; mfb_receive_blocks_*).

@@ -298,8 +298,8 @@ def test_a_live_source_gets_every_complete_block_out_at_its_markers(with_decoder
         # the pipelined form takes the same source
         rc, _ = a.run_stream(live(), pipelined=True)
         assert len(rc) == nblocks
-        # a marked source gets batches without being configured (they cost it no latency): 2^15-sample blocks -> up to 16 per call
-        assert a.auto_blocks_per_call() == 16 and a.blocks_per_call() == 1
+        # a marked source gets batches without being configured (they cost it no latency): 2^15-sample blocks -> up to 32 per call
+        assert a.auto_blocks_per_call() == 32 and a.blocks_per_call() == 1
         seen = []
         inner_a = a.demod.beginBlocks
         a.demod.beginBlocks = lambda which, nb, **kw: (seen.append(nb), inner_a(which, nb, **kw))[1]
