@@ -441,6 +441,72 @@ def test_a_failing_source_or_sink_leaves_the_runner_usable():
         fresh.close()
 
 
+def test_c_entry_points_of_the_batch_path_refuse_bad_arguments():
+    """mfb_window_buffer / mfb_receive_blocks_* / mfb_set_stream_stages / mfb_stream_seed called straight through ctypes with
+    arguments outside their contract: a status code every time (MFB_ERR_ARG / MFB_ERR_STATE), never a crash, and the handle works
+    afterwards."""
+    import ctypes as C
+    from pycusdr_amd import _lib
+    bs = 13
+    conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=8)
+    p = loadProtocol('bench_GMSK')(conf=conf)
+    d = UHF.Demodulator(conf, p, 'UHF-H')
+    try:
+        lib, h, bank = _lib.load(), d.bank._h, d.bank
+        N, ov = 1 << bs, 1 << 10
+        ptr = C.POINTER(C.c_float)()
+        ARG, STATE = _lib.MFB_ERR_ARG, _lib.MFB_ERR_STATE
+        for which, nb, stride in ((2, 2, N - ov), (-1, 2, N - ov), (0, 0, N - ov), (0, 2000, N - ov), (0, 2, 0), (0, 2, N + 1)):
+            assert lib.mfb_window_buffer(h, which, nb, stride, C.byref(ptr)) == ARG, (which, nb, stride)
+        assert lib.mfb_window_buffer(h, 0, 2, N - ov, None) == ARG and lib.mfb_window_buffer(None, 0, 2, N - ov, C.byref(ptr)) == ARG
+        P = bank._block_params(d.codeRateAndPhaseOffsetLow if hasattr(d, 'codeRateAndPhaseOffsetLow') else 400, 200, 8, 0, 5, None, 'window', None)
+        assert lib.mfb_receive_blocks_begin(h, C.byref(P), 2, 0) == STATE          # no window yet
+        w = d.blockWindows(3)
+        w[0][:] = sg.s1_stream(3, N, ov, 'GMSK', snr_db=12.0, seed=1)[:len(w[0])]
+        for nb, slot in ((0, 0), (-3, 0), (2, 2), (2, -1)):
+            assert lib.mfb_receive_blocks_begin(h, C.byref(P), nb, slot) == ARG, (nb, slot)
+        assert lib.mfb_receive_blocks_begin(h, None, 2, 0) == ARG
+        assert lib.mfb_receive_blocks_begin(h, C.byref(P), 4, 0) == STATE          # more blocks than the window holds
+        Q = bank._block_params(400, 200, 8, 0, 5, None, 'window', None, block_stride=N - ov - 1)
+        assert lib.mfb_receive_blocks_begin(h, C.byref(Q), 2, 0) == ARG            # not the window's stride
+        Q = bank._block_params(400, 200, 8, 0, 5, None, 'device', None, block_stride=N - ov)
+        assert lib.mfb_receive_blocks_begin(h, C.byref(Q), 2, 0) == ARG            # device input without a pointer
+        lay = _lib.RecordLayout()
+        buf = np.empty(1 << 20, np.uint8)
+        assert lib.mfb_receive_blocks_end_record(h, 0, buf.ctypes.data, buf.size, C.byref(lay)) == STATE      # nothing in flight
+        assert lib.mfb_receive_blocks_end_record(h, 3, buf.ctypes.data, buf.size, C.byref(lay)) == ARG
+        assert lib.mfb_receive_blocks_end(h, 0, None, None, None, None, 0, None) != 0
+        # stream stages
+        S = _lib.StreamParams()
+        assert lib.mfb_set_stream_stages(h, C.byref(S)) == ARG                    # all zero: no LUT mode
+        lut = np.array([0, 1] * 4, np.uint8)
+        S.overlap_samples, S.overlap_offset, S.match_threshold, S.error_threshold = ov, 20, 10, 1000
+        S.lut_mode, S.lut_rows, S.lut = 1, 8, lut.ctypes.data
+        for field, bad in (('lut_mode', 3), ('lut_rows', 0), ('lut_rows', 257), ('overlap_samples', 1), ('overlap_samples', N),
+                           ('overlap_offset', 0), ('overlap_offset', 32), ('num_templates', 3), ('num_templates', -1)):
+            keep = getattr(S, field)
+            setattr(S, field, bad)
+            assert lib.mfb_set_stream_stages(h, C.byref(S)) == ARG, (field, bad)
+            setattr(S, field, keep)
+        S.num_templates = 1                                                       # templates announced, none given
+        assert lib.mfb_set_stream_stages(h, C.byref(S)) == ARG
+        S.num_templates = 0
+        assert lib.mfb_stream_seed(h, None, 0, None, 0, None, 0) == STATE          # stages are off
+        assert lib.mfb_set_stream_stages(h, C.byref(S)) == 0
+        z = np.zeros(5000, np.uint8)
+        for npost, nend, nring in ((-1, 0, 0), (513, 0, 0), (0, 33, 0), (0, 0, 4097)):
+            assert lib.mfb_stream_seed(h, z.ctypes.data, npost, z.ctypes.data, nend, z.ctypes.data, nring) == ARG, (npost, nend, nring)
+        assert lib.mfb_stream_seed(h, None, 4, None, 0, None, 0) == ARG            # a length without an array
+        assert lib.mfb_stream_seed(h, None, 0, None, 0, None, 0) == 0
+        assert lib.mfb_set_stream_stages(h, None) == 0                            # off again
+        # the handle still works
+        d.beginBlocks(0, 3)
+        got = d.endBlocks(0)
+        assert len(got) == 3 and all(len(r['symbols']) > 200 for _, r in got)
+    finally:
+        d.close()
+
+
 def test_cc11xx_stream_with_blocks_per_call():
     """The production protocol (config/CC11xx.json: FSK-2 at 128 samples per symbol, 384-tap filters -> 2048-point segments, IF offset,
     numBitsOverlap 2048, a 64-tap header mask and a 32-tap sync flag, FIXED packets of 2136 bits) through the batched loop with the
