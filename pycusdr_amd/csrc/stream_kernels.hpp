@@ -13,6 +13,9 @@
 // The previous block's tail (the bits behind its window, the last offset + 1 bits inside it) is a function of that block's
 // DEVICE results alone (the +-1 repair moves a window's start, never its last bits), so every block of a batch is aligned in
 // parallel; the first block's predecessor comes from a device-resident carry the previous batch left (double-buffered).
+// Kernels: k_stream_align (A12 + A13, one workgroup per block), k_stream_search (A14 with the stream bit-packed in LDS, its
+// would-be stash edges and the ring for the next batch: one launch, templates of <= 256 taps in {-1, 0, +1}); k_stream_sync /
+// k_stream_ring / k_stream_edges are the byte forms of the same three steps for templates the packing does not take.
 #pragma once
 #include <stdint.h>
 
@@ -306,7 +309,7 @@ __global__ void __launch_bounds__(STREAM_ALIGN_THREADS) k_stream_align(StreamArg
     }
 }
 
-// ---- A14 on the windows without a stash -----------------------------------------------------------------------------------
+// ---- A14 on the windows without a stash: the byte kernels (templates of > 256 taps or other tap values) -------------------------
 // V = ring (the numBitsOverlap bits before the batch) ++ bitsWin_0 ++ bitsWin_1 ++ ...; block b's stream is
 // V[cum_b : cum_b + nOv + nwin_b] (cum_b = kept bits of the blocks before it).  Workgroup (template, block) walks over its stream
 // in segments with a running offset, so hits come out ordered without atomics (as k_sync_small does for the decoder's own call).
