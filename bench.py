@@ -197,9 +197,10 @@ def segment_roofline_core(info, Dl, Mu, launches, kernel_ms_total):
             'flops_per_launch': fl}
 
 
-def bank_figure(dev, local_rank, protocol, D, log2N, blocks, esz, nblocks, steps=10, warmup=2):
+def bank_figure(dev, local_rank, protocol, D, log2N, blocks, esz, nblocks, steps=10, warmup=2, s2_blocks=None):
     """Untimed-region figure of another BASELINE bank on the same device: its own handle, the same step as the headline
-    (forward FFT, search over D bins, pick, 8-byte read-back), HIP-event kernel time, the same flop formula."""
+    (forward FFT, search over D bins, pick, 8-byte read-back), HIP-event kernel time, the same flop formula.  With `s2_blocks`
+    (white noise resident in HBM) the same loop once more on them, behind a settle of its own: `s2_msamples`."""
     import torch
     from pycusdr_amd import config as cfg
     from pycusdr_amd.mfbank import MFBank
@@ -224,31 +225,40 @@ def bank_figure(dev, local_rank, protocol, D, log2N, blocks, esz, nblocks, steps
         info = bank.get_search_path()
         Mu = bank.get_info()[2]
 
-        def one(i):
-            bank.upload_device(blocks.data_ptr() + (i % nblocks) * esz)
-            return bank.find_carrier()
-        # untimed: at least `warmup` steps and at least 50 ms of them -- building the handle (filter generation and analysis on
-        # the host) left the device idle, and it needs ~30 ms of work to settle its clock again (tools/ramp_probe.py)
-        t_w, i = time.perf_counter(), 0
-        while i < 1 + warmup or time.perf_counter() - t_w < 0.05:
-            one(i)
-            i += 1
-        settle = i
-        torch.cuda.synchronize(dev)
-        bank.profile_enable(True)
-        t0 = time.perf_counter()
-        for i in range(steps):
-            one(i)
-        torch.cuda.synchronize(dev)
-        dt = (time.perf_counter() - t0) / steps
-        counts, kms = bank.profile_read()
-        bank.profile_enable(False)
+        def leg(src):
+            def one(i):
+                bank.upload_device(src.data_ptr() + (i % nblocks) * esz)
+                return bank.find_carrier()
+            # untimed: at least `warmup` steps and at least 50 ms of them -- building the handle (filter generation and analysis
+            # on the host) left the device idle, and it needs ~30 ms of work to settle its clock again (tools/ramp_probe.py)
+            t_w, i = time.perf_counter(), 0
+            while i < 1 + warmup or time.perf_counter() - t_w < SETTLE_S:
+                one(i)
+                i += 1
+            torch.cuda.synchronize(dev)
+            bank.profile_enable(True)
+            t0 = time.perf_counter()
+            for k in range(steps):
+                one(k)
+            torch.cuda.synchronize(dev)
+            dt_ = (time.perf_counter() - t0) / steps
+            counts_, kms_ = bank.profile_read()
+            bank.profile_enable(False)
+            return i, dt_, counts_, kms_
+        settle, dt, counts, kms = leg(blocks)
         out = {'protocol': protocol, 'D': D, 'M': M, 'M_unique': Mu, 'samplesPerSym': sps, 'taps': info['taps'], 'path': info,
                'steps': steps, 'untimed_steps_before': settle, 'ms_per_step': round(dt * 1e3, 4), 'msamples': round((N - ov) / dt / 1e6, 2),
                'filter_generation_s': round(t_gen, 2), 'mfb_set_filters_s': round(t_set, 2),
                'rangeRateMax_used': rr, 'signal': 'S1 blocks of the headline (throughput only: the stimulus does not match this bank)'}
         if info['path'] == 'segment':
             out['roofline'] = segment_roofline_core(info, D, Mu, counts[0], kms[0])
+        if s2_blocks is not None:
+            _, dt2, c2, k2 = leg(s2_blocks)
+            out['s2_ms_per_step'] = round(dt2 * 1e3, 4)
+            out['s2_msamples'] = round((N - ov) / dt2 / 1e6, 2)
+            out['s2_over_s1'] = round(dt / dt2, 4)
+            if info['path'] == 'segment':
+                out['s2_roofline_frac'] = segment_roofline_core(info, D, Mu, c2[0], k2[0])['frac']
         return out
     finally:
         bank.close()
@@ -517,6 +527,9 @@ def main():
     ap.add_argument('--log2n', type=int, default=20)
     ap.add_argument('--bins', type=int, default=256, help='Doppler bins per GPU')
     ap.add_argument('--protocol', default='bench_GMSK')
+    ap.add_argument('--signal', choices=['S1', 'S2'], default='S1',
+                    help='stimulus of the timed loop: S1 = GMSK bench packet at +fs/4 with AWGN 10 dB (default), S2 = white noise '
+                         '(the default run times S2 as well, config.s2_*; this switch is for profile runs of the whole line on S2)')
     ap.add_argument('--path', choices=['auto', 'segment', 'twopass'], default='auto')
     ap.add_argument('--seg', default='', help='segment path tuning: log2L,wg_per_cu,filters_per_pass (0 = default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -632,6 +645,14 @@ def main():
     host_blocks = np.stack([stream[b * (N - ov): b * (N - ov) + N] for b in range(nblocks)])
     blocks = torch.from_numpy(host_blocks.view(np.float32).reshape(nblocks, 2 * N)).to(dev)
     esz = blocks.element_size() * 2 * N
+    # S2 (unit-variance white noise, what a receiver sees between passes; the reference's bench adds exactly such
+    # noise, examples/benchmark/create_signals.py:115-141): sixteen blocks resident in HBM as well, generated BEFORE the warm-up --
+    # half a second of host work with an idle device in front of a timed loop would put that loop into the clock ramp
+    s2_blocks = None
+    if G == 1 and not args.force_dist and not args.no_extras or args.signal == 'S2':
+        s2_blocks = torch.from_numpy(sg.s2_noise(nblocks, N).view(np.float32).reshape(nblocks, 2 * N)).to(dev)
+    if args.signal == 'S2':            # profiling runs: the whole line on S2
+        blocks, host_blocks = s2_blocks, s2_blocks.cpu().numpy().view(np.complex64).reshape(nblocks, N)
     torch.cuda.synchronize(dev)        # the blocks are resident before any other stream reads them
 
     def block_index(i):
@@ -715,12 +736,34 @@ def main():
     last_block = block_index(first - 1)
     gscores = bank.get_scores()[:, 0].astype(np.float64)
 
+    # ---- S2: the SAME loop on white noise (same settle rule, --steps, --repeats, sixteen blocks resident) --------------------
+    s2 = None
+    if s2_blocks is not None and shard is None and args.signal == 'S1':
+        t_w, i2 = time.perf_counter(), 0
+        while time.perf_counter() - t_w < SETTLE_S or i2 < 8:
+            for _ in range(8):
+                step(i2, s2_blocks)
+                i2 += 1
+        bank.profile_enable(True)
+        times2 = []
+        for rep in range(args.repeats):
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(i2, i2 + args.steps):
+                step(i, s2_blocks)
+            barrier()
+            times2.append(time.perf_counter() - t0)
+            i2 += args.steps
+        c2, k2 = bank.profile_read()
+        bank.profile_enable(False)
+        s2 = {'times': times2, 'counts': c2, 'kms': k2, 'untimed_steps_before': i2 - args.steps * args.repeats}
+
     # live sanity: the pick must land on the +fs/4 carrier
     frac_idx = float(res[0])
     pick_shift = float(np.interp(frac_idx, np.arange(D_total), np.where(shifts > N // 2, shifts - N, shifts)))
     spacing = float(np.median(np.diff(np.sort(shifts))))
     # (only the GMSK bank matches the S1 stimulus; the other banks are timed on it for throughput alone)
-    carrier_ok = abs(pick_shift - N / 4) <= 1.5 * spacing if args.protocol == 'bench_GMSK' else None
+    carrier_ok = abs(pick_shift - N / 4) <= 1.5 * spacing if args.protocol == 'bench_GMSK' and args.signal == 'S1' else None
 
     # ---- untimed secondary figures -----------------------------------------------------
     extras = {}
@@ -750,17 +793,6 @@ def main():
         for i in range(reps):
             bank.receive_block(k_off, k_len, 8, source='device', device_ptr=blocks.data_ptr() + block_index(i) * esz)
         extras['receive_block_one_call_ms'] = round((time.perf_counter() - t1) / reps * 1e3, 4)
-        # S2: pure-throughput signal (unit-variance white noise, RandomState(0)), same step
-        s2 = sg.s2_noise(4, N)
-        if s2 is not None:
-            s2_dev = torch.from_numpy(s2.view(np.float32).reshape(4, 2 * N)).to(dev)
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            for i in range(8):
-                bank.upload_device(s2_dev.data_ptr() + (i % 4) * esz)
-                bank.find_carrier()
-            torch.cuda.synchronize(dev)
-            extras['S2_white_noise_msamples'] = round((N - ov) / ((time.perf_counter() - t1) / 8) / 1e6, 2)
         # the other search path, same blocks, a few steps (its own roofline accounting)
         if G == 1:
             try:
@@ -864,7 +896,7 @@ def main():
 
     if shard is None and G == 1 and not args.no_extras and not args.no_other_banks:
         # the other BASELINE-named banks at the same geometry (C5's two filter sets at D = 256) and C3 (D = 1024)
-        extras['other_banks'] = [bank_figure(dev, local_rank, p, args.bins, log2N, blocks, esz, nblocks)
+        extras['other_banks'] = [bank_figure(dev, local_rank, p, args.bins, log2N, blocks, esz, nblocks, s2_blocks=s2_blocks)
                                  for p in ('CC11xx', 'bench_BPSK') if p != args.protocol]
         extras['c3'] = bank_figure(dev, local_rank, args.protocol, 1024, log2N, blocks, esz, nblocks, steps=4, warmup=1)
 
@@ -966,7 +998,8 @@ def main():
             'config': {
                 'workload': workload, 'path': pinfo,
                 'D_total': D_total, 'D_per_gpu': Dl, 'M': M, 'M_unique': Mu, 'log2N': log2N, 'overlap': ov,
-                'signal': 'S1: GMSK bench packet at +fs/4, tiled, AWGN 10 dB (RandomState(1)), resident in HBM',
+                'signal': ('S1: GMSK bench packet at +fs/4, tiled, AWGN 10 dB (RandomState(1)), resident in HBM' if args.signal == 'S1' else
+                           'S2: unit-variance white noise (RandomState(0)), sixteen blocks resident in HBM'),
                 'rangeRateMax_used': rr, 'twopass_tuning(chunk,mpb,rows,jsplit)': list(tun),
                 'units': 'samples through a 256-bin bank, summed over ranks',
                 'stream_msamples': round((N - ov) / (elapsed / args.steps) / 1e6, 3) if not by_blocks else round(value, 3),
@@ -988,11 +1021,31 @@ def main():
             'ms_per_step_min': round(min(times) / args.steps * 1e3, 4), 'ms_per_step_max': round(max(times) / args.steps * 1e3, 4),
             'value_min': round(per_step / (max(times) / args.steps), 3), 'value_max': round(per_step / (min(times) / args.steps), 3),
             'roofline_frac': roof.get('frac'), 'roofline_bound': roof.get('bound')}
+        if s2 is not None:
+            # the headline's loop on S2: median repeat, the same flop formula on the HIP-event time of its own launches
+            el2 = float(np.median(s2['times']))
+            s2_roof = segment_roofline(pinfo, Dl, s2['counts'], s2['kms']) if pinfo['path'] == 'segment' else \
+                twopass_roofline(Dl, s2['counts'], s2['kms'], tun, timed_steps)
+            out['config']['s2'] = {
+                'signal': 'S2: unit-variance white noise (RandomState(0)), sixteen blocks resident in HBM; same loop, settle rule, '
+                          '--steps and --repeats as the headline',
+                'ms_per_step': round(el2 / args.steps * 1e3, 4), 'msamples': round(per_step / (el2 / args.steps), 3),
+                'ms_per_step_min': round(min(s2['times']) / args.steps * 1e3, 4), 'ms_per_step_max': round(max(s2['times']) / args.steps * 1e3, 4),
+                'untimed_steps_before': s2['untimed_steps_before'], 'roofline_frac': s2_roof['frac'], 'avg_launch_ms': s2_roof['avg_launch_ms'],
+                'over_s1': round(elapsed / el2, 4),
+                'note': 'profiles/r06_s1_vs_s2.md: same cycles per launch, same clock, same watts as S1; the -10 ... -13 % of earlier '
+                        'rounds was an 8-step timing inside the clock ramp that follows host-side noise generation'}
+            flat['s2_msamples'] = out['config']['s2']['msamples']
+            flat['s2_roofline_frac'] = s2_roof['frac']
+            flat['s2_over_s1'] = out['config']['s2']['over_s1']
         for key, fig in [(b['protocol'].replace('bench_', '').lower(), b) for b in extras.get('other_banks', [])] + \
                         ([('c3', extras['c3'])] if 'c3' in extras else []):
             flat[f'{key}_msamples'] = fig['msamples']
             flat[f'{key}_ms_per_step'] = fig['ms_per_step']
             flat[f'{key}_roofline_frac'] = fig.get('roofline', {}).get('frac')
+            if 's2_msamples' in fig:
+                flat[f'{key}_s2_msamples'] = fig['s2_msamples']
+                flat[f'{key}_s2_over_s1'] = fig['s2_over_s1']
         if 'sync_correlator' in extras:
             flat['sync_streams_per_s'] = extras['sync_correlator']['streams_per_s']
         for key in ('span_basis_search', 'energy_search'):
