@@ -197,7 +197,23 @@ def segment_roofline_core(info, Dl, Mu, launches, kernel_ms_total):
             'flops_per_launch': fl}
 
 
-def bank_figure(dev, local_rank, protocol, D, log2N, blocks, esz, nblocks, steps=10, warmup=2, s2_blocks=None):
+def twopass_roofline_core(N, Dl, Mu, counts, kms, nsteps):
+    """HBM roofline of the two-pass path's dominant kernel from its own launch durations: algorithmic bytes per launch (DESIGN.md
+    4.2) over the HIP-event average."""
+    dom = 0 if kms[0] >= kms[1] else 1
+    launches = max(counts[dom], 1)
+    bins_per_launch = Dl * nsteps / launches
+    if dom == 0:
+        k_bytes = 8.0 * bins_per_launch * Mu * N + 8.0 * N * (1 + Mu)   # Z write + spectrum + filter bank read once
+    else:
+        k_bytes = 8.0 * bins_per_launch * Mu * N + 4.0 * bins_per_launch * Mu  # Z read + partial sums
+    k_avg_s = kms[dom] / launches * 1e-3
+    return {'bound': 'hbm', 'kernel': ['k_pass1<BANK>', 'k_pass2<REDUCE>'][dom], 'achieved': round(k_bytes / k_avg_s / 1e9, 2),
+            'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': round(k_bytes / k_avg_s / HBM_PEAK, 4), 'launches': launches,
+            'avg_launch_ms': round(k_avg_s * 1e3, 4), 'alg_bytes_per_launch': k_bytes}
+
+
+def bank_figure(dev, local_rank, protocol, D, log2N, blocks, esz, nblocks, steps=10, warmup=2, s2_blocks=None, span=False, twopass_steps=0):
     """Untimed-region figure of another BASELINE bank on the same device: its own handle, the same step as the headline
     (forward FFT, search over D bins, pick, 8-byte read-back), HIP-event kernel time, the same flop formula.  With `s2_blocks`
     (white noise resident in HBM) the same loop once more on them, behind a settle of its own: `s2_msamples`."""
@@ -225,7 +241,7 @@ def bank_figure(dev, local_rank, protocol, D, log2N, blocks, esz, nblocks, steps
         info = bank.get_search_path()
         Mu = bank.get_info()[2]
 
-        def leg(src):
+        def leg(src, steps=steps):
             def one(i):
                 bank.upload_device(src.data_ptr() + (i % nblocks) * esz)
                 return bank.find_carrier()
@@ -252,6 +268,36 @@ def bank_figure(dev, local_rank, protocol, D, log2N, blocks, esz, nblocks, steps
                'rangeRateMax_used': rr, 'signal': 'S1 blocks of the headline (throughput only: the stimulus does not match this bank)'}
         if info['path'] == 'segment':
             out['roofline'] = segment_roofline_core(info, D, Mu, counts[0], kms[0])
+        if span and info['path'] == 'segment':
+            # opt-in span basis of the SUM_ALL search: rank(bank) filters transformed instead of M; same table to
+            # fp32 rounding -- never part of `msamples`
+            try:
+                sc_f = bank.get_scores()[:, 0].astype(np.float64)
+                last_i = (steps - 1) % nblocks
+                bank.set_search_basis('span')
+                sb = bank.get_search_basis()
+                _, dts, _, _ = leg(blocks)
+                sc_s = bank.get_scores()[:, 0].astype(np.float64)
+                out['span_basis'] = {'filters_transformed': sb[1], 'of': M, 'ms_per_step': round(dts * 1e3, 4),
+                                     'msamples': round((N - ov) / dts / 1e6, 2),
+                                     'max_rel_diff_vs_default_search': float(np.abs(sc_s - sc_f).max() / sc_f.max()), 'block': last_i}
+            except (ValueError, RuntimeError) as e:
+                out['span_basis'] = {'error': str(e)[:100]}
+            finally:
+                bank.set_search_basis('filters')
+        if twopass_steps:
+            # the HBM-bound formulation at this geometry (BASELINE C3: "HBM-bound stress, rocprof GB/s vs roofline")
+            try:
+                bank.set_search_path('twopass')
+                _, dtt, ct_, kt_ = leg(blocks, twopass_steps)
+                tp = twopass_roofline_core(N, D, Mu, ct_, kt_, twopass_steps)
+                tp.update({'ms_per_step': round(dtt * 1e3, 4), 'msamples': round((N - ov) / dtt / 1e6, 2), 'steps': twopass_steps,
+                           'tuning(chunk,mpb,rows,jsplit)': list(bank.get_tuning())})
+                out['twopass'] = tp
+            except (ValueError, RuntimeError) as e:
+                out['twopass'] = {'error': str(e)[:100]}
+            finally:
+                bank.set_search_path('auto')
         if s2_blocks is not None:
             _, dt2, c2, k2 = leg(s2_blocks)
             out['s2_ms_per_step'] = round(dt2 * 1e3, 4)
@@ -594,10 +640,14 @@ def main():
         if args.backend == 'gloo':                      # rehearsal: ranks may share a device
             local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
+        # peers that never arrive must cost a worker 90 s, not the 10-minute default (the driver's whole budget): it then exits
+        # non-zero in time for the supervisor's fallback attempt to print a line
+        from datetime import timedelta
+        pg_timeout = timedelta(seconds=float(os.environ.get('BENCH_PG_TIMEOUT_S', '90')))
         if args.backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank), timeout=pg_timeout)
         else:
-            dist.init_process_group('gloo')
+            dist.init_process_group('gloo', timeout=pg_timeout)
         if dist.get_world_size() != G:       # never report a smaller world under the requested --gpus
             sys.stderr.write(f'bench.py: --gpus {G} but the process group has {dist.get_world_size()} ranks\n')
             sys.exit(2)
@@ -896,9 +946,9 @@ def main():
 
     if shard is None and G == 1 and not args.no_extras and not args.no_other_banks:
         # the other BASELINE-named banks at the same geometry (C5's two filter sets at D = 256) and C3 (D = 1024)
-        extras['other_banks'] = [bank_figure(dev, local_rank, p, args.bins, log2N, blocks, esz, nblocks, s2_blocks=s2_blocks)
+        extras['other_banks'] = [bank_figure(dev, local_rank, p, args.bins, log2N, blocks, esz, nblocks, s2_blocks=s2_blocks, span=True)
                                  for p in ('CC11xx', 'bench_BPSK') if p != args.protocol]
-        extras['c3'] = bank_figure(dev, local_rank, args.protocol, 1024, log2N, blocks, esz, nblocks, steps=4, warmup=1)
+        extras['c3'] = bank_figure(dev, local_rank, args.protocol, 1024, log2N, blocks, esz, nblocks, steps=4, warmup=1, twopass_steps=3)
 
     blocks_leg = None
     if dist is not None and G > 1 and shard is not None and not args.no_blocks_leg:
@@ -1046,6 +1096,12 @@ def main():
             if 's2_msamples' in fig:
                 flat[f'{key}_s2_msamples'] = fig['s2_msamples']
                 flat[f'{key}_s2_over_s1'] = fig['s2_over_s1']
+            if 'msamples' in fig.get('span_basis', {}):
+                flat[f'span_{key}_msamples'] = fig['span_basis']['msamples']
+                flat[f'span_{key}_max_rel_diff'] = fig['span_basis']['max_rel_diff_vs_default_search']
+            if 'msamples' in fig.get('twopass', {}):
+                flat[f'{key}_twopass_msamples'] = fig['twopass']['msamples']
+                flat[f'{key}_twopass_hbm_frac'] = fig['twopass']['frac']
         if 'sync_correlator' in extras:
             flat['sync_streams_per_s'] = extras['sync_correlator']['streams_per_s']
         for key in ('span_basis_search', 'energy_search'):

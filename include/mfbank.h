@@ -321,7 +321,8 @@ int mfb_stream_seed(mfb_ctx *ctx, const uint8_t *post, int npost, const uint8_t 
  * with the stream stages on: kept bits / centres mod 256 / trust bytes (uint8, a13_nwin valid), the block's tail (post: a13_npost
  * bytes, end: a13_nend), the sync hits (per template: int32 idx[max_hits] | score[max_hits]; sync_count valid).  One copy per
  * batch instead of one call per array and block: what mfb_receive_blocks_end hands out, read in place (DB:1000-1006 reads
- * three arrays per block with three memcpy_dtoh). */
+ * three arrays per block with three memcpy_dtoh).  capacity < nblocks * record_bytes: MFB_ERR_ARG with layout->nblocks and
+ * layout->record_bytes filled in (everything else zero) and the batch STILL in flight -- call again with a buffer of that size. */
 typedef struct mfb_record_layout {
     int32_t nblocks, scalars_bytes, symbols, band_capacity, mode, fixed_shift, stream_stages, max_hits, templates, reserved;
     int32_t edge_candidates, edge_hits;   /* per block: the leading T - 1 positions of the stream a FIXED-mode decoder would restart

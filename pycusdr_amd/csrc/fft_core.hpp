@@ -493,6 +493,293 @@ DEVI void fft_w32(cf (&v)[32], cf *xbuf, const int lane, const W32Regs &r, Store
     });
 }
 
+// ---- fused-twiddle radix-2 transforms (round 6; MFB_FFT_FUSED) ------------------------------------------------------------
+// The radix-16 chain above multiplies by every twiddle on its own -- v_pk_mul + v_pk_fma -- and adds afterwards: a radix-2 butterfly
+// a +- w b costs four packed operations.  With the twiddle in "tangent form", w = c (1 + i t), t = tan(arg w), c = cos(arg w)
+// (Linzer & Feig's fused-multiply-add butterflies), it costs THREE, all v_pk_fma_f32:
+//       b' = b + t (i b)          a + c b'          a - c b'
+// and one rounding less per output.  A transform is then a radix-2 decimation-in-time chain in which only ONE input of a butterfly
+// ever carries a twiddle.  For the second pass of a two-pass transform this needs the inter-pass twiddle on the READ side of
+// the exchange: lane p reads b_i = B[i][p], i < n, and owes out[q] = sum_i b_i (W_n^q w)^i with w = W_L^p, which is the recursion
+//       F(b, w, n)[q], F[q + n/2] = F(b_even, w^2, n/2)[q] +- (W_n^q w) F(b_odd, w^2, n/2)[q]
+// -- stage s (sub-transforms of 2^s points) uses the twiddles W_(2^s)^q w^(n >> s), q < 2^(s-1); q and q + 2^(s-2) differ by the
+// factor i, which is an operand swizzle (ROT), so a lane keeps 1 + 1 + 2 + 4 (+ 8) = 8 (16) pairs (c, t) for n = 16 (32) -- 16
+// (32) VGPRs where the radix-16 chain kept 30 (62) -- and none of their angles reaches pi/2 except in stage 1, where the one lane
+// whose twiddle is exactly i gets (2^-40, 2^40): c t = 1 exactly and c b vanishes in the rounding.  In-place slots: stage s pairs
+// slot a with a + (n >> s); output q ends in slot bitrev(q).  tests/test_fft_algebra.py holds the numpy model (fp32 rounding per
+// operation) of exactly this; per 256-point transform 170 packed operations instead of 190, per 2048-point transform 498
+// instead of 655 (profiles/r06_fft_ops.md).
+#ifndef MFB_FFT_FUSED
+#define MFB_FFT_FUSED 1
+#endif
+// the write side (constant twiddles) as a fused chain too (1), or as the radix-4 butterflies of the older transforms (0: fewer
+// multiplier operations, more instructions -- the A/B of profiles/r06_fft_ops.md)
+#ifndef MFB_FUSED_FIRST
+#define MFB_FUSED_FIRST 1
+#endif
+constexpr int brevc(int x, int bits) { return bits <= 0 ? 0 : (((x & 1) << (bits - 1)) | brevc(x >> 1, bits - 1)); }
+
+// (a, b) <- (a + w b, a - w b), w = i^ROT c (1 + i t), tw = (c, t) in a VGPR pair (SREG: an SGPR pair).  NX / NY: which of the
+// two outputs is wanted (a dead half of a last-stage butterfly is not computed).  One asm statement per butterfly: the hazard
+// recogniser would pad every hand-over between separate statements (see cmul).  b' overwrites b, the sum goes to a fresh pair.
+#define MFB_I1(B) "v_pk_fma_f32 %[" B "], %[w], %[" B "], %[" B "] op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+#define MFB_IX0(X, B, A) "v_pk_fma_f32 %[" X "], %[w], %[" B "], %[" A "] op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+#define MFB_IY0(B, A) "v_pk_fma_f32 %[" B "], %[w], %[" B "], %[" A "] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+#define MFB_IX1(X, B, A) "v_pk_fma_f32 %[" X "], %[w], %[" B "], %[" A "] op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]\n\t"
+#define MFB_IY1(B, A) "v_pk_fma_f32 %[" B "], %[w], %[" B "], %[" A "] op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]\n\t"
+template <int ROT, bool NX, bool NY, bool SREG>
+DEVI void bf_ct(cf &a, cf &b, const cf tw) {
+    static_assert(NX || NY, "a butterfly nobody wants");
+    cf x;
+#define MFB_BF1(BODY, OUTS)                                                          \
+    do {                                                                             \
+        if constexpr (SREG) asm(BODY : OUTS : [w] "s"(tw), [a] "v"(a));              \
+        else asm(BODY : OUTS : [w] "v"(tw), [a] "v"(a));                             \
+    } while (0)
+#define MFB_OUT_XB [x] "=&v"(x), [b] "+v"(b)
+#define MFB_OUT_B [b] "+v"(b)
+    if constexpr (NX && NY) {
+        if constexpr (ROT) MFB_BF1(MFB_I1("b") MFB_IX1("x", "b", "a") MFB_IY1("b", "a"), MFB_OUT_XB);
+        else MFB_BF1(MFB_I1("b") MFB_IX0("x", "b", "a") MFB_IY0("b", "a"), MFB_OUT_XB);
+        a = x;
+    } else if constexpr (NX) {
+        if constexpr (ROT) MFB_BF1(MFB_I1("b") MFB_IX1("x", "b", "a"), MFB_OUT_XB);
+        else MFB_BF1(MFB_I1("b") MFB_IX0("x", "b", "a"), MFB_OUT_XB);
+        a = x;
+    } else {
+        if constexpr (ROT) MFB_BF1(MFB_I1("b") MFB_IY1("b", "a"), MFB_OUT_B);
+        else MFB_BF1(MFB_I1("b") MFB_IY0("b", "a"), MFB_OUT_B);
+    }
+#undef MFB_BF1
+#undef MFB_OUT_XB
+#undef MFB_OUT_B
+}
+// Two butterflies with the SAME twiddle pair in one statement, instruction by instruction in turn: inside one butterfly every
+// instruction waits for the one before it, and the compiler cannot move anything into an asm statement -- two side by side give
+// the wave an independent instruction between each dependent pair.  ROTA / ROTB as above; NYB = false: the second butterfly's
+// difference is dead (last stage of a transform whose upper outputs nobody wants).
+// Measured (profiles/r06_fft_ops.md, one device, three banks): pairs are 0 ... 1 % SLOWER than single butterflies -- with three
+// (two) waves per SIMD the other waves fill the slot behind a dependent instruction anyway, and a six-instruction statement takes
+// freedom from the scheduler.  Off; kept as the knob of that A/B.
+#ifndef MFB_BF_PAIR
+#define MFB_BF_PAIR 0
+#endif
+template <int ROTA, int ROTB, bool NYB, bool SREG>
+DEVI void bf_ct2(cf &a, cf &b, cf &c, cf &d, const cf tw) {
+    cf x, y;
+#define MFB_BF2(BODY)                                                                                                            \
+    do {                                                                                                                         \
+        if constexpr (SREG) asm(BODY : [x] "=&v"(x), [b] "+v"(b), [y] "=&v"(y), [d] "+v"(d) : [w] "s"(tw), [a] "v"(a), [c] "v"(c)); \
+        else asm(BODY : [x] "=&v"(x), [b] "+v"(b), [y] "=&v"(y), [d] "+v"(d) : [w] "v"(tw), [a] "v"(a), [c] "v"(c));               \
+    } while (0)
+    if constexpr (!ROTA && !ROTB) {
+        static_assert(NYB, "same-rotation pairs are whole");
+        MFB_BF2(MFB_I1("b") MFB_I1("d") MFB_IX0("x", "b", "a") MFB_IX0("y", "d", "c") MFB_IY0("b", "a") MFB_IY0("d", "c"));
+    } else if constexpr (ROTA && ROTB) {
+        static_assert(NYB, "same-rotation pairs are whole");
+        MFB_BF2(MFB_I1("b") MFB_I1("d") MFB_IX1("x", "b", "a") MFB_IX1("y", "d", "c") MFB_IY1("b", "a") MFB_IY1("d", "c"));
+    } else {
+        static_assert(!ROTA && ROTB, "last-stage pairs: q and q + half");
+        if constexpr (NYB) MFB_BF2(MFB_I1("b") MFB_I1("d") MFB_IX0("x", "b", "a") MFB_IX1("y", "d", "c") MFB_IY0("b", "a") MFB_IY1("d", "c"));
+        else MFB_BF2(MFB_I1("b") MFB_I1("d") MFB_IX0("x", "b", "a") MFB_IX1("y", "d", "c") MFB_IY0("b", "a"));
+    }
+#undef MFB_BF2
+    a = x;
+    c = y;
+}
+// e = a + c (b + t (i b)): half a butterfly (the lane pair of the 2048-point transform shares one: each lane keeps its own sign in
+// c), two of them side by side
+DEVI void half_ct2(cf &e0, cf &e1, const cf a0, cf b0, const cf a1, cf b1, const cf tw) {
+    asm(MFB_I1("b") MFB_I1("d") MFB_IX0("x", "b", "a") MFB_IX0("y", "d", "c")
+        : [x] "=&v"(e0), [b] "+v"(b0), [y] "=&v"(e1), [d] "+v"(b1)
+        : [w] "v"(tw), [a] "v"(a0), [c] "v"(a1));
+}
+// (cos, tan) of k pi / 16: the constant twiddles inside a 16- or 32-point transform
+template <int K> struct CtK;
+template <> struct CtK<1> { static constexpr float c = 0.98078528040323043058f, t = 0.19891236737965800607f; };
+template <> struct CtK<2> { static constexpr float c = 0.92387953251128673848f, t = 0.41421356237309503445f; };
+template <> struct CtK<3> { static constexpr float c = 0.83146961230254523567f, t = 0.66817863791929887896f; };
+template <> struct CtK<4> { static constexpr float c = 0.70710678118654757274f, t = 1.0f; };
+template <> struct CtK<5> { static constexpr float c = 0.55557023301960228867f, t = 1.49660576266548894786f; };
+template <> struct CtK<6> { static constexpr float c = 0.38268343236508983729f, t = 2.41421356237309492343f; };
+template <> struct CtK<7> { static constexpr float c = 0.19509032201612833135f, t = 5.02733949212584629862f; };
+
+// table index of the twiddle pair of stage s (1-based), reduced index qb
+constexpr int ct_half(int s) { return s >= 2 ? (1 << (s >= 2 ? s - 2 : 0)) : 1; }        // twiddles of stage s up to the factor i
+constexpr int ct_index(int s, int qb) { return (s == 1 ? 0 : ct_half(s)) + qb; }
+constexpr int ct_count(int levels) { return 1 << (levels - 1); }
+
+// In-place radix-2 decimation-in-time transform of n = 2^LEVELS register slots (natural input order; output q in slot
+// brevc(q, LEVELS)), stages S0 ... LEVELS.  LANE_TW: per-lane twiddles twr[ct_index(s, qb)] (the second pass of a two-pass
+// transform, above); otherwise the plain n-point transform with its constant twiddles (from SGPR pairs).  Only outputs
+// q < LIVE are wanted.
+// slot of the u-th butterfly's first input in a stage that pairs a with a + off: u with a zero bit inserted at off
+constexpr int bf_slot(int u, int off) { return (u / off) * 2 * off + (u % off); }
+template <int LEVELS, int LIVE, bool LANE_TW, int S0 = 1, int NTW>
+DEVI void dit_fused(cf (&v)[1 << LEVELS], const cf (&twr)[NTW]) {
+    constexpr int n = 1 << LEVELS;
+    sfor<S0, LEVELS + 1>([&](auto s_) {
+        constexpr int s = decltype(s_)::value;
+        constexpr int off = n >> s;
+        constexpr int half = ct_half(s);
+        constexpr bool last = s == LEVELS;
+        // butterflies u = 2k, 2k + 1 share their twiddle pair: the same q in every stage but the last, q and q + half -- a
+        // rotation by i -- in the last
+        sfor<0, n / 4>([&](auto k_) {
+            constexpr int ua = 2 * decltype(k_)::value, ub = ua + 1;
+            constexpr int a = bf_slot(ua, off), c = bf_slot(ub, off);
+            constexpr int qa = brevc(a >> (LEVELS - s + 1), s - 1), qc = brevc(c >> (LEVELS - s + 1), s - 1);
+            constexpr bool rota = s >= 2 && qa >= half, rotc = s >= 2 && qc >= half;
+            constexpr int qb = rota ? qa - half : qa;
+            static_assert(qb == (rotc ? qc - half : qc), "a pair shares its twiddle");
+            constexpr bool nxa = !last || qa < LIVE, nya = !last || (qa + n / 2) < LIVE;
+            constexpr bool nxc = !last || qc < LIVE, nyc = !last || (qc + n / 2) < LIVE;
+            auto one = [&](auto slot_, auto rot_, auto nx_, auto ny_) {
+                constexpr int sl = decltype(slot_)::value;
+                constexpr bool rot = decltype(rot_)::value, nx = decltype(nx_)::value, ny = decltype(ny_)::value;
+                if constexpr (nx || ny) {
+                    if constexpr (LANE_TW) {
+                        bf_ct<rot, nx, ny, false>(v[sl], v[sl + off], twr[ct_index(s, qb)]);
+                    } else if constexpr (qb == 0) {
+                        if constexpr (rot) b2_bi(v[sl], v[sl + off]);
+                        else b2(v[sl], v[sl + off]);
+                    } else {
+                        using K = CtK<qb * (32 >> s)>;
+                        bf_ct<rot, nx, ny, true>(v[sl], v[sl + off], mkc(K::c, K::t));
+                    }
+                }
+            };
+            constexpr bool pairable = MFB_BF_PAIR && (LANE_TW || qb != 0) && nxa && nya && nxc && (nyc || (!rota && rotc)) &&
+                                      (rota == rotc || (!rota && rotc));
+            if constexpr (pairable) {
+                if constexpr (LANE_TW) {
+                    static_assert(NTW >= ct_count(LEVELS), "twiddle pairs");
+                    bf_ct2<rota, rotc, nyc, false>(v[a], v[a + off], v[c], v[c + off], twr[ct_index(s, qb)]);
+                } else {
+                    static_assert(s <= 5, "constant twiddles of up to 32 points");
+                    using K = CtK<qb * (32 >> s)>;
+                    bf_ct2<rota, rotc, nyc, true>(v[a], v[a + off], v[c], v[c + off], mkc(K::c, K::t));
+                }
+            } else {
+                one(std::integral_constant<int, a>{}, std::integral_constant<bool, rota>{}, std::integral_constant<bool, nxa>{}, std::integral_constant<bool, nya>{});
+                one(std::integral_constant<int, c>{}, std::integral_constant<bool, rotc>{}, std::integral_constant<bool, nxc>{}, std::integral_constant<bool, nyc>{});
+            }
+        });
+    });
+}
+
+// 256 points = 16 lanes x 16 registers, two fused 16-point transforms around one exchange (exchange image as in fft_passes:
+// element pos at padi(pos)).  Lane g: register i holds element g + 16 i on entry; output q is element g + 16 q.
+//   ct: the lane's 8 twiddle pairs, (cos, tan) of 2 pi u / 256 with u = 8g | 4g | 2g, 2g + 32 | g, g + 16, g + 32, g + 48
+struct F256Regs {
+    cf ct[8];
+};
+// table: [16 lanes][8] pairs behind the W_L table (mfbank.hip, append_fused_tables)
+DEVI void f256_setup(F256Regs &r, const cf *__restrict__ table, const int g) {
+    sfor<0, 8>([&](auto k) { r.ct[decltype(k)::value] = table[g * 8 + decltype(k)::value]; });
+}
+template <int LIVE, class Store>
+DEVI void fft256_fused(cf (&v)[16], cf *buf, const int g, const F256Regs &r, Store &store) {
+#if MFB_FUSED_FIRST
+    const cf none[1] = {mkc(0.f, 0.f)};
+    dit_fused<4, 16, false>(v, none);
+    {
+        cf *wr = buf + g;
+        sfor<0, 16>([&](auto p) { wr[decltype(p)::value * 17] = v[brevc(decltype(p)::value, 4)]; });      // padi(16 p + g)
+    }
+#else
+    bfly<16, 0>(v);
+    {
+        cf *wr = buf + g;
+        sfor<0, 16>([&](auto p) { wr[decltype(p)::value * 17] = v[rev(16, decltype(p)::value)]; });
+    }
+#endif
+    xsync<1>();
+    {
+        const cf *rd = buf + g * 17;                                                                      // padi(16 g + i)
+        sfor<0, 16>([&](auto i) { v[decltype(i)::value] = rd[decltype(i)::value]; });
+    }
+    xsync<1>();
+    dit_fused<4, LIVE, true>(v, r.ct);
+    sfor<0, 16>([&](auto q) {
+        constexpr int Q = decltype(q)::value;
+        store(16 * Q + g, v[brevc(Q, 4)], std::integral_constant<int, Q>{}, std::integral_constant<int, 16 * Q>{});
+    });
+}
+
+// 2048 points = 64 lanes x 32 registers (layout of fft_w32 above: lane l at pi(l) = (l >> 1) + 32 (l & 1), register i = element
+// pi(l) + 64 i, output m' = element pi(l) + 64 m').  Write side: plain 32-point transform, rows of the exchange buffer untwiddled.
+// Read side, lane l' = 2 p' + h: e_j = b_j + (-1)^h W_64^p' b_(j+32) -- HALF a fused butterfly, the sign in the lane's c -- then
+// F(e, W_2048^pi(l'), 32): the inter-pass twiddle, the lane-pair level's twiddle W_64^(h j) and the second transform's own are one set
+// of 16 pairs per lane.
+struct F2048Regs {
+    cf ct[16];     // (cos, tan) of 2 pi u / 2048, u = 16 g' | 8 g' | 4 g' + 256 q (q < 2) | 2 g' + 128 q (q < 4) | g' + 64 q (q < 8), g' = pi(lane)
+    cf t0;         // (+-cos, tan) of 2 pi p' / 64, p' = lane >> 1; minus on odd lanes
+};
+// table: [64 positions][16] pairs, then [32] pairs, behind the W_L table
+DEVI void f2048_setup(F2048Regs &r, const cf *__restrict__ table, const int lane) {
+    const int g = (lane >> 1) + 32 * (lane & 1);
+    sfor<0, 16>([&](auto k) { r.ct[decltype(k)::value] = table[g * 16 + decltype(k)::value]; });
+    cf t0 = table[64 * 16 + (lane >> 1)];
+    if (lane & 1) t0.x = -t0.x;
+    r.t0 = t0;
+}
+#ifndef MFB_F2048_DEPTH
+#define MFB_F2048_DEPTH 4
+#endif
+template <int LIVE, class Store>
+DEVI void fft_w32_fused(cf (&v)[32], cf *xbuf, const int lane, const F2048Regs &r, Store &store) {
+#if MFB_FUSED_FIRST
+    const cf none[1] = {mkc(0.f, 0.f)};
+    dit_fused<5, 32, false>(v, none);
+    {
+        cf *wr = xbuf + lane;
+        sfor<0, 32>([&](auto p) { wr[decltype(p)::value * W32Cfg::ROW] = v[brevc(decltype(p)::value, 5)]; });
+    }
+#else
+    bfly32(v);
+    {
+        cf *wr = xbuf + lane;
+        sfor<0, 32>([&](auto p) { wr[decltype(p)::value * W32Cfg::ROW] = v[slot32(decltype(p)::value)]; });
+    }
+#endif
+    xsync<1>();
+    {
+        // 16-byte reads (elements 2J, 2J + 1 of the row = what lanes 2J and 2J + 1 wrote = positions J and J + 32), software-
+        // pipelined by hand as in fft_w32; pairs go out in the order stage 1 of the second transform pairs them (j, j + 16), and
+        // its butterflies run inside the loop, as soon as both halves are in
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 *rd = reinterpret_cast<const f4 *>(xbuf + (lane >> 1) * W32Cfg::ROW);
+        constexpr int DEPTH = MFB_F2048_DEPTH;
+        f4 q0[16], q1[16];
+        auto issue = [&](auto kk) {
+            constexpr int K = decltype(kk)::value;
+            constexpr int J = 2 * (K >> 1) + 16 * (K & 1);          // k-th pair issued -> elements J, J + 1
+            q0[K] = rd[J];
+            q1[K] = rd[J + 1];
+        };
+        sfor<0, DEPTH>([&](auto kk) { issue(kk); });
+        __builtin_amdgcn_sched_barrier(0);
+        sfor<0, 16>([&](auto kk) {
+            constexpr int K = decltype(kk)::value;
+            constexpr int J = 2 * (K >> 1) + 16 * (K & 1);
+            if constexpr (K + DEPTH < 16) {
+                issue(std::integral_constant<int, K + DEPTH>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            half_ct2(v[J], v[J + 1], mkc(q0[K].x, q0[K].y), mkc(q0[K].z, q0[K].w), mkc(q1[K].x, q1[K].y), mkc(q1[K].z, q1[K].w), r.t0);
+            if constexpr (K & 1) bf_ct2<0, 0, true, false>(v[J - 16], v[J], v[J - 15], v[J + 1], r.ct[0]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    xsync<1>();      // the rows are rewritten by the next transform of this wave
+    dit_fused<5, LIVE, true, 2>(v, r.ct);
+    sfor<0, 32>([&](auto m) {
+        constexpr int M = decltype(m)::value;
+        store(64 * M + ((lane >> 1) + 32 * (lane & 1)), v[brevc(M, 5)], std::integral_constant<int, M>{}, std::integral_constant<int, 64 * M>{});
+    });
+}
+
 // v    : the thread's 16 points; on entry of pass 0 slot i holds element g + (L/16)*i
 // lds  : exchange buffer: element (pos, col) at padi(pos)*T + col.  With PP (ping-pong) the buffer
 //        holds two halves of HALF elements used alternately (one barrier per exchange: a half is

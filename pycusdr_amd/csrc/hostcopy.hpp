@@ -12,6 +12,17 @@
 // One thread, one queue: the receive loop hands it the chunk -> window copies of the next batch and runs the host stages of the
 // previous batch meanwhile.  The worker spins for a few microseconds before it sleeps (chunks arrive in bursts; a futex wake costs
 // more than a 128 KiB copy).
+// a polite spin: the x86 pause, the aarch64 yield, a compiler barrier anywhere else
+static inline void mfb_cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    asm volatile("" ::: "memory");
+#endif
+}
+
 struct mfb_hostcopy {
     struct Job {
         void *dst;
@@ -33,7 +44,7 @@ struct mfb_hostcopy {
                 if (jobs.empty() && !stop) {
                     lk.unlock();
                     for (int spin = 0; spin < 4000 && submitted.load(std::memory_order_acquire) == done.load(std::memory_order_relaxed); ++spin)
-                        __builtin_ia32_pause();
+                        mfb_cpu_relax();
                     lk.lock();
                 }
                 cv_work.wait(lk, [&] { return stop || !jobs.empty(); });
@@ -57,13 +68,16 @@ struct mfb_hostcopy {
         }
         return true;
     }
-    void submit(void *dst, const void *src, size_t bytes) {
-        {
+    bool submit(void *dst, const void *src, size_t bytes) {       // false: the queue could not grow (nothing was queued)
+        try {
             std::lock_guard<std::mutex> lk(mu);
             jobs.push_back({dst, src, bytes});
             submitted.fetch_add(1, std::memory_order_release);
+        } catch (...) {
+            return false;
         }
         cv_work.notify_one();
+        return true;
     }
     void drain() {
         std::unique_lock<std::mutex> lk(mu);

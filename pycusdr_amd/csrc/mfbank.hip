@@ -221,6 +221,33 @@ static void make_twiddles(std::vector<cf> &v, int count, double denom, double st
     }
 }
 
+// (cos, tan) pairs of the fused-twiddle transforms (fft_core.hpp, MFB_FFT_FUSED), appended to the W_L table: angle 2 pi u / L.
+// An angle of exactly pi/2 (one lane of stage 1) becomes (2^-40, 2^40): c t = 1 exactly, and c b vanishes in the rounding of the sum.
+static cf ct_pair(long u, int L) {
+    const double ang = 2.0 * M_PI * (double)u / (double)L;
+    double c = cos(ang);
+    const double s = sin(ang);
+    if (fabs(c) < 1e-9) c = 0x1p-40;
+    return (cf){(float)c, (float)(s / c)};
+}
+static void append_fused_tables(std::vector<cf> &v, int L) {
+    if (L == 256) {            // F256Regs: [16 lanes][8]
+        for (int g = 0; g < 16; ++g) {
+            const long u[8] = {8 * g, 4 * g, 2 * g, 2 * g + 32, g, g + 16, g + 32, g + 48};
+            for (int k = 0; k < 8; ++k) v.push_back(ct_pair(u[k], L));
+        }
+    } else if (L == 2048) {    // F2048Regs: [64 positions][16], then W_64^p, p < 32
+        for (int g = 0; g < 64; ++g) {
+            v.push_back(ct_pair(16 * g, L));
+            v.push_back(ct_pair(8 * g, L));
+            for (int q = 0; q < 2; ++q) v.push_back(ct_pair(4 * g + 256 * q, L));
+            for (int q = 0; q < 4; ++q) v.push_back(ct_pair(2 * g + 128 * q, L));
+            for (int q = 0; q < 8; ++q) v.push_back(ct_pair(g + 64 * q, L));
+        }
+        for (int p = 0; p < 32; ++p) v.push_back(ct_pair(32 * p, L));
+    }
+}
+
 static int upload_tw(cf **dst, const std::vector<cf> &v) {
     HIPCHK(dev_alloc((void **)dst, v.size() * sizeof(cf)));
     HIPCHK(hipMemcpy(*dst, v.data(), v.size() * sizeof(cf), hipMemcpyHostToDevice));
@@ -672,6 +699,7 @@ static int resolve_path(mfb_ctx *c) {
                 c->twL_len = 0;
                 std::vector<cf> t;
                 make_twiddles(t, L, (double)L, 1.0);
+                append_fused_tables(t, L);
                 int rc = upload_tw(&c->d_twL, t);
                 if (rc) return rc;
                 c->twL_len = L;
@@ -2106,7 +2134,13 @@ extern "C" int mfb_receive_blocks_end_record(mfb_ctx *c, int slot, void *dst, si
     if (!c || slot < 0 || slot > 1 || !dst || !lay) return MFB_ERR_ARG;
     BlockFlight &f = c->flight[slot];
     if (!f.active || !f.nb) return MFB_ERR_STATE;
-    if (capacity < f.rec * (size_t)f.nb) return MFB_ERR_ARG;
+    if (capacity < f.rec * (size_t)f.nb) {
+        // too small: say what the batch needs (nblocks * record_bytes) and leave it in flight for the caller's second attempt
+        memset(lay, 0, sizeof(*lay));
+        lay->nblocks = f.nb;
+        lay->record_bytes = (int64_t)f.rec;
+        return MFB_ERR_ARG;
+    }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventSynchronize(c->ev_blk[slot]));
     f.active = false;
@@ -3017,7 +3051,7 @@ extern "C" int mfb_hostcopy_create(mfb_hostcopy **out) {
 
 extern "C" int mfb_hostcopy_submit(mfb_hostcopy *q, void *dst, const void *src, size_t bytes) {
     if (!q || (bytes && (!dst || !src))) return MFB_ERR_ARG;
-    if (bytes) q->submit(dst, src, bytes);
+    if (bytes && !q->submit(dst, src, bytes)) return MFB_ERR_ALLOC;        // (no exception crosses the C ABI)
     return MFB_OK;
 }
 

@@ -90,6 +90,12 @@ constexpr int seg_block_threads(int NT) { return NT <= 64 ? MFB_SEG_BLOCK : (NT 
 #ifndef MFB_SEG_G0EARLY
 #define MFB_SEG_G0EARLY 1
 #endif
+// half of the next filter's spectrum fetched during the running transform of the fused 2048-point kernel: measured 1 % SLOWER on
+// the 384-tap bank (2.353 against 2.332 ms, three interleaved runs; profiles/r06_fft_ops.md) -- as in round 4, the spectrum loads
+// cost bandwidth and registers, not latency.  Off.
+#ifndef MFB_SEG_PREHALF
+#define MFB_SEG_PREHALF 0
+#endif
 // 2048-point segments as ONE wave per segment, 32 points per lane, one LDS exchange per transform (fft_core.hpp, fft_w32)
 // instead of two-wave barrier teams with 16 points per lane and two exchanges.
 #ifndef MFB_SEG_W32
@@ -205,9 +211,19 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
     [[maybe_unused]] float *lacc = reinterpret_cast<float *>(lphase + (REL ? Cfg::PHASE_ELEMS : 0)) + wave * (a.mpb * SEG_ACC_STRIDE);
     int ebuf = 0;
 
-    TwRegs<W32 ? 16 : L, Cfg::LTW> twr;
+    // fused-twiddle transforms (fft_core.hpp, round 6): 256 points and the wave-local 2048 points; their (cos, tan) tables sit
+    // behind the W_L table
+    constexpr bool F256 = MFB_FFT_FUSED && L == 256;
+    constexpr bool F2048 = MFB_FFT_FUSED && W32;
+    TwRegs<(W32 || F256) ? 16 : L, Cfg::LTW> twr;
     [[maybe_unused]] W32Regs w32;
-    if constexpr (W32) {
+    [[maybe_unused]] F256Regs f256;
+    [[maybe_unused]] F2048Regs f2048;
+    if constexpr (F256) {
+        f256_setup(f256, a.twL + L, g);
+    } else if constexpr (F2048) {
+        f2048_setup(f2048, a.twL + L, lane);
+    } else if constexpr (W32) {
         w32_setup(w32, a.twL, ltw, lane, tid, Cfg::BLOCK);
         __syncthreads();
     } else {
@@ -218,11 +234,17 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
             __syncthreads();
         }
     }
-    // one transform of this team on v; store(n, value, slot, nu) gets natural output n = nu + g
-    auto transform = [&](cf (&vv)[PPL], auto &store) {
-        if constexpr (W32) fft_w32(vv, mylds, lane, w32, store);
+    // one transform of this team on v; store(n, value, slot, nu) gets natural output n = nu + g; only the outputs of the first
+    // `live` register slots are wanted (the fused transforms skip the dead halves of their last butterflies)
+    auto transform = [&](cf (&vv)[PPL], auto &store, auto live) {
+        constexpr int LIVE = decltype(live)::value;
+        if constexpr (F256) fft256_fused<LIVE>(vv, mylds, g, f256, store);
+        else if constexpr (F2048) fft_w32_fused<LIVE>(vv, mylds, lane, f2048, store);
+        else if constexpr (W32) fft_w32(vv, mylds, lane, w32, store);
         else fft_passes<L, 1, 0, true, Cfg::PP, Cfg::HALF, SYNC>(vv, mylds, ebuf, g, 0, twr, a.twL, store);
     };
+    constexpr std::integral_constant<int, PPL> all_live{};
+    constexpr std::integral_constant<int, (MASKED || MODE != SEG_REDUCE) ? PPL : PV> sum_live{};
 
     // ---- which Doppler bins and which slots this team owns -----------------------------------
     int grp, mg, bstream, ssub;
@@ -306,7 +328,17 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
         // A/B of two builds: the next slot's x in the same registers during the last filter -- no gain, 20 spilled
         // VGPRs at the 3-wave budget; the next filter's product in the shadow of the LDS exchange -- 7 % slower than
         // the compiler's own schedule.)
-        [[maybe_unused]] cf gk[Cfg::PREFETCH ? PPL : 1];
+        // The fused 2048-point kernel (round 6: 212 instead of 254 VGPRs) has room for HALF of the next filter's spectrum: register
+        // slots 0 ... 15 are fetched while the running transform computes, slots 16 ... 31 at the top of the product, behind which
+        // the first half's multiplies hide part of their latency (MFB_SEG_PREHALF; profiles/r06_fft_ops.md)
+        constexpr bool PREHALF = F2048 && MFB_SEG_PREHALF && !MASKED && MODE == SEG_REDUCE && !Cfg::PREFETCH;
+        [[maybe_unused]] cf gk[Cfg::PREFETCH ? PPL : (PREHALF ? PPL / 2 : 1)];
+        [[maybe_unused]] auto load_g_half = [&](cf (&dst)[PPL / 2], int row, auto first) {
+            constexpr int I0 = decltype(first)::value;
+#pragma unroll
+            for (int ii = 0; ii < PPL / 4; ++ii)
+                buf_load_cf2(gr, vo_g2, row * (L * (int)sizeof(cf)) + (I0 + ii) * so_g2, dst[2 * ii], dst[2 * ii + 1]);
+        };
 
         for (int it = 0; it < niter; ++it) {
             const int slot = s0 + it;
@@ -334,11 +366,12 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
             const int mfirst = (ngrp > 1 ? 0 : mg) * a.mpb;
             const int r0 = a.rows ? a.rows[mfirst] : mfirst;
             if constexpr (Cfg::PREFETCH && MFB_SEG_G0EARLY) load_g(gk, r0);    // lands while the forward transform runs
+            if constexpr (PREHALF) load_g_half(gk, r0, std::integral_constant<int, 0>{});
             cf A[PPL];                            // A[k] = conj(U[g + NT*k])
             {
                 auto keep = [&](int, cf val, auto, auto nu) { A[decltype(nu)::value / NT] = val; };
                 if constexpr (Cfg::DUAL) xsync<SYNC>();        // the previous slot's last pair may still be read by other waves
-                transform(v, keep);
+                transform(v, keep, all_live);
             }
             if constexpr (Cfg::PREFETCH && !MFB_SEG_G0EARLY) load_g(gk, r0);
 
@@ -410,6 +443,14 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
 #pragma unroll
                     for (int i = 0; i < PPL; ++i) w[i] = cmul_cj(A[i], gk[i]);    // conj(A) * G = U * G
                     if (mi + 1 < nm) load_g(gk, a.rows ? a.rows[m0 + mi + 1] : (m0 + mi + 1));
+                } else if constexpr (PREHALF) {
+                    cf gh[PPL / 2];
+                    load_g_half(gh, rm, std::integral_constant<int, PPL / 4>{});
+#pragma unroll
+                    for (int i = 0; i < PPL / 2; ++i) w[i] = cmul_cj(A[i], gk[i]);
+                    if (mi + 1 < nm) load_g_half(gk, a.rows ? a.rows[m0 + mi + 1] : (m0 + mi + 1), std::integral_constant<int, 0>{});
+#pragma unroll
+                    for (int i = 0; i < PPL / 2; ++i) w[PPL / 2 + i] = cmul_cj(A[PPL / 2 + i], gh[i]);
                 } else {
 #pragma unroll
                     for (int ii = 0; ii < PPL / 2; ++ii) {
@@ -437,7 +478,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                             racc[k & 3] = __builtin_elementwise_fma(val, val, racc[k & 3]);
                         }
                     };
-                    transform(w, acc);
+                    transform(w, acc, sum_live);
                     const cf rsum = (racc[0] + racc[1]) + (racc[2] + racc[3]);
                     lacc[mi * SEG_ACC_STRIDE + lane] = rsum.x + rsum.y;       // reduced over the lanes after the last filter
                 } else {
@@ -450,7 +491,7 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
                         // same fp32 order as k_envelope: s = s + fma(re, re, im * im), filters ascending
                         if (in_env) envacc[k] = __fadd_rn(envacc[k], __fmaf_rn(val.x, val.x, __fmul_rn(val.y, val.y)));
                     };
-                    transform(w, put);
+                    transform(w, put, all_live);
                 }
             }
             if constexpr (MODE == SEG_REDUCE) {

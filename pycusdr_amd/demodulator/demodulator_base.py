@@ -415,8 +415,14 @@ class Demodulator:
                     SNR = snr[b]
                 else:
                     l0, l1 = s['band_len'][b]
-                    bands = (R.bands[b, 0, :l0], R.bands[b, 1, :l1]) if (R.bands is not None and l0 <= R.bcap and l1 <= R.bcap) else None
-                    SNR = self.computeSNR(lowIdx, highIdx, 5, bands=bands)
+                    if R.bands is not None and l0 <= R.bcap and l1 <= R.bcap:
+                        SNR = self.computeSNR(lowIdx, highIdx, 5, bands=(R.bands[b, 0, :l0], R.bands[b, 1, :l1]))
+                    else:
+                        # a batch's spectra live in the batch workspace, never in the handle's one-block spectrum: windows
+                        # beyond the record's capacity (capped at 2^16 elements, _snr_band_capacity) cannot be fetched later
+                        log.error('[%s]: the SNR windows of this block (%d + %d elements) exceed the %d delivered with a batch: SNR = nan',
+                                  self.radioName, l0, l1, R.bcap)
+                        SNR = float('nan')
                 est = (bestDopplerScaled - hz_off, float(picks[b][1]) / self.Nfft * self.sampleRate, clipped, SNR)
             n = counts[b]
             if s['rate_fallback'][b]:

@@ -416,6 +416,12 @@ class DemodulatorRunner:
         # the device flags as irregular go through the host code, and the device's state is then seeded again
         confGPU = self.conf['GPU'][self.confRadio['CUDA_settings']]
         stages = bool(confGPU.get('HIP', {}).get('stream_stages', True)) and hasattr(self.demod, 'enableStreamStages')
+        if stages and B > 64:
+            # the library runs the stream stages for batches of up to 64 blocks (include/mfbank.h): with more, every block would
+            # come back without them, the chain would be marked dirty and re-seeded once per batch -- the host code does all of it
+            log.info('[%s]: %d blocks per call: the integer stages stay on the host (the device takes them for batches of <= 64 blocks)',
+                     self.radioName, B)
+            stages = False
         if stages:
             key = id(decoder) if decoder is not None else None
             if getattr(self, '_stages_for', ()) != (key,):

@@ -398,7 +398,7 @@ class BlockShard:
         n_post, n_end, dt = int(head[1]), int(head[2]), _TAIL_DTYPES[int(head[3])]
         return int(head[0]), {'post': body[:n_post].astype(dt), 'end': body[n_post:n_post + n_end].astype(dt), 'exact': bool(head[4])}
 
-    def pack(self, d, tail, time_device):
+    def pack(self, d, tail):
         """Owner -> root: the finished block -- estimates, the kept symbols' bits / centres / trust (uint8 each, as the
         caller gets them, DB:859), and the block's tail (the root carries it as its own alignment state)."""
         bits, trust = np.ascontiguousarray(d['data'], dtype=np.uint8), np.ascontiguousarray(d['trust'], dtype=np.uint8)
@@ -467,8 +467,8 @@ class BlockShard:
             raise RuntimeError(f'tail of block {got} arrived where block {index} was expected')
         return tail
 
-    def send_result(self, d, tail, time_device):
-        head, body = self.pack(d, tail, time_device)
+    def send_result(self, d, tail):
+        head, body = self.pack(d, tail)
         self._isend(head, body, self.root, self.TAG_RESULT)
 
     def recv_result(self, index):
@@ -598,7 +598,7 @@ class BlockShard:
             state['local_tail'] = (i, tail)
             d = runner.feed_host(part, prev_tail=prev)
             if not is_root:
-                self.send_result(d, tail, part['time_device'])
+                self.send_result(d, tail)
             self.stats['host_s'] += time.perf_counter() - t_in
             self.stats['own_blocks'] += 1
             return (d, tail) if is_root else None

@@ -449,17 +449,17 @@ class MFBank:
         slot = int(slot)
         lay = _lib.RecordLayout()
         buf = np.empty(getattr(self, '_recbuf_need', 1 << 16), np.uint8)      # a fresh buffer per batch: the views handed out keep it alive
-        try:
+        rc = self._lib.mfb_receive_blocks_end_record(self._h, slot, _ptr(buf), buf.size, C.byref(lay))
+        if rc == _lib.MFB_ERR_ARG and lay.nblocks > 0 and lay.record_bytes > 0:
+            # too small for this batch: the library said what it needs and left the batch in flight
+            self._recbuf_need = int(lay.nblocks) * int(lay.record_bytes)
+            buf = np.empty(self._recbuf_need, np.uint8)
             rc = self._lib.mfb_receive_blocks_end_record(self._h, slot, _ptr(buf), buf.size, C.byref(lay))
-            if rc == _lib.MFB_ERR_ARG and self._batch.get(slot):
-                # too small for this batch: size it from the geometry and take the batch (it is still in flight)
-                nb, nsym = self._batch[slot]
-                self._recbuf_need = nb * (8192 + 16 * self.BAND_CAPACITY + 16 * min(nsym, self.N // 2))
-                buf = np.empty(self._recbuf_need, np.uint8)
-                rc = self._lib.mfb_receive_blocks_end_record(self._h, slot, _ptr(buf), buf.size, C.byref(lay))
-            _lib.check(rc, 'mfb_receive_blocks_end_record')
-        finally:
+        if rc == _lib.MFB_OK or rc == _lib.MFB_ERR_STATE:
+            # taken (or never there): the slot is free.  Any other status leaves the batch in flight, and `flights` must go on
+            # saying so (computeSNR's stale-spectrum guard reads it)
             self._flying = getattr(self, '_flying', set()) - {slot}
+        _lib.check(rc, 'mfb_receive_blocks_end_record')
         return BatchRecord(buf, lay, self._searched.get(slot, True))
 
     def end_blocks(self, slot):

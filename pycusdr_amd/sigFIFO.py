@@ -39,23 +39,6 @@ class BlockAssembler:
         self.fill = self.ov              # the first block starts behind whatever the caller left in buffer[:overlap]
         self.blocks = 0
 
-    def full(self):
-        return self.fill == len(self.buf)
-
-    def take(self, chunk):
-        take = min(len(chunk), len(self.buf) - self.fill)
-        if take:
-            if self.copier is not None and (self.copy_all_async or not chunk.flags.writeable):
-                self.copier.submit(self.buf, self.fill, chunk[:take])
-            else:
-                self.buf[self.fill:self.fill + take] = chunk[:take]
-            self.fill += take
-            done = (self.fill - self.ov) // self.stride
-            if len(self.stamps) < done:
-                now = time.time()
-                self.stamps.extend([now] * (done - len(self.stamps)))
-        return take
-
     def push(self, chunk):
         chunk = np.asarray(chunk)
         n, pos, size = len(chunk), 0, len(self.buf)
@@ -94,7 +77,11 @@ class WindowAssembler:
     ``copier`` (``mfbank.HostCopy``) ``take`` only QUEUES the copy of a READ-ONLY chunk (``np.frombuffer`` of a received message
     is one; a replay marks its array ``flags.writeable = False``) for the library's copy thread -- the caller goes on (the host
     stages of the previous batch) and calls ``copier.drain()`` before it hands the window to the device.  A writable chunk may be
-    storage its source fills again for the next chunk: it is copied on the spot (``copy_all_async``: queue those too)."""
+    storage its source fills again for the next chunk: it is copied on the spot (``copy_all_async``: queue those too).
+    CONTRACT of the queued form: ``flags.writeable == False`` is taken as the source's promise that the samples stay as they
+    are until the window has been handed to the device (``copier.drain()``).  A read-only VIEW over storage somebody else
+    rewrites (a transport's reused receive ring) breaks that promise: such a source passes writable chunks, copies, or runs
+    with ``"HIP": {"async_copies": false}``."""
 
     def __init__(self, window, overlap, stride, blocks, copier=None, copy_all_async=False):
         if len(window) != blocks * stride + overlap or overlap < 0 or stride < 1:

@@ -4,6 +4,7 @@ its own (the two instances time-share the GPUs), blocks of the two streams alter
 must equal its unsharded handle's bit for bit, and every rank must demodulate the same bits.  argv: backend log2N bins.
 Prints one JSON line per rank."""
 import json
+import datetime
 import os
 import sys
 import zlib
@@ -27,7 +28,8 @@ D = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 if backend == 'gloo':
     local = local % torch.cuda.device_count()
 torch.cuda.set_device(local)
-dist.init_process_group(backend, device_id=torch.device('cuda', local) if backend == 'nccl' else None)
+dist.init_process_group(backend, device_id=torch.device('cuda', local) if backend == 'nccl' else None,
+                        timeout=datetime.timedelta(seconds=90))     # peers that never arrive cost 90 s, not ten minutes
 dev = torch.device('cuda', local)
 ok, failed = True, []
 inst, sharded, plain = {}, {}, {}

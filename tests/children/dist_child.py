@@ -2,6 +2,7 @@
 must pick, bit for bit, what one unsharded handle picks on the full bin table, and every rank must demodulate the same
 bits.  argv: backend [log2N [bins_total [noise_bin]]].  Prints one JSON line per rank."""
 import json
+import datetime
 import os
 import sys
 import zlib
@@ -26,7 +27,8 @@ noise = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 if backend == 'gloo':                      # rehearsal on a 1-GPU box: the ranks share the device
     local = local % torch.cuda.device_count()
 torch.cuda.set_device(local)
-dist.init_process_group(backend, device_id=torch.device('cuda', local) if backend == 'nccl' else None)
+dist.init_process_group(backend, device_id=torch.device('cuda', local) if backend == 'nccl' else None,
+                        timeout=datetime.timedelta(seconds=90))     # peers that never arrive cost 90 s, not ten minutes
 N = 1 << bs
 conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=D, device=local)
 if noise:

@@ -4,6 +4,7 @@ stages and the decoder.  The result must equal one process with the whole bin ta
 argv: backend bin_ranks [log2N [bins]].  With gloo the ranks share the device (rehearsal on a 1-GPU box).  Prints one JSON
 line per rank."""
 import json
+import datetime
 import os
 import sys
 
@@ -28,7 +29,8 @@ D = int(sys.argv[4]) if len(sys.argv) > 4 else 64
 if backend == 'gloo':
     local = local % torch.cuda.device_count()
 torch.cuda.set_device(local)
-dist.init_process_group(backend, device_id=torch.device('cuda', local) if backend == 'nccl' else None)
+dist.init_process_group(backend, device_id=torch.device('cuda', local) if backend == 'nccl' else None,
+                        timeout=datetime.timedelta(seconds=90))     # peers that never arrive cost 90 s, not ten minutes
 N, ov = 1 << bs, 1 << 10
 conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=D, device=local)
 p = loadProtocol('bench_GMSK')(conf=conf)

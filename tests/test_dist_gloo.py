@@ -529,7 +529,7 @@ def test_block_shard_wire_format_round_trip():
          'timestamp': 1759560000.123456,        # the owner's block stamp travels with the block (epoch seconds, float64: exact to ~0.2 us)
          'data': rs.randint(0, 2, S).astype(np.uint8), 'trust': rs.randint(0, 256, S).astype(np.uint8)}
     sh = BlockShard.__new__(BlockShard)
-    head, body = BlockShard.pack(sh, d, tail, 1e-3)
+    head, body = BlockShard.pack(sh, d, tail)
     assert head.dtype == np.float64 and len(head) == BlockShard.HEADER and body.dtype == np.uint8 and len(body) == 2 * S + 54
     back = BlockShard.unpack(head, body)
     assert back['count'] == 41 and back['doppler'] == -123.456 and np.isnan(back['SNR']) and back['spSym'] == d['spSymEst']
@@ -537,5 +537,5 @@ def test_block_shard_wire_format_round_trip():
     assert back['timestamp'] == d['timestamp']
     assert all(np.array_equal(back['tail'][k], tail[k]) and back['tail'][k].dtype == tail[k].dtype for k in ('post', 'end'))
     empty = dict(d, data=d['data'][:0], trust=d['trust'][:0])
-    h2, b2 = BlockShard.pack(sh, empty, {'post': tail['post'][:0], 'end': tail['end'][:0], 'exact': True}, 0.0)
+    h2, b2 = BlockShard.pack(sh, empty, {'post': tail['post'][:0], 'end': tail['end'][:0], 'exact': True})
     assert len(b2) == 0 and len(BlockShard.unpack(h2, b2)['bits']) == 0

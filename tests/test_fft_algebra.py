@@ -172,3 +172,142 @@ def test_wave_local_2048_point_transform_is_an_inverse_dft():
     for grp in ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], list(range(4, 12)) + [16, 17, 18, 19, 28, 29, 30, 31]):
         slots = {(((l >> 1) * ROW * 2) % 64) // 4 for l in grp}          # 16-byte slot (of 16 per 256-byte line) each pair reads, j = 0
         assert len(slots) == len({l >> 1 for l in grp})
+
+
+# ---- the fused-twiddle transforms of round 6 (fft_core.hpp: bf_ct, dit_fused, fft256_fused, fft_w32_fused; mfbank.hip: ct_pair) ----
+# Register-level model with fp32 rounding after every packed operation: radix-2 decimation in time, in place, every twiddled
+# butterfly in tangent form -- b' = b + t (i b), a +- c b' -- the same slots, stage twiddles, table order and exchange addresses.
+def _r32(x):
+    return np.asarray(x).astype(np.complex64).astype(np.complex128)
+
+
+def _ct_pair(u, L):
+    """(cos, tan) of 2 pi u / L as the host builds them (mfbank.hip ct_pair): fp32 values; exactly pi/2 becomes (2^-40, 2^40)."""
+    ang = 2.0 * np.pi * u / L
+    c, s = np.cos(ang), np.sin(ang)
+    if abs(c) < 1e-9:
+        c = 2.0 ** -40
+    return float(np.float32(c)), float(np.float32(s / c))
+
+
+def _brev(x, bits):
+    y = 0
+    for _ in range(bits):
+        y, x = (y << 1) | (x & 1), x >> 1
+    return y
+
+
+def _ct_index(s, qb):
+    return (0 if s == 1 else 1 << (s - 2)) + qb
+
+
+def _bf_ct(v, a, b, c, t, rot):
+    bp = _r32(v[b] + t * (1j * v[b]))                 # v_pk_fma: one rounding per component
+    w = (1j if rot else 1.0) * c
+    v[a], v[b] = _r32(v[a] + w * bp), _r32(v[a] - w * bp)
+
+
+def _dit_fused(v, levels, tables=None, s0=1):
+    """tables: per-lane arrays [lanes][2^(levels-1)][2] of (c, t) in ct_index order (LANE_TW); None: the plain transform with its
+    constant twiddles (cos, tan of k pi / 16)."""
+    n = 1 << levels
+    for s in range(s0, levels + 1):
+        off = n >> s
+        half = 1 << (s - 2) if s >= 2 else 1
+        for a in range(n):
+            if a & off:
+                continue
+            q = _brev(a >> (levels - s + 1), s - 1)
+            rot = s >= 2 and q >= half
+            qb = q - half if rot else q
+            if tables is not None:
+                c, t = tables[:, _ct_index(s, qb), 0], tables[:, _ct_index(s, qb), 1]
+                _bf_ct(v, a, a + off, c, t, rot)
+            elif qb == 0:
+                w = 1j if rot else 1.0
+                v[a], v[a + off] = _r32(v[a] + w * v[a + off]), _r32(v[a] - w * v[a + off])
+            else:
+                k = qb * (32 >> s)                     # CtK<k>: angle k pi / 16
+                _bf_ct(v, a, a + off, float(np.float32(np.cos(k * np.pi / 16))), float(np.float32(np.tan(k * np.pi / 16))), rot)
+
+
+def _f256_tables():
+    # append_fused_tables, L = 256: [16 lanes][8]
+    return np.array([[_ct_pair(u, 256) for u in (8 * g, 4 * g, 2 * g, 2 * g + 32, g, g + 16, g + 32, g + 48)] for g in range(16)])
+
+
+def _f2048_tables():
+    rows = []
+    for g in range(64):
+        us = [16 * g, 8 * g] + [4 * g + 256 * q for q in range(2)] + [2 * g + 128 * q for q in range(4)] + [g + 64 * q for q in range(8)]
+        rows.append([_ct_pair(u, 2048) for u in us])
+    return np.array(rows), np.array([_ct_pair(32 * p, 2048) for p in range(32)])
+
+
+def fft256_fused_model(x):
+    g = np.arange(16)
+    v = [_r32(x[g + 16 * i]) for i in range(16)]
+    _dit_fused(v, 4)
+    lds = np.zeros(16 * 17, complex)
+    for p in range(16):
+        lds[p * 17 + g] = v[_brev(p, 4)]                  # padi(16 p + g) = 17 p + g
+    w = [lds[g * 17 + i] for i in range(16)]              # padi(16 g + i)
+    _dit_fused(w, 4, _f256_tables())
+    out = np.zeros(256, complex)
+    for q in range(16):
+        out[g + 16 * q] = w[_brev(q, 4)]
+    return out
+
+
+def fft2048_fused_model(x):
+    lane = np.arange(64)
+    pos = (lane >> 1) + 32 * (lane & 1)
+    v = [_r32(x[pos + 64 * i]) for i in range(32)]
+    _dit_fused(v, 5)
+    ROW = 66
+    lds = np.zeros(32 * ROW, complex)
+    for p in range(32):
+        lds[p * ROW + lane] = v[_brev(p, 5)]
+    ct, t0 = _f2048_tables()
+    row, h = lane >> 1, lane & 1
+    c0 = np.where(h == 0, t0[row, 0], -t0[row, 0])        # f2048_setup: minus on odd lanes
+    e = []
+    for j in range(32):
+        b1, b2 = lds[row * ROW + 2 * j], lds[row * ROW + 2 * j + 1]
+        bp = _r32(b2 + t0[row, 1] * (1j * b2))
+        e.append(_r32(b1 + c0 * bp))                      # half_ct2
+    _dit_fused(e, 5, ct[pos])
+    out = np.zeros(2048, complex)
+    for m in range(32):
+        out[pos + 64 * m] = e[_brev(m, 5)]
+    return out
+
+
+@pytest.mark.parametrize('L,model', [(256, fft256_fused_model), (2048, fft2048_fused_model)])
+def test_fused_twiddle_transforms_are_inverse_dfts_to_fp32_rounding(L, model):
+    worst = 0.0
+    for seed in range(6):
+        rs = np.random.RandomState(1000 * L + seed)
+        x = _r32(rs.standard_normal(L) + 1j * rs.standard_normal(L))
+        ref = np.fft.ifft(x) * L
+        worst = max(worst, np.abs(model(x) - ref).max() / np.abs(ref).max())
+    # one rounding fewer per twiddled output than multiply-then-add; the radix-16 chain's model reads 1.4e-7 on the same inputs
+    assert worst < 3e-7, worst
+
+
+def test_fused_twiddle_tables():
+    # no angle of a lane's set reaches pi/2 except stage 1 (and the lane-pair level of the 2048-point transform), where exactly
+    # one lane holds w = i as (2^-40, 2^40): c t = 1 exactly
+    t256 = _f256_tables()
+    assert t256.shape == (16, 8, 2) and np.isfinite(t256).all()
+    assert t256[8, 0, 0] == 2.0 ** -40 and t256[8, 0, 0] * t256[8, 0, 1] == 1.0
+    assert np.abs(t256[:, 1:, 1]).max() < 41.0             # tan(2 pi 63 / 256)
+    ct, t0 = _f2048_tables()
+    assert ct.shape == (64, 16, 2) and t0.shape == (32, 2) and np.isfinite(ct).all() and np.isfinite(t0).all()
+    assert ct[32, 0, 0] == 2.0 ** -40 and t0[16, 0] == 2.0 ** -40
+    assert np.abs(ct[:, 1:, 1]).max() < 330.0              # tan(2 pi 511 / 2048)
+    # c (1 + i t) IS the twiddle: every pair against exp(i angle), relative to fp32 rounding
+    for g in range(64):
+        us = [16 * g, 8 * g] + [4 * g + 256 * q for q in range(2)] + [2 * g + 128 * q for q in range(4)] + [g + 64 * q for q in range(8)]
+        w = ct[g, :, 0] * (1 + 1j * ct[g, :, 1])
+        assert np.abs(w - np.exp(2j * np.pi * np.array(us) / 2048)).max() < 2e-7

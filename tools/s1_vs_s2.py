@@ -10,6 +10,7 @@ search launches; then a summary with the medians and S2 / S1.  Stimuli beyond th
   N10    S1's own noise without the packet (AWGN at S1's level: -10 dB)
   S1c    S1 without the noise (the clean packet and its zero padding)
   S2q    S2 quantised to 8 bits (an SDR's ADC: the low mantissa bits of every sample are zero)
+  P<n>   white noise of period n samples (P208 at C2: every 256-point segment holds the same numbers)
 """
 import sys
 import time
@@ -58,6 +59,15 @@ def stimulus(kind):
         return s
     if kind == 'Z':
         return np.zeros((NB, N), dtype=np.complex64)
+    if kind.startswith('P'):
+        # white noise of period P samples: with P = V (valid outputs per segment) every segment of a block holds the same numbers,
+        # so the four segments a wave carries side by side -- lanes l, l + 16, l + 32, l + 48, which pass through one ALU lane in
+        # consecutive cycles -- toggle nothing between them (the power experiment of profiles/r06_fft_ops.md)
+        P = int(kind[1:])
+        rs = np.random.RandomState(7)
+        base = (rs.standard_normal(P) + 1j * rs.standard_normal(P)).astype(np.complex64)
+        row = np.tile(base, -(-N // P))[:N]
+        return np.stack([row] * NB)
     raise SystemExit(f'unknown stimulus {kind}')
 
 
