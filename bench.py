@@ -171,11 +171,13 @@ def chain_figures(local_rank, blocks_per_call=None, n_packets=240):
         stim = bm.make_stream('GMSK', n_packets, 12.0, log2n, 2)          # one stimulus for every run at this size
         bm.run_snr('GMSK', n_packets, 12.0, log2n, 'transforms', 2, 64, blocks_per_call=Bn, stimulus=stim)    # handles, code objects, clock
         out[f'chain_n{log2n}_blocks_per_call'] = Bn
-        for B, tag in ((Bn, ''), (1, '_b1')):
+        # '' = B configured; '_auto' = nothing configured, a plain chunk iterator: the loop batches what the source has ready
+        # (run_stream, adaptive); '_b1' = "blocks_per_call": 1, the reference's one-block loop
+        for B, tag in ((Bn, ''), ('auto', '_auto'), (1, '_b1')):
             for decode, name in ((True, 'chain'), (False, 'recv')):
                 # the loop is host-bound and shares its CPUs with whatever else runs on the box: median of three runs
                 runs = [bm.run_snr('GMSK', n_packets, 12.0, log2n, 'transforms', 2, 64, blocks_per_call=B, decode=decode, stimulus=stim)
-                        for _ in range(3 if not tag else 1)]
+                        for _ in range(3 if tag != '_b1' else 1)]
                 r = sorted(runs, key=lambda q: q['ksamples_per_s'])[len(runs) // 2]
                 out[f'{name}{tag}_n{log2n}_d64_msamples'] = round(r['ksamples_per_s'] / 1e3, 1)
                 if not tag:
@@ -183,6 +185,107 @@ def chain_figures(local_rank, blocks_per_call=None, n_packets=240):
                 if decode:
                     out[f'{name}{tag}_n{log2n}_d64_packets'] = f"{r['packets']}/{r['sent']}"
     return out
+
+
+def c5_concurrent_figures(seconds=2.0, D=512):
+    """BASELINE C5 as worded: two CONCURRENT demodulator instances -- CC11xx (FSK-2 at 128 samples per symbol, 384 taps) and the
+    custom BPSK filter set (M = 32) -- at 512 bins, N = 2^20, on ONE MI355X, each a process and device context of its own (as
+    the reference runs its radios: pyCuSDR.py:245-251, DB:177-181).  Fresh children (tools/c5_rate_child.py), first one after the
+    other, then started together on the same moment; every leg `seconds` of the search step on resident blocks."""
+    import subprocess
+    child = os.path.join(ROOT, 'tools', 'c5_rate_child.py')
+
+    def run(names):
+        procs = [subprocess.Popen([sys.executable, child, n, str(D), str(seconds)], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                  stderr=subprocess.DEVNULL, text=True, cwd=ROOT) for n in names]
+        try:
+            for p in procs:
+                line = p.stdout.readline()
+                if line.strip() != 'ready':
+                    raise RuntimeError(f'c5 child said {line!r}')
+            t_go = time.time() + 0.4
+            for p in procs:
+                p.stdin.write(f'go {t_go}\n')
+                p.stdin.flush()
+            outs = [json.loads(p.stdout.readline()) for p in procs]
+            for p in procs:
+                p.wait(timeout=60)
+            return outs
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    out = {}
+    try:
+        (cc,), (bp,) = run(['CC11xx']), run(['bench_BPSK'])
+        cc2, bp2 = run(['CC11xx', 'bench_BPSK'])
+        out = {'c5_cc11xx_alone': cc['msamples'], 'c5_bpsk_alone': bp['msamples'], 'c5_cc11xx_beside': cc2['msamples'],
+               'c5_bpsk_beside': bp2['msamples'],
+               'c5_sum_over_alone': round(cc2['msamples'] / cc['msamples'] + bp2['msamples'] / bp['msamples'], 4),
+               'c5_seconds_per_leg': seconds, 'c5_bins': D,
+               'c5_note': 'two processes, two device contexts, one MI355X, started on the same moment; 1.0 = the device is shared '
+                          'without loss, < 1 = what time-slicing between the two contexts costs'}
+    except Exception as e:       # noqa: BLE001 -- a secondary figure must not cost the line
+        out = {'c5_error': str(e)[:110]}
+    return out
+
+
+def c5_inprocess_figures(dev, local_rank, blocks, esz, nblocks, seconds=1.0, D=512, log2N=20):
+    """The same two instances as two handles of ONE process (two streams, two threads; the library calls release the
+    interpreter lock): alone, then beside each other."""
+    import threading
+    import torch
+    from pycusdr_amd import config as cfg
+    from pycusdr_amd.mfbank import MFBank
+    from pycusdr_amd.protocol import loadProtocol
+    N, ov = 1 << log2N, 1 << 10
+    banks = {}
+    try:
+        for name in ('CC11xx', 'bench_BPSK'):
+            if name == 'CC11xx':
+                conf, sps, msz = cfg.cc11xx_config(blockSize=log2N, doppCarrierSteps=D, device=local_rank), 128, 3
+            else:
+                conf, sps, msz = cfg.bench_config(name, blockSize=log2N, doppCarrierSteps=D, device=local_rank), 16, 5
+            rr, shifts = widen_range_rate(conf, 'UHF-H', N, D)
+            conf['Radios']['rangeRateMax'] = rr
+            M, masks = loadProtocol(name)(conf=conf).get_filter(N, sps, msz)
+            b = MFBank(log2N, D, M, window_width=7, sum_all_masks=True, device=local_rank)
+            b.set_filters(masks)
+            b.set_shifts(shifts)
+            banks[name] = b
+
+        def loop(b, res, key, t_end):
+            i = n = 0
+            while time.perf_counter() < t_end[0] - seconds:         # settle until the common start
+                b.upload_device(blocks.data_ptr() + (i % nblocks) * esz)
+                b.find_carrier()
+                i += 1
+            t0 = time.perf_counter()
+            while time.perf_counter() < t_end[0]:
+                b.upload_device(blocks.data_ptr() + (i % nblocks) * esz)
+                b.find_carrier()
+                i += 1
+                n += 1
+            res[key] = round((N - ov) * n / (time.perf_counter() - t0) / 1e6, 2)
+
+        def run(names):
+            res, t_end = {}, [time.perf_counter() + 0.1 + seconds]
+            ths = [threading.Thread(target=loop, args=(banks[k], res, k, t_end)) for k in names]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            torch.cuda.synchronize(dev)
+            return res
+        a1, a2, both = run(['CC11xx']), run(['bench_BPSK']), run(['CC11xx', 'bench_BPSK'])
+        return {'c5_inproc_cc11xx_alone': a1['CC11xx'], 'c5_inproc_bpsk_alone': a2['bench_BPSK'],
+                'c5_inproc_cc11xx_beside': both['CC11xx'], 'c5_inproc_bpsk_beside': both['bench_BPSK'],
+                'c5_inproc_sum_over_alone': round(both['CC11xx'] / a1['CC11xx'] + both['bench_BPSK'] / a2['bench_BPSK'], 4)}
+    except Exception as e:       # noqa: BLE001
+        return {'c5_inproc_error': str(e)[:110]}
+    finally:
+        for b in banks.values():
+            b.close()
 
 
 def segment_roofline_core(info, Dl, Mu, launches, kernel_ms_total):
@@ -598,6 +701,7 @@ def main():
     ap.add_argument('--fallback-from', default=None, help='(set by the launcher ladder) the mode whose failure led to this run')
     ap.add_argument('--no-blocks-leg', action='store_true', help='N>1: skip the short time-chunk-sharded leg after the bins-mode loop')
     ap.add_argument('--no-chain', action='store_true', help='N=1: skip the receive-chain figures at the reference block sizes')
+    ap.add_argument('--no-c5', action='store_true', help='N=1: skip the two-concurrent-instances leg (BASELINE C5: CC11xx + BPSK at 512 bins)')
     ap.add_argument('--no-other-banks', action='store_true',
                     help='skip the untimed per-bank figures (CC11xx sps 128, BPSK M=32 at D=256; C3 D=1024) in config.other_banks / config.c3')
     args = ap.parse_args()
@@ -950,6 +1054,10 @@ def main():
                                  for p in ('CC11xx', 'bench_BPSK') if p != args.protocol]
         extras['c3'] = bank_figure(dev, local_rank, args.protocol, 1024, log2N, blocks, esz, nblocks, steps=4, warmup=1, twopass_steps=3)
 
+    c5 = None
+    if shard is None and G == 1 and not args.no_extras and not args.no_c5 and rank == 0 and log2N == 20 and args.bins == 256:
+        c5 = c5_inprocess_figures(dev, local_rank, blocks, esz, nblocks)
+        c5.update(c5_concurrent_figures())
     blocks_leg = None
     if dist is not None and G > 1 and shard is not None and not args.no_blocks_leg:
         blocks_leg = run_blocks_leg(args, dist, rank, G, local_rank, dev)
@@ -1120,6 +1228,8 @@ def main():
                 flat[f"{o_info['path']}_traffic_over_alg"] = round(o_roof['traffic'] / o_roof['alg_bytes_per_launch'], 3)
         if chain:
             flat.update(chain)
+        if c5:
+            flat.update(c5)
         if blocks_leg:
             flat.update(blocks_leg)
         if shard is not None:
@@ -1129,10 +1239,15 @@ def main():
         flat['stream_msamples'] = out['config']['stream_msamples']
         # ORDER: `workload`, then the scalars a reader that keeps only the first twenty scalar keys must see (key names <= 40
         # characters, strings <= 120), then everything else
-        LEAD = ['roofline_frac', 'dist_mode', 'fallback_from', 'blocks_stream_msamples', 'blocks_efficiency_vs_1gpu', 'c3_msamples',
-                'c3_roofline_frac', 'cc11xx_msamples', 'cc11xx_roofline_frac', 'bpsk_msamples', 'bpsk_roofline_frac', 'twopass_msamples',
-                'twopass_hbm_frac', 'twopass_traffic_over_alg', 'ms_per_step_min', 'ms_per_step_max', 'repeats', 'sync_streams_per_s',
-                'chain_n15_d64_msamples', 'chain_n17_d64_msamples', 'recv_n15_d64_msamples', 'recv_n17_d64_msamples', 'stream_msamples']
+        LEAD = ['roofline_frac', 'dist_mode', 'fallback_from', 'blocks_stream_msamples', 'blocks_efficiency_vs_1gpu',
+                's2_msamples', 's2_over_s1', 's2_roofline_frac', 'cc11xx_msamples', 'cc11xx_roofline_frac', 'cc11xx_s2_msamples',
+                'bpsk_msamples', 'bpsk_roofline_frac', 'c3_msamples', 'c3_roofline_frac', 'c3_twopass_msamples', 'c3_twopass_hbm_frac',
+                'c5_sum_over_alone', 'c5_cc11xx_beside', 'c5_bpsk_beside', 'recv_n15_d64_msamples', 'chain_n15_d64_msamples',
+                'chain_auto_n15_d64_msamples', 'stream_msamples',
+                # (behind the first twenty)
+                'c5_cc11xx_alone', 'c5_bpsk_alone', 'span_cc11xx_msamples', 'span_bpsk_msamples', 'recv_auto_n15_d64_msamples',
+                'recv_n17_d64_msamples', 'chain_n17_d64_msamples', 'chain_auto_n17_d64_msamples', 'twopass_msamples', 'twopass_hbm_frac',
+                'twopass_traffic_over_alg', 'ms_per_step_min', 'ms_per_step_max', 'repeats', 'sync_streams_per_s']
         lead = {k: flat[k] for k in LEAD if flat.get(k) is not None}
         rest = {k: v for k, v in out['config'].items() if k != 'workload' and k not in lead}
         rest.update({k: v for k, v in flat.items() if k not in lead})

@@ -55,8 +55,8 @@ def run_snr(modulation, n_runs, snr, block_size, search, seed, doppler_bins=64, 
     spSym, baud = 16, 9600
     pname = 'bench_' + modulation
     conf = cfg.bench_config(pname, blockSize=block_size, doppCarrierSteps=doppler_bins)
-    if blocks_per_call > 1:         # B consecutive blocks per device call (mfb_receive_blocks_*)
-        conf['GPU']['UHF'].setdefault('HIP', {})['blocks_per_call'] = int(blocks_per_call)
+    if blocks_per_call not in (None, 'auto'):     # B consecutive blocks per device call (mfb_receive_blocks_*); 1 = the reference's
+        conf['GPU']['UHF'].setdefault('HIP', {})['blocks_per_call'] = int(blocks_per_call)      # loop; None / 'auto': what the source has ready
     proto = loadProtocol(pname)(conf=conf)
     # the stimulus is made before the clock starts: the rate below is the receive chain's, not the noise generator's
     stream, bit_data, bw = stimulus if stimulus is not None else make_stream(modulation, n_runs, snr, block_size, seed)
@@ -104,7 +104,7 @@ def run_cc11xx(n_frames, snr, block_size, doppler_bins=64, blocks_per_call=1, de
     """The receive chain on the CC11xx geometry of config/CC11xx.json (FSK-2, 128 samples per symbol -> 384-tap filters, IF offset,
     64 bins): samples in, frames out; a frame counts when its de-whitened payload equals one that was sent."""
     conf = cfg.cc11xx_config(blockSize=block_size, doppCarrierSteps=doppler_bins, samplesPerSym=128)
-    if blocks_per_call > 1:
+    if blocks_per_call not in (None, 'auto'):
         conf['GPU']['UHF'].setdefault('HIP', {})['blocks_per_call'] = int(blocks_per_call)
     proto = loadProtocol('CC11xx')(conf=conf)
     proto.CRC_CHECK = 'framer'        # the stimulus is a TX-framer frame: its CRC sits inside the length-counted bytes

@@ -52,7 +52,8 @@ const char *mfb_strerror(int status);
 int mfb_abi_version(void);   /* 2: search paths, mfb_xcorr; 3: mfb_set_search_mode, mfb_sync_find_multi; 4: mfb_receive_block,
                               * mfb_export_rows_async, mfb_sync_find_packed; 5: mfb_debug_block_scalars; 6: mfb_receive_blocks_*,
                               * mfb_window_buffer, mfb_block_params.block_stride; 7: mfb_set_stream_stages, mfb_stream_seed,
-                              * mfb_receive_blocks_end_record; 8: mfb_hostcopy_* */
+                              * mfb_receive_blocks_end_record; 8: mfb_hostcopy_*; 9: mfb_set_batch_overlap, mfb_get_batch_scores, mfb_receive_blocks_end_record
+                              * reports the size it needs */
 
 /* Create a handle on HIP device `device` for blocks of N = 2^log2N samples, `num_dopplers`
  * Doppler bins plus `doppler_offset` leading noise-reference bins (DB:150-159), M matched
@@ -277,6 +278,21 @@ int mfb_input_buffer2(mfb_ctx *ctx, float **host_c64);
  *                         its two SNR windows at bands_c64 + b * 4 * band_capacity floats. */
 int mfb_window_buffer(mfb_ctx *ctx, int which, int max_blocks, int block_stride, float **host_c64);
 int mfb_receive_blocks_begin(mfb_ctx *ctx, const mfb_block_params *params, int nblocks, int slot);
+/* The doppSum table (num_dopplers + doppler_offset rows of M floats, as mfb_get_scores: GPU_bufDoppSum, DB:594-601) of block
+ * `block` of the batch begun LAST, once that batch has been collected and before the next one is begun.  MFB_ERR_STATE otherwise
+ * (no batch, a fixed-shift batch, block beyond it). */
+int mfb_get_batch_scores(mfb_ctx *ctx, int block, float *host_scores);
+/* A batch as two parts on two streams (no reference counterpart: its loop waits for every stage of a block, DP:284-338).  Part 1 --
+ * forward transforms, Doppler search, pick: the launches that fill the chip -- stays on the handle's stream; part 2 -- matched
+ * filters at the picked shift, envelope, its spectrum, rate / phase, centres, the integer stages, the read-back: a chain of a dozen
+ * small launches -- goes to a second stream (highest priority, transforms through an intermediate of its own, the two flights'
+ * records in buffers of their own), so that the NEXT batch's part 1 runs beside this batch's part 2.  Same numbers, bit for bit
+ * (the kernels and their order inside a batch do not change).  Worth +12 ... 20 % to a caller that keeps two batches in flight and is
+ * not bound by its own per-block work (1.72 -> 1.92 ... 2.0 Gsamples/s at 2^15 x 64 bins x 32 blocks, 2^17 x 8: tools/batch_device_rate.py,
+ * profiles/r06_chain.md); it costs a caller that waits for batch k - 1 right after it has begun batch k and is bound by its own
+ * work -- the Python receive loop: -7 % -- because batch k - 1's part 2 then shares the chip with batch k's search and finishes later.
+ * Off by default (0); the environment's MFB_BATCH_SPLIT=0/1 overrides every handle. */
+int mfb_set_batch_overlap(mfb_ctx *ctx, int on);
 int mfb_receive_blocks_end(mfb_ctx *ctx, int slot, mfb_block_result *results, int32_t *sym, int32_t *centres, float *magnitude,
                            int symbol_stride, float *bands_c64);
 /* The integer stages behind the symbol decisions, on the device, for the blocks of a batch (mfb_receive_blocks_*; UHF search
@@ -298,7 +314,11 @@ int mfb_receive_blocks_end(mfb_ctx *ctx, int slot, mfb_block_result *results, in
  * overlap_offset + 1 bits inside it: posSymEnd, DB:977-979) and the last bits_overlap bits of the stream -- stays on the device
  * from batch to batch; mfb_stream_seed sets it from the host's (start of a stream, after an irregular block, after blocks
  * that went another way).  Batches of more than 64 blocks run without the stages (their records carry layout.stream_stages = 0: the
- * host does A12 ... A14 for them).  p == NULL switches the stages off. */
+ * host does A12 ... A14 for them): one workgroup chains the kept-bit counts of a batch's blocks through one wave, 64 lanes.  So do
+ * batches at a FIXED shift (MFB_BLOCK_FIXED_SHIFT, the S-band back end demodulator/STX.py:8-24): that back end clips interference
+ * peaks out of every block on the host before the block is transformed and tags the symbols next to them in the trust bytes
+ * afterwards (DB:670-707, 830-837) -- from sample indices only the host holds, block by block, so the bits of such a block are
+ * finished on the host anyway.  p == NULL switches the stages off. */
 typedef struct mfb_stream_params {
     int32_t overlap_samples;     /* 2^overlap (config GPU.overlap) */
     int32_t overlap_offset;      /* symbol_check_overlap_offset (DB:19-26): 20 */

@@ -101,6 +101,8 @@ PROTOTYPES = {
     'mfb_input_buffer2': (_i, [_vp, C.POINTER(_fp)]),
     'mfb_window_buffer': (_i, [_vp, _i, _i, _i, C.POINTER(_fp)]),
     'mfb_receive_blocks_begin': (_i, [_vp, C.POINTER(BlockParams), _i, _i]),
+    'mfb_set_batch_overlap': (_i, [_vp, _i]),
+    'mfb_get_batch_scores': (_i, [_vp, _i, _vp]),
     'mfb_receive_blocks_end': (_i, [_vp, _i, C.POINTER(BlockResult), _vp, _vp, _vp, _i, _vp]),
     'mfb_receive_blocks_end_record': (_i, [_vp, _i, _vp, C.c_size_t, C.POINTER(RecordLayout)]),
     'mfb_debug_stream_stages': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.POINTER(RecordLayout)]),

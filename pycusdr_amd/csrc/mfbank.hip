@@ -153,8 +153,22 @@ struct mfb_ctx {
     int bat_cap;                  // blocks the batch work buffers below hold
     cf *d_Xb, *d_xcb, *d_Pb;      // spectra [B][N], matched-filter outputs [B][M][N], envelope spectra [B][N]
     float *d_envb, *d_sumb, *d_resb, *d_crb;   // envelopes [B][N], doppSum [B][Dtot][M], picks [B][2], rate triples [B][3]
-    uint8_t *d_batout;            // result records [B][rec]
+    uint8_t *d_batout;            // result records [B][rec] of the batch in flight slot 0 ...
+    uint8_t *d_batout2;           // ... and slot 1 (the next batch's search writes its picks while this one's records are still read)
     size_t batout_cap;
+    // A batch in two parts on two streams (round 6).  Part 1 -- forward transforms, search, pick: the kernels that fill the chip --
+    // stays on `stream`; part 2 -- matched filters at the picked shift, envelope, its spectrum, rate, centres, the integer stages,
+    // the read-back: a chain of small launches that leaves most of the chip idle -- goes to `s2`, behind an event, with an
+    // intermediate of its own for its transforms (d_Z2).  The next batch's part 1 then runs beside this batch's part 2.
+    hipStream_t s2;
+    hipEvent_t ev_p1[2];          // [slot]: part 1 of the batch in that flight has been enqueued and finished
+    cf *d_Z2;
+    size_t z2_rows;
+    bool use_z2;                  // the transforms being enqueued use d_Z2 (part 2)
+    bool s2_busy;                 // something was enqueued on s2 since the last wait for it
+    bool batch_overlap;           // mfb_set_batch_overlap
+    int last_batch_blocks;        // blocks of the batch begun last (mfb_get_batch_scores)
+    BlockGraph wgraph2[2][2][2][WG_NB + 1];     // part 2's recorded graphs (wgraph holds part 1's)
     // [window][slot][carry parity][blocks of the batch]: a receive loop that takes whatever is complete (1 ... B blocks per call)
     // keeps one recorded graph per batch size it has met twice; sizes above WG_NB share entry 0 (recorded again when the size changes)
     BlockGraph wgraph[2][2][2][WG_NB + 1];
@@ -182,6 +196,15 @@ struct mfb_ctx {
     } while (0)
 
 static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+// the handle's stream and -- when a batch has put work there since the last wait -- the second stream of the batch path
+static hipError_t sync_streams(mfb_ctx *c) {
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && c->s2 && c->s2_busy) {
+        e = hipStreamSynchronize(c->s2);
+        if (e == hipSuccess) c->s2_busy = false;
+    }
+    return e;
+}
 
 // Device allocations of a handle go through dev_alloc so that a test can make the n-th one fail
 // (mfb_debug_fail_alloc): the only way to exercise the free-on-error path of mfb_create without driving
@@ -211,7 +234,7 @@ extern "C" const char *mfb_strerror(int s) {
         default: return "unknown status";
     }
 }
-extern "C" int mfb_abi_version(void) { return 8; }
+extern "C" int mfb_abi_version(void) { return 9; }
 
 static void make_twiddles(std::vector<cf> &v, int count, double denom, double stepmul) {
     v.resize(count);
@@ -288,7 +311,7 @@ static int alloc_Z(mfb_ctx *c) {
     const size_t need = z_rows_needed(c);
     if (c->d_Z && c->z_rows >= need) return MFB_OK;
     if (c->d_Z) {
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(sync_streams(c));
         HIPCHK(hipFree(c->d_Z));
         c->d_Z = nullptr;
         c->z_rows = 0;
@@ -301,7 +324,7 @@ static int alloc_Z(mfb_ctx *c) {
 static int reserve_partials(mfb_ctx *c, size_t floats) {
     if (c->part_cap >= floats) return MFB_OK;
     if (c->d_part) {
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(sync_streams(c));
         ++c->epoch;          // recorded block graphs hold the old address
         HIPCHK(hipFree(c->d_part));
         c->d_part = nullptr;
@@ -320,7 +343,7 @@ static size_t blkout_bytes(int bcap, int nthreads) {
 }
 static int blkout_reserve(mfb_ctx *c, int bcap) {
     if (c->d_blkout && bcap <= c->band_cap) return MFB_OK;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_streams(c));
     if (c->d_blkout) {
         ++c->epoch;          // captured block graphs hold the old record's address (and d_scal): none of them may replay
         HIPCHK(hipFree(c->d_blkout));
@@ -527,11 +550,12 @@ extern "C" int mfb_destroy(mfb_ctx *c) {
     if (!c) return MFB_ERR_ARG;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->s2) (void)hipStreamSynchronize(c->s2);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     void *bufs[] = {c->d_uniq, c->d_rep, c->d_x,  c->d_X,    c->d_masks, c->d_Z,   c->d_xc,  c->d_P,   c->d_env, c->d_shifts, c->d_tw1,
                     c->d_tw2, c->d_twLo, c->d_twHi,  c->d_part, c->d_sum, c->d_res, c->d_cr,  c->d_sym,    c->d_cen, c->d_mag,
                     c->d_G, c->d_twL, c->d_Gb, c->d_pow, c->d_W, c->d_blkout, c->d_x2,
-                    c->d_win[0], c->d_win[1], c->d_Xb, c->d_xcb, c->d_Pb, c->d_envb, c->d_sumb, c->d_resb, c->d_crb, c->d_batout,
+                    c->d_win[0], c->d_win[1], c->d_Xb, c->d_xcb, c->d_Pb, c->d_envb, c->d_sumb, c->d_resb, c->d_crb, c->d_batout, c->d_batout2, c->d_Z2,
                     c->d_lut8, c->d_lut3, c->d_sttmpl, c->d_carry[0], c->d_carry[1]};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -548,10 +572,16 @@ extern "C" int mfb_destroy(mfb_ctx *c) {
         for (auto &col : row)
             for (auto &par : col)
                 for (auto &g : par) graph_drop(g);
+    for (auto &row : c->wgraph2)
+        for (auto &col : row)
+            for (auto &par : col)
+                for (auto &g : par) graph_drop(g);
     for (int i = 0; i < 2; ++i) {
         if (c->h_blk[i]) (void)hipHostFree(c->h_blk[i]);
         if (c->ev_blk[i]) (void)hipEventDestroy(c->ev_blk[i]);
+        if (c->ev_p1[i]) (void)hipEventDestroy(c->ev_p1[i]);
     }
+    if (c->s2) (void)hipStreamDestroy(c->s2);
     if (c->h_back) (void)hipHostFree(c->h_back);
     if (c->h_seed) (void)hipHostFree(c->h_seed);
     if (c->h_X) (void)hipHostFree(c->h_X);
@@ -580,7 +610,7 @@ extern "C" int mfb_destroy(mfb_ctx *c) {
 extern "C" int mfb_set_stream(mfb_ctx *c, void *s) {
     if (!c) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_streams(c));
     c->stream = s ? (hipStream_t)s : c->own_stream;
     ++c->epoch;
     return MFB_OK;
@@ -590,7 +620,7 @@ extern "C" int mfb_set_tuning(mfb_ctx *c, int chunk, int mpb, int rows_per_block
     if (!c || chunk < 0 || mpb < 0 || rows_per_block < 0 || jsplit < 0) return MFB_ERR_ARG;
     ++c->epoch;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_streams(c));
     if (rows_per_block > 0) set_rows_per_block(c, rows_per_block);
     if (jsplit > 0) c->jsplit = jsplit;
     if (chunk > 0) {
@@ -679,7 +709,7 @@ static int resolve_path(mfb_ctx *c) {
         }
     }
     if (c->path_req == MFB_PATH_SEGMENT && !l) return MFB_ERR_UNSUPPORTED;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_streams(c));
     if (!l) {
         c->path = MFB_PATH_TWOPASS;
         c->segl = 0;
@@ -853,7 +883,7 @@ extern "C" int mfb_set_filters(mfb_ctx *c, const float *masks, int M, int N) {
     // impulse-response window and taps of every filter (double precision, host threads)
     if (!c->bank) c->bank = new taps::Bank();
     taps::analyse(masks, M, N, c->bank);
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_streams(c));
     c->have_filters = true;
     c->have_xc = false;
     c->W_valid = false;
@@ -875,7 +905,7 @@ extern "C" int mfb_set_shifts(mfb_ctx *c, const int32_t *shifts, int count) {
         if (shifts[i] < 0 || shifts[i] >= c->N) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c->d_shifts, shifts, (size_t)count * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_streams(c));
     c->have_shifts = true;
     ++c->epoch;
     return MFB_OK;
@@ -965,7 +995,7 @@ static P1Args p1_base(mfb_ctx *c) {
     P1Args a;
     memset(&a, 0, sizeof(a));
     a.masks = c->d_masks;
-    a.Z = c->d_Z;
+    a.Z = c->use_z2 ? c->d_Z2 : c->d_Z;
     a.tw1 = c->d_tw1;
     a.twLo = c->d_twLo;
     a.twHi = c->d_twHi;
@@ -990,7 +1020,7 @@ static void p2_store_split(mfb_ctx *c, P2Args &b, int rows) {
 static P2Args p2_base(mfb_ctx *c) {
     P2Args a;
     memset(&a, 0, sizeof(a));
-    a.Z = c->d_Z;
+    a.Z = c->use_z2 ? c->d_Z2 : c->d_Z;
     a.tw2 = c->d_tw2;
     a.N = c->N;
     a.N1 = c->N1;
@@ -1003,7 +1033,7 @@ static P2Args p2_base(mfb_ctx *c) {
 
 static int launch_transpose(mfb_ctx *c, cf *dst, int rows, int conj) {
     dim3 grid((c->N2 + 31) / 32, (c->N1 + 31) / 32, rows);
-    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, c->stream, (const cf *)c->d_Z, dst, c->N1, c->N2, conj);
+    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, c->stream, (const cf *)(c->use_z2 ? c->d_Z2 : c->d_Z), dst, c->N1, c->N2, conj);
     HIPCHK(hipGetLastError());
     return MFB_OK;
 }
@@ -1012,7 +1042,7 @@ static int launch_transpose(mfb_ctx *c, cf *dst, int rows, int conj) {
 // dst + r * N): complex (src_c) or real (src_r) input -> dst natural order.  d_Z must hold `rows` rows.
 static int forward_fft(mfb_ctx *c, const cf *src_c, const float *src_r, cf *dst, int conj_out = 1, int rows = 1, size_t in_stride = 0);
 static int forward_fft(mfb_ctx *c, const cf *src_c, const float *src_r, cf *dst, int conj_out, int rows, size_t in_stride) {
-    if (rows < 1 || (size_t)rows > c->z_rows || in_stride > 0x7fffffffu) return MFB_ERR_ARG;
+    if (rows < 1 || (size_t)rows > (c->use_z2 ? c->z2_rows : c->z_rows) || in_stride > 0x7fffffffu) return MFB_ERR_ARG;
     P1Args a = p1_base(c);
     a.X = src_c;
     a.Xr = src_r;
@@ -1229,7 +1259,7 @@ extern "C" int mfb_upload_from(mfb_ctx *c, const float *host, int N) {
     if (!c || !host || N != c->N) return MFB_ERR_ARG;
     if ((const void *)host != (const void *)c->h_in) {
         HIPCHK(hipSetDevice(c->device));
-        HIPCHK(hipStreamSynchronize(c->stream));  // pinned buffer may still be in flight
+        HIPCHK(sync_streams(c));  // pinned buffer may still be in flight
         memcpy(c->h_in, host, (size_t)N * sizeof(cf));
     }
     return mfb_upload(c);
@@ -1384,7 +1414,7 @@ static int read_back(mfb_ctx *c, const BackPiece *p, int n) {
         HIPCHK(hipMemcpyAsync(staged ? (void *)(c->h_back + off) : p[i].host, p[i].dev, p[i].bytes, hipMemcpyDeviceToHost, c->stream));
         off += (p[i].bytes + 15) & ~(size_t)15;
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_streams(c));
     if (staged) {
         off = 0;
         for (int i = 0; i < n; ++i) {
@@ -1457,7 +1487,17 @@ extern "C" int mfb_get_scores(mfb_ctx *c, float *host) {
     if (!c || !host) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(host, c->d_sum, (size_t)c->Dtot * c->M * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_streams(c));
+    return MFB_OK;
+}
+
+// doppSum of block `block` of the LAST batch (mfb_receive_blocks_*), as mfb_get_scores gives the one-block table
+extern "C" int mfb_get_batch_scores(mfb_ctx *c, int block, float *host) {
+    if (!c || !host || block < 0) return MFB_ERR_ARG;
+    if (!c->d_sumb || block >= c->bat_cap || block >= c->last_batch_blocks) return MFB_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(sync_streams(c));
+    HIPCHK(hipMemcpy(host, c->d_sumb + (size_t)block * c->Dtot * c->M, (size_t)c->Dtot * c->M * sizeof(float), hipMemcpyDeviceToHost));
     return MFB_OK;
 }
 
@@ -1613,8 +1653,28 @@ static void stream_search_launch(mfb_ctx *c, const StreamArgs &sa, int nb, int T
     hipLaunchKernelGGL(k_stream_ring, dim3(1), dim3(256), 0, c->stream, sa);
     hipLaunchKernelGGL(k_stream_edges, dim3(nb), dim3(256), 0, c->stream, sa);
 }
-static int block_enqueue(mfb_ctx *c, const mfb_block_params *p, const BlkBufs &bb, uint8_t *h_dst, int nthreads, int bcap, int capacity,
-                         int *shift_out) {
+// where the pieces of a result record sit
+struct RecPtrs {
+    size_t rec;
+    uint8_t *d;
+    BlockScalars *scal;
+    cf *bands;
+    int *sym, *cen;
+    float *mag;
+};
+static RecPtrs rec_ptrs(const BlkBufs &bb, int nthreads, int bcap) {
+    RecPtrs r;
+    r.rec = bb.rec ? bb.rec : blkout_bytes(bcap, nthreads);
+    r.d = bb.out;
+    r.scal = (BlockScalars *)r.d;
+    r.bands = (cf *)(r.d + BLK_HEAD);
+    r.sym = (int *)(r.d + BLK_HEAD + align16((size_t)2 * bcap * sizeof(cf)));
+    r.cen = (int *)((uint8_t *)r.sym + align16((size_t)nthreads * sizeof(int)));
+    r.mag = (float *)((uint8_t *)r.cen + align16((size_t)nthreads * sizeof(int)));
+    return r;
+}
+// Part 1 of a block / batch: forward transform(s), Doppler search, pick (or, at a fixed shift, the cleared scalars).
+static int block_enqueue_p1(mfb_ctx *c, const mfb_block_params *p, const BlkBufs &bb, int nthreads, int bcap) {
     int rc;
     const int nb = bb.nb;
     const bool batch = bb.rec != 0;
@@ -1631,15 +1691,7 @@ static int block_enqueue(mfb_ctx *c, const mfb_block_params *p, const BlkBufs &b
             c->have_xc = false;
         }
     }
-    const size_t rec = batch ? bb.rec : blkout_bytes(bcap, nthreads);
-    uint8_t *d = bb.out;
-    BlockScalars *scal = (BlockScalars *)d;
-    cf *d_bands = (cf *)(d + BLK_HEAD);
-    int *d_sym = (int *)(d + BLK_HEAD + align16((size_t)2 * bcap * sizeof(cf)));
-    int *d_cen = (int *)((uint8_t *)d_sym + align16((size_t)nthreads * sizeof(int)));
-    float *d_mag = (float *)((uint8_t *)d_cen + align16((size_t)nthreads * sizeof(int)));
-    const int *shift_dev = nullptr;
-    int shift = 0;
+    const RecPtrs r = rec_ptrs(bb, nthreads, bcap);
     if (p->mode == MFB_BLOCK_SEARCH) {
         if (batch) {
             if (c->path != MFB_PATH_SEGMENT || c->search_mode != MFB_SEARCH_TRANSFORMS) return MFB_ERR_UNSUPPORTED;
@@ -1648,14 +1700,31 @@ static int block_enqueue(mfb_ctx *c, const mfb_block_params *p, const BlkBufs &b
             return rc;
         }
         hipLaunchKernelGGL(k_pick_block, dim3(nb), dim3(64), 0, c->stream, (const float *)bb.sum, bb.res, c->D, c->Doff, c->M, c->sum_all,
-                           (const int *)c->d_shifts, c->Dtot, c->N, p->snr_window, (const cf *)bb.X, scal, d_bands, bcap, rec);
+                           (const int *)c->d_shifts, c->Dtot, c->N, p->snr_window, (const cf *)bb.X, r.scal, r.bands, bcap, r.rec);
         HIPCHK(hipGetLastError());
-        shift_dev = &scal->shift;
     } else {
-        hipLaunchKernelGGL(k_block_clear, dim3(nb), dim3(1), 0, c->stream, scal, rec);
+        hipLaunchKernelGGL(k_block_clear, dim3(nb), dim3(1), 0, c->stream, r.scal, r.rec);
         HIPCHK(hipGetLastError());
-        shift = ((p->fixed_shift % c->N) + c->N) % c->N;
     }
+    return MFB_OK;
+}
+// Part 2: matched filters at the picked (or fixed) shift, envelope, its spectrum, rate / phase, symbol centres, the integer stages
+// of a batch, and the ONE device-to-host copy of the record(s).
+static int block_enqueue_p2(mfb_ctx *c, const mfb_block_params *p, const BlkBufs &bb, uint8_t *h_dst, int nthreads, int bcap, int capacity,
+                            int *shift_out) {
+    int rc;
+    const int nb = bb.nb;
+    const bool batch = bb.rec != 0;
+    const RecPtrs r = rec_ptrs(bb, nthreads, bcap);
+    const size_t rec = r.rec;
+    uint8_t *d = r.d;
+    BlockScalars *scal = r.scal;
+    int *d_sym = r.sym, *d_cen = r.cen;
+    float *d_mag = r.mag;
+    const int *shift_dev = nullptr;
+    int shift = 0;
+    if (p->mode == MFB_BLOCK_SEARCH) shift_dev = &scal->shift;
+    else shift = ((p->fixed_shift % c->N) + c->N) % c->N;
     if ((rc = demod_enqueue(c, bb, shift, shift_dev, (int)(rec / sizeof(int)), p->k_offset, p->k_len, p->spsym_min, capacity, scal))) return rc;
     // (entries past nthreads are not part of the record: the kernel's capacity bounds what it writes; the k* == 0 fallback --
     // spSym = 10, DB:737-740, unreachable while the rate window starts above bin 0 -- is completed in block_end)
@@ -1695,6 +1764,11 @@ static int block_enqueue(mfb_ctx *c, const mfb_block_params *p, const BlkBufs &b
     HIPCHK(hipMemcpyAsync(h_dst, d, rec * nb, hipMemcpyDeviceToHost, c->stream));
     *shift_out = shift;
     return MFB_OK;
+}
+static int block_enqueue(mfb_ctx *c, const mfb_block_params *p, const BlkBufs &bb, uint8_t *h_dst, int nthreads, int bcap, int capacity,
+                         int *shift_out) {
+    const int rc = block_enqueue_p1(c, p, bb, nthreads, bcap);
+    return rc ? rc : block_enqueue_p2(c, p, bb, h_dst, nthreads, bcap, capacity, shift_out);
 }
 
 // Host-to-device copy of a page-locked input buffer into its own device copy, on the input stream: it starts as soon as the
@@ -1807,6 +1881,10 @@ static int staging_reserve(mfb_ctx *c, int slot, size_t need) {
     for (auto &row : c->wgraph)
         for (auto &par : row[slot])
             for (auto &g : par) graph_drop(g);
+    for (auto &row : c->wgraph2)
+        for (auto &par : row[slot])
+            for (auto &g : par) graph_drop(g);
+    if (c->s2) HIPCHK(hipStreamSynchronize(c->s2));
     if (c->h_blk[slot]) HIPCHK(hipHostFree(c->h_blk[slot]));
     c->h_blk[slot] = nullptr;
     c->blk_cap[slot] = 0;
@@ -1951,9 +2029,27 @@ extern "C" int mfb_receive_block(mfb_ctx *c, const mfb_block_params *p, mfb_bloc
 // estimates, the centres of all blocks, one device-to-host copy of B result records.
 static int window_samples(const mfb_ctx *c, int nb) { return nb * c->win_stride + (c->N - c->win_stride); }
 
+// A batch on two streams (mfb_set_batch_overlap; include/mfbank.h): the handle's setting, or -- every handle -- MFB_BATCH_SPLIT=0/1 in
+// the environment (the A/B switch of profiles/r06_chain.md)
+static bool batch_split(const mfb_ctx *c) {
+    static const int env = getenv("MFB_BATCH_SPLIT") ? atoi(getenv("MFB_BATCH_SPLIT")) : -1;
+    return env >= 0 ? env != 0 : c->batch_overlap;
+}
+extern "C" int mfb_set_batch_overlap(mfb_ctx *c, int on) {
+    if (!c || on < 0 || on > 1) return MFB_ERR_ARG;
+    for (int s = 0; s < 2; ++s)
+        if (c->flight[s].active && c->flight[s].nb) return MFB_ERR_STATE;      // a batch is in flight
+    if (c->batch_overlap != (on != 0)) {
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(sync_streams(c));
+        ++c->epoch;               // the recorded graphs belong to the other arrangement
+        c->batch_overlap = on != 0;
+    }
+    return MFB_OK;
+}
 static int batch_reserve(mfb_ctx *c, int nb, size_t rec) {
     if (nb > c->bat_cap) {
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(sync_streams(c));
         ++c->epoch;        // recorded graphs hold the old addresses
         void **bufs[] = {(void **)&c->d_Xb, (void **)&c->d_xcb, (void **)&c->d_Pb, (void **)&c->d_envb, (void **)&c->d_sumb, (void **)&c->d_resb,
                          (void **)&c->d_crb};
@@ -1973,7 +2069,7 @@ static int batch_reserve(mfb_ctx *c, int nb, size_t rec) {
         c->bat_cap = nb;
     }
     if ((size_t)nb > c->z_rows) {       // the plain forward transforms of the batch take one row of the intermediate each
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(sync_streams(c));
         ++c->epoch;
         if (c->d_Z) HIPCHK(hipFree(c->d_Z));
         c->d_Z = nullptr;
@@ -1982,13 +2078,24 @@ static int batch_reserve(mfb_ctx *c, int nb, size_t rec) {
         c->z_rows = (size_t)nb;
     }
     if (rec * nb > c->batout_cap) {
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(sync_streams(c));
         ++c->epoch;
         if (c->d_batout) HIPCHK(hipFree(c->d_batout));
-        c->d_batout = nullptr;
+        if (c->d_batout2) HIPCHK(hipFree(c->d_batout2));
+        c->d_batout = c->d_batout2 = nullptr;
         c->batout_cap = 0;
         HIPCHK(dev_alloc((void **)&c->d_batout, rec * nb));
+        HIPCHK(dev_alloc((void **)&c->d_batout2, rec * nb));
         c->batout_cap = rec * nb;
+    }
+    if (batch_split(c) && (size_t)nb > c->z2_rows) {       // part 2's transforms (the envelopes' spectra) get an intermediate of their own
+        HIPCHK(sync_streams(c));
+        ++c->epoch;
+        if (c->d_Z2) HIPCHK(hipFree(c->d_Z2));
+        c->d_Z2 = nullptr;
+        c->z2_rows = 0;
+        HIPCHK(dev_alloc((void **)&c->d_Z2, (size_t)nb * c->N * sizeof(cf)));
+        c->z2_rows = (size_t)nb;
     }
     return MFB_OK;
 }
@@ -2000,7 +2107,7 @@ extern "C" int mfb_window_buffer(mfb_ctx *c, int which, int max_blocks, int bloc
     if (c->win_blocks != max_blocks || c->win_stride != block_stride) {
         for (int s = 0; s < 2; ++s)
             if (c->flight[s].active && c->flight[s].nb) return MFB_ERR_STATE;      // a batch is reading the windows
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(sync_streams(c));
         if (c->in_stream) HIPCHK(hipStreamSynchronize(c->in_stream));
         ++c->epoch;
         for (int i = 0; i < 2; ++i) {
@@ -2058,18 +2165,53 @@ extern "C" int mfb_receive_blocks_begin(mfb_ctx *c, const mfb_block_params *p, i
     if (win_in && (rc = input_copy(c, c->h_win[which], c->d_win[which], (size_t)(nblocks * stride + (c->N - stride)), c->ev_wh2d, c->ev_wfree, which)))
         return rc;
     const int parity = c->carry_cur;
+    // (the two flights' records live in buffers of their own: the next batch's pick writes into its records while this batch's
+    // are still being read on the other stream)
     BlkBufs bb{nblocks, win_in ? (const cf *)c->d_win[which] : (const cf *)p->device_block, stride, c->d_Xb, c->d_sumb, c->d_resb, c->d_xcb,
-               c->d_envb, c->d_Pb, c->d_crb, c->d_batout, rec, stages ? core : 0, parity};
+               c->d_envb, c->d_Pb, c->d_crb, slot ? c->d_batout2 : c->d_batout, rec, stages ? core : 0, parity};
     int shift = p->mode == MFB_BLOCK_FIXED_SHIFT ? ((p->fixed_shift % c->N) + c->N) % c->N : 0;
     const bool allowed = win_in && graphs_allowed() && !c->prof;
     mfb_block_params q = *p;
     q.block_stride = stride;
-    rc = graph_or_launch(c, c->wgraph[which][slot][parity][nblocks <= WG_NB ? nblocks : 0], &q, nblocks, allowed,
-                         [&]() { return block_enqueue(c, &q, bb, c->h_blk[slot], nthreads, bcap, capacity, &shift); });
-    if (rc) return rc;
+    const int gi = nblocks <= WG_NB ? nblocks : 0;
+    if (!batch_split(c)) {
+        rc = graph_or_launch(c, c->wgraph[which][slot][parity][gi], &q, nblocks, allowed,
+                             [&]() { return block_enqueue(c, &q, bb, c->h_blk[slot], nthreads, bcap, capacity, &shift); });
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(c->ev_blk[slot], c->stream));
+        if (win_in) HIPCHK(hipEventRecord(c->ev_wfree[which], c->stream));
+    } else {
+        // part 1 on the handle's stream, part 2 behind it on the second stream: the NEXT batch's part 1 is enqueued behind this
+        // one's part 1 only, and runs beside this batch's part 2
+        if (!c->s2) {
+            // (the highest priority: part 2 is a latency chain whose workgroups should get the slots the big kernel frees first)
+            int least = 0, greatest = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIPCHK(hipStreamCreateWithPriority(&c->s2, hipStreamNonBlocking, greatest));
+        }
+        if (!c->ev_p1[slot]) HIPCHK(hipEventCreateWithFlags(&c->ev_p1[slot], hipEventDisableTiming));
+        rc = graph_or_launch(c, c->wgraph[which][slot][parity][gi], &q, nblocks, allowed,
+                             [&]() { return block_enqueue_p1(c, &q, bb, nthreads, bcap); });
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(c->ev_p1[slot], c->stream));
+        hipStream_t s1 = c->stream;
+        c->stream = c->s2;            // every launch helper enqueues on c->stream
+        c->use_z2 = true;
+        c->s2_busy = true;
+        hipError_t e = hipStreamWaitEvent(c->s2, c->ev_p1[slot], 0);
+        rc = e != hipSuccess ? MFB_ERR_HIP
+                             : graph_or_launch(c, c->wgraph2[which][slot][parity][gi], &q, nblocks, allowed,
+                                               [&]() { return block_enqueue_p2(c, &q, bb, c->h_blk[slot], nthreads, bcap, capacity, &shift); });
+        if (!rc) {
+            e = hipEventRecord(c->ev_blk[slot], c->s2);
+            if (e == hipSuccess && win_in) e = hipEventRecord(c->ev_wfree[which], c->s2);
+            if (e != hipSuccess) rc = MFB_ERR_HIP;
+        }
+        c->stream = s1;
+        c->use_z2 = false;
+        if (rc) return rc;
+    }
     if (stages) c->carry_cur = 1 - parity;        // this batch's tail and ring are the next batch's start
-    HIPCHK(hipEventRecord(c->ev_blk[slot], c->stream));
-    if (win_in) HIPCHK(hipEventRecord(c->ev_wfree[which], c->stream));
     const size_t sym_off = BLK_HEAD + align16((size_t)2 * bcap * sizeof(cf)), arr = align16((size_t)nthreads * sizeof(int));
     f.off[0] = 0;
     f.off[4] = BLK_HEAD;
@@ -2086,6 +2228,7 @@ extern "C" int mfb_receive_blocks_begin(mfb_ctx *c, const mfb_block_params *p, i
     f.nb = nblocks;
     f.rec = rec;
     f.ext = stages ? core : 0;
+    c->last_batch_blocks = p->mode == MFB_BLOCK_SEARCH ? nblocks : 0;
     // the handle's one-block buffers (spectrum, matched-filter outputs) hold nothing of this batch
     c->have_xc = false;
     return MFB_OK;
@@ -2179,7 +2322,7 @@ extern "C" int mfb_receive_blocks_end_record(mfb_ctx *c, int slot, void *dst, si
 extern "C" int mfb_set_stream_stages(mfb_ctx *c, const mfb_stream_params *p) {
     if (!c) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_streams(c));
     ++c->epoch;
     c->st_on = false;
     if (!p) return MFB_OK;                 // switched off
@@ -2260,7 +2403,7 @@ extern "C" int mfb_stream_seed(mfb_ctx *c, const uint8_t *post, int npost, const
     if (!c->st_on) return MFB_ERR_STATE;
     if (npost > STREAM_POST_MAX || nend > STREAM_END_MAX || ring_len > STREAM_NOV_MAX) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));          // h_seed may still be on its way from the last seed
+    HIPCHK(sync_streams(c));          // h_seed may still be on its way from the last seed
     StreamCarry *h = c->h_seed;
     memset(h, 0, sizeof(*h));
     h->valid = 1;
@@ -2331,7 +2474,7 @@ extern "C" int mfb_debug_stream_stages(mfb_ctx *c, int nb, int symbols, const in
     HIPCHK(hipGetLastError());
     c->carry_cur = 1 - c->carry_cur;
     HIPCHK(hipMemcpyAsync(dst, c->d_batout, rec * (size_t)nb, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_streams(c));
     memset(lay, 0, sizeof(*lay));
     lay->nblocks = nb;
     lay->record_bytes = (int64_t)rec;
@@ -2378,7 +2521,7 @@ extern "C" int mfb_debug_block_scalars(mfb_ctx *c, int n, const float *picks, co
         hipLaunchKernelGGL(k_block_scalars_debug, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, (const float *)d_in,
                            (const float *)(d_in + 2 * (size_t)n), (const int *)c->d_shifts, c->Dtot, c->N, snr_window, spsym_min, capacity,
                            d_out);
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
+        if (hipGetLastError() != hipSuccess || sync_streams(c) != hipSuccess ||
             hipMemcpy(h.data(), d_out, (size_t)n * sizeof(BlockScalars), hipMemcpyDeviceToHost) != hipSuccess)
             rc = MFB_ERR_HIP;
     }
@@ -2451,7 +2594,7 @@ extern "C" int mfb_get_xcorr(mfb_ctx *c, float *host) {
     if (!c->have_xc) return MFB_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(host, c->d_xc, (size_t)c->M * c->N * sizeof(cf), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_streams(c));
     return MFB_OK;
 }
 
@@ -2460,7 +2603,7 @@ extern "C" int mfb_get_envelope(mfb_ctx *c, float *host) {
     if (!c->have_xc) return MFB_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(host, c->d_env, (size_t)c->N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_streams(c));
     return MFB_OK;
 }
 
@@ -2953,7 +3096,7 @@ extern "C" int mfb_xcorr(mfb_ctx *c, const float *a, int Na, const float *b, int
     if ((rc = stage(a, Na))) return rc;
     if ((rc = before_fft(c))) return rc;                                        // d_X is scratch here
     if ((rc = forward_fft(c, nullptr, c->d_env, c->d_X, 1))) return rc;        // A = fft(a, N)
-    HIPCHK(hipStreamSynchronize(c->stream));                                    // d_env is reused
+    HIPCHK(sync_streams(c));                                    // d_env is reused
     if ((rc = stage(b, Nb))) return rc;
     if ((rc = forward_fft(c, nullptr, c->d_env, c->d_masks, 0))) return rc;    // conj(fft(b, N)) into filter row 0
     // inverse transform of A * conj(B): the two-pass bank kernels at shift 0, one filter row
@@ -2975,7 +3118,7 @@ extern "C" int mfb_xcorr(mfb_ctx *c, const float *a, int Na, const float *b, int
     hipLaunchKernelGGL(k_scale_c, dim3(256), dim3(256), 0, c->stream, c->d_xc, 1.0f / (float)N, N);   // numpy's ifft is 1/N
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_c64, c->d_xc, (size_t)N * sizeof(cf), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_streams(c));
     c->have_filters = false;   // the scratch use clobbered the bank, the spectrum and the outputs
     c->have_input = false;
     c->have_xc = false;
@@ -3013,7 +3156,7 @@ extern "C" int mfb_profile_enable(mfb_ctx *c, int on) {
 extern "C" int mfb_profile_read(mfb_ctx *c, int counts[2], float total_ms[2]) {
     if (!c || !counts || !total_ms) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_streams(c));
     for (int w = 0; w < 2; ++w) {
         counts[w] = (int)(c->ev[w].size() / 2);
         double tot = 0.0;
@@ -3031,7 +3174,7 @@ extern "C" int mfb_profile_read(mfb_ctx *c, int counts[2], float total_ms[2]) {
 extern "C" int mfb_sync(mfb_ctx *c) {
     if (!c) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_streams(c));
     return MFB_OK;
 }
 

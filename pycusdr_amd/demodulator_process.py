@@ -243,9 +243,13 @@ class DemodulatorRunner:
 
     def blocks_per_call(self):
         """``"HIP": {"blocks_per_call": B}`` of the radio's GPU settings (next to the reference's "CUDA" block): B > 1 makes
-        ``run_stream`` hand the device B consecutive blocks per call (mfb_receive_blocks_*).  Default 1."""
+        ``run_stream`` hand the device B consecutive blocks per call (mfb_receive_blocks_*), 1 is the reference's loop (one
+        block per turn, DP:284-338).  Absent or "auto" (None here): ``run_stream`` batches what the source has ready -- up to
+        ``auto_blocks_per_call()`` blocks while chunks come faster than the device takes them, every complete block at once
+        while they do not."""
         confGPU = self.conf['GPU'][self.confRadio['CUDA_settings']]
-        return max(1, int(confGPU.get('HIP', {}).get('blocks_per_call', 1)))
+        v = confGPU.get('HIP', {}).get('blocks_per_call', 'auto')
+        return None if v in (None, 'auto') else max(1, int(v))
 
     def run_stream(self, chunk_source, sink=None, decoder=None, pipelined=False, overlapped=True, blocks_per_call=None):
         """The reference's loop shape (DP:284-338): chunks of ANY size (GNU Radio ~4096 samples, the BER bench
@@ -268,19 +272,23 @@ class DemodulatorRunner:
         if not (overlapped and self.radioBackend == 'UHF' and getattr(self.demod, '_one_call', False)):
             asm = BlockAssembler(self.raw, self.overlap)
             return self.run((None for chunk in chunk_source if chunk is not None for _ in asm.push(chunk)), sink=sink, decoder=decoder)
-        if blocks_per_call is None:
-            confGPU = self.conf['GPU'][self.confRadio['CUDA_settings']]
-            marked = isinstance(chunk_source, MarkedSource) and 'blocks_per_call' not in confGPU.get('HIP', {})
-            B = self.auto_blocks_per_call() if marked else self.blocks_per_call()
-        else:
-            B = max(1, int(blocks_per_call))
+        # how many blocks per device call: the caller's word, else the configuration's, else ("auto") whatever the source has ready.
+        # A source that marks where it would block (MarkedSource) says so itself; a plain iterator cannot be asked, so the loop
+        # watches how long each chunk takes to come (``_run_stream_batched``, adaptive): chunks that are there at once (a
+        # recording, a backlog, a chunk of several blocks) fill windows of auto_blocks_per_call() blocks, and a block whose last
+        # chunk had to be waited for goes out alone, at once -- the one-block loop's latency.
+        B = max(1, int(blocks_per_call)) if blocks_per_call not in (None, 'auto') else self.blocks_per_call()
+        adaptive = B is None and not isinstance(chunk_source, MarkedSource)
+        if B is None:
+            B = self.auto_blocks_per_call()
         if B > 1:       # (a batch of ONE block is slower than the one-block loop below: 211 against 254 Msamples/s at 2^15 x 64 -- more launches)
             bank = self.demod.bank
             if bank.get_search_path()['path'] == 'segment' and bank.get_search_mode() == 'transforms':
-                return self._run_stream_batched(chunk_source, sink, decoder, B)
+                return self._run_stream_batched(chunk_source, sink, decoder, B, adaptive=adaptive)
             # batches run on the segment search path (filters with a short impulse response: every shipped protocol) and the
             # default search mode: anything else takes the one-block loop
-            log.warning('[%s]: blocks_per_call = %d ignored: the filter bank / search mode of this handle runs one block per call', self.radioName, B)
+            if not adaptive:
+                log.warning('[%s]: blocks_per_call = %d ignored: the filter bank / search mode of this handle runs one block per call', self.radioName, B)
         # Overlapped form: block i is on the device while this thread runs the sequential host stages and the decoder of
         # block i-1 and assembles block i+1 in the other page-locked buffer.  Same calls in the same order on the same data
         # as the plain loop, so the same results; only the waiting moves.
@@ -395,7 +403,11 @@ class DemodulatorRunner:
         found best."""
         return max(1, min(32, (1 << 20) // self.blockSize))
 
-    def _run_stream_batched(self, chunk_source, sink, decoder, B):
+    # a chunk that took longer than this to come had to be WAITED for: the source is live and has no backlog (a generator over a
+    # recording answers in ~1 us, a queue with a backlog in a few; 4096 samples at 100 Msamples/s take 41 us to exist)
+    PULL_SLOW_S = 25e-6
+
+    def _run_stream_batched(self, chunk_source, sink, decoder, B, adaptive=False):
         """``run_stream`` with B consecutive blocks per device call (``"HIP": {"blocks_per_call": B}``; mfb_receive_blocks_*).
         The reference's loop hands the device one block per turn (DP:284-338); at its own block sizes (2^15 ... 2^17 samples,
         64 bins: config/base.json:13,33) a block is a few tens of microseconds of device work and the turn is all host.  Here the
@@ -406,9 +418,18 @@ class DemodulatorRunner:
         last, partly filled window are processed as a shorter batch -- and so they are whenever the source yields ``None``
         ("nothing more right now"): a live source that puts a ``None`` where it would block gets B blocks per call while it has
         a backlog and every block out as soon as it is complete while it has not (``drain_marked`` builds such a source from
-        a poll function)."""
+        a poll function).  ``adaptive`` (a plain iterator, nothing configured): the loop decides the same thing from the time
+        each ``next()`` took -- a block whose last chunk had to be waited for (> PULL_SLOW_S) goes out at once with whatever
+        else is complete; chunks that were simply there keep filling the window."""
         from .sigFIFO import WindowAssembler
         wins = self.demod.blockWindows(B)
+        # "HIP": {"batch_overlap": true}: the next batch's search beside this batch's small kernels (mfb_set_batch_overlap).  Off
+        # by default HERE: this loop is bound by its own per-block work and waits for batch k - 1 right after it has begun batch
+        # k, and a batch k - 1 whose tail shares the chip with batch k's search arrives later (profiles/r06_chain.md: -7 %).
+        want = bool(self.conf['GPU'][self.confRadio['CUDA_settings']].get('HIP', {}).get('batch_overlap', False))
+        if getattr(self, '_batch_overlap', False) != want and hasattr(self.demod.bank, 'set_batch_overlap'):
+            self.demod.bank.set_batch_overlap(want)
+            self._batch_overlap = want
         names = ('window', 'window2')
         cur = 0
         # the integer stages behind the symbol decisions (bit lookup, block-overlap alignment, the decoder's searches on the
@@ -517,10 +538,13 @@ class DemodulatorRunner:
             """Chunks from the source into the window (copies queued, not waited for) until it is complete ('full'), the source
             says it has nothing more right now ('dry') or ends ('end')."""
             t0 = time.time()
+            waited = False
             try:
                 while True:
                     if rest[0] is None:
+                        tp = time.perf_counter()
                         chunk = next(it, END)
+                        waited = adaptive and time.perf_counter() - tp > self.PULL_SLOW_S
                         if chunk is END:
                             return 'end'
                         if chunk is None:
@@ -530,6 +554,8 @@ class DemodulatorRunner:
                     rest[0] = rest[0][n:] if n < len(rest[0]) else None
                     if asm.full():
                         return 'full'
+                    if waited and asm.complete_blocks():
+                        return 'dry'     # the source had nothing ready: what is complete goes out now
             finally:
                 fill_s[0] = time.time() - t0
 

@@ -444,6 +444,18 @@ class MFBank:
         self._batch[int(slot)] = (int(nblocks), int(k_offset) + int(k_len) + 1)
         self._flying = getattr(self, '_flying', set()) | {int(slot)}
 
+    def get_batch_scores(self, block):
+        """``get_scores`` for block ``block`` of the batch begun last (collected, and no later batch begun)."""
+        out = np.empty((self.Dtot, self.M), dtype=np.float32)
+        _lib.check(self._lib.mfb_get_batch_scores(self._h, int(block), _ptr(out)), 'mfb_get_batch_scores')
+        return out
+
+    def set_batch_overlap(self, on=True):
+        """A batch as two parts on two streams (mfb_set_batch_overlap): the next batch's search runs beside this batch's matched
+        filters, rate / phase, centres and integer stages.  For callers that keep two batches in flight and are not bound by
+        their own per-block work; off by default."""
+        _lib.check(self._lib.mfb_set_batch_overlap(self._h, 1 if on else 0), 'mfb_set_batch_overlap')
+
     def end_blocks_record(self, slot):
         """Wait for the batch begun in ``slot`` and return it as a ``BatchRecord`` (one copy, read in place)."""
         slot = int(slot)

@@ -67,7 +67,7 @@ def test_python_binding_covers_the_header(lib_path):
     from pycusdr_amd import _lib
     assert sorted(_lib.PROTOTYPES) == _declared_functions()
     lib = _lib.load()
-    assert lib.mfb_abi_version() == 8
+    assert lib.mfb_abi_version() == 9
     assert lib.mfb_strerror(0) == b'ok' and b'argument' in lib.mfb_strerror(1)
 
 

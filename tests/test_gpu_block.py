@@ -118,7 +118,7 @@ def test_runner_stream_in_place_assembly_equals_ring_buffer_path():
         ra, _ = a.run([sig[i * step:(i + 1) * step] for i in range(6)])
         for chunk, overlapped in ((4096, True), (16384, True), (1000, False), (3 * step + 17, True), (16384, False)):
             b2 = DemodulatorRunner(conf, p, 'UHF-H')
-            rb, _ = b2.run_stream((sig[i:i + chunk] for i in range(0, 6 * step, chunk)), overlapped=overlapped)
+            rb, _ = b2.run_stream((sig[i:i + chunk] for i in range(0, 6 * step, chunk)), overlapped=overlapped, blocks_per_call=1)
             b2.close()
             assert len(rb) == 6
             for u, v in zip(ra, rb):

@@ -16,6 +16,14 @@ from pycusdr_amd.protocol import loadProtocol
 pytestmark = pytest.mark.gpu
 
 
+def _one(conf):
+    """The configuration with ``"blocks_per_call": 1``: the reference's loop, one block per turn (DP:284-338) -- what the batched
+    loops are held against.  (Without the key ``run_stream`` batches whatever its source has ready.)"""
+    c = copy.deepcopy(conf)
+    c['GPU']['UHF'].setdefault('HIP', {})['blocks_per_call'] = 1
+    return c
+
+
 def _same(a, b):
     return bool(np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True))
 
@@ -148,7 +156,7 @@ def test_batched_stream_equals_one_block_stream(B):
         sig.flags.writeable = False
     elif B == 8:
         confB['GPU']['UHF']['HIP']['async_copies'] = True
-    a, b = DemodulatorRunner(conf, p, 'UHF-H'), DemodulatorRunner(confB, p, 'UHF-H')
+    a, b = DemodulatorRunner(_one(conf), p, 'UHF-H'), DemodulatorRunner(confB, p, 'UHF-H')
 
     def slipping(run):
         """Drop one symbol decision at the front of block B (first block of the second batch) -- what a +1 slip of the
@@ -207,7 +215,7 @@ def test_more_blocks_per_call_than_the_device_stages_take():
     sig = sg.s1_stream(nblocks, N, ov, 'GMSK', snr_db=12.0, seed=9)[ov:]
     confB = copy.deepcopy(conf)
     confB['GPU']['UHF'].setdefault('HIP', {})['blocks_per_call'] = B
-    a, b = DemodulatorRunner(conf, p, 'UHF-H'), DemodulatorRunner(confB, p, 'UHF-H')
+    a, b = DemodulatorRunner(_one(conf), p, 'UHF-H'), DemodulatorRunner(confB, p, 'UHF-H')
     try:
         da, db = Decoder(conf, p), Decoder(conf, p)
         ra, pa = a.run_stream([sig], decoder=da)
@@ -299,16 +307,166 @@ def test_a_live_source_gets_every_complete_block_out_at_its_markers(with_decoder
         rc, _ = a.run_stream(live(), pipelined=True)
         assert len(rc) == nblocks
         # a marked source gets batches without being configured (they cost it no latency): 2^15-sample blocks -> up to 32 per call
-        assert a.auto_blocks_per_call() == 32 and a.blocks_per_call() == 1
+        assert a.auto_blocks_per_call() == 32 and a.blocks_per_call() is None
         seen = []
         inner_a = a.demod.beginBlocks
         a.demod.beginBlocks = lambda which, nb, **kw: (seen.append(nb), inner_a(which, nb, **kw))[1]
         rd, _ = a.run_stream(live())
         assert len(rd) == nblocks and sum(seen) == nblocks and max(seen) > 1
-        # ... and a plain iterator does not
+        # ... and so does a plain iterator whose chunks are simply there (a recording): windows of up to 32 blocks, same results
         del seen[:]
         re_, _ = a.run_stream(iter(chunks))
-        assert len(re_) == nblocks and not seen
+        assert len(re_) == nblocks and sum(seen) == nblocks and max(seen) > 1, seen
+        # "blocks_per_call": 1 (or the argument) keeps the reference's one-block loop
+        del seen[:]
+        rf, _ = a.run_stream(iter(chunks), blocks_per_call=1)
+        assert len(rf) == nblocks and not seen
+    finally:
+        a.close()
+        b.close()
+
+
+@pytest.mark.parametrize('overlap', [False, True])
+def test_a_batch_beside_the_oracle_directly(monkeypatch, overlap):
+    """Five blocks of 2^15 samples x 64 bins through ONE batched call (mfb_receive_blocks_*), every block held to the ORACLE -- not
+    to the one-block call: the whole doppSum table of every block against ``orc.doppler_scores`` (north_star's 1e-5), the pick
+    against ``orc.find_doppler_est``, and the bits, centres and alignment state against the same host driver over the CPU
+    oracle bank, block after block.  Both arrangements of a batch on the device (one stream, two streams)."""
+    import pycusdr_amd.demodulator.demodulator_base as dbm
+    from oracle import mfbank_oracle as orc
+    from oracle_bank import OracleBank
+    from pycusdr_amd.demodulator import UHF
+    bs, ov, D, B = 15, 1 << 10, 64, 5
+    N = 1 << bs
+    step = N - ov
+    conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=D)
+    p = loadProtocol('bench_GMSK')(conf=conf)
+    gpu = UHF.Demodulator(conf, p, 'UHF-H')
+    with monkeypatch.context() as m:
+        m.setattr(dbm, 'MFBank', OracleBank)
+        cpu = UHF.Demodulator(conf, loadProtocol('bench_GMSK')(conf=conf), 'UHF-H')
+    assert type(gpu.bank).__name__ == 'MFBank' and isinstance(cpu.bank, OracleBank)
+    sig = sg.s1_stream(B, N, ov, 'GMSK', snr_db=10.0, seed=31)
+    try:
+        gpu.bank.set_batch_overlap(overlap)
+        win = gpu.blockWindows(B)[0]
+        win[:] = sig[:B * step + ov]
+        gpu.beginBlocks(0, B)
+        recs = gpu.endBlocks(0)
+        assert len(recs) == B
+        for b, (est, rec) in enumerate(recs):
+            x = sig[b * step: b * step + N]
+            oc = cpu.uploadAndFindCarrier(x.copy())
+            ref = cpu.bank.get_scores().astype(np.float64)
+            got = gpu.bank.get_batch_scores(b).astype(np.float64)
+            assert got.shape == ref.shape and np.abs(got - ref).max() / ref.max() < 1e-5, b       # correlation magnitudes
+            # the pick: the oracle's scan over the DEVICE's table gives the frequency the batch reported, bit for bit
+            oidx, _ = orc.find_doppler_est(gpu.bank.get_batch_scores(b), gpu.num_dopplers, gpu.doppIdxArrayOffset, True)
+            mine = orc.interpolate_doppler(oidx, gpu.doppCyperSymNorm, gpu.doppHzLUT, gpu.centreFreqOffset)
+            assert mine['freqOffset'] == est[0], (b, mine['freqOffset'], est[0])
+            assert abs(est[0] - oc[0]) <= 1e-3 * max(1.0, abs(oc[0])) + 0.05 and abs(est[3] - oc[3]) < 1e-3     # Hz, SNR dB
+            bg, cg, tg, spg = gpu.demodulateHost(rec)
+            bc, cc, tc, spc = cpu.demodulate()
+            assert spg == spc and len(bg) == len(bc) > 0.9 * N / 16, b
+            assert np.array_equal(bg, bc), f'block {b}: {np.count_nonzero(np.asarray(bg) != np.asarray(bc))} symbol decisions differ'
+            # a matched-filter peak that ties between neighbouring samples to fp32-vs-fp64 round-off may sit one sample off
+            dc = (np.asarray(cg).astype(np.int16) - np.asarray(cc).astype(np.int16) + 128) % 256 - 128
+            assert np.abs(dc).max() <= 1 and np.count_nonzero(dc) <= 2, (b, np.count_nonzero(dc))
+            assert np.array_equal(np.asarray(gpu.poswinP), np.asarray(cpu.poswinP)), b
+    finally:
+        gpu.close()
+
+
+@pytest.mark.parametrize('pname,mod,bs,D,B', [('bench_GMSK', 'GMSK', 15, 32, 5), ('bench_BPSK', 'BPSK', 14, 16, 3)])
+def test_a_batch_on_two_streams_changes_no_number(pname, mod, bs, D, B):
+    """``"HIP": {"batch_overlap": true}`` (mfb_set_batch_overlap): part 2 of a batch -- matched filters at the picked shift, rate,
+    centres, the integer stages, the read-back -- on a second stream beside the next batch's search.  Every result dict, packet and
+    the alignment state equal the one-stream loop's, and the handle goes back and forth between the two arrangements."""
+    N, ov = 1 << bs, 1 << 10
+    conf = cfg.bench_config(pname, blockSize=bs, doppCarrierSteps=D)
+    p = loadProtocol(pname)(conf=conf)
+    nblocks = 4 * B + 2
+    sig = sg.s1_stream(nblocks, N, ov, mod, snr_db=10.0, seed=21)[ov:]
+    confA, confB = copy.deepcopy(conf), copy.deepcopy(conf)
+    confA['GPU']['UHF'].setdefault('HIP', {})['blocks_per_call'] = B
+    confB['GPU']['UHF'].setdefault('HIP', {}).update(blocks_per_call=B, batch_overlap=True)
+    a, b = DemodulatorRunner(confA, p, 'UHF-H'), DemodulatorRunner(confB, p, 'UHF-H')
+    try:
+        da, db = Decoder(conf, p), Decoder(conf, p)
+        ra, pa = a.run_stream((sig[i:i + 9000] for i in range(0, len(sig), 9000)), decoder=da)
+        rb, pb = b.run_stream((sig[i:i + 9000] for i in range(0, len(sig), 9000)), decoder=db)
+        assert len(ra) == len(rb) == nblocks
+        for x, y in zip(ra, rb):
+            for k in ('doppler', 'doppler_std', 'SNR', 'spSymEst', 'numSyncSig'):
+                assert _same(x[k], y[k]), (x['count'], k)
+            assert _same(x['data'], y['data']) and _same(x['trust'], y['trust']), x['count']
+        assert len(pa) == len(pb) and all(_same(u.bits, v.bits) for u, v in zip(pa, pb))
+        assert _same(a.demod.poswinP, b.demod.poswinP) and _same(a.demod.posSymEnd, b.demod.posSymEnd)
+        # the device did the integer stages on the second stream too (all but the blocks the noiseless padding makes irregular,
+        # and what was in flight behind them), exactly as often as on one stream
+        assert b.demod.stage_blocks == a.demod.stage_blocks >= nblocks // 2, (a.demod.stage_blocks, b.demod.stage_blocks)
+        # the same handle, back to one stream and on to two again: a second stream of samples, still equal
+        more = sg.s1_stream(2 * B + 1, N, ov, mod, snr_db=10.0, seed=22)[ov:]
+        b.conf['GPU']['UHF']['HIP']['batch_overlap'] = False
+        ra2, _ = a.run_stream([more], decoder=da)
+        rb2, _ = b.run_stream([more], decoder=db)
+        b.conf['GPU']['UHF']['HIP']['batch_overlap'] = True
+        ra3, _ = a.run_stream([more], decoder=da)
+        rb3, _ = b.run_stream([more], decoder=db)
+        for u, v in zip(ra2 + ra3, rb2 + rb3):
+            assert _same(u['data'], v['data']) and _same(u['SNR'], v['SNR']) and _same(u['trust'], v['trust'])
+        # a batch in flight refuses the switch
+        wins = b.demod.blockWindows(B)
+        wins[0][:] = 0
+        b.demod.beginBlocks(0, 2)
+        with pytest.raises(Exception):
+            b.demod.bank.set_batch_overlap(False)
+        b.demod.endBlocks(0)
+    finally:
+        a.close()
+        b.close()
+
+
+def test_a_plain_iterator_gets_batches_while_it_has_a_backlog_and_single_blocks_while_it_is_live():
+    """Nothing configured, no markers: ``run_stream`` decides from how long each chunk took to come.  A source that hands over a
+    backlog (chunks that are there at once, one of them several blocks long) gets them in batches; the same source turned live
+    (every chunk has to be waited for) gets every block out as soon as its last chunk is in -- delivered before the next chunk is
+    asked for -- and everything equals the one-block loop."""
+    import time
+    bs, ov = 13, 1 << 10
+    N = 1 << bs
+    step = N - ov
+    conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=16)
+    p = loadProtocol('bench_GMSK')(conf=conf)
+    nblocks = 26
+    sig = sg.s1_stream(nblocks, N, ov, 'GMSK', snr_db=12.0, seed=11)[ov:]
+    backlog = 14 * step + 1000                        # the first 14 blocks and a bit are there at once
+    a, b = DemodulatorRunner(_one(conf), p, 'UHF-H'), DemodulatorRunner(conf, p, 'UHF-H')
+    try:
+        ra, _ = a.run_stream([sig])
+        sizes, out, asked = [], [], []
+        inner = b.demod.beginBlocks
+        b.demod.beginBlocks = lambda which, nb, **kw: (sizes.append(nb), inner(which, nb, **kw))[1]
+
+        def source():
+            yield sig[:5 * step]                      # one chunk of five blocks
+            for i in range(5 * step, backlog, 3000):
+                yield sig[i:min(i + 3000, backlog)]
+            for i in range(backlog, len(sig), 2048):  # live: every chunk takes a while to exist
+                time.sleep(2e-3)
+                asked.append((i, len(out)))           # what had been delivered when the loop came back for this chunk
+                yield sig[i:i + 2048]
+        rb, _ = b.run_stream(source(), sink=out.append)
+        assert len(out) == nblocks == len(ra)
+        for x, y in zip(ra, out):
+            assert x['count'] == y['count'] and _same(x['data'], y['data']) and _same(x['trust'], y['trust']) and _same(x['SNR'], y['SNR'])
+        assert sum(sizes) == nblocks and max(sizes) >= 5, sizes                 # the backlog went through in batches
+        live_sizes = sizes[-(nblocks - 15):]
+        assert all(n == 1 for n in live_sizes), sizes                           # the live part block by block
+        # whenever the loop asked for a live chunk, every block complete by then had been delivered (the first live requests
+        # aside: the backlog's last batch is collected when the source turns out to be dry)
+        for i, n in asked[2:]:
+            assert n == i // step, (i, n)
     finally:
         a.close()
         b.close()
@@ -330,7 +488,7 @@ def test_device_stream_stages_equal_the_host_stages(mod, pname, bs, D, snr):
     confB, confH = copy.deepcopy(conf), copy.deepcopy(conf)
     confB['GPU']['UHF'].setdefault('HIP', {})['blocks_per_call'] = B
     confH['GPU']['UHF'].setdefault('HIP', {}).update(blocks_per_call=B, stream_stages=False)
-    runs = [DemodulatorRunner(c, p, 'UHF-H') for c in (conf, confB, confH)]
+    runs = [DemodulatorRunner(c, p, 'UHF-H') for c in (_one(conf), confB, confH)]
     decs = [Decoder(conf, p) for _ in runs]
     try:
         outs = [r.run_stream((sig[i:i + 7000] for i in range(0, len(sig), 7000)), decoder=d) for r, d in zip(runs, decs)]
@@ -363,7 +521,7 @@ def test_batches_fall_back_to_the_one_block_loop_where_they_do_not_apply():
     conf['GPU']['UHF'].setdefault('HIP', {}).update(search_path='twopass')
     p = loadProtocol('bench_GMSK')(conf=conf)
     sig = sg.s1_stream(7, N, ov, 'GMSK', snr_db=10.0, seed=2)[ov:]
-    a, b = DemodulatorRunner(conf, p, 'UHF-H'), DemodulatorRunner(confB, p, 'UHF-H')
+    a, b = DemodulatorRunner(_one(conf), p, 'UHF-H'), DemodulatorRunner(confB, p, 'UHF-H')
     try:
         ra, _ = a.run_stream([sig])
         rb, _ = b.run_stream([sig])
@@ -527,7 +685,7 @@ def test_cc11xx_stream_with_blocks_per_call():
     sig = sg.awgn(sig * np.exp(2j * np.pi * 148320 / fs * np.arange(len(sig))), 12.0, rng=np.random.RandomState(2)).astype(np.complex64)
     confB = copy.deepcopy(conf)
     confB['GPU']['UHF'].setdefault('HIP', {})['blocks_per_call'] = B
-    a, b = DemodulatorRunner(conf, p, 'UHF-H'), DemodulatorRunner(confB, p, 'UHF-H')
+    a, b = DemodulatorRunner(_one(conf), p, 'UHF-H'), DemodulatorRunner(confB, p, 'UHF-H')
     da, db = Decoder(conf, p), Decoder(conf, p)
     try:
         ra, pa = a.run_stream((sig[i:i + 30000] for i in range(0, len(sig), 30000)), decoder=da)

@@ -291,9 +291,11 @@ def test_one_runner_streams_twice(first):
     ref, ref_packets = one.run_stream([sig[:nblk * step]], decoder=Decoder(conf, p))
     one.close()
     run, dec = DemodulatorRunner(conf, p, 'UHF-H'), Decoder(conf, p)
-    got, packets = run.run_stream([sig[:first * step]], decoder=dec)
+    # (the one-block loop: its two page-locked buffers alternate block by block; `ref` above went through whatever the default
+    # loop is -- batches of what the source has ready)
+    got, packets = run.run_stream([sig[:first * step]], decoder=dec, blocks_per_call=1)
     assert run.raw is (run.demod.bank.input2 if first % 2 else run.demod.bank.input)
-    more, pk = run.run_stream([sig[first * step:(first + 3) * step]], decoder=dec)
+    more, pk = run.run_stream([sig[first * step:(first + 3) * step]], decoder=dec, blocks_per_call=1)
     got, packets = got + more, packets + pk
     for i in range(first + 3, nblk):          # ... and on through the two-halves call, one block in flight
         run.feed_device_begin(sig[i * step:(i + 1) * step])

@@ -58,8 +58,11 @@ def _stimulus(kind, N, ov, nblocks):
     return sg.awgn(sig, 12.0, rng=np.random.RandomState(2)).astype(np.complex64)
 
 
+# basis 'span' (round 6): the opt-in span basis of the SUM_ALL search (mfb_set_search_basis: rank(bank) filters transformed instead
+# of M -- GMSK 6 of 8, CC11xx 4 of 8, BPSK 5 of 32) held to the SAME gate: the oracle's full bank, the same pick, the same bits.
+@pytest.mark.parametrize('basis', ['filters', 'span'])
 @pytest.mark.parametrize('kind,pname,D', [('GMSK', 'bench_GMSK', 256), ('CC11xx', 'CC11xx', 512), ('BPSK', 'bench_BPSK', 512)])
-def test_fullsize_symbol_decisions_equal_the_oracle_chain(monkeypatch, kind, pname, D, capsys):
+def test_fullsize_symbol_decisions_equal_the_oracle_chain(monkeypatch, kind, pname, D, basis, capsys):
     bs, ov = 20, 1 << 10
     N = 1 << bs
     if pname == 'CC11xx':
@@ -72,6 +75,10 @@ def test_fullsize_symbol_decisions_equal_the_oracle_chain(monkeypatch, kind, pna
         m.setattr(dbm, 'MFBank', NearCarrierOracleBank)
         cpu = UHF.Demodulator(conf, loadProtocol(pname)(conf=conf), 'UHF-H')
     assert type(gpu.bank).__name__ == 'MFBank' and isinstance(cpu.bank, NearCarrierOracleBank)
+    if basis == 'span':
+        gpu.bank.set_search_basis('span')
+        name, transformed = gpu.bank.get_search_basis()
+        assert name == 'span' and transformed < gpu.bank.M, (name, transformed)      # the shortcut really is in force
     for dm in (gpu, cpu):                      # tap the un-truncated centres of the kept symbols
         def tapped(*a, _orig=dm.checkSymbolOverlap, _dm=dm, **k):
             out = _orig(*a, **k)
@@ -109,6 +116,6 @@ def test_fullsize_symbol_decisions_equal_the_oracle_chain(monkeypatch, kind, pna
             assert np.array_equal(np.asarray(gpu.poswinP), np.asarray(cpu.poswinP))
         assert worst_phase < PHASE_TOL, worst_phase
         with capsys.disabled():
-            print(f'\n[fullsize decisions] {pname} D={D}: |arg| difference <= {worst_phase:.2e} rad, centres off by one: {moved}')
+            print(f'\n[fullsize decisions] {pname} D={D} basis={basis}: |arg| difference <= {worst_phase:.2e} rad, centres off by one: {moved}')
     finally:
         gpu.close()

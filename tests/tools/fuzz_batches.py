@@ -56,7 +56,7 @@ def one_case(rs, log=print):
         cut = int(rs.randint(1, nblocks)) * step
         ok = True
         for part in (sig[:cut], sig[cut:]):              # two calls per runner: the second goes on where the first stopped
-            ra, pa = a.run_stream(chunks(part, 16384), decoder=da)
+            ra, pa = a.run_stream(chunks(part, 16384), decoder=da, blocks_per_call=1)
             rb, pb = b.run_stream(chunks(part, chunk), decoder=db)
             ok = ok and len(ra) == len(rb) and len(pa) == len(pb)
             for x, y in zip(ra, rb):

@@ -15,7 +15,7 @@ log2N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 240
 D = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 mod = sys.argv[4] if len(sys.argv) > 4 else 'GMSK'
-Bs = [int(x) for x in sys.argv[5].split(',')] if len(sys.argv) > 5 else [1, 4, 8, 16]
+Bs = [x if x == 'auto' else int(x) for x in sys.argv[5].split(',')] if len(sys.argv) > 5 else [1, 4, 8, 16]      # 'auto': nothing configured
 if mod == 'CC11xx':
     # the reference's production protocol at its own geometry (config/CC11xx.json: 128 samples per symbol, 384-tap filters, IF offset)
     stim = bm.make_cc11xx_stream(n, 12.0, log2N, 3)
@@ -24,7 +24,7 @@ if mod == 'CC11xx':
         for decode in (True, False):
             r = max((bm.run_cc11xx(n, 12.0, log2N, D, blocks_per_call=B, decode=decode, stimulus=stim) for _ in range(3)),
                     key=lambda q: q['ksamples_per_s'])
-            print(f"CC11xx N=2^{log2N} D={D} blocks_per_call={B:2d} decoder={decode!s:5s}: {r['ksamples_per_s'] / 1e3:8.1f} Msamples/s, "
+            print(f"CC11xx N=2^{log2N} D={D} blocks_per_call={B!s:>4s} decoder={decode!s:5s}: {r['ksamples_per_s'] / 1e3:8.1f} Msamples/s, "
                   f"{r['blocks']} blocks, frames {r['frames']}/{r['sent']} ({r['packets']} candidates)", flush=True)
     sys.exit(0)
 bm.run_snr(mod, 2, 12.0, log2N, 'transforms', 1, D)
@@ -34,7 +34,7 @@ for B in Bs:
         # host-bound loop on shared CPUs: the best of three runs on the same stimulus
         r = max((bm.run_snr(mod, n, 12.0, log2N, 'transforms', 2, D, False, blocks_per_call=B, decode=decode, stimulus=stim) for _ in range(3)),
                 key=lambda q: q['ksamples_per_s'])
-        print(f"{mod} N=2^{log2N} D={D} blocks_per_call={B:2d} decoder={decode!s:5s}: {r['ksamples_per_s'] / 1e3:8.1f} Msamples/s, "
+        print(f"{mod} N=2^{log2N} D={D} blocks_per_call={B!s:>4s} decoder={decode!s:5s}: {r['ksamples_per_s'] / 1e3:8.1f} Msamples/s, "
               f"{r['blocks']} blocks, packets {r['packets']}/{r['sent']}, BER {r['BER']:.2e}", flush=True)
 if len(sys.argv) > 6 and sys.argv[6] == 'all':
     for search in ('energy',):
