@@ -47,12 +47,17 @@ def b_ref(D, M, N):
     return 32.0 * D * M * N + 8.0 * N * (3 + M) + 4.0 * D * (1 + M)
 
 
-def seg_flops(D, Q, Mu, L, V):
-    """Nominal flops of one block on the segment path: per segment one forward transform of the mixed
-    input and, per filter, a pointwise product, an inverse transform and the |.|^2 sums.
-    5 L log2 L per transform, 6 per complex multiply, 4 per accumulated output."""
+def seg_flops(D, Q, Mu, L, V, bins_per_forward=1, filter_side=False):
+    """Nominal flops of one block on the segment path, as the kernel that ran performs them: per (bin, segment, filter) a pointwise
+    product, an inverse transform and the |.|^2 sums; forward transforms of the segments -- one per (bin, segment) together with
+    the mixing multiply when the Doppler shift is applied to the samples (k_seg: the round 1-5 formula), ONE per segment and
+    `bins_per_forward` bins, unmixed, when it sits on the filters' side (k_segf, round 6).  5 L log2 L per transform, 6 per
+    complex multiply, 4 per accumulated output."""
     fft = 5.0 * L * np.log2(L)
-    return float(D) * Q * ((6.0 * L + fft) + Mu * (6.0 * L + fft + 4.0 * V))
+    per_filter = float(D) * Q * Mu * (6.0 * L + fft + 4.0 * V)
+    if filter_side:
+        return per_filter + float(Q) * np.ceil(D / max(bins_per_forward, 1)) * fft
+    return per_filter + float(D) * Q * (6.0 * L + fft)
 
 
 def widen_range_rate(conf, radio, N, D):
@@ -288,16 +293,21 @@ def c5_inprocess_figures(dev, local_rank, blocks, esz, nblocks, seconds=1.0, D=5
             b.close()
 
 
-def segment_roofline_core(info, Dl, Mu, launches, kernel_ms_total):
-    """fp32-vector roofline of the segment kernel from its own launch durations (HIP events on the library's stream)."""
+def segment_roofline_core(info, Dl, Mu, launches, kernel_ms_total, sinfo=None):
+    """fp32-vector roofline of the segment kernel from its own launch durations (HIP events on the library's stream).  `sinfo`:
+    MFBank.get_search_info() -- which form of the kernel ran."""
     L, V, Q = 1 << info['log2L'], info['valid_per_segment'], info['segments']
-    fl = seg_flops(Dl, Q, Mu, L, V)
+    sinfo = sinfo or {'filter_side': False, 'bins_per_forward': 1}
+    fl = seg_flops(Dl, Q, Mu, L, V, sinfo['bins_per_forward'], sinfo['filter_side'])
+    fl_r05 = seg_flops(Dl, Q, Mu, L, V)
     launches = max(launches, 1)
     k_avg_s = kernel_ms_total / launches * 1e-3
-    return {'bound': 'valu_fp32', 'kernel': f'{info.get("kernel", "k_seg")}<{L},REDUCE> ({V} valid outputs of {L}, {Q} segments per bin)',
+    kname = 'k_segf' if sinfo['filter_side'] else 'k_seg'
+    return {'bound': 'valu_fp32', 'kernel': f'{kname}<{L},REDUCE> ({V} valid outputs of {L}, {Q} segments per bin)',
             'achieved': round(fl / k_avg_s / 1e12, 2), 'peak': VALU_FP32_PEAK / 1e12, 'unit': 'TFLOP/s',
             'frac': round(fl / k_avg_s / VALU_FP32_PEAK, 4), 'launches': launches, 'avg_launch_ms': round(k_avg_s * 1e3, 4),
-            'flops_per_launch': fl}
+            'flops_per_launch': fl, 'filter_side_shift': bool(sinfo['filter_side']), 'bins_per_forward': int(sinfo['bins_per_forward']),
+            'frac_r05_formula': round(fl_r05 / k_avg_s / VALU_FP32_PEAK, 4), 'flops_per_launch_r05_formula': fl_r05}
 
 
 def twopass_roofline_core(N, Dl, Mu, counts, kms, nsteps):
@@ -342,6 +352,7 @@ def bank_figure(dev, local_rank, protocol, D, log2N, blocks, esz, nblocks, steps
         t_set = time.perf_counter() - t0
         bank.set_shifts(shifts)
         info = bank.get_search_path()
+        sinfo = bank.get_search_info()
         Mu = bank.get_info()[2]
 
         def leg(src, steps=steps):
@@ -370,7 +381,7 @@ def bank_figure(dev, local_rank, protocol, D, log2N, blocks, esz, nblocks, steps
                'filter_generation_s': round(t_gen, 2), 'mfb_set_filters_s': round(t_set, 2),
                'rangeRateMax_used': rr, 'signal': 'S1 blocks of the headline (throughput only: the stimulus does not match this bank)'}
         if info['path'] == 'segment':
-            out['roofline'] = segment_roofline_core(info, D, Mu, counts[0], kms[0])
+            out['roofline'] = segment_roofline_core(info, D, Mu, counts[0], kms[0], sinfo)
         if span and info['path'] == 'segment':
             # opt-in span basis of the SUM_ALL search: rank(bank) filters transformed instead of M; same table to
             # fp32 rounding -- never part of `msamples`
@@ -407,7 +418,7 @@ def bank_figure(dev, local_rank, protocol, D, log2N, blocks, esz, nblocks, steps
             out['s2_msamples'] = round((N - ov) / dt2 / 1e6, 2)
             out['s2_over_s1'] = round(dt / dt2, 4)
             if info['path'] == 'segment':
-                out['s2_roofline_frac'] = segment_roofline_core(info, D, Mu, c2[0], k2[0])['frac']
+                out['s2_roofline_frac'] = segment_roofline_core(info, D, Mu, c2[0], k2[0], sinfo)['frac']
         return out
     finally:
         bank.close()
@@ -788,6 +799,7 @@ def main():
     if args.tuning:
         bank.set_tuning(*[int(v) for v in args.tuning.split(',')])
     pinfo = bank.get_search_path()
+    sinfo = bank.get_search_info()
     shard = None
     if (G > 1 or args.force_dist) and not by_blocks:
         shard = DopplerShard(rank=rank, world=G, device=dev, concurrent_broadcast=not args.single_comm)
@@ -963,7 +975,7 @@ def main():
                 o_el = time.perf_counter() - t1
                 o_counts, o_kms = bank.profile_read()
                 bank.profile_enable(False)
-                other = (o_info, o_el / osteps, o_counts, o_kms, bank.get_tuning(), osteps)
+                other = (o_info, o_el / osteps, o_counts, o_kms, bank.get_tuning(), osteps, bank.get_search_info())
             except ValueError:
                 other = None
             bank.set_search_path(args.path if args.path != 'auto' or not seg else 'segment', *seg)
@@ -1108,11 +1120,9 @@ def main():
                     'launches': launches, 'avg_launch_ms': round(k_avg_s * 1e3, 4), 'alg_bytes_per_launch': k_bytes,
                     'other_kernel_avg_ms': round(kms_[1 - dom] / max(counts_[1 - dom], 1), 4)}
 
-        def segment_roofline(info, Dl_, counts_, kms_):
-            L, V, Q = 1 << info['log2L'], info['valid_per_segment'], info['segments']
-            fl = seg_flops(Dl_, Q, Mu, L, V)
-            launches = max(counts_[0], 1)
-            k_avg_s = kms_[0] / launches * 1e-3
+        def segment_roofline(info, Dl_, counts_, kms_, sinfo_=None):
+            L, V = 1 << info['log2L'], info['valid_per_segment']
+            core = segment_roofline_core(info, Dl_, Mu, counts_[0], kms_[0], sinfo_ if sinfo_ is not None else sinfo)
             traffic, tsrc = None, None
             tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
             if os.path.exists(tfile):
@@ -1121,16 +1131,24 @@ def main():
                     traffic, tsrc = rec.get('bytes'), rec.get('source')
                 except Exception:
                     pass
-            return {'bound': 'valu_fp32', 'kernel': f'k_seg<{L},REDUCE,{V // (L // 16)}> (mix + forward FFT + per filter: product, inverse FFT, '
-                                                    f'|.|^2 sums; segments of {L} points, {V} valid outputs, {Q} segments per bin)',
-                    'achieved': round(fl / k_avg_s / 1e12, 2), 'peak': VALU_FP32_PEAK / 1e12, 'unit': 'TFLOP/s',
-                    'frac': round(fl / k_avg_s / VALU_FP32_PEAK, 4), 'traffic': traffic, 'traffic_source': tsrc,
-                    'launches': launches, 'avg_launch_ms': round(k_avg_s * 1e3, 4), 'flops_per_launch': fl,
-                    'flops_formula': 'D*Q*((6L + 5L log2 L) + Mu*(6L + 5L log2 L + 4V))',
-                    'hbm_note': 'no length-N intermediate exists on this path: HBM traffic per launch is the 8 MiB block plus partial sums '
-                                '(see traffic); the two-pass algorithmic bytes below are context, not bytes moved',
-                    'twopass_formulation_alg_bytes_per_block': b_alg(Dl_, Mu, N),
-                    'twopass_alg_bytes_over_time_GBps': round(b_alg(Dl_, Mu, N) / t_block_dev / 1e9, 1)}
+            fs_ = core['filter_side_shift']
+            core['kernel'] = (f"{'k_segf' if fs_ else 'k_seg'}<{L},REDUCE,{V // (L // (32 if L == 2048 else 16))}> (" +
+                              (f"one forward FFT per segment and {core['bins_per_forward']} bins; per (bin, filter): product with that bin's "
+                               f"segment spectra, inverse FFT, |.|^2 sums" if fs_ else
+                               'mix + forward FFT per (bin, segment); per filter: product, inverse FFT, |.|^2 sums') +
+                              f"; segments of {L} points, {V} valid outputs, {info['segments']} segments per bin)")
+            core.update({
+                'traffic': traffic, 'traffic_source': tsrc,
+                'flops_formula': ('D*Q*Mu*(6L + 5L log2 L + 4V) + Q*ceil(D/bins_per_forward)*5L log2 L' if fs_ else
+                                  'D*Q*((6L + 5L log2 L) + Mu*(6L + 5L log2 L + 4V))'),
+                'frac_note': 'frac counts the flops THIS kernel performs (the forward transform of a segment is shared by bins_per_forward '
+                             'bins and there is no mixing multiply when the shift sits on the filters); frac_r05_formula is the count of '
+                             'rounds 1-5 (a forward transform and a mixing multiply per (bin, segment)) over the same time, for comparison',
+                'hbm_note': 'no length-N intermediate exists on this path: HBM traffic per launch is the 8 MiB block plus partial sums '
+                            '(see traffic); the two-pass algorithmic bytes below are context, not bytes moved',
+                'twopass_formulation_alg_bytes_per_block': b_alg(Dl_, Mu, N),
+                'twopass_alg_bytes_over_time_GBps': round(b_alg(Dl_, Mu, N) / t_block_dev / 1e9, 1)})
+            return core
 
         if pinfo['path'] == 'segment':
             roof = segment_roofline(pinfo, Dl, counts, kms)
@@ -1178,7 +1196,7 @@ def main():
             'repeats': args.repeats, 'untimed_steps_before': first - timed_steps,
             'ms_per_step_min': round(min(times) / args.steps * 1e3, 4), 'ms_per_step_max': round(max(times) / args.steps * 1e3, 4),
             'value_min': round(per_step / (max(times) / args.steps), 3), 'value_max': round(per_step / (min(times) / args.steps), 3),
-            'roofline_frac': roof.get('frac'), 'roofline_bound': roof.get('bound')}
+            'roofline_frac': roof.get('frac'), 'roofline_bound': roof.get('bound'), 'roofline_frac_r05_formula': roof.get('frac_r05_formula')}
         if s2 is not None:
             # the headline's loop on S2: median repeat, the same flop formula on the HIP-event time of its own launches
             el2 = float(np.median(s2['times']))
@@ -1201,6 +1219,7 @@ def main():
             flat[f'{key}_msamples'] = fig['msamples']
             flat[f'{key}_ms_per_step'] = fig['ms_per_step']
             flat[f'{key}_roofline_frac'] = fig.get('roofline', {}).get('frac')
+            flat[f'{key}_frac_r05_formula'] = fig.get('roofline', {}).get('frac_r05_formula')
             if 's2_msamples' in fig:
                 flat[f'{key}_s2_msamples'] = fig['s2_msamples']
                 flat[f'{key}_s2_over_s1'] = fig['s2_over_s1']
@@ -1216,8 +1235,8 @@ def main():
             if key in extras:
                 flat[f'{key}_msamples'] = extras[key]['msamples']
         if other is not None:
-            o_info, o_t, o_counts, o_kms, o_tun, osteps = other
-            o_roof = (segment_roofline(o_info, Dl, o_counts, o_kms) if o_info['path'] == 'segment'
+            o_info, o_t, o_counts, o_kms, o_tun, osteps, o_sinfo = other
+            o_roof = (segment_roofline(o_info, Dl, o_counts, o_kms, o_sinfo) if o_info['path'] == 'segment'
                       else twopass_roofline(Dl, o_counts, o_kms, o_tun, osteps))
             o_roof['ms_per_step'] = round(o_t * 1e3, 4)
             o_roof['msamples'] = round((N - ov) / o_t / 1e6, 2)

@@ -52,7 +52,7 @@ const char *mfb_strerror(int status);
 int mfb_abi_version(void);   /* 2: search paths, mfb_xcorr; 3: mfb_set_search_mode, mfb_sync_find_multi; 4: mfb_receive_block,
                               * mfb_export_rows_async, mfb_sync_find_packed; 5: mfb_debug_block_scalars; 6: mfb_receive_blocks_*,
                               * mfb_window_buffer, mfb_block_params.block_stride; 7: mfb_set_stream_stages, mfb_stream_seed,
-                              * mfb_receive_blocks_end_record; 8: mfb_hostcopy_*; 9: mfb_set_batch_overlap, mfb_get_batch_scores, mfb_receive_blocks_end_record
+                              * mfb_receive_blocks_end_record; 8: mfb_hostcopy_*; 9: mfb_set_batch_overlap, mfb_get_batch_scores, mfb_get_search_info, mfb_receive_blocks_end_record
                               * reports the size it needs */
 
 /* Create a handle on HIP device `device` for blocks of N = 2^log2N samples, `num_dopplers`
@@ -278,6 +278,13 @@ int mfb_input_buffer2(mfb_ctx *ctx, float **host_c64);
  *                         its two SNR windows at bands_c64 + b * 4 * band_capacity floats. */
 int mfb_window_buffer(mfb_ctx *ctx, int which, int max_blocks, int block_stride, float **host_c64);
 int mfb_receive_blocks_begin(mfb_ctx *ctx, const mfb_block_params *params, int nblocks, int slot);
+/* How the segment search of the next block will run (no reference counterpart; bench.py's flop count reads it): filter_side = 1 when
+ * the Doppler shift sits on the FILTERS' side -- the segment of samples is transformed once for `bins_per_forward` neighbouring bins
+ * and every (bin, filter) brings segment spectra of its own, built from the shift table (DB:130-165) when shifts or filters change:
+ * 256-point segments always, wave-local 2048-point segments for up to 8 filters and 256 MiB of spectra --, 0 when every (bin, segment)
+ * is mixed in time and transformed.  Either way the table is the reference's |IFFT(X[(k + s) mod N] H_m[k])|^2 sums (CU:339-373,
+ * 421-480) to fp32 rounding.  MFB_SEG_FSM=0 in the environment keeps the time-side form. */
+int mfb_get_search_info(mfb_ctx *ctx, int *filter_side, int *bins_per_forward);
 /* The doppSum table (num_dopplers + doppler_offset rows of M floats, as mfb_get_scores: GPU_bufDoppSum, DB:594-601) of block
  * `block` of the batch begun LAST, once that batch has been collected and before the next one is begun.  MFB_ERR_STATE otherwise
  * (no batch, a fixed-shift batch, block beyond it). */

@@ -210,6 +210,41 @@ static inline void segment_spectra(const Bank &b, int L, int Te, std::vector<flo
     }
 }
 
+// The same spectra with the Doppler shift on the FILTER side (seg_kernels.hpp, segf_body): the search needs |y_s[n]|^2 only, and
+//     y_s[n] = sum_k h[k] x[n-k] e^{-2 pi i s (n-k) / N} = e^{-2 pi i s n / N} sum_k (h[k] e^{+2 pi i s k / N}) x[n-k],
+// so the segment of x can be transformed ONCE for all bins and each bin brings its own spectra of h_s[k] = h[k] e^{+2 pi i s k / N}
+// (k counted from the window start: a constant phase drops out of |y|^2).  Storage: [shift][row][ii][g][e], `rows` = the bank
+// rows wanted (nullptr: all of them), the slot-pair order of segment_spectra.
+static inline void segment_spectra_shifted(const Bank &b, const int *rows, int nrows, const int *shifts, int nshifts, int L, int Te,
+                                           std::vector<float> *out, int ppl = 16) {
+    const Fft plan(L);
+    out->assign((size_t)nshifts * nrows * 2 * L, 0.f);
+    std::vector<cd> buf(L);
+    const double scale = (double)b.N / (double)L;
+    const int NT = L / ppl;
+    for (int j = 0; j < nshifts; ++j) {
+        const long long s = shifts[j];
+        for (int u = 0; u < nrows; ++u) {
+            const int m = rows ? rows[u] : u;
+            std::fill(buf.begin(), buf.end(), cd(0.0, 0.0));
+            for (int r = 0; r < b.T; ++r) {
+                const double ang = 2.0 * M_PI * (double)((s * r) % b.N) / (double)b.N;
+                buf[(r - (Te - 1)) & (L - 1)] = tap(b, m, r) * cd(cos(ang), sin(ang));
+            }
+            plan.run(buf.data(), -1);
+            float *o = out->data() + ((size_t)j * nrows + u) * 2 * L;
+            for (int ii = 0; ii < ppl / 2; ++ii)
+                for (int g = 0; g < NT; ++g)
+                    for (int e = 0; e < 2; ++e) {
+                        const cd v = buf[g + NT * (2 * ii + e)] * scale;
+                        const size_t pos = ((size_t)(ii * NT + g) * 2 + e) * 2;
+                        o[pos] = (float)v.real();
+                        o[pos + 1] = (float)v.imag();
+                    }
+        }
+    }
+}
+
 // ---- span basis (opt-in, SUM_ALL_MASKS search only) ---------------------------------------------------------
 // With SUM_ALL_MASKS the search needs  sum_m |y_m[n]|^2 = x_n^H (C C^H) x_n  only, C = [c_1 ... c_M] the taps.
 // Any F with F F^H = C C^H gives the same number from rank(C) filters instead of M.  The shipped banks are

@@ -184,6 +184,13 @@ struct mfb_ctx {
     StreamCarry *h_seed;          // page-locked staging of mfb_stream_seed
     std::vector<hipEvent_t> ev[2];
     std::vector<hipEvent_t> ev_pool;
+    // the search with the Doppler shift on the filter side (seg_kernels.hpp, segf_body; 256-point segments): per-bin spectra
+    std::vector<int> h_shifts, h_uniq;   // host copies of the shift table and of the unique-filter map
+    cf *d_Gs = nullptr;                  // [Dtot][rows][L]: rows = the unique filters, or the span basis
+    int gs_rows = 0;                     // rows per bin d_Gs was built for (0: not built)
+    int gs_span = -1;                    // ... and for which basis
+    int gs_l = 0;                        // ... and segment length (log2)
+    int fsm_fb = 0, fsm_fs = 0;          // rectangle of a wave: bins x slots (0: default)
 };
 
 #define HIPCHK(x)                                                                            \
@@ -418,6 +425,17 @@ static int set_kernel_attributes(const mfb_ctx *c) {
     }
     if (rc) return rc;
     if ((rc = attr_seg<256>())) return rc;
+    {
+        const int b = (int)(SegCfg<256>::LDS_ELEMS * sizeof(cf) + (size_t)(SegCfg<256>::BLOCK / 64) * SEG_MPB_MAX * SEG_ACC_STRIDE * sizeof(float));
+#define MFB_ATTR_F(PV_) HIPCHK(hipFuncSetAttribute((const void *)k_segf<256, PV_>, hipFuncAttributeMaxDynamicSharedMemorySize, b))
+        MFB_ATTR_F(8); MFB_ATTR_F(9); MFB_ATTR_F(10); MFB_ATTR_F(11); MFB_ATTR_F(12); MFB_ATTR_F(13); MFB_ATTR_F(14); MFB_ATTR_F(15); MFB_ATTR_F(16);
+#undef MFB_ATTR_F
+        const int b2 = (int)(SegCfg<2048>::LDS_ELEMS * sizeof(cf) + (size_t)(SegCfg<2048>::BLOCK / 64) * 8 * SEG_ACC_STRIDE * sizeof(float));
+#define MFB_ATTR_F(PV_) HIPCHK(hipFuncSetAttribute((const void *)k_segf<2048, PV_>, hipFuncAttributeMaxDynamicSharedMemorySize, b2))
+        MFB_ATTR_F(16); MFB_ATTR_F(17); MFB_ATTR_F(18); MFB_ATTR_F(19); MFB_ATTR_F(20); MFB_ATTR_F(21); MFB_ATTR_F(22); MFB_ATTR_F(23); MFB_ATTR_F(24);
+        MFB_ATTR_F(25); MFB_ATTR_F(26); MFB_ATTR_F(27); MFB_ATTR_F(28); MFB_ATTR_F(29); MFB_ATTR_F(30); MFB_ATTR_F(31); MFB_ATTR_F(32);
+#undef MFB_ATTR_F
+    }
     if ((rc = attr_seg<512>())) return rc;
     if ((rc = attr_seg<1024>())) return rc;
     if ((rc = attr_seg<2048>())) return rc;
@@ -602,6 +620,7 @@ extern "C" int mfb_destroy(mfb_ctx *c) {
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->d_Gs) (void)hipFree(c->d_Gs);
     delete c->bank;
     delete c;
     return MFB_OK;
@@ -878,6 +897,8 @@ extern "C" int mfb_set_filters(mfb_ctx *c, const float *masks, int M, int N) {
         rep[m] = found;
     }
     c->MU = (int)uniq.size();
+    c->h_uniq = uniq;
+    c->gs_rows = 0;
     HIPCHK(hipMemcpyAsync(c->d_uniq, uniq.data(), uniq.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_rep, rep.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, c->stream));
     // impulse-response window and taps of every filter (double precision, host threads)
@@ -906,6 +927,8 @@ extern "C" int mfb_set_shifts(mfb_ctx *c, const int32_t *shifts, int count) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c->d_shifts, shifts, (size_t)count * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(sync_streams(c));
+    c->h_shifts.assign(shifts, shifts + count);
+    c->gs_rows = 0;               // the per-bin spectra belong to the old table
     c->have_shifts = true;
     ++c->epoch;
     return MFB_OK;
@@ -1279,6 +1302,160 @@ extern "C" int mfb_upload_device(mfb_ctx *c, const void *dev) {
     return MFB_OK;
 }
 
+// ---- the search with the shift on the filter side (seg_kernels.hpp, segf_body) ------------------------------------------------------
+// MFB_SEG_FSM=0 in the environment keeps the search on seg_body (the A/B switch of profiles/r06_fft_ops.md); MFB_SEG_FSM_RECT="fb,fs"
+// sets the rectangle a wave takes (bins x slots).
+static bool fsm_enabled() {
+    static const int on = getenv("MFB_SEG_FSM") ? atoi(getenv("MFB_SEG_FSM")) : 1;
+    return on != 0 && MFB_FFT_FUSED;
+}
+// per-bin spectra of the bank in force (the unique filters, or the span basis), built when the shifts or the filters have changed
+static int fsm_prepare(mfb_ctx *c, bool span, int rows) {
+    if (c->d_Gs && c->gs_rows == rows && c->gs_span == (span ? 1 : 0) && c->gs_l == c->segl) return MFB_OK;
+    if ((int)c->h_shifts.size() != c->Dtot || !c->bank) return MFB_ERR_STATE;
+    std::vector<float> G;
+    const int L = 1 << c->segl, Te = L - seg_valid(c->segl, c->bank->T) + 1;
+    if (span) {
+        taps::Bank sb;
+        if (taps::span_basis(*c->bank, &sb) != rows) return MFB_ERR_STATE;
+        taps::segment_spectra_shifted(sb, nullptr, rows, c->h_shifts.data(), c->Dtot, L, Te, &G, seg_ppl(L));
+    } else {
+        if ((int)c->h_uniq.size() != rows) return MFB_ERR_STATE;
+        taps::segment_spectra_shifted(*c->bank, c->h_uniq.data(), rows, c->h_shifts.data(), c->Dtot, L, Te, &G, seg_ppl(L));
+    }
+    HIPCHK(sync_streams(c));
+    if (c->d_Gs) HIPCHK(hipFree(c->d_Gs));
+    c->d_Gs = nullptr;
+    c->gs_rows = 0;
+    HIPCHK(dev_alloc((void **)&c->d_Gs, G.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(c->d_Gs, G.data(), G.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->gs_rows = rows;
+    c->gs_span = span ? 1 : 0;
+    c->gs_l = c->segl;
+    return MFB_OK;
+}
+// A wave's rectangle (bins x slots) and what a group of the grid is.  The forward transform is shared by fb bins -- 1 / (fb MU) of
+// the inverse work --; small rectangles keep the grid over-subscribed (the surplus evens out CUs that finish at different times, as
+// in plan_seg).  Measured (profiles/r06_fft_ops.md): 128 (bin, filter) transforms of 256 points per forward transform -- 16 bins
+// of the 8-filter banks, 8 of the BPSK bank's 16 --, 64 of 2048 points.  Groups (blockIdx % 8 = XCD): an eighth of the BINS when
+// there are enough of them -- every XCD then keeps its share of the per-bin spectra in its L2 (C3: +4.5 %; the 2048-point kernel,
+// 32 MiB of spectra at 256 bins: 2.09 against 2.49 ms) and the samples stream through all of them --, else an eighth of the slots.
+struct FsmPlan {
+    bool ok;
+    int nsg, gbins, fb, fs, nbc, nsc;
+};
+static FsmPlan fsm_plan(const mfb_ctx *c, int MU, int nfull) {
+    static int env_fb = 0, env_fs = 0;
+    static const bool env_read = [] {
+        const char *e = getenv("MFB_SEG_FSM_RECT");
+        if (e) sscanf(e, "%d,%d", &env_fb, &env_fs);
+        return true;
+    }();
+    (void)env_read;
+    static const int env_gb = getenv("MFB_SEG_FSM_GROUP") ? atoi(getenv("MFB_SEG_FSM_GROUP")) : -1;
+    FsmPlan p;
+    memset(&p, 0, sizeof(p));
+    const bool w32 = c->segl == 11;
+    p.nsg = nfull >= 64 ? 8 : 1;
+    const int per_fwd = w32 ? 64 : 128;
+    int fb = c->fsm_fb > 0 ? c->fsm_fb : (env_fb > 0 ? env_fb : (per_fwd / MU > 2 ? per_fwd / MU : 2));
+    int fs = c->fsm_fs > 0 ? c->fsm_fs : (env_fs > 0 ? env_fs : 1);
+    if (fb > c->Dtot) fb = c->Dtot;
+    p.gbins = env_gb >= 0 ? (env_gb != 0) : (p.nsg > 1 && c->Dtot >= p.nsg * fb ? 1 : 0);
+    if (p.gbins && c->Dtot < p.nsg) p.gbins = 0;
+    if (w32 && !p.gbins && p.nsg > 1 && env_gb < 0) {
+        // the long kernel's spectra (16 KiB per (bin, filter)) must stay in an L2: fewer bins per rectangle, or not this kernel
+        fb = c->Dtot / p.nsg;
+        if (fb < 2) return p;
+        p.gbins = 1;
+    }
+    const int glen = p.gbins ? nfull : (nfull + p.nsg - 1) / p.nsg;
+    const int gblen = p.gbins ? (c->Dtot + p.nsg - 1) / p.nsg : c->Dtot;
+    if (fs > glen) fs = glen;
+    if (fb > gblen) fb = gblen;
+    if (fb < 1 || fs < 1) return p;
+    p.fb = fb;
+    p.fs = fs;
+    p.nbc = (gblen + fb - 1) / fb;
+    p.nsc = (glen + fs - 1) / fs;
+    p.ok = true;
+    return p;
+}
+template <int L, int PV0, int PV1>
+static int launch_segf_pv(mfb_ctx *c, const SegFArgs &a, int grid, size_t lds, int pv) {
+    if constexpr (PV0 > PV1) {
+        return MFB_ERR_UNSUPPORTED;
+    } else {
+        if (pv == PV0) {
+            hipLaunchKernelGGL((k_segf<L, PV0>), dim3(grid), dim3(SegCfg<L>::BLOCK), lds, c->stream, a);
+            HIPCHK(hipGetLastError());
+            return MFB_OK;
+        }
+        return launch_segf_pv<L, PV0 + 1, PV1>(c, a, grid, lds, pv);
+    }
+}
+// the complete slots of nb blocks through k_segf; the caller has the partial sums reserved
+static int launch_fsm(mfb_ctx *c, int nb, const cf *x, int xstride, int MU, int nfull, int parts, int pv) {
+    SegFArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.Gs = c->d_Gs;
+    a.twL = c->d_twL;
+    a.partials = c->d_part;
+    a.N = c->N;
+    a.V = c->V;
+    a.slot0 = 0;
+    a.nslots = nfull;
+    a.MU = MU;
+    a.dper = c->Dtot;
+    a.nblk = nb;
+    a.xstride = xstride;
+    const FsmPlan fp = fsm_plan(c, MU, nfull);
+    if (!fp.ok) return MFB_ERR_UNSUPPORTED;
+    a.nsg = fp.nsg;
+    a.gbins = fp.gbins;
+    a.fb = fp.fb;
+    a.fs = fp.fs;
+    a.nbc = fp.nbc;
+    a.nsc = fp.nsc;
+    a.part_row0 = 0;
+    a.parts = parts;
+    a.scale = 1.0f / 262144.0f;
+    const bool w32 = c->segl == 11;
+    const long long waves = (long long)nb * a.nbc * a.nsc;
+    const int wpb = SegCfg<256>::BLOCK / 64;
+    static_assert(SegCfg<256>::BLOCK == SegCfg<2048>::BLOCK || !MFB_SEG_W32, "four independent waves per workgroup");
+    const int grid = a.nsg * (int)((waves + wpb - 1) / wpb);
+    if (w32) {
+        const size_t lds = SegCfg<2048>::LDS_ELEMS * sizeof(cf) + (size_t)wpb * MU * SEG_ACC_STRIDE * sizeof(float);
+        return launch_segf_pv<2048, 16, 32>(c, a, grid, lds, pv);
+    }
+    const size_t lds = SegCfg<256>::LDS_ELEMS * sizeof(cf) + (size_t)wpb * MU * SEG_ACC_STRIDE * sizeof(float);
+    return launch_segf_pv<256, 8, 16>(c, a, grid, lds, pv);
+}
+
+// how the segment search of the next block will run: filter_side = 1 when the Doppler shift sits on the filters' side (k_segf: one
+// forward transform per segment for `bins_per_forward` bins), 0 when every (bin, segment) is mixed and transformed (k_seg)
+extern "C" int mfb_get_search_info(mfb_ctx *c, int *filter_side, int *bins_per_forward) {
+    if (!c || !filter_side || !bins_per_forward) return MFB_ERR_ARG;
+    *filter_side = 0;
+    *bins_per_forward = 1;
+    if (c->path != MFB_PATH_SEGMENT || !c->have_filters) return MFB_OK;
+    const bool span = c->basis == MFB_BASIS_SPAN;
+    const int MU = span ? c->MB : c->MU;
+    int nfull, ntotal;
+    seg_slots(c, &nfull, &ntotal);
+    const bool fsm_l = c->segl == 8 || (c->segl == 11 && MFB_SEG_W32 && MU <= 8 && (size_t)c->Dtot * MU * 16384 <= ((size_t)256 << 20));
+    if (fsm_l && fsm_enabled() && MU <= SEG_MPB_MAX && nfull > 0 && (int)c->h_shifts.size() == c->Dtot) {
+        const FsmPlan p = fsm_plan(c, MU, nfull);
+        if (p.ok) {
+            *filter_side = 1;
+            *bins_per_forward = p.fb;
+        }
+    }
+    return MFB_OK;
+}
+
 // The segment-path search of nb blocks in ONE launch (+ the masked tail launch + k_finalize): stream jl of the launch is bin
 // jl % Dtot of block jl / Dtot, block b's samples start at x + b * xstride, its doppSum rows at dsum + b * Dtot * M.  nb = 1 is
 // the plain search of one block.  A score depends on the block, the shift and the filter only (seg_kernels.hpp), so a
@@ -1298,6 +1475,11 @@ static int seg_search_enqueue(mfb_ctx *c, int nb, const cf *x, int xstride, floa
     const int parts = ntotal * seg_geom(c).WPT;
     int rc = reserve_partials(c, (size_t)rows * MU * parts);
     if (rc) return rc;
+    // 256-point segments: the shift on the filter side -- one forward transform per segment for all bins (segf_body)
+    // (the wave-local 2048-point kernel too: 8 filters per pass there, and per-bin spectra of 16 KiB per (bin, filter) -- up to 256 MiB)
+    const bool fsm_l = c->segl == 8 || (c->segl == 11 && MFB_SEG_W32 && MU <= 8 && (size_t)c->Dtot * MU * 16384 <= ((size_t)256 << 20));
+    const bool fsm = fsm_l && fsm_enabled() && MU <= SEG_MPB_MAX && nfull > 0 && (int)c->h_shifts.size() == c->Dtot && fsm_plan(c, MU, nfull).ok;
+    if (fsm && (rc = fsm_prepare(c, span, MU))) return rc;       // (built by the first block: nothing is allocated inside a graph capture)
     SegArgs am = seg_base(c, pm), at = seg_base(c, pt);
     for (SegArgs *q : {&am, &at}) {
         if (span) {
@@ -1323,7 +1505,8 @@ static int seg_search_enqueue(mfb_ctx *c, int nb, const cf *x, int xstride, floa
     const int pv = c->V / seg_geom(c).NT;
     prof_mark(c, 0);
     // (both roles inside one grid were tried: the merged kernel ran 8-10 % slower than two launches)
-    if (nfull > 0) rc = launch_seg(c, am, pm.grid, SEG_REDUCE, pv);
+    if (fsm) rc = launch_fsm(c, nb, x, xstride, MU, nfull, parts, pv);
+    else if (nfull > 0) rc = launch_seg(c, am, pm.grid, SEG_REDUCE, pv);
     if (!rc && ntotal > nfull) rc = launch_seg(c, at, pt.grid, SEG_REDUCE, -1);
     if (rc) return rc;
     prof_mark(c, 0);

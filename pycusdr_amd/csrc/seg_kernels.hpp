@@ -529,6 +529,175 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
     }
 }
 
+// ---- the search with the Doppler shift on the FILTER side (round 6; 256- and wave-local 2048-point segments) --------------------------------------------
+// seg_body mixes the SAMPLES of a segment with the bin's frequency and transforms them once per (bin, segment): 1 forward + MU
+// inverse transforms and a phasor multiply per point.  The search only needs |y|^2, and the shift can sit on the filter instead
+// (filter_taps.hpp, segment_spectra_shifted): the segment is transformed ONCE -- unmixed -- for all bins a wave takes it through,
+// and every (bin, filter) brings spectra of its own, Gs[bin][filter] (D * MU * 2 KiB: 4 MiB at C2, served by L2).  Per (bin, slot):
+// MU x (product + inverse transform + |.|^2) and nothing else -- 1/9 of the transforms and all the mixing multiplies of the
+// 8-filter banks gone, for L2 reads of 2 KiB per (slot, bin, filter) that used to hit in L1.
+//   * A wave owns a rectangle: `fb` neighbouring bins x `fs` slots of one block (a slot = the four segments it carries side by
+//     side), slots outside, bins inside; the grid deals rectangles XCD-aware as seg_body does (blockIdx % nsg = the eighth of
+//     the block whose samples stay in that XCD's L2).
+//   * The forward transform runs as the inverse one on swapped samples: (im, re) = i conj(x), so the registers hold i conj(U),
+//     and conj(.) G = -i U G -- a constant unit factor, gone in |.|^2.  The swap is a renaming of registers, not an instruction.
+//   * The same partial sums at the same indices in the same lane order as seg_body (k_finalize does not know which kernel ran):
+//     a score is still a function of the block, the shift and the filter only.
+struct SegFArgs {
+    const cf *x;         // block (or window of a batch)
+    const cf *Gs;        // [Dtot][MU][PPL / 2][NT][2]: spectra of filter slot u at bin j, slot-pair layout
+    const cf *twL;       // W_L table with the fused (cos, tan) pairs behind it
+    float *partials;
+    int N, V;
+    int slot0, nslots;   // slots [slot0, slot0 + nslots) of every block
+    int MU;              // filter slots per bin (<= SEG_MPB_MAX)
+    int dper;            // bins per block (Dtot)
+    int nblk, xstride;   // blocks in the launch; block b's samples start at x + b * xstride
+    int nsg;             // groups (blockIdx % nsg = the XCD under round-robin placement)
+    int gbins;           // 1: a group is an nsg-th of the BINS (its share of Gs stays in that XCD's L2, the samples stream through
+                         // every XCD); 0: an nsg-th of the slots (the samples stay, all of Gs passes through every L2)
+    int fb, fs;          // bins / slots per rectangle
+    int nbc, nsc;        // bin chunks per block (gbins: per group), slot chunks per group (gbins: per block)
+    int part_row0, parts;
+    float scale;
+};
+template <int L, int PV>
+DEVI void segf_body(const SegFArgs &a, const int blk) {
+    static_assert(MFB_FFT_FUSED && (L == 256 || (L == 2048 && MFB_SEG_W32)), "the fused 256- and 2048-point transforms");
+    using Cfg = SegCfg<L>;
+    constexpr int NT = Cfg::NT, CT = Cfg::CT, PPL = Cfg::PPL;
+    constexpr bool W32 = Cfg::W32;
+    extern __shared__ __attribute__((aligned(16))) cf lds[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int g = W32 ? ((lane >> 1) + 32 * (lane & 1)) : lane % NT;
+    const int col = W32 ? 0 : lane / NT;
+    cf *mylds = lds + wave * Cfg::LDS_PER_TEAM + col * padlen(L);
+    float *lacc = reinterpret_cast<float *>(lds + Cfg::LDS_ELEMS) + wave * (a.MU * SEG_ACC_STRIDE);
+    [[maybe_unused]] F256Regs f256;
+    [[maybe_unused]] F2048Regs f2048;
+    if constexpr (W32) f2048_setup(f2048, a.twL + L, lane);
+    else f256_setup(f256, a.twL + L, g);
+    auto transform = [&](cf (&vv)[PPL], auto &store, auto live) {
+        constexpr int LIVE = decltype(live)::value;
+        if constexpr (W32) fft_w32_fused<LIVE>(vv, mylds, lane, f2048, store);
+        else fft256_fused<LIVE>(vv, mylds, g, f256, store);
+    };
+
+    // ---- this wave's rectangle ----
+    const int grp = blk % a.nsg;
+    const int u = (blk / a.nsg) * (Cfg::BLOCK / 64) + wave;        // rectangle index inside the group: bin chunk fastest
+    const int per_sc = a.nblk * a.nbc;
+    const int sc = u / per_sc, rest = u - sc * per_sc;
+    const int bk = rest / a.nbc, bc = rest - bk * a.nbc;
+    // the group's share: of the slots (all bins), or of the bins (all slots)
+    const int gs0 = a.gbins ? 0 : (int)((long long)grp * a.nslots / a.nsg);
+    const int glen = a.gbins ? a.nslots : (int)((long long)(grp + 1) * a.nslots / a.nsg) - gs0;
+    const int gb0 = a.gbins ? (int)((long long)grp * a.dper / a.nsg) : 0;
+    const int gblen = a.gbins ? (int)((long long)(grp + 1) * a.dper / a.nsg) - gb0 : a.dper;
+    const int s0 = __builtin_amdgcn_readfirstlane(a.slot0 + gs0 + sc * a.fs);
+    const int s1 = __builtin_amdgcn_readfirstlane(min(a.slot0 + gs0 + glen, s0 + a.fs));
+    const int jb0 = __builtin_amdgcn_readfirstlane(gb0 + bc * a.fb);
+    const int jb1 = __builtin_amdgcn_readfirstlane(min(gb0 + gblen, jb0 + a.fb));
+    if (sc >= a.nsc || s0 >= s1 || jb0 >= jb1 || bk >= a.nblk) return;           // (wave-uniform)
+
+    const unsigned nmask = (unsigned)a.N - 1u;
+    const auto xr = mk_rsrc(a.x + (size_t)bk * (size_t)a.xstride, (unsigned)a.N * sizeof(cf));
+    const auto gr = mk_rsrc(a.Gs, (unsigned)a.dper * (unsigned)a.MU * (unsigned)(L * sizeof(cf)));
+    constexpr int so_x = NT * (int)sizeof(cf);
+    const int vo_g2 = g * 2 * (int)sizeof(cf);
+    constexpr int so_g2 = NT * 2 * (int)sizeof(cf);
+    // (one set of prefetch registers for the next filter's spectra, as in seg_body -- the 2048-point form has no room for it and
+    // fetches inside the product)
+    constexpr bool PREFETCH = !W32;
+    [[maybe_unused]] auto load_g = [&](cf (&dst)[PPL], int row) {
+#pragma unroll
+        for (int ii = 0; ii < PPL / 2; ++ii) buf_load_cf2(gr, vo_g2, row * (L * (int)sizeof(cf)) + ii * so_g2, dst[2 * ii], dst[2 * ii + 1]);
+    };
+    const int MU = __builtin_amdgcn_readfirstlane(a.MU);
+    constexpr std::integral_constant<int, PPL> all_live{};
+    constexpr std::integral_constant<int, PV> sum_live{};
+    [[maybe_unused]] cf gk[PREFETCH ? PPL : 1];
+
+    for (int slot = s0; slot < s1; ++slot) {
+        // ---- the segments of the slot, unmixed, swapped: the forward transform via the inverse one ----
+        cf v[PPL];
+        {
+            const unsigned e0 = (unsigned)(slot * CT + col) * (unsigned)a.V + (unsigned)g;
+            const unsigned last = (unsigned)(slot * CT + CT - 1) * (unsigned)a.V + (unsigned)L;      // wave-uniform
+            if (__builtin_amdgcn_readfirstlane(last <= (unsigned)a.N ? 1 : 0)) {
+                const int vo_x = (int)(e0 * sizeof(cf));
+#pragma unroll
+                for (int i = 0; i < PPL; ++i) {
+                    const cf t = buf_load_cf(xr, vo_x, i * so_x);
+                    v[i] = mkc(t.y, t.x);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < PPL; ++i) {
+                    const cf t = buf_load_cf(xr, (int)(((e0 + (unsigned)(NT * i)) & nmask) * sizeof(cf)), 0);
+                    v[i] = mkc(t.y, t.x);
+                }
+            }
+        }
+        if constexpr (PREFETCH) load_g(gk, jb0 * MU);      // lands while the forward transform runs
+        cf A[PPL];                                         // A[k] = i conj(U[g + NT k])
+        {
+            auto keep = [&](int, cf val, auto, auto nu) { A[decltype(nu)::value / NT] = val; };
+            transform(v, keep, all_live);
+        }
+        for (int jb = jb0; jb < jb1; ++jb) {
+            for (int mi = 0; mi < MU; ++mi) {
+                cf w[PPL];
+                if constexpr (PREFETCH) {
+#pragma unroll
+                    for (int i = 0; i < PPL; ++i) w[i] = cmul_cj(A[i], gk[i]);
+                    // the next filter's spectra -- or the next bin's first -- during this transform
+                    const int nxt = jb * MU + mi + 1;
+                    if (nxt < jb1 * MU) load_g(gk, nxt);
+                } else {
+                    const int row = jb * MU + mi;
+#pragma unroll
+                    for (int ii = 0; ii < PPL / 2; ++ii) {
+                        cf g0, g1;
+                        buf_load_cf2(gr, vo_g2, row * (L * (int)sizeof(cf)) + ii * so_g2, g0, g1);
+                        w[2 * ii] = cmul_cj(A[2 * ii], g0);
+                        w[2 * ii + 1] = cmul_cj(A[2 * ii + 1], g1);
+                    }
+                }
+                cf racc[4] = {mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f)};
+                auto acc = [&](int, cf val, auto, auto nu) {
+                    constexpr int k = decltype(nu)::value / NT;
+                    if constexpr (k < PV) racc[k & 3] = __builtin_elementwise_fma(val, val, racc[k & 3]);
+                };
+                transform(w, acc, sum_live);
+                const cf rsum = (racc[0] + racc[1]) + (racc[2] + racc[3]);
+                lacc[mi * SEG_ACC_STRIDE + lane] = rsum.x + rsum.y;
+            }
+            // the wave's lanes in seg_body's fixed order: lane (f, j) adds elements j, j + 4, ... of filter f's row, two quad steps
+            xsync<1>();
+            const int f = lane >> 2, j = lane & 3;
+            const float *row = lacc + min(f, MU - 1) * SEG_ACC_STRIDE + j;
+            float t[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t[k] = row[4 * k];
+            float sm = (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) +
+                       (((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15])));
+            sm += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sm), 0xB1, 0xF, 0xF, true));
+            sm += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sm), 0x4E, 0xF, 0xF, true));
+            if (j == 0 && f < MU)
+                a.partials[((size_t)(a.part_row0 + bk * a.dper + jb) * MU + f) * a.parts + slot] = sm * a.scale;
+            xsync<1>();
+        }
+    }
+}
+template <int L, int PV>
+__global__ void __launch_bounds__(SegCfg<L>::BLOCK) __attribute__((amdgpu_waves_per_eu(SegCfg<L>::WAVES, SegCfg<L>::WAVES)))
+k_segf(SegFArgs a) {
+    segf_body<L, PV>(a, (int)blockIdx.x);
+}
+
 // amdgpu_waves_per_eu pins the register budget: without the upper bound the scheduler chases a fourth
 // wave per SIMD (which the LDS footprint does not admit anyway) by serialising every load behind an
 // s_waitcnt vmcnt(0).

@@ -216,6 +216,13 @@ class MFBank:
         return dict(path=names.get(v[0].value, 'twopass'), log2L=v[1].value, taps=v[2].value,
                     valid_per_segment=v[3].value, segments=v[4].value)
 
+    def get_search_info(self):
+        """{'filter_side': bool, 'bins_per_forward': int} -- whether the segment search transforms a segment once for several
+        bins, the Doppler shift sitting on the filters' side (mfb_get_search_info)."""
+        f, b = C.c_int(), C.c_int()
+        _lib.check(self._lib.mfb_get_search_info(self._h, C.byref(f), C.byref(b)), 'mfb_get_search_info')
+        return {'filter_side': bool(f.value), 'bins_per_forward': int(b.value)}
+
     def xcorr(self, a, b):
         """ifft(fft(a, N) * conj(fft(b, N))) for real sequences a, b (reference lib/customXCorr.py:5-18);
         N is this handle's block length.  The handle's filters and input are invalidated."""
