@@ -177,18 +177,22 @@ def chain_figures(local_rank, blocks_per_call=None, n_packets=240):
         bm.run_snr('GMSK', n_packets, 12.0, log2n, 'transforms', 2, 64, blocks_per_call=Bn, stimulus=stim)    # handles, code objects, clock
         out[f'chain_n{log2n}_blocks_per_call'] = Bn
         # '' = B configured; '_auto' = nothing configured, a plain chunk iterator: the loop batches what the source has ready
-        # (run_stream, adaptive); '_b1' = "blocks_per_call": 1, the reference's one-block loop
-        for B, tag in ((Bn, ''), ('auto', '_auto'), (1, '_b1')):
-            for decode, name in ((True, 'chain'), (False, 'recv')):
-                # the loop is host-bound and shares its CPUs with whatever else runs on the box: median of three runs
-                runs = [bm.run_snr('GMSK', n_packets, 12.0, log2n, 'transforms', 2, 64, blocks_per_call=B, decode=decode, stimulus=stim)
-                        for _ in range(3 if tag != '_b1' else 1)]
-                r = sorted(runs, key=lambda q: q['ksamples_per_s'])[len(runs) // 2]
-                out[f'{name}{tag}_n{log2n}_d64_msamples'] = round(r['ksamples_per_s'] / 1e3, 1)
-                if not tag:
-                    out[f'{name}_n{log2n}_d64_best'] = round(max(q['ksamples_per_s'] for q in runs) / 1e3, 1)
-                if decode:
-                    out[f'{name}{tag}_n{log2n}_d64_packets'] = f"{r['packets']}/{r['sent']}"
+        # (run_stream, adaptive); '_b1' = "blocks_per_call": 1, the reference's one-block loop.  The loop is host-bound and shares
+        # its CPUs with whatever else runs on the box: three runs per figure, the configured and the adaptive loop taking turns
+        # (a drifting host hits both alike), the median of each
+        runs = {}
+        for rep in range(3):
+            for B, tag in ((Bn, ''), ('auto', '_auto')) + (((1, '_b1'),) if rep == 0 else ()):
+                for decode, name in ((True, 'chain'), (False, 'recv')):
+                    runs.setdefault((name, tag, decode), []).append(
+                        bm.run_snr('GMSK', n_packets, 12.0, log2n, 'transforms', 2, 64, blocks_per_call=B, decode=decode, stimulus=stim))
+        for (name, tag, decode), rr in runs.items():
+            r = sorted(rr, key=lambda q: q['ksamples_per_s'])[len(rr) // 2]
+            out[f'{name}{tag}_n{log2n}_d64_msamples'] = round(r['ksamples_per_s'] / 1e3, 1)
+            if tag != '_b1':
+                out[f'{name}{tag}_n{log2n}_d64_best'] = round(max(q['ksamples_per_s'] for q in rr) / 1e3, 1)
+            if decode:
+                out[f'{name}{tag}_n{log2n}_d64_packets'] = f"{r['packets']}/{r['sent']}"
     return out
 
 

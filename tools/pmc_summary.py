@@ -46,15 +46,19 @@ for suffix, title, roof, msamples, csvname in cols:
         for r in csv.DictReader(open(f)):
             agg[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
     m = {c: sum(x) / len(x) for c, x in agg[main['Name']].items()}
-    tail_name = main['Name'].rsplit(',', 1)[0] + ', -1>(SegArgs)'
+    if 'k_segf<' in main['Name']:        # round 6: the shift on the filters' side; the masked tail launch stays on k_seg
+        tail_name = 'void k_seg<' + main['Name'].split('k_segf<')[1].split(',')[0] + ', 0, -1>(SegArgs)'
+    else:
+        tail_name = main['Name'].rsplit(',', 1)[0] + ', -1>(SegArgs)'
     tl = {c: sum(x) / len(x) for c, x in agg.get(tail_name, {}).items()}
     bm = 2 * m['FETCH_SIZE'] * 1024 + m['WRITE_SIZE'] * 1024
     bt = 2 * tl.get('FETCH_SIZE', 0) * 1024 + tl.get('WRITE_SIZE', 0) * 1024
     cyc = m['GRBM_GUI_ACTIVE'] / 8
     put('', title)
-    put('dominant kernel', '`' + main['Name'].replace('void ', '').replace('(SegArgs)', '').replace(', 0, ', ',REDUCE,') + '`')
+    put('dominant kernel', '`' + main['Name'].replace('void ', '').replace('(SegArgs)', '').replace('(SegFArgs)', '').replace(', 0, ', ',REDUCE,') + '`')
     put('average launch, kernel trace', f"{float(main['AverageNs']) / 1e3:.1f} us ({main['Percentage']} % of GPU time, {main['Calls']} launches)")
-    put('bench line, HIP events', f"{roof['avg_launch_ms'] * 1e3:.1f} us, {msamples} Msamples/s, **{roof['frac']:.3f}** of the fp32 vector peak")
+    put('bench line, HIP events', f"{roof['avg_launch_ms'] * 1e3:.1f} us, {msamples} Msamples/s, **{roof['frac']:.3f}** of the fp32 vector peak "
+                                  f"({roof.get('frac_r05_formula', roof['frac']):.3f} by the flop count of rounds 1-5)")
     put('nominal flops per launch', f"{roof['flops_per_launch'] / 1e9:.2f} G")
     put('SQ_INSTS_VALU', f"{m['SQ_INSTS_VALU']:.4g}")
     put('GRBM_GUI_ACTIVE / 8 XCDs', f'{cyc:.4g} cycles')
@@ -79,13 +83,15 @@ with open(f'profiles/{rnd}_pmc_summary.md', 'w') as f:
             first = False
     f.write("\nAll three are compute-bound kernels (`roofline.bound = valu_fp32`); their HBM-side traffic is three orders below the two-pass formulation's\n"
             "34.45 GB per block (SURVEY 8d) because no length-N intermediate exists on this path: the 8.39 MB block once, one float per (bin, filter,\n"
-            "slot) of partial sums, the segment spectra from L2.  `profiles/pmc_traffic.json` carries these traffic figures into `roofline.traffic` of\n"
+            "slot) of partial sums, the segment spectra -- since round 6 one set per Doppler bin, 4 MiB at C2, 32 MiB for the 384-tap bank -- from L2 (each XCD\n"
+            "keeps its eighth of the bins).  `profiles/pmc_traffic.json` carries these traffic figures into `roofline.traffic` of\n"
             f"the bench line (labelled as stored from this profile).  The two-pass fallback has a file of its own (`{rnd}_pmc_twopass.md`); the\n"
-            f"2048-point kernel's cost table, A/B runs and taps sweeps are in `r04_long_filter.md`, the costed LDS-DMA variant in `r05_long_filter.md`.\n")
+            f"2048-point kernel's cost table, A/B runs and taps sweeps are in `r04_long_filter.md`, the costed LDS-DMA variant in `r05_long_filter.md`, round 6's\n"
+            f"operation counts, power experiment and the filter-side shift in `r06_fft_ops.md`.\n")
 p = 'profiles/pmc_traffic.json'
 d = json.load(open(p))
-keys = {'': ('segment_D256_M8_N20_L8', 'k_seg<256,REDUCE,13> + masked tail'), '_cc': ('segment_D256_M8_N20_L11', 'bench.py --protocol CC11xx: k_seg<2048,REDUCE,26> (wave-local) + masked tail'),
-        '_bpsk': ('segment_D256_M32_N20_L8', 'bench.py --protocol bench_BPSK: k_seg<256,REDUCE,11> + masked tail; 16 unique filter rows')}
+keys = {'': ('segment_D256_M8_N20_L8', 'k_segf<256,13> + masked tail k_seg<256,REDUCE,-1>'), '_cc': ('segment_D256_M8_N20_L11', 'bench.py --protocol CC11xx: k_segf<2048,26> (wave-local) + masked tail'),
+        '_bpsk': ('segment_D256_M32_N20_L8', 'bench.py --protocol bench_BPSK: k_segf<256,11> + masked tail; 16 unique filter rows')}
 for sfx, (key, what) in keys.items():
     tot, bm, bt = traffic[sfx]
     d[key] = {'bytes': tot, 'main_kernel': bm, 'tail_kernel': bt,

@@ -19,7 +19,7 @@ for s in S1 S2 Z; do
   echo "== power $s" | tee -a $out/progress.txt
   python3 tools/s1_vs_s2.py one $s bench_GMSK 256 6000 > $out/power_run_$s.log 2>&1 &
   pid=$!
-  sleep 9
+  sleep 7
   for i in $(seq 1 10); do
     /opt/rocm/bin/rocm-smi --showpower --showclocks --showtemp 2>/dev/null | grep -E "Power|sclk|Temperature \(Sensor (junction|hotspot)" | tr '\n' ';'
     echo

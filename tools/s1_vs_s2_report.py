@@ -8,7 +8,7 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r06_s1s2'
 out = open(sys.argv[2], 'w') if len(sys.argv) > 2 else sys.stdout
 root = f'gpurun_out/{tag}'
-KERNEL = 'k_seg<256, 0, 13>'
+KERNELS = ('k_segf<256, 13>', 'k_seg<256, 0, 13>')       # the search kernel of C2: round 6's form, or (MFB_SEG_FSM=0) the time-side one
 
 
 def p(*a):
@@ -36,7 +36,7 @@ for f in ('ab_gmsk.txt', 'ab_cc11xx.txt'):
 
 p('## Cycles per launch and the clock they ran at\n')
 p(f'`rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU` (its own pass) and `--kernel-trace --stats` (its own pass) per')
-p(f'stimulus, kernel `{KERNEL}`.  GRBM_GUI_ACTIVE is summed over the 8 XCDs; cycles = /8; clock = cycles / the un-countered average duration.\n')
+p(f'stimulus, the search kernel of C2 (`{KERNELS[0]}`; `{KERNELS[1]}` with MFB_SEG_FSM=0).  GRBM_GUI_ACTIVE is summed over the 8 XCDs; cycles = /8; clock = cycles / the un-countered average duration.\n')
 p('| stimulus | launches (pmc / trace) | GRBM_GUI_ACTIVE / 8 | SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU | avg duration (trace) | effective clock | VALU busy (4·ACTIVE_INST_VALU / (1024 SIMDs · cycles)) |')
 p('|---|---|---|---|---|---|---|---|')
 rows = {}
@@ -44,12 +44,12 @@ for s in ('S1', 'S2', 'Z'):
     agg = collections.defaultdict(list)
     for f in glob.glob(f'{root}/pmc_{s}/*/*counter_collection.csv'):
         for r in csv.DictReader(open(f)):
-            if KERNEL in r['Kernel_Name']:
+            if any(k in r['Kernel_Name'] for k in KERNELS):
                 agg[r['Counter_Name']].append(float(r['Counter_Value']))
     dur, calls = None, 0
     for f in glob.glob(f'{root}/trace_{s}/*/*kernel_stats.csv'):
         for r in csv.DictReader(open(f)):
-            if KERNEL in r['Name']:
+            if any(k in r['Name'] for k in KERNELS):
                 dur, calls = float(r['AverageNs']), int(r['Calls'])
     if not agg or dur is None:
         p(f'| {s} | (missing) | | | | | | |')
@@ -63,7 +63,7 @@ for s in ('S1', 'S2', 'Z'):
       f'{ghz:.3f} GHz | {busy:.3f} |')
 p('')
 
-p('## Package power and sclk beside a 6000-step run (rocm-smi, 10 samples 0.4 s apart, from second 9 of the process)\n')
+p('## Package power and sclk beside a 6000-step run (rocm-smi, 10 samples 0.4 s apart, from second 7 of the process)\n')
 p('| stimulus | run | power W (median, min … max) | sclk MHz (median, min … max) | junction °C |')
 p('|---|---|---|---|---|')
 for s in ('S1', 'S2', 'Z'):
