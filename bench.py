@@ -204,9 +204,10 @@ def c5_concurrent_figures(seconds=2.0, D=512):
     import subprocess
     child = os.path.join(ROOT, 'tools', 'c5_rate_child.py')
 
-    def run(names):
-        procs = [subprocess.Popen([sys.executable, child, n, str(D), str(seconds)], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
-                                  stderr=subprocess.DEVNULL, text=True, cwd=ROOT) for n in names]
+    def run(names, shared=False):
+        procs = [subprocess.Popen([sys.executable, child, n, str(D), str(seconds)] + ([str(i), str(len(names))] if shared else []),
+                                  stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd=ROOT)
+                 for i, n in enumerate(names)]
         try:
             for p in procs:
                 line = p.stdout.readline()
@@ -236,6 +237,14 @@ def c5_concurrent_figures(seconds=2.0, D=512):
                           'without loss, < 1 = what time-slicing between the two contexts costs'}
     except Exception as e:       # noqa: BLE001 -- a secondary figure must not cost the line
         out = {'c5_error': str(e)[:110]}
+    try:
+        # ... and with the device's compute units dealt out between the two (mfb_set_cu_share: even CUs / odd CUs)
+        cc3, bp3 = run(['CC11xx', 'bench_BPSK'], shared=True)
+        out.update({'c5_cc11xx_shared': cc3['msamples'], 'c5_bpsk_shared': bp3['msamples']})
+        if 'c5_cc11xx_alone' in out:
+            out['c5_shared_sum_over_alone'] = round(cc3['msamples'] / out['c5_cc11xx_alone'] + bp3['msamples'] / out['c5_bpsk_alone'], 4)
+    except Exception as e:       # noqa: BLE001
+        out['c5_shared_error'] = str(e)[:110]
     return out
 
 

@@ -52,7 +52,7 @@ const char *mfb_strerror(int status);
 int mfb_abi_version(void);   /* 2: search paths, mfb_xcorr; 3: mfb_set_search_mode, mfb_sync_find_multi; 4: mfb_receive_block,
                               * mfb_export_rows_async, mfb_sync_find_packed; 5: mfb_debug_block_scalars; 6: mfb_receive_blocks_*,
                               * mfb_window_buffer, mfb_block_params.block_stride; 7: mfb_set_stream_stages, mfb_stream_seed,
-                              * mfb_receive_blocks_end_record; 8: mfb_hostcopy_*; 9: mfb_set_batch_overlap, mfb_get_batch_scores, mfb_get_search_info, mfb_receive_blocks_end_record
+                              * mfb_receive_blocks_end_record; 8: mfb_hostcopy_*; 9: mfb_set_batch_overlap, mfb_get_batch_scores, mfb_get_search_info, mfb_set_cu_share, mfb_receive_blocks_end_record
                               * reports the size it needs */
 
 /* Create a handle on HIP device `device` for blocks of N = 2^log2N samples, `num_dopplers`
@@ -278,6 +278,14 @@ int mfb_input_buffer2(mfb_ctx *ctx, float **host_c64);
  *                         its two SNR windows at bands_c64 + b * 4 * band_capacity floats. */
 int mfb_window_buffer(mfb_ctx *ctx, int which, int max_blocks, int block_stride, float **host_c64);
 int mfb_receive_blocks_begin(mfb_ctx *ctx, const mfb_block_params *params, int nblocks, int slot);
+/* Several demodulator instances on ONE device (the reference starts one process and one context per radio, possibly on the same
+ * GPU: pyCuSDR.py:245-251, DB:177-181): give this handle's launches part `part` of `parts` equal parts of the compute units (CU i
+ * belongs to part i % parts; parts = 1: the whole device again).  Without it two instances share the device without loss but not
+ * evenly -- workgroups of the long-filter kernel (76 KiB of LDS) find no room beside the short-filter kernel's (52 KiB): 16 % / 85 % of
+ * their stand-alone rates at BASELINE C5 --; with (0, 2) and (1, 2) each runs on its own half, whatever the other does
+ * (bench.py: c5_*_shared).  The handle's own stream is re-created with a CU mask (a stream set with mfb_set_stream is the caller's
+ * business); nothing may be in flight. */
+int mfb_set_cu_share(mfb_ctx *ctx, int part, int parts);
 /* How the segment search of the next block will run (no reference counterpart; bench.py's flop count reads it): filter_side = 1 when
  * the Doppler shift sits on the FILTERS' side -- the segment of samples is transformed once for `bins_per_forward` neighbouring bins
  * and every (bin, filter) brings segment spectra of its own, built from the shift table (DB:130-165) when shifts or filters change:

@@ -104,6 +104,7 @@ PROTOTYPES = {
     'mfb_set_batch_overlap': (_i, [_vp, _i]),
     'mfb_get_batch_scores': (_i, [_vp, _i, _vp]),
     'mfb_get_search_info': (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    'mfb_set_cu_share': (_i, [_vp, _i, _i]),
     'mfb_receive_blocks_end': (_i, [_vp, _i, C.POINTER(BlockResult), _vp, _vp, _vp, _i, _vp]),
     'mfb_receive_blocks_end_record': (_i, [_vp, _i, _vp, C.c_size_t, C.POINTER(RecordLayout)]),
     'mfb_debug_stream_stages': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.POINTER(RecordLayout)]),

@@ -168,6 +168,7 @@ struct mfb_ctx {
     bool s2_busy;                 // something was enqueued on s2 since the last wait for it
     bool batch_overlap;           // mfb_set_batch_overlap
     int last_batch_blocks;        // blocks of the batch begun last (mfb_get_batch_scores)
+    int cu_part, cu_parts;        // mfb_set_cu_share (0, 0: the whole device)
     BlockGraph wgraph2[2][2][2][WG_NB + 1];     // part 2's recorded graphs (wgraph holds part 1's)
     // [window][slot][carry parity][blocks of the batch]: a receive loop that takes whatever is complete (1 ... B blocks per call)
     // keeps one recorded graph per batch size it has met twice; sizes above WG_NB share entry 0 (recorded again when the size changes)
@@ -631,6 +632,39 @@ extern "C" int mfb_set_stream(mfb_ctx *c, void *s) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(sync_streams(c));
     c->stream = s ? (hipStream_t)s : c->own_stream;
+    ++c->epoch;
+    return MFB_OK;
+}
+
+// A share of the device's compute units for this handle's launches (include/mfbank.h): the handle's own stream is replaced by one
+// created with a CU mask -- compute unit i belongs to part i % parts.
+extern "C" int mfb_set_cu_share(mfb_ctx *c, int part, int parts) {
+    if (!c || parts < 1 || parts > 16 || part < 0 || part >= parts) return MFB_ERR_ARG;
+    for (int s = 0; s < 2; ++s)
+        if (c->flight[s].active) return MFB_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(sync_streams(c));
+    hipStream_t fresh = nullptr;
+    if (parts == 1) {
+        HIPCHK(hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+    } else {
+        const int words = (c->num_cus + 31) / 32;
+        std::vector<uint32_t> mask((size_t)words, 0u);
+        int mine = 0;
+        for (int i = 0; i < c->num_cus; ++i)
+            if (i % parts == part) {
+                mask[(size_t)i / 32] |= 1u << (i % 32);
+                ++mine;
+            }
+        if (!mine) return MFB_ERR_ARG;
+        HIPCHK(hipExtStreamCreateWithCUMask(&fresh, (uint32_t)words, mask.data()));
+    }
+    const bool was_own = c->stream == c->own_stream;
+    if (c->own_stream) HIPCHK(hipStreamDestroy(c->own_stream));
+    c->own_stream = fresh;
+    if (was_own) c->stream = fresh;
+    c->cu_part = part;
+    c->cu_parts = parts;
     ++c->epoch;
     return MFB_OK;
 }

@@ -216,6 +216,11 @@ class MFBank:
         return dict(path=names.get(v[0].value, 'twopass'), log2L=v[1].value, taps=v[2].value,
                     valid_per_segment=v[3].value, segments=v[4].value)
 
+    def set_cu_share(self, part, parts):
+        """This handle's launches on part ``part`` of ``parts`` equal parts of the device's compute units (mfb_set_cu_share):
+        for several demodulator instances on one device.  ``parts = 1``: the whole device."""
+        _lib.check(self._lib.mfb_set_cu_share(self._h, int(part), int(parts)), 'mfb_set_cu_share')
+
     def get_search_info(self):
         """{'filter_side': bool, 'bins_per_forward': int} -- whether the segment search transforms a segment once for several
         bins, the Doppler shift sitting on the filters' side (mfb_get_search_info)."""

@@ -57,6 +57,59 @@ def test_c5_two_instances_one_process():
     _ok(rb, 'bench_BPSK')
 
 
+def test_c5_instances_on_shares_of_the_compute_units():
+    """mfb_set_cu_share: the two C5 instances on the even and the odd compute units of one device, searching at the same time in two
+    threads -- every table bit for bit the whole-device one (a score is a function of the block, the shift and the filter only), the
+    oracle gates as above; the share can be changed back, bad shares and a block in flight are refused."""
+    from c5_common import c5_instance, check_instance
+    from pycusdr_amd._lib import MFBankError
+    insts = [c5_instance('CC11xx', 20, 512), c5_instance('bench_BPSK', 20, 512)]
+    banks = [MFBank(20, 512, i['M']) for i in insts]
+    try:
+        whole = []
+        for bk, inst in zip(banks, insts):
+            bk.set_filters(inst['masks'])
+            bk.set_shifts(inst['shifts'])
+            bk.upload(inst['x'])
+            bk.find_carrier()
+            whole.append(bk.get_scores().copy())
+        for k, bk in enumerate(banks):
+            bk.set_cu_share(k, 2)
+        got = [None, None]
+
+        def search(k):
+            for _ in range(6):
+                banks[k].upload(insts[k]['x'])
+                banks[k].find_carrier()
+            got[k] = banks[k].get_scores().copy()
+        ths = [threading.Thread(target=search, args=(k,)) for k in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        for k in range(2):
+            assert np.array_equal(got[k], whole[k]), k
+        res = [check_instance(bk, inst) for bk, inst in zip(banks, insts)]
+        with pytest.raises(ValueError):
+            banks[0].set_cu_share(2, 2)
+        with pytest.raises(ValueError):
+            banks[0].set_cu_share(0, 0)
+        banks[0].set_cu_share(0, 1)                      # the whole device again
+        banks[0].upload(insts[0]['x'])
+        banks[0].find_carrier()
+        assert np.array_equal(banks[0].get_scores(), whole[0])
+        k_off, k_len = 1000, 4000
+        banks[0].begin_block(0, k_off, k_len, 8, source='uploaded')
+        with pytest.raises(MFBankError):
+            banks[0].set_cu_share(0, 2)                  # a block is in flight
+        banks[0].end_block(0)
+    finally:
+        for bk in banks:
+            bk.close()
+    _ok(res[0], 'CC11xx')
+    _ok(res[1], 'bench_BPSK')
+
+
 def test_c5_two_processes_one_device():
     """C5 as the reference deploys it: one OS process (and device context) per demodulator instance, both on
     the same device at the same time."""

@@ -2,7 +2,8 @@
 device context, pyCuSDR.py:245-251, demodulator_base.py:177-181): the search step of bench.py (forward FFT, Doppler search over D bins,
 pick, 8-byte read-back) on blocks resident in HBM, for a set time from a set moment.  Started by bench.py's C5 leg (and
 tools/c5_concurrent.py), alone and beside a sibling on the same device.
-usage: c5_rate_child.py <CC11xx|bench_BPSK> <D> <seconds>      -- prints 'ready', waits for 'go <epoch>' on stdin, prints one JSON line"""
+usage: c5_rate_child.py <CC11xx|bench_BPSK> <D> <seconds> [part parts]   -- prints 'ready', waits for 'go <epoch>' on stdin, prints one JSON
+line; part / parts: the instance's share of the compute units (mfb_set_cu_share)"""
 import json
 import os
 import sys
@@ -30,6 +31,8 @@ else:
 _, _, shifts, _ = doppler_bin_table(conf['Radios']['Rx']['UHF-H'], conf['Radios']['rangeRateMax'], N)
 M, masks = loadProtocol(name)(conf=conf).get_filter(N, sps, ms)
 bank = MFBank(log2N, D, M)
+if len(sys.argv) > 5:
+    bank.set_cu_share(int(sys.argv[4]), int(sys.argv[5]))
 bank.set_filters(masks)
 bank.set_shifts(shifts)
 rs = np.random.RandomState(5)

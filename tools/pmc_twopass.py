@@ -40,8 +40,8 @@ for name, alg, what in (('void k_pass1<256, 0>(P1Args)', 8.0 * Dc * M * N + 8.0 
 with open(f'profiles/{rnd}_pmc_twopass.md', 'w') as o:
     o.write(f"# Round {int(rnd[1:])} -- the two-pass fallback at HEAD: kernel trace and HBM-traffic counters re-cut\n\n"
             f"`tools/prof_bench.sh {t} --path twopass --steps 12` on the box of `{rnd}_bench.json` (C2: D = 256, M = 8, N = 2^20; 128 bins per launch,\n"
-            "two launches of each pass per block); written by `tools/pmc_twopass.py`.  Nothing of this path changed in round 5 (the plain forward\n"
-            "transforms gained a row index for batches of blocks, `k_pass1<FWDC/FWDR>`: same arithmetic); the figures confirm round 4's.\n\n"
+            f"two launches of each pass per block); written by `tools/pmc_twopass.py`.  Nothing of this path changed in round {int(rnd[1:])} (round 5 gave the plain forward\n"
+            f"transforms a row index for batches of blocks, `k_pass1<FWDC/FWDR>`: same arithmetic); the figures confirm the earlier rounds'.\n\n"
             "| kernel | average per launch (kernel trace) | algorithmic bytes per launch | achieved | of 8 TB/s | FETCH_SIZE (KiB, mean; min ... max) | WRITE_SIZE (KiB) | counter bytes per launch | over algorithmic |\n|---|---|---|---|---|---|---|---|---|\n")
     for (name, what, avg, calls, alg, tbs, fm, fmin, fmax, wm, b, ratio, n) in rows:
         short = name.replace('void ', '').replace('(P1Args)', '').replace('(P2Args)', '')
