@@ -972,6 +972,27 @@ def main():
         for i in range(reps):
             bank.receive_block(k_off, k_len, 8, source='device', device_ptr=blocks.data_ptr() + block_index(i) * esz)
         extras['receive_block_one_call_ms'] = round((time.perf_counter() - t1) / reps * 1e3, 4)
+        # the same call as begin / end with two blocks in flight (the next block's launches are enqueued before this block's
+        # results are waited for), on one stream and -- mfb_set_batch_overlap -- as two parts on two streams: the next block's search
+        # beside this block's matched filters, envelope transform, rate, centres and read-back (Next 8)
+        def begin_end_loop(n):
+            bank.begin_block(0, k_off, k_len, 8, source='device', device_ptr=blocks.data_ptr())
+            for k in range(1, n):
+                bank.begin_block(k & 1, k_off, k_len, 8, source='device', device_ptr=blocks.data_ptr() + block_index(k) * esz)
+                bank.end_block((k - 1) & 1)
+            bank.end_block((n - 1) & 1)
+        for key, on in (('receive_block_begin_end_ms', False), ('receive_block_pipelined_ms', True)):
+            try:
+                bank.set_batch_overlap(on)
+                begin_end_loop(8)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                begin_end_loop(24)
+                extras[key] = round((time.perf_counter() - t1) / 24 * 1e3, 4)
+            except Exception as e:       # noqa: BLE001 -- a secondary figure must not cost the line
+                extras[key + '_error'] = str(e)[:100]
+            finally:
+                bank.set_batch_overlap(False)
         # the other search path, same blocks, a few steps (its own roofline accounting)
         if G == 1:
             try:

@@ -306,7 +306,9 @@ int mfb_get_batch_scores(mfb_ctx *ctx, int block, float *host_scores);
  * not bound by its own per-block work (1.72 -> 1.92 ... 2.0 Gsamples/s at 2^15 x 64 bins x 32 blocks, 2^17 x 8: tools/batch_device_rate.py,
  * profiles/r06_chain.md); it costs a caller that waits for batch k - 1 right after it has begun batch k and is bound by its own
  * work -- the Python receive loop: -7 % -- because batch k - 1's part 2 then shares the chip with batch k's search and finishes later.
- * Off by default (0); the environment's MFB_BATCH_SPLIT=0/1 overrides every handle. */
+ * The one-block calls mfb_receive_block_begin / _end split the same way when it is on (input = a page-locked buffer or a device block):
+ * at C2 the next block's search then runs beside this block's 0.16 ms of demodulation stage, 1.578 -> 1.518 ms per block with two
+ * blocks in flight (tools/block_device_rate.py).  Off by default (0); the environment's MFB_BATCH_SPLIT=0/1 overrides every handle. */
 int mfb_set_batch_overlap(mfb_ctx *ctx, int on);
 int mfb_receive_blocks_end(mfb_ctx *ctx, int slot, mfb_block_result *results, int32_t *sym, int32_t *centres, float *magnitude,
                            int symbol_stride, float *bands_c64);

@@ -219,29 +219,45 @@ static inline void segment_spectra_shifted(const Bank &b, const int *rows, int n
                                            std::vector<float> *out, int ppl = 16) {
     const Fft plan(L);
     out->assign((size_t)nshifts * nrows * 2 * L, 0.f);
-    std::vector<cd> buf(L);
     const double scale = (double)b.N / (double)L;
     const int NT = L / ppl;
-    for (int j = 0; j < nshifts; ++j) {
-        const long long s = shifts[j];
-        for (int u = 0; u < nrows; ++u) {
-            const int m = rows ? rows[u] : u;
-            std::fill(buf.begin(), buf.end(), cd(0.0, 0.0));
-            for (int r = 0; r < b.T; ++r) {
-                const double ang = 2.0 * M_PI * (double)((s * r) % b.N) / (double)b.N;
-                buf[(r - (Te - 1)) & (L - 1)] = tap(b, m, r) * cd(cos(ang), sin(ang));
+    // one host thread per stripe of bins (as analyse does per filter row): D * MU transforms of L points -- 2048 of 256 points at C2,
+    // 2048 of 2048 points for the 384-tap bank at 256 bins
+    unsigned hw = std::thread::hardware_concurrency();
+    int nthr = (int)std::min<unsigned>(hw ? hw : 1, 16);
+    if ((long long)nshifts * nrows * L < (1 << 18)) nthr = 1;
+    if (nthr > nshifts) nthr = nshifts;
+    if (nthr < 1) nthr = 1;
+    auto work = [&](int t) {
+        std::vector<cd> buf(L);
+        for (int j = t; j < nshifts; j += nthr) {
+            const long long s = shifts[j];
+            for (int u = 0; u < nrows; ++u) {
+                const int m = rows ? rows[u] : u;
+                std::fill(buf.begin(), buf.end(), cd(0.0, 0.0));
+                for (int r = 0; r < b.T; ++r) {
+                    const double ang = 2.0 * M_PI * (double)((s * r) % b.N) / (double)b.N;
+                    buf[(r - (Te - 1)) & (L - 1)] = tap(b, m, r) * cd(cos(ang), sin(ang));
+                }
+                plan.run(buf.data(), -1);
+                float *o = out->data() + ((size_t)j * nrows + u) * 2 * L;
+                for (int ii = 0; ii < ppl / 2; ++ii)
+                    for (int g = 0; g < NT; ++g)
+                        for (int e = 0; e < 2; ++e) {
+                            const cd v = buf[g + NT * (2 * ii + e)] * scale;
+                            const size_t pos = ((size_t)(ii * NT + g) * 2 + e) * 2;
+                            o[pos] = (float)v.real();
+                            o[pos + 1] = (float)v.imag();
+                        }
             }
-            plan.run(buf.data(), -1);
-            float *o = out->data() + ((size_t)j * nrows + u) * 2 * L;
-            for (int ii = 0; ii < ppl / 2; ++ii)
-                for (int g = 0; g < NT; ++g)
-                    for (int e = 0; e < 2; ++e) {
-                        const cd v = buf[g + NT * (2 * ii + e)] * scale;
-                        const size_t pos = ((size_t)(ii * NT + g) * 2 + e) * 2;
-                        o[pos] = (float)v.real();
-                        o[pos + 1] = (float)v.imag();
-                    }
         }
+    };
+    if (nthr == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthr; ++t) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
     }
 }
 

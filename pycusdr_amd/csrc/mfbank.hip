@@ -143,6 +143,8 @@ struct mfb_ctx {
     BlockGraph bgraph[2][2];  // [input buffer][slot]: the block's launches as a HIP graph
     unsigned long long epoch; // bumped by every change that invalidates them
     uint8_t *d_blkout;        // mfb_receive_block: the block's result record (scalars | SNR windows | symbols), one copy to the host
+    uint8_t *d_blkout2;       // ... of flight slot 1 when a block runs as two parts on two streams (mfb_set_batch_overlap)
+    BlockGraph bgraph2[2][2]; // part 2's recorded graphs ([input buffer][slot]; bgraph holds part 1's, or the whole block)
     BlockScalars *d_scal;     // = d_blkout
     int band_cap;
     bool W_valid;
@@ -359,6 +361,9 @@ static int blkout_reserve(mfb_ctx *c, int bcap) {
     c->d_blkout = nullptr;
     c->band_cap = 0;
     HIPCHK(dev_alloc((void **)&c->d_blkout, blkout_bytes(bcap, c->cap)));
+    if (c->d_blkout2) HIPCHK(hipFree(c->d_blkout2));
+    c->d_blkout2 = nullptr;
+    HIPCHK(dev_alloc((void **)&c->d_blkout2, blkout_bytes(bcap, c->cap)));        // flight slot 1 (two streams: mfb_set_batch_overlap)
     c->band_cap = bcap;
     c->d_scal = (BlockScalars *)c->d_blkout;
     return MFB_OK;
@@ -573,7 +578,7 @@ extern "C" int mfb_destroy(mfb_ctx *c) {
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     void *bufs[] = {c->d_uniq, c->d_rep, c->d_x,  c->d_X,    c->d_masks, c->d_Z,   c->d_xc,  c->d_P,   c->d_env, c->d_shifts, c->d_tw1,
                     c->d_tw2, c->d_twLo, c->d_twHi,  c->d_part, c->d_sum, c->d_res, c->d_cr,  c->d_sym,    c->d_cen, c->d_mag,
-                    c->d_G, c->d_twL, c->d_Gb, c->d_pow, c->d_W, c->d_blkout, c->d_x2,
+                    c->d_G, c->d_twL, c->d_Gb, c->d_pow, c->d_W, c->d_blkout, c->d_blkout2, c->d_x2,
                     c->d_win[0], c->d_win[1], c->d_Xb, c->d_xcb, c->d_Pb, c->d_envb, c->d_sumb, c->d_resb, c->d_crb, c->d_batout, c->d_batout2, c->d_Z2,
                     c->d_lut8, c->d_lut3, c->d_sttmpl, c->d_carry[0], c->d_carry[1]};
     for (void *p : bufs)
@@ -586,6 +591,8 @@ extern "C" int mfb_destroy(mfb_ctx *c) {
         if (c->ev_wfree[i]) (void)hipEventDestroy(c->ev_wfree[i]);
     }
     for (auto &row : c->bgraph)
+        for (auto &g : row) graph_drop(g);
+    for (auto &row : c->bgraph2)
         for (auto &g : row) graph_drop(g);
     for (auto &row : c->wgraph)
         for (auto &col : row)
@@ -748,6 +755,7 @@ static int choose_segl(const mfb_ctx *c, int T, bool may_decline) {
     return best;
 }
 
+static int fsm_prepare_eager(mfb_ctx *c);
 // settle path and segment length from the request and the analysed bank; (re)build G and W_L
 static int resolve_path(mfb_ctx *c) {
     ++c->epoch;               // whatever changes here changes the launches of a block
@@ -824,7 +832,9 @@ static int resolve_path(mfb_ctx *c) {
         c->d_Z = nullptr;
         c->z_rows = 0;
     }
-    return alloc_Z(c);
+    int rc = alloc_Z(c);
+    if (rc) return rc;
+    return fsm_prepare_eager(c);
 }
 
 extern "C" int mfb_set_search_path(mfb_ctx *c, int path, int log2L, int wg_per_cu, int filters_per_pass) {
@@ -965,7 +975,7 @@ extern "C" int mfb_set_shifts(mfb_ctx *c, const int32_t *shifts, int count) {
     c->gs_rows = 0;               // the per-bin spectra belong to the old table
     c->have_shifts = true;
     ++c->epoch;
-    return MFB_OK;
+    return fsm_prepare_eager(c);
 }
 
 extern "C" int mfb_input_buffer(mfb_ctx *c, float **p) {
@@ -1378,7 +1388,7 @@ struct FsmPlan {
     bool ok;
     int nsg, gbins, fb, fs, nbc, nsc;
 };
-static FsmPlan fsm_plan(const mfb_ctx *c, int MU, int nfull) {
+static FsmPlan fsm_plan(const mfb_ctx *c, int MU, int nfull, int nb = 1) {
     static int env_fb = 0, env_fs = 0;
     static const bool env_read = [] {
         const char *e = getenv("MFB_SEG_FSM_RECT");
@@ -1400,7 +1410,7 @@ static FsmPlan fsm_plan(const mfb_ctx *c, int MU, int nfull) {
     if (w32 && !p.gbins && p.nsg > 1 && env_gb < 0) {
         // the long kernel's spectra (16 KiB per (bin, filter)) must stay in an L2: fewer bins per rectangle, or not this kernel
         fb = c->Dtot / p.nsg;
-        if (fb < 2) return p;
+        if (fb < 1) return p;
         p.gbins = 1;
     }
     const int glen = p.gbins ? nfull : (nfull + p.nsg - 1) / p.nsg;
@@ -1408,6 +1418,14 @@ static FsmPlan fsm_plan(const mfb_ctx *c, int MU, int nfull) {
     if (fs > glen) fs = glen;
     if (fb > gblen) fb = gblen;
     if (fb < 1 || fs < 1) return p;
+    // Small problems (one block of 2^15 samples x 64 bins: 2496 (bin, slot) units) must not be folded into a few long waves: the
+    // rectangle shrinks until the launch has twice the waves the device holds at once -- at one bin per rectangle the forward
+    // transform is no longer shared, and what is left of the gain is the mixing multiply (measured: bench.py's one-block loop at
+    // 2^15 x 64 fell from 250 to 155 Msamples/s with 16-bin rectangles: 156 waves on 1024 SIMDs)
+    if (c->fsm_fb <= 0 && env_fb <= 0) {
+        const long long want = 2LL * c->num_cus * 4 * (w32 ? 2 : 3);
+        while (fb > 1 && (long long)nb * p.nsg * ((gblen + fb - 1) / fb) * ((glen + fs - 1) / fs) < want) fb >>= 1;
+    }
     p.fb = fb;
     p.fs = fs;
     p.nbc = (gblen + fb - 1) / fb;
@@ -1444,7 +1462,7 @@ static int launch_fsm(mfb_ctx *c, int nb, const cf *x, int xstride, int MU, int 
     a.dper = c->Dtot;
     a.nblk = nb;
     a.xstride = xstride;
-    const FsmPlan fp = fsm_plan(c, MU, nfull);
+    const FsmPlan fp = fsm_plan(c, MU, nfull, nb);
     if (!fp.ok) return MFB_ERR_UNSUPPORTED;
     a.nsg = fp.nsg;
     a.gbins = fp.gbins;
@@ -1468,6 +1486,19 @@ static int launch_fsm(mfb_ctx *c, int nb, const cf *x, int xstride, int MU, int 
     return launch_segf_pv<256, 8, 16>(c, a, grid, lds, pv);
 }
 
+// Build the per-bin spectra as soon as filters, shifts and the path are known (mfb_set_filters / mfb_set_shifts / mfb_set_search_*),
+// not inside the first search: 512 transforms of 2048 points for the 384-tap bank at 64 bins are 10-20 ms of host work, which does
+// not belong into a receive loop's first block.  (The search still checks, and builds what is missing.)
+static int fsm_prepare_eager(mfb_ctx *c) {
+    if (!c->have_filters || !c->have_shifts || c->path != MFB_PATH_SEGMENT || !fsm_enabled()) return MFB_OK;
+    const bool span = c->basis == MFB_BASIS_SPAN;
+    const int MU = span ? c->MB : c->MU;
+    int nfull, ntotal;
+    seg_slots(c, &nfull, &ntotal);
+    const bool fsm_l = c->segl == 8 || (c->segl == 11 && MFB_SEG_W32 && MU <= 8 && (size_t)c->Dtot * MU * 16384 <= ((size_t)256 << 20));
+    if (!(fsm_l && MU <= SEG_MPB_MAX && nfull > 0 && (int)c->h_shifts.size() == c->Dtot && fsm_plan(c, MU, nfull).ok)) return MFB_OK;
+    return fsm_prepare(c, span, MU);
+}
 // how the segment search of the next block will run: filter_side = 1 when the Doppler shift sits on the filters' side (k_segf: one
 // forward transform per segment for `bins_per_forward` bins), 0 when every (bin, segment) is mixed and transformed (k_seg)
 extern "C" int mfb_get_search_info(mfb_ctx *c, int *filter_side, int *bins_per_forward) {
@@ -2095,6 +2126,7 @@ static int check_block_params(const mfb_ctx *c, const mfb_block_params *p) {
 static int staging_reserve(mfb_ctx *c, int slot, size_t need) {
     if (need <= c->blk_cap[slot]) return MFB_OK;
     for (auto &row : c->bgraph) graph_drop(row[slot]);
+    for (auto &row : c->bgraph2) graph_drop(row[slot]);
     for (auto &row : c->wgraph)
         for (auto &par : row[slot])
             for (auto &g : par) graph_drop(g);
@@ -2110,6 +2142,8 @@ static int staging_reserve(mfb_ctx *c, int slot, size_t need) {
     return MFB_OK;
 }
 
+static bool batch_split(const mfb_ctx *c);
+static int second_stream(mfb_ctx *c, int slot);
 // Enqueue: everything up to and including the ONE device-to-host copy into the flight's page-locked staging; no wait.
 static int block_begin(mfb_ctx *c, const mfb_block_params *p, int slot) {
     if (!c || !p || slot < 0 || slot > 1) return MFB_ERR_ARG;
@@ -2137,12 +2171,47 @@ static int block_begin(mfb_ctx *c, const mfb_block_params *p, int slot) {
     if (pinned_in) c->d_in = which ? c->d_x2 : c->d_x;
     else if (p->input == MFB_INPUT_DEVICE) c->d_in = (const cf *)p->device_block;
     const bool allowed = pinned_in && graphs_allowed() && !c->prof && !c->mirror && (p->input == MFB_INPUT_PINNED || c->h_in2);
-    rc = graph_or_launch(c, c->bgraph[which][slot], p, 0, allowed,
-                         [&]() { return block_enqueue(c, p, single_bufs(c), c->h_blk[slot], nthreads, bcap, capacity, &shift); });
-    if (rc) return rc;
-    c->have_input = true;
-    HIPCHK(hipEventRecord(c->ev_blk[slot], c->stream));
-    if (pinned_in) HIPCHK(hipEventRecord(c->ev_xfree[which], c->stream));      // this device copy may be overwritten from here on
+    // two parts on two streams (mfb_set_batch_overlap), as for batches: the NEXT block's forward transform and search run beside this
+    // block's matched filters, envelope transform, rate, centres and read-back.  Part 2 reads the samples (the STORE kernel), so the
+    // input has to be one of the two page-locked buffers' device copies or the caller's device block -- not the handle's upload
+    const bool split = batch_split(c) && p->input != MFB_INPUT_UPLOADED && c->path == MFB_PATH_SEGMENT;
+    if (!split) {
+        rc = graph_or_launch(c, c->bgraph[which][slot], p, 0, allowed,
+                             [&]() { return block_enqueue(c, p, single_bufs(c), c->h_blk[slot], nthreads, bcap, capacity, &shift); });
+        if (rc) return rc;
+        c->have_input = true;
+        HIPCHK(hipEventRecord(c->ev_blk[slot], c->stream));
+        if (pinned_in) HIPCHK(hipEventRecord(c->ev_xfree[which], c->stream));      // this device copy may be overwritten from here on
+    } else {
+        if ((rc = second_stream(c, slot))) return rc;
+        if (c->z2_rows < 1) {
+            HIPCHK(sync_streams(c));
+            HIPCHK(dev_alloc((void **)&c->d_Z2, (size_t)c->N * sizeof(cf)));
+            c->z2_rows = 1;
+        }
+        BlkBufs bb = single_bufs(c);
+        bb.out = slot ? c->d_blkout2 : c->d_blkout;
+        rc = graph_or_launch(c, c->bgraph[which][slot], p, -1, allowed, [&]() { return block_enqueue_p1(c, p, bb, nthreads, bcap); });
+        if (rc) return rc;
+        c->have_input = true;
+        HIPCHK(hipEventRecord(c->ev_p1[slot], c->stream));
+        hipStream_t s1 = c->stream;
+        c->stream = c->s2;
+        c->use_z2 = true;
+        c->s2_busy = true;
+        hipError_t e = hipStreamWaitEvent(c->s2, c->ev_p1[slot], 0);
+        rc = e != hipSuccess ? MFB_ERR_HIP
+                             : graph_or_launch(c, c->bgraph2[which][slot], p, -1, allowed,
+                                               [&]() { return block_enqueue_p2(c, p, bb, c->h_blk[slot], nthreads, bcap, capacity, &shift); });
+        if (!rc) {
+            e = hipEventRecord(c->ev_blk[slot], c->s2);
+            if (e == hipSuccess && pinned_in) e = hipEventRecord(c->ev_xfree[which], c->s2);
+            if (e != hipSuccess) rc = MFB_ERR_HIP;
+        }
+        c->stream = s1;
+        c->use_z2 = false;
+        if (rc) return rc;
+    }
     const size_t sym_off = BLK_HEAD + align16((size_t)2 * bcap * sizeof(cf)), arr = align16((size_t)nthreads * sizeof(int));
     f.off[0] = 0;
     f.off[4] = BLK_HEAD;
@@ -2246,6 +2315,17 @@ extern "C" int mfb_receive_block(mfb_ctx *c, const mfb_block_params *p, mfb_bloc
 // estimates, the centres of all blocks, one device-to-host copy of B result records.
 static int window_samples(const mfb_ctx *c, int nb) { return nb * c->win_stride + (c->N - c->win_stride); }
 
+// the second stream of a block / batch in two parts, and the event of the flight's part 1
+static int second_stream(mfb_ctx *c, int slot) {
+    if (!c->s2) {
+        // (the highest priority: part 2 is a latency chain whose workgroups should get the slots the big kernel frees first)
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&c->s2, hipStreamNonBlocking, greatest));
+    }
+    if (!c->ev_p1[slot]) HIPCHK(hipEventCreateWithFlags(&c->ev_p1[slot], hipEventDisableTiming));
+    return MFB_OK;
+}
 // A batch on two streams (mfb_set_batch_overlap; include/mfbank.h): the handle's setting, or -- every handle -- MFB_BATCH_SPLIT=0/1 in
 // the environment (the A/B switch of profiles/r06_chain.md)
 static bool batch_split(const mfb_ctx *c) {
@@ -2400,13 +2480,7 @@ extern "C" int mfb_receive_blocks_begin(mfb_ctx *c, const mfb_block_params *p, i
     } else {
         // part 1 on the handle's stream, part 2 behind it on the second stream: the NEXT batch's part 1 is enqueued behind this
         // one's part 1 only, and runs beside this batch's part 2
-        if (!c->s2) {
-            // (the highest priority: part 2 is a latency chain whose workgroups should get the slots the big kernel frees first)
-            int least = 0, greatest = 0;
-            HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            HIPCHK(hipStreamCreateWithPriority(&c->s2, hipStreamNonBlocking, greatest));
-        }
-        if (!c->ev_p1[slot]) HIPCHK(hipEventCreateWithFlags(&c->ev_p1[slot], hipEventDisableTiming));
+        if ((rc = second_stream(c, slot))) return rc;
         rc = graph_or_launch(c, c->wgraph[which][slot][parity][gi], &q, nblocks, allowed,
                              [&]() { return block_enqueue_p1(c, &q, bb, nthreads, bcap); });
         if (rc) return rc;

@@ -292,6 +292,7 @@ class DemodulatorRunner:
         # Overlapped form: block i is on the device while this thread runs the sequential host stages and the decoder of
         # block i-1 and assembles block i+1 in the other page-locked buffer.  Same calls in the same order on the same data
         # as the plain loop, so the same results; only the waiting moves.
+        self._apply_batch_overlap()
         bufs, cur = self._block_buffers()       # goes on in the buffer (and behind the overlap) the last call ended in
         names = ('pinned', 'pinned2')
         asm = BlockAssembler(bufs[cur], self.overlap)
@@ -397,6 +398,13 @@ class DemodulatorRunner:
         ``run_stream`` takes them without being asked (``auto_blocks_per_call``) unless the configuration says otherwise."""
         return MarkedSource(poll, wait)
 
+    def _apply_batch_overlap(self):
+        """``"HIP": {"batch_overlap": true}`` -> mfb_set_batch_overlap (a block / batch as two parts on two streams); off by default."""
+        want = bool(self.conf['GPU'][self.confRadio['CUDA_settings']].get('HIP', {}).get('batch_overlap', False))
+        if getattr(self, '_batch_overlap', False) != want and hasattr(self.demod.bank, 'set_batch_overlap'):
+            self.demod.bank.set_batch_overlap(want)
+            self._batch_overlap = want
+
     def auto_blocks_per_call(self):
         """Blocks per device call for a source that marks where it would block: windows of about 2^20 samples, at most 32 blocks
         (2^15-sample blocks: 32, 2^17: 8, 2^20 and above: one block per call) -- the sizes the sweep in profiles/r05_chain.md
@@ -426,10 +434,7 @@ class DemodulatorRunner:
         # "HIP": {"batch_overlap": true}: the next batch's search beside this batch's small kernels (mfb_set_batch_overlap).  Off
         # by default HERE: this loop is bound by its own per-block work and waits for batch k - 1 right after it has begun batch
         # k, and a batch k - 1 whose tail shares the chip with batch k's search arrives later (profiles/r06_chain.md: -7 %).
-        want = bool(self.conf['GPU'][self.confRadio['CUDA_settings']].get('HIP', {}).get('batch_overlap', False))
-        if getattr(self, '_batch_overlap', False) != want and hasattr(self.demod.bank, 'set_batch_overlap'):
-            self.demod.bank.set_batch_overlap(want)
-            self._batch_overlap = want
+        self._apply_batch_overlap()
         names = ('window', 'window2')
         cur = 0
         # the integer stages behind the symbol decisions (bit lookup, block-overlap alignment, the decoder's searches on the

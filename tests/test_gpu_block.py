@@ -227,3 +227,31 @@ def test_one_call_equals_stage_by_stage_randomised(seed):
     finally:
         one.close()
         stages.close()
+
+
+def test_a_block_on_two_streams_changes_no_number():
+    """``"HIP": {"batch_overlap": true}`` with one block per call (mfb_receive_block_begin / _end as two parts on two streams: the next
+    block's forward transform and search beside this block's matched filters, envelope transform, rate, centres and read-back):
+    every result dict of the stream equals the one-stream loop's -- 2^16-sample blocks, the GMSK bank and the 384-tap CC11xx bank."""
+    import copy
+    for pname, bs, D in (('bench_GMSK', 16, 48), ('CC11xx', 17, 32)):
+        N, ov = 1 << bs, 1 << 10
+        conf = cfg.cc11xx_config(blockSize=bs, doppCarrierSteps=D, samplesPerSym=128) if pname == 'CC11xx' else \
+            cfg.bench_config(pname, blockSize=bs, doppCarrierSteps=D)
+        conf['GPU']['UHF'].setdefault('HIP', {})['blocks_per_call'] = 1
+        confB = copy.deepcopy(conf)
+        confB['GPU']['UHF']['HIP']['batch_overlap'] = True
+        p = loadProtocol(pname)(conf=conf)
+        sig = sg.s1_stream(9, N, ov, 'GMSK', snr_db=10.0, seed=15)[ov:]
+        a, b = DemodulatorRunner(conf, p, 'UHF-H'), DemodulatorRunner(confB, p, 'UHF-H')
+        try:
+            ra, _ = a.run_stream((sig[i:i + 20000] for i in range(0, len(sig), 20000)))
+            rb, _ = b.run_stream((sig[i:i + 20000] for i in range(0, len(sig), 20000)))
+            assert len(ra) == len(rb) == 9
+            for x, y in zip(ra, rb):
+                for k in ('doppler', 'doppler_std', 'SNR', 'spSymEst'):
+                    assert _same(x[k], y[k]), (pname, x['count'], k)
+                assert _same(x['data'], y['data']) and _same(x['trust'], y['trust']), (pname, x['count'])
+        finally:
+            a.close()
+            b.close()

@@ -276,13 +276,16 @@ def test_span_basis_refused_without_sum_all():
         bank.close()
 
 
-@pytest.mark.parametrize('name,log2N,D,Doff', [('bench_GMSK', 17, 96, 0), ('bench_BPSK', 16, 40, 2), ('CC11xx', 17, 64, 0), ('bench_GMSK', 15, 9, 1)])
-def test_the_shift_on_the_filters_side_equals_the_shift_on_the_samples(tmp_path, name, log2N, D, Doff):
+@pytest.mark.parametrize('name,log2N,D,Doff,rect', [('bench_GMSK', 17, 96, 0, None), ('bench_GMSK', 17, 96, 0, '16,1'), ('bench_BPSK', 16, 40, 2, '8,1'),
+                                                     ('CC11xx', 17, 64, 0, None), ('CC11xx', 17, 64, 0, '8,1'), ('bench_GMSK', 15, 9, 1, '5,2')])
+def test_the_shift_on_the_filters_side_equals_the_shift_on_the_samples(tmp_path, name, log2N, D, Doff, rect):
     """Round 6's form of the segment search -- a segment transformed once for several bins, the Doppler shift on the filters' side
     (k_segf, seg_kernels.hpp) -- against the form of rounds 2-5 -- every (bin, segment) mixed in time and transformed (k_seg) -- on the
     same seeded block: two processes (MFB_SEG_FSM is read once per process), the same table to fp32 rounding, the same pick; 256-point
     segments (8 and 16 unique filters, with and without noise-reference rows, bins that do not fill a rectangle) and the wave-local
-    2048-point ones (CC11xx, 384 taps)."""
+    2048-point ones (CC11xx, 384 taps).  ``rect`` = MFB_SEG_FSM_RECT: a wave's rectangle of bins x slots; None = the library's own
+    choice, which for problems this small shrinks the rectangle to keep the launch wide (down to one bin: the forward transform is
+    then not shared, only the mixing multiply is gone)."""
     import os
     import subprocess
     import sys
@@ -291,10 +294,13 @@ def test_the_shift_on_the_filters_side_equals_the_shift_on_the_samples(tmp_path,
     for fsm in ('0', '1'):
         out = str(tmp_path / f'fsm{fsm}.npz')
         env = dict(os.environ, MFB_SEG_FSM=fsm)
+        env.pop('MFB_SEG_FSM_RECT', None)
+        if rect:
+            env['MFB_SEG_FSM_RECT'] = rect
         subprocess.run([sys.executable, child, name, str(log2N), str(D), str(Doff), out], check=True, env=env, timeout=300)
         res[fsm] = np.load(out)
     a, b = res['0'], res['1']
-    assert int(a['filter_side']) == 0 and int(b['filter_side']) == 1 and int(b['bins_per_forward']) >= 2
+    assert int(a['filter_side']) == 0 and int(b['filter_side']) == 1 and int(b['bins_per_forward']) >= (2 if rect else 1)
     assert int(a['log2L']) == int(b['log2L']) == (11 if name == 'CC11xx' else 8)
     sa, sb = a['scores'].astype(np.float64), b['scores'].astype(np.float64)
     assert sa.shape == sb.shape == (D + Doff, sa.shape[1])
