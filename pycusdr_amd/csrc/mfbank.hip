@@ -733,7 +733,13 @@ static int seg_valid(int l, int T) {
 // eight-wave team per CU, four passes): 4.67 ms at 2049 taps, 5.05 at 2050, 5.48 at 3000, 6.61 at 4097 -> 3.45 per point; in
 // these units the two-pass path costs 6.45 whatever the filter (6.5 ms), so the longest filters of the range stay there.
 static double seg_cost(int l, int T) {
-    static const double per_point[14] = {0, 0, 0, 0, 0, 0, 0, 0, 1.35, 1.94, 2.02, MFB_SEG_W32 ? 2.03 : 2.20, 2.55, 3.45};
+    // Round 6 (fused transforms, the shift on the filters' side for 256 and 2048 points; gpurun_out/r06_taps.txt: random banks at C2,
+    // lengths forced beside the chosen one): 256 points 1.49 ms at 64 taps, 1.74 at 96 -> 1.10; 2048 points 1.90 at 100 taps, 2.28 at 512,
+    // 2.68 at 768, 3.24 at 1025 -> 1.75 (1.62 ... 1.78: dead register slots are pruned as the valid share shrinks); 4096 points 2.98 at
+    // 768 taps, 3.53 at 1150 -> 2.43.  The 2048-point kernel now keeps 650 ... ~850 taps that went to 4096 points (2.68 against 2.98 ms
+    // at 768 taps); the hand-over from 256 points stays just under 100 taps (1.91 against 1.90 ms at 100).
+    static const double per_point[14] = {0, 0, 0, 0, 0, 0, 0, 0, MFB_FFT_FUSED ? 1.10 : 1.35, 1.94, 2.02,
+                                         MFB_SEG_W32 ? (MFB_FFT_FUSED ? 1.75 : 2.03) : 2.20, MFB_FFT_FUSED ? 2.43 : 2.55, 3.45};
     const int V = seg_valid(l, T);
     if (!V) return 1e30;
     return per_point[l] * (double)(1 << l) / (double)V;
