@@ -477,11 +477,11 @@ int mfb_sync(mfb_ctx *ctx);
 /* A host copy worker for the receive loop: the reference's loop copies every chunk of samples twice on its one thread, into the
  * ring buffer (sigFIFO.py:62-84) and from there into the page-locked input buffer (`raw[ov:] = sigIn.getBlock()`, DP:287,337).
  * Here a chunk is copied once, into the sample window of its batch (mfb_window_buffer) -- and with this worker that copy runs on a
- * threads of its own (two by default, MFB_HOSTCOPY_THREADS in the environment: one thread's memcpy rate, ~11 GB/s, was what bounded the
- * batched loop) while the caller's thread does the host stages of the previous batch.  No GPU involved (plain memory; usable before
- * any handle exists).  mfb_hostcopy_submit returns at once; the copies submitted between two drains run in ANY order, so their
- * destinations must not overlap (the chunks of a window do not); source and destination must stay valid and untouched until
- * mfb_hostcopy_drain has returned.  One submitting thread per worker object. */
+ * thread of its own while the caller's thread does the host stages of the previous batch.  No GPU involved (plain memory; usable
+ * before any handle exists).  mfb_hostcopy_submit returns at once; copies run in submission order; source and destination must
+ * stay valid and untouched until mfb_hostcopy_drain has returned.  One submitting thread per worker.  (Round 6 tried two and three
+ * worker threads: no gain -- 1363 ... 1432 Msamples/s with one, 1360 ... 1419 with two, 1248 ... 1346 with three at 2^15 x 64 x 32 blocks
+ * per call --, the loop is bound by its own thread, not by the copies.) */
 typedef struct mfb_hostcopy mfb_hostcopy;
 int mfb_hostcopy_create(mfb_hostcopy **out);
 int mfb_hostcopy_submit(mfb_hostcopy *q, void *dst, const void *src, size_t bytes);

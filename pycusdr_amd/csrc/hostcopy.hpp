@@ -1,7 +1,6 @@
 // hostcopy.hpp -- the host copy worker behind mfb_hostcopy_* (include/mfbank.h).  Plain C++17, no GPU: also compiled on its own under
 // ThreadSanitizer / AddressSanitizer (tests/csrc/hostcopy_sanitize.cpp).
 #pragma once
-#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -9,10 +8,9 @@
 #include <deque>
 #include <mutex>
 #include <thread>
-#include <vector>
 
-// One queue, a couple of threads: the receive loop hands them the chunk -> window copies of the next batch and runs the host stages of
-// the previous batch meanwhile.  The worker spins for a few microseconds before it sleeps (chunks arrive in bursts; a futex wake costs
+// One thread, one queue: the receive loop hands it the chunk -> window copies of the next batch and runs the host stages of the
+// previous batch meanwhile.  The worker spins for a few microseconds before it sleeps (chunks arrive in bursts; a futex wake costs
 // more than a 128 KiB copy).
 // a polite spin: the x86 pause, the aarch64 yield, a compiler barrier anywhere else
 static inline void mfb_cpu_relax() {
@@ -36,10 +34,7 @@ struct mfb_hostcopy {
     std::deque<Job> jobs;
     std::atomic<long long> submitted{0}, done{0};
     bool stop = false;
-    // Two workers by default (MFB_HOSTCOPY_THREADS in the environment: 1 ... 8): the jobs are independent copies into disjoint
-    // destinations, and ONE thread's memcpy rate (~11 GB/s from pageable into page-locked memory) turned out to be what bounded the
-    // batched receive loop at the reference's block sizes -- 8 MiB of samples per window of 32 blocks in 0.73 ms (profiles/r06_chain.md)
-    std::vector<std::thread> workers;
+    std::thread worker;
 
     void run() {
         for (;;) {
@@ -66,13 +61,9 @@ struct mfb_hostcopy {
         }
     }
     bool start() {
-        int n = 2;
-        if (const char *e = getenv("MFB_HOSTCOPY_THREADS")) n = atoi(e);
-        n = n < 1 ? 1 : (n > 8 ? 8 : n);
         try {
-            for (int i = 0; i < n; ++i) workers.emplace_back([this] { run(); });
+            worker = std::thread([this] { run(); });
         } catch (...) {
-            shutdown();
             return false;
         }
         return true;
@@ -98,9 +89,7 @@ struct mfb_hostcopy {
             stop = true;
         }
         cv_work.notify_all();
-        for (auto &w : workers)
-            if (w.joinable()) w.join();
-        workers.clear();
+        if (worker.joinable()) worker.join();
     }
 };
 

@@ -19,26 +19,16 @@ static int one_worker(unsigned seed, int bursts) {
         return (s >> 8) % n;
     };
     int bad = 0;
-    size_t cur = 0;                            // between two drains the destinations are DISJOINT (the contract: the workers -- two by
-                                               // default -- take the jobs in any order), as the receive loop's chunk copies are
     for (int b = 0; b < bursts; ++b) {
         const int jobs = 1 + (int)rnd(40);
         for (int j = 0; j < jobs; ++j) {
-            const size_t n = 1 + rnd(20000), from = rnd((unsigned)(src.size() - n));
-            if (cur + n > dst.size()) {
-                q.drain();
-                for (size_t i = 0; i < dst.size(); i += 97) bad += dst[i] != want[i];
-                cur = 0;
-            }
-            const size_t at = cur;
-            cur += n;
+            const size_t n = 1 + rnd(20000), at = rnd((unsigned)(dst.size() - n)), from = rnd((unsigned)(src.size() - n));
             q.submit(dst.data() + at, src.data() + from, n * sizeof(float));
-            for (size_t i = 0; i < n; ++i) want[at + i] = src[from + i];
+            for (size_t i = 0; i < n; ++i) want[at + i] = src[from + i];      // submission order: later copies win
         }
         if (b % 3 != 2) {                      // (every third burst runs into the next one without a drain)
             q.drain();
             for (size_t i = 0; i < dst.size(); i += 97) bad += dst[i] != want[i];
-            cur = 0;
         }
     }
     q.shutdown();                              // finishes what was submitted

@@ -10,7 +10,7 @@ from pycusdr_amd import _lib
 from pycusdr_amd.mfbank import HostCopy
 
 
-def test_copies_complete_at_drain():
+def test_copies_arrive_in_order_and_complete_at_drain():
     rs = np.random.RandomState(0)
     hc = HostCopy()
     try:
@@ -24,9 +24,7 @@ def test_copies_complete_at_drain():
                 hc.submit(dst, pos, src)
                 want[pos:pos + n] = src
                 pos += n
-            # copies submitted between two drains may run in any order (two worker threads): an overlapping destination goes behind
-            # a drain of its own
-            hc.drain()
+            # overlapping destinations: the later copy wins (submission order)
             late = np.full(1000, rep + 2j, np.complex64)
             hc.submit(dst, 500, late)
             want[500:1500] = late
