@@ -977,8 +977,10 @@ extern "C" int mfb_set_shifts(mfb_ctx *c, const int32_t *shifts, int count) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c->d_shifts, shifts, (size_t)count * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(sync_streams(c));
+    // (a caller that sets the same table again -- a tracking loop, a re-attached shard -- keeps the per-bin spectra: 35 ms at C2)
+    const bool same = (int)c->h_shifts.size() == count && std::equal(shifts, shifts + count, c->h_shifts.begin());
     c->h_shifts.assign(shifts, shifts + count);
-    c->gs_rows = 0;               // the per-bin spectra belong to the old table
+    if (!same) c->gs_rows = 0;    // the per-bin spectra belong to the old table
     c->have_shifts = true;
     ++c->epoch;
     return fsm_prepare_eager(c);
