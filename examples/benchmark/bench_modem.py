@@ -138,7 +138,9 @@ def main():
     ap.add_argument('--doppler-bins', type=int, default=64)
     ap.add_argument('--pipelined', action='store_true', help='source, demodulator and decoder as three threads (the reference: three processes)')
     ap.add_argument('--search', choices=['transforms', 'energy'], default='transforms')
-    ap.add_argument('--blocks-per-call', type=int, default=1, help='consecutive blocks handed to the device per call')
+    ap.add_argument('--blocks-per-call', type=lambda v: None if v == 'auto' else int(v), default=None,
+                    help="consecutive blocks handed to the device per call: a number (1 = the reference's one block per turn), or "
+                         "'auto' (default): whatever the source has ready")
     ap.add_argument('--out', default=None, help='write the table as JSON')
     a = ap.parse_args()
     # the noise generator's np.linalg.norm wakes one BLAS worker per core; under a container's CPU quota their spinning gets the

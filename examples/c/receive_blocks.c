@@ -81,6 +81,9 @@ int main(void) {
 
     /* the stream, written straight into the window the device reads: ONE copy per sample, the overlap is shared storage */
     float *win = NULL, *win2 = NULL;
+    /* a C caller is not bound by per-block host work: run a batch as two parts on two streams, so that the NEXT batch's search would
+     * run beside this batch's matched filters, rate estimate, centres and alignment (same records, bit for bit; include/mfbank.h) */
+    CHECK(mfb_set_batch_overlap(h, 1));
     CHECK(mfb_window_buffer(h, 0, B, STRIDE, &win));
     CHECK(mfb_window_buffer(h, 1, B, STRIDE, &win2));
     unsigned char *sent = (unsigned char *)malloc(nsym);
