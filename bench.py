@@ -208,16 +208,23 @@ def c5_concurrent_figures(seconds=2.0, D=512):
         procs = [subprocess.Popen([sys.executable, child, n, str(D), str(seconds)] + ([str(i), str(len(names))] if shared else []),
                                   stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd=ROOT)
                  for i, n in enumerate(names)]
+        import select
+
+        def line_of(p, timeout_s):
+            # (a child that hangs must cost this leg its figures, not the bench its line)
+            if not select.select([p.stdout], [], [], timeout_s)[0]:
+                raise RuntimeError(f'c5 child silent for {timeout_s} s')
+            return p.stdout.readline()
         try:
             for p in procs:
-                line = p.stdout.readline()
+                line = line_of(p, 90.0)
                 if line.strip() != 'ready':
                     raise RuntimeError(f'c5 child said {line!r}')
             t_go = time.time() + 0.4
             for p in procs:
                 p.stdin.write(f'go {t_go}\n')
                 p.stdin.flush()
-            outs = [json.loads(p.stdout.readline()) for p in procs]
+            outs = [json.loads(line_of(p, 30.0 + seconds)) for p in procs]
             for p in procs:
                 p.wait(timeout=60)
             return outs
