@@ -615,14 +615,22 @@ constexpr int ct_count(int levels) { return 1 << (levels - 1); }
 // q < LIVE are wanted.
 // slot of the u-th butterfly's first input in a stage that pairs a with a + off: u with a zero bit inserted at off
 constexpr int bf_slot(int u, int off) { return (u / off) * 2 * off + (u % off); }
-template <int LEVELS, int LIVE, bool LANE_TW, int S0 = 1, int NTW>
+// Is the value that slot `slot` holds AFTER stage s wanted, when only the outputs q in [lo, hi) are?  After the last stage the slot
+// holds output brevc(slot); a value of an earlier stage is wanted when one of the two outputs of its next butterfly is.
+constexpr bool dit_need(int levels, int s, int slot, int lo, int hi) {
+    if (s >= levels) return brevc(slot, levels) >= lo && brevc(slot, levels) < hi;
+    const int off = (1 << levels) >> (s + 1);
+    return dit_need(levels, s + 1, slot, lo, hi) || dit_need(levels, s + 1, slot ^ off, lo, hi);
+}
+// Only the outputs q in [LO, HI) are wanted: every butterfly half that feeds none of them is left out (round 6: LO > 0 is the
+// "complement" form of the search -- the energy of the INVALID outputs of a segment, seg_kernels.hpp segf_body).
+template <int LEVELS, int LO, int HI, bool LANE_TW, int S0 = 1, int NTW>
 DEVI void dit_fused(cf (&v)[1 << LEVELS], const cf (&twr)[NTW]) {
     constexpr int n = 1 << LEVELS;
     sfor<S0, LEVELS + 1>([&](auto s_) {
         constexpr int s = decltype(s_)::value;
         constexpr int off = n >> s;
         constexpr int half = ct_half(s);
-        constexpr bool last = s == LEVELS;
         // butterflies u = 2k, 2k + 1 share their twiddle pair: the same q in every stage but the last, q and q + half -- a
         // rotation by i -- in the last
         sfor<0, n / 4>([&](auto k_) {
@@ -632,8 +640,8 @@ DEVI void dit_fused(cf (&v)[1 << LEVELS], const cf (&twr)[NTW]) {
             constexpr bool rota = s >= 2 && qa >= half, rotc = s >= 2 && qc >= half;
             constexpr int qb = rota ? qa - half : qa;
             static_assert(qb == (rotc ? qc - half : qc), "a pair shares its twiddle");
-            constexpr bool nxa = !last || qa < LIVE, nya = !last || (qa + n / 2) < LIVE;
-            constexpr bool nxc = !last || qc < LIVE, nyc = !last || (qc + n / 2) < LIVE;
+            constexpr bool nxa = dit_need(LEVELS, s, a, LO, HI), nya = dit_need(LEVELS, s, a + off, LO, HI);
+            constexpr bool nxc = dit_need(LEVELS, s, c, LO, HI), nyc = dit_need(LEVELS, s, c + off, LO, HI);
             auto one = [&](auto slot_, auto rot_, auto nx_, auto ny_) {
                 constexpr int sl = decltype(slot_)::value;
                 constexpr bool rot = decltype(rot_)::value, nx = decltype(nx_)::value, ny = decltype(ny_)::value;
@@ -678,11 +686,11 @@ struct F256Regs {
 DEVI void f256_setup(F256Regs &r, const cf *__restrict__ table, const int g) {
     sfor<0, 8>([&](auto k) { r.ct[decltype(k)::value] = table[g * 8 + decltype(k)::value]; });
 }
-template <int LIVE, class Store>
+template <int LO, int HI, class Store>
 DEVI void fft256_fused(cf (&v)[16], cf *buf, const int g, const F256Regs &r, Store &store) {
 #if MFB_FUSED_FIRST
     const cf none[1] = {mkc(0.f, 0.f)};
-    dit_fused<4, 16, false>(v, none);
+    dit_fused<4, 0, 16, false>(v, none);
     {
         cf *wr = buf + g;
         sfor<0, 16>([&](auto p) { wr[decltype(p)::value * 17] = v[brevc(decltype(p)::value, 4)]; });      // padi(16 p + g)
@@ -700,7 +708,7 @@ DEVI void fft256_fused(cf (&v)[16], cf *buf, const int g, const F256Regs &r, Sto
         sfor<0, 16>([&](auto i) { v[decltype(i)::value] = rd[decltype(i)::value]; });
     }
     xsync<1>();
-    dit_fused<4, LIVE, true>(v, r.ct);
+    dit_fused<4, LO, HI, true>(v, r.ct);
     sfor<0, 16>([&](auto q) {
         constexpr int Q = decltype(q)::value;
         store(16 * Q + g, v[brevc(Q, 4)], std::integral_constant<int, Q>{}, std::integral_constant<int, 16 * Q>{});
@@ -727,11 +735,11 @@ DEVI void f2048_setup(F2048Regs &r, const cf *__restrict__ table, const int lane
 #ifndef MFB_F2048_DEPTH
 #define MFB_F2048_DEPTH 4
 #endif
-template <int LIVE, class Store>
+template <int LO, int HI, class Store>
 DEVI void fft_w32_fused(cf (&v)[32], cf *xbuf, const int lane, const F2048Regs &r, Store &store) {
 #if MFB_FUSED_FIRST
     const cf none[1] = {mkc(0.f, 0.f)};
-    dit_fused<5, 32, false>(v, none);
+    dit_fused<5, 0, 32, false>(v, none);
     {
         cf *wr = xbuf + lane;
         sfor<0, 32>([&](auto p) { wr[decltype(p)::value * W32Cfg::ROW] = v[brevc(decltype(p)::value, 5)]; });
@@ -773,7 +781,7 @@ DEVI void fft_w32_fused(cf (&v)[32], cf *xbuf, const int lane, const F2048Regs &
         });
     }
     xsync<1>();      // the rows are rewritten by the next transform of this wave
-    dit_fused<5, LIVE, true, 2>(v, r.ct);
+    dit_fused<5, LO, HI, true, 2>(v, r.ct);
     sfor<0, 32>([&](auto m) {
         constexpr int M = decltype(m)::value;
         store(64 * M + ((lane >> 1) + 32 * (lane & 1)), v[brevc(M, 5)], std::integral_constant<int, M>{}, std::integral_constant<int, 64 * M>{});

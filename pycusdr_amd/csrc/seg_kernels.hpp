@@ -93,6 +93,10 @@ constexpr int seg_block_threads(int NT) { return NT <= 64 ? MFB_SEG_BLOCK : (NT 
 // half of the next filter's spectrum fetched during the running transform of the fused 2048-point kernel: measured 1 % SLOWER on
 // the 384-tap bank (2.353 against 2.332 ms, three interleaved runs; profiles/r06_fft_ops.md) -- as in round 4, the spectrum loads
 // cost bandwidth and registers, not latency.  Off.
+// valid energy = total energy (Parseval on the product) - energy of the invalid outputs (segf_body): 1 on, 0 = every valid output
+#ifndef MFB_SEG_COMPLEMENT
+#define MFB_SEG_COMPLEMENT 1
+#endif
 #ifndef MFB_SEG_PREHALF
 #define MFB_SEG_PREHALF 0
 #endif
@@ -238,8 +242,8 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
     // `live` register slots are wanted (the fused transforms skip the dead halves of their last butterflies)
     auto transform = [&](cf (&vv)[PPL], auto &store, auto live) {
         constexpr int LIVE = decltype(live)::value;
-        if constexpr (F256) fft256_fused<LIVE>(vv, mylds, g, f256, store);
-        else if constexpr (F2048) fft_w32_fused<LIVE>(vv, mylds, lane, f2048, store);
+        if constexpr (F256) fft256_fused<0, LIVE>(vv, mylds, g, f256, store);
+        else if constexpr (F2048) fft_w32_fused<0, LIVE>(vv, mylds, lane, f2048, store);
         else if constexpr (W32) fft_w32(vv, mylds, lane, w32, store);
         else fft_passes<L, 1, 0, true, Cfg::PP, Cfg::HALF, SYNC>(vv, mylds, ebuf, g, 0, twr, a.twL, store);
     };
@@ -579,11 +583,18 @@ DEVI void segf_body(const SegFArgs &a, const int blk) {
     [[maybe_unused]] F2048Regs f2048;
     if constexpr (W32) f2048_setup(f2048, a.twL + L, lane);
     else f256_setup(f256, a.twL + L, g);
-    auto transform = [&](cf (&vv)[PPL], auto &store, auto live) {
-        constexpr int LIVE = decltype(live)::value;
-        if constexpr (W32) fft_w32_fused<LIVE>(vv, mylds, lane, f2048, store);
-        else fft256_fused<LIVE>(vv, mylds, g, f256, store);
+    auto transform = [&](cf (&vv)[PPL], auto &store, auto lo, auto hi) {          // only the outputs of register slots [lo, hi) are wanted
+        constexpr int LO = decltype(lo)::value, HI = decltype(hi)::value;
+        if constexpr (W32) fft_w32_fused<LO, HI>(vv, mylds, lane, f2048, store);
+        else fft256_fused<LO, HI>(vv, mylds, g, f256, store);
     };
+    // The energy of the VALID outputs of a segment as the energy of ALL its outputs minus that of the invalid ones: sum_{i < L} |v[i]|^2
+    // = L sum_k |W[k]|^2 (Parseval; W = the product the inverse transform starts from: PPL packed FMAs per lane, no transform), and the
+    // invalid outputs -- register slots PV ... PPL - 1 of every lane -- are few: with 13 of 16 slots valid the second pass computes 3
+    // outputs per lane instead of 13 (62 instead of 93 packed operations, 3 instead of 13 for the squares, 16 for Parseval: 81
+    // instead of 106 per filter; 210 instead of 260 in the 2048-point form at 26 of 32).  Worth it from 11 (22) valid slots up.
+    // Same number to fp32 rounding: the difference is 4/5 of the minuend, nothing cancels (profiles/r06_fft_ops.md section 4).
+    constexpr bool COMPL = MFB_SEG_COMPLEMENT && PV < PPL && (W32 ? PV >= 22 : PV >= 11);
 
     // ---- this wave's rectangle ----
     const int grp = blk % a.nsg;
@@ -645,7 +656,7 @@ DEVI void segf_body(const SegFArgs &a, const int blk) {
         cf A[PPL];                                         // A[k] = i conj(U[g + NT k])
         {
             auto keep = [&](int, cf val, auto, auto nu) { A[decltype(nu)::value / NT] = val; };
-            transform(v, keep, all_live);
+            transform(v, keep, std::integral_constant<int, 0>{}, all_live);
         }
         for (int jb = jb0; jb < jb1; ++jb) {
             for (int mi = 0; mi < MU; ++mi) {
@@ -667,13 +678,27 @@ DEVI void segf_body(const SegFArgs &a, const int blk) {
                     }
                 }
                 cf racc[4] = {mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f)};
-                auto acc = [&](int, cf val, auto, auto nu) {
-                    constexpr int k = decltype(nu)::value / NT;
-                    if constexpr (k < PV) racc[k & 3] = __builtin_elementwise_fma(val, val, racc[k & 3]);
-                };
-                transform(w, acc, sum_live);
-                const cf rsum = (racc[0] + racc[1]) + (racc[2] + racc[3]);
-                lacc[mi * SEG_ACC_STRIDE + lane] = rsum.x + rsum.y;
+                if constexpr (COMPL) {
+                    cf pacc[4] = {mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f)};
+#pragma unroll
+                    for (int i = 0; i < PPL; ++i) pacc[i & 3] = __builtin_elementwise_fma(w[i], w[i], pacc[i & 3]);
+                    auto acc = [&](int, cf val, auto, auto nu) {
+                        constexpr int k = decltype(nu)::value / NT;
+                        if constexpr (k >= PV) racc[k & 3] = __builtin_elementwise_fma(val, val, racc[k & 3]);
+                    };
+                    transform(w, acc, sum_live, all_live);                 // slots [PV, PPL): the invalid outputs
+                    const cf all = (pacc[0] + pacc[1]) + (pacc[2] + pacc[3]);
+                    const cf inv = (racc[0] + racc[1]) + (racc[2] + racc[3]);
+                    lacc[mi * SEG_ACC_STRIDE + lane] = __builtin_fmaf((float)L, all.x + all.y, -(inv.x + inv.y));
+                } else {
+                    auto acc = [&](int, cf val, auto, auto nu) {
+                        constexpr int k = decltype(nu)::value / NT;
+                        if constexpr (k < PV) racc[k & 3] = __builtin_elementwise_fma(val, val, racc[k & 3]);
+                    };
+                    transform(w, acc, std::integral_constant<int, 0>{}, sum_live);
+                    const cf rsum = (racc[0] + racc[1]) + (racc[2] + racc[3]);
+                    lacc[mi * SEG_ACC_STRIDE + lane] = rsum.x + rsum.y;
+                }
             }
             // the wave's lanes in seg_body's fixed order: lane (f, j) adds elements j, j + 4, ... of filter f's row, two quad steps
             xsync<1>();
