@@ -732,17 +732,25 @@ static int seg_valid(int l, int T) {
 // 2.51 against 2.72 ms on one device for the 384-tap bank (profiles/r04_long_filter.md), hence 2.20 -> 2.03.  8192 points (one
 // eight-wave team per CU, four passes): 4.67 ms at 2049 taps, 5.05 at 2050, 5.48 at 3000, 6.61 at 4097 -> 3.45 per point; in
 // these units the two-pass path costs 6.45 whatever the filter (6.5 ms), so the longest filters of the range stay there.
-static double seg_cost(int l, int T) {
+static double seg_cost(int l, int T, int MU = 8) {
     // Round 6 (fused transforms, the shift on the filters' side for 256 and 2048 points; gpurun_out/r06_taps.txt: random banks at C2,
     // lengths forced beside the chosen one): 256 points 1.49 ms at 64 taps, 1.74 at 96 -> 1.10; 2048 points 1.90 at 100 taps, 2.28 at 512,
     // 2.68 at 768, 3.24 at 1025 -> 1.75 (1.62 ... 1.78: dead register slots are pruned as the valid share shrinks); 4096 points 2.98 at
     // 768 taps, 3.53 at 1150 -> 2.43.  The 2048-point kernel now keeps 650 ... ~850 taps that went to 4096 points (2.68 against 2.98 ms
     // at 768 taps); the hand-over from 256 points stays just under 100 taps (1.91 against 1.90 ms at 100).
-    static const double per_point[14] = {0, 0, 0, 0, 0, 0, 0, 0, MFB_FFT_FUSED ? 1.10 : 1.35, 1.94, 2.02,
-                                         MFB_SEG_W32 ? (MFB_FFT_FUSED ? 1.75 : 2.03) : 2.20, MFB_FFT_FUSED ? 2.43 : 2.55, 3.45};
+    // ... and once more with the complement second pass (gpurun_out/r06_taps2.txt), whose cost falls with the share of valid slots:
+    // 256 points 1.28 ms at 48 taps, 1.44 at 64, 1.60 at 80, 1.75 at 88 / 96 (10 valid slots: no complement) -> 1.08; 2048 points 1.45 ms
+    // at 64 taps, 1.60 at 72 ... 100, 2.45 at 640, 2.69 at 768, 3.16 at 900 -> 1.60.  The hand-over from 256 to 2048 points moves from
+    // just under 100 taps to 81 (1.75 against 1.60 ms at 88 and 96 taps; a tie at 64 ... 80), 2048 points keep everything up to 1025.
+    static const double per_point[14] = {0, 0, 0, 0, 0, 0, 0, 0, MFB_FFT_FUSED ? (MFB_SEG_COMPLEMENT ? 1.08 : 1.10) : 1.35, 1.94, 2.02,
+                                         MFB_SEG_W32 ? (MFB_FFT_FUSED ? (MFB_SEG_COMPLEMENT ? 1.60 : 1.75) : 2.03) : 2.20,
+                                         MFB_FFT_FUSED ? 2.43 : 2.55, 3.45};
     const int V = seg_valid(l, T);
     if (!V) return 1e30;
-    return per_point[l] * (double)(1 << l) / (double)V;
+    // (the 2048-point kernel takes the filter-side shift and the complement pass for up to 8 filters per bin only: with more it runs
+    // round 6's fused transforms on seg_body -- 2.32 ms on the 384-tap bank, 1.89 per point)
+    const double pp = (l == 11 && MFB_SEG_W32 && MFB_FFT_FUSED && MU > 8) ? 1.89 : per_point[l];
+    return pp * (double)(1 << l) / (double)V;
 }
 
 static int choose_segl(const mfb_ctx *c, int T, bool may_decline) {
@@ -750,7 +758,7 @@ static int choose_segl(const mfb_ctx *c, int T, bool may_decline) {
     double bc = 1e30;
     for (int l = 8; l <= SEG_LOG2L_MAX; ++l) {
         if (!seg_valid(l, T) || (4 << l) > c->N) continue;    // at least half of every segment valid, >= 4 segments
-        const double cost = seg_cost(l, T);
+        const double cost = seg_cost(l, T, c->MU);
         if (cost < bc) {
             bc = cost;
             best = l;
