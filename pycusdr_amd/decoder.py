@@ -8,6 +8,7 @@ state machine around them is host logic, as in the reference.  ``correlator`` ma
 pin the host logic on CPU-only machines with the oracle's correlator); the default is the HIP path
 and raises if libmfbank.so is unavailable.
 """
+import functools
 import logging
 
 import numpy as np
@@ -56,7 +57,9 @@ class Decoder:
         self.device = _config_device(config) if device is None else int(device)
         # default: thresholded correlation on the GPU (positions + scores only come back); an injected
         # correlator returns the full np.convolve-style score array and is thresholded on the host
-        self.correlate = correlator if correlator is not None else (lambda b, t: _hip_correlator(b, t, device=self.device))
+        # (a partial, not a lambda over self: a decoder must not sit in a reference cycle -- its device-side finder, page-locked
+        # staging included, goes when the last reference does, not whenever the cycle collector next runs)
+        self.correlate = correlator if correlator is not None else functools.partial(_hip_correlator, device=self.device)
         self._finder = _hip_finder if correlator is None else None
         self._multi = None
         self._flight = None
@@ -94,6 +97,13 @@ class Decoder:
     def findFrames(self, bits_raw, frameStartIdx, debugMode=False):
         self.findFrames_begin(bits_raw, frameStartIdx)
         return self.findFrames_end()
+
+    def close(self):
+        """Release the device-side finder (stream, templates, page-locked staging) now; a later block creates it again."""
+        if self._multi is not None:
+            self._multi.close()
+            self._multi = None
+        self._flight = None
 
     def prepare(self):
         """Create the device-side finder now (page-locked staging, stream, templates on the device) instead of inside the

@@ -208,3 +208,28 @@ def test_findframes_batch_equals_call_by_call_flags_and_cc11xx():
         _packets_equal(pw, pg)
         assert nw == ng
     assert np.array_equal(np.asarray(a.bitsOverlapBuf), np.asarray(b.bitsOverlapBuf))
+
+
+def test_a_decoder_is_released_with_its_last_reference():
+    """A decoder owns device-side state (the sync finder: a stream, templates, page-locked staging).  It must not sit in a
+    reference cycle -- then that state would stay until the cycle collector next runs, and a process that creates receivers
+    in a loop grows (tools/leak_probe.py: +0.1 MiB of host memory per create / stream / close cycle before this)."""
+    import gc
+    import weakref
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        for correlator in (None, orc.correlate_convolve if hasattr(orc, 'correlate_convolve') else (lambda b, t: np.convolve(b, t))):
+            conf = cfg.bench_config()
+            d = Decoder(conf, loadProtocol('bench_GMSK')(conf=conf), correlator=correlator)
+            if correlator is not None:          # with host work behind it: blocks through the packet state machine
+                rs = np.random.RandomState(5)
+                for _ in range(3):
+                    d.findFrames(rs.randint(0, 2, 4000).astype(np.uint8), 0)
+            r = weakref.ref(d)
+            d.close()                            # explicit release is there too, and harmless without a finder
+            del d
+            assert r() is None
+    finally:
+        if was:
+            gc.enable()

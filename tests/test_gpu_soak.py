@@ -23,6 +23,9 @@ def test_receive_chain_soak_is_flat():
     # margins: half a MiB of device memory, one MiB of RSS and half a descriptor per cycle over the second half of the cycles;
     # 8 MiB of device memory and no descriptor over the long stream
     assert abs(out['device_mib_per_cycle']) < 0.5 and out['rss_mib_per_cycle'] < 1.0 and out['fds_per_cycle'] < 0.5, report
+    # ... and in total over that half no more than one 2 MiB granule of device memory and 10 MiB of RSS (0.03 MiB and 0.16 MiB per
+    # cycle -- decoders waiting for the cycle collector with their finders -- passed the per-cycle margins for five rounds)
+    assert out['device_mib_second_half'] < 2.5 and out['rss_mib_second_half'] < 10.0, report
     assert out['long_blocks'] == 2000 and out['long_packets'] > 0, report
     # (one-sided: the allocator handing an 8 MiB granule BACK during the stream is not growth)
     assert -64 < out['long_device_mib'] < 8.5 and out['long_fds'] == 0 and out['long_rss_mib'] < 64, report

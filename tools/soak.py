@@ -113,7 +113,7 @@ def soak(cycles=40, per=30, long_blocks=4000, budget_s=None, min_cycles=12, log=
     same = len(resB) == len(res) and len(pkB) == len(pk) and all(np.array_equal(x['data'], y['data']) for x, y in zip(res[::97], resB[::97]))
     out = {'batched_blocks': len(resB), 'batched_packets': len(pkB), 'batched_device_mib': aB[0] - bB[0], 'batched_fds': bB[2] - aB[2],
            'batched_rss_mib': bB[1] - aB[1], 'batched_equals_one_block_loop': bool(same), 'batched_msamples': len(resB) * step / dtB / 1e6,
-           'cycles': done, 'device_mib_per_cycle': d_dev, 'rss_mib_per_cycle': d_rss, 'fds_per_cycle': d_fd,
+           'cycles': done, 'device_mib_second_half': mid[1] - last[1], 'rss_mib_second_half': last[2] - mid[2], 'device_mib_per_cycle': d_dev, 'rss_mib_per_cycle': d_rss, 'fds_per_cycle': d_fd,
            'long_blocks': len(res), 'long_packets': len(pk), 'long_device_mib': a[0] - b[0], 'long_rss_mib': b[1] - a[1],
            'long_fds': b[2] - a[2], 'long_msamples': len(res) * step / dt / 1e6}
     # (device figures one-sided: the allocator handing a granule back during a stream is not growth)
