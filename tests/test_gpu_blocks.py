@@ -657,10 +657,31 @@ def test_c_entry_points_of_the_batch_path_refuse_bad_arguments():
         assert lib.mfb_stream_seed(h, None, 4, None, 0, None, 0) == ARG            # a length without an array
         assert lib.mfb_stream_seed(h, None, 0, None, 0, None, 0) == 0
         assert lib.mfb_set_stream_stages(h, None) == 0                            # off again
+        # the entry points of round 6 (ABI 9): the scores of a batch's blocks, the two-stream arrangement, the search's description
+        sc = np.empty(d.num_dopplers * 8 + 64, np.float32)
+        fs_, bpf = C.c_int(-1), C.c_int(-1)
+        assert lib.mfb_get_batch_scores(h, 0, sc.ctypes.data) == STATE           # no batch yet
+        assert lib.mfb_get_batch_scores(h, -1, sc.ctypes.data) == ARG
+        assert lib.mfb_get_batch_scores(h, 0, None) == ARG and lib.mfb_get_batch_scores(None, 0, sc.ctypes.data) == ARG
+        for on in (-1, 2):
+            assert lib.mfb_set_batch_overlap(h, on) == ARG
+        assert lib.mfb_set_batch_overlap(None, 1) == ARG
+        assert lib.mfb_get_search_info(h, None, C.byref(bpf)) == ARG and lib.mfb_get_search_info(h, C.byref(fs_), None) == ARG
+        assert lib.mfb_get_search_info(None, C.byref(fs_), C.byref(bpf)) == ARG
+        assert lib.mfb_get_search_info(h, C.byref(fs_), C.byref(bpf)) == 0 and fs_.value in (0, 1) and bpf.value >= 1
         # the handle still works
         d.beginBlocks(0, 3)
+        assert lib.mfb_set_batch_overlap(h, 1) == STATE                           # a batch is in flight
         got = d.endBlocks(0)
         assert len(got) == 3 and all(len(r['symbols']) > 200 for _, r in got)
+        assert lib.mfb_get_batch_scores(h, 3, sc.ctypes.data) == STATE           # the batch had three blocks
+        assert lib.mfb_get_batch_scores(h, 2, sc.ctypes.data) == 0
+        # ... and on two streams, switched while nothing is in flight: the same three blocks
+        assert lib.mfb_set_batch_overlap(h, 1) == 0
+        d.beginBlocks(0, 3)
+        again = d.endBlocks(0)
+        assert all(_same(a[1]['symbols'], b[1]['symbols']) for a, b in zip(got, again))
+        assert lib.mfb_set_batch_overlap(h, 0) == 0
     finally:
         d.close()
 
