@@ -93,6 +93,10 @@ constexpr int seg_block_threads(int NT) { return NT <= 64 ? MFB_SEG_BLOCK : (NT 
 // half of the next filter's spectrum fetched during the running transform of the fused 2048-point kernel: measured 1 % SLOWER on
 // the 384-tap bank (2.353 against 2.332 ms, three interleaved runs; profiles/r06_fft_ops.md) -- as in round 4, the spectrum loads
 // cost bandwidth and registers, not latency.  Off.
+// measurement only, never shipped on: every (bin, filter) of k_segf<256> reads the spectra of row 0 (profiles/r06_fft_ops.md section 6)
+#ifndef MFB_SEG_FSM_PROBE_ONE_ROW
+#define MFB_SEG_FSM_PROBE_ONE_ROW 0
+#endif
 // valid energy = total energy (Parseval on the product) - energy of the invalid outputs (segf_body): 1 on, 0 = every valid output
 #ifndef MFB_SEG_COMPLEMENT
 #define MFB_SEG_COMPLEMENT 1
@@ -623,6 +627,9 @@ DEVI void segf_body(const SegFArgs &a, const int blk) {
     // fetches inside the product)
     constexpr bool PREFETCH = !W32;
     [[maybe_unused]] auto load_g = [&](cf (&dst)[PPL], int row) {
+#if MFB_SEG_FSM_PROBE_ONE_ROW        // measurement only (wrong scores): every (bin, filter) reads row 0 -- what the L2 reads of Gs cost
+        row = 0;
+#endif
 #pragma unroll
         for (int ii = 0; ii < PPL / 2; ++ii) buf_load_cf2(gr, vo_g2, row * (L * (int)sizeof(cf)) + ii * so_g2, dst[2 * ii], dst[2 * ii + 1]);
     };
