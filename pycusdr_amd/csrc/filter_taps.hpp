@@ -103,6 +103,25 @@ static inline bool window_of(const std::vector<uint8_t> &mark, int N, int *start
     return true;
 }
 
+// work(t) for stripes t = 0 ... n - 1, one host thread each beside the caller's (stripe 0).  A thread that cannot be created (a process
+// at its thread limit) is not an error: its stripe runs on the caller's thread -- nothing is thrown across the C ABI for it.
+template <class Work>
+static inline void run_striped(int n, Work &&work) {
+    std::vector<std::thread> th;
+    int started = 0;
+    try {
+        th.reserve((size_t)(n > 1 ? n - 1 : 0));
+        for (int t = 1; t < n; ++t) {
+            th.emplace_back(work, t);
+            ++started;
+        }
+    } catch (...) {
+    }
+    work(0);
+    for (int t = started + 1; t < n; ++t) work(t);
+    for (auto &x : th) x.join();
+}
+
 static inline void analyse_row(const Fft &plan, const float *H, int N, RowTaps *out, std::vector<cd> &buf,
                                std::vector<uint8_t> &mark) {
     buf.resize(N);
@@ -145,13 +164,7 @@ static inline void analyse(const float *masks, int M, int N, Bank *bank) {
         std::vector<uint8_t> mark;
         for (int m = t; m < M; m += nthr) analyse_row(plan, masks + (size_t)m * 2 * N, N, &bank->rows[m], buf, mark);
     };
-    if (nthr == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nthr; ++t) th.emplace_back(work, t);
-        for (auto &x : th) x.join();
-    }
+    run_striped(nthr, work);
     // common window: union of the rows' windows
     std::vector<uint8_t> cover(N, 0);
     bool any = false, too_long = false;
@@ -252,13 +265,7 @@ static inline void segment_spectra_shifted(const Bank &b, const int *rows, int n
             }
         }
     };
-    if (nthr == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nthr; ++t) th.emplace_back(work, t);
-        for (auto &x : th) x.join();
-    }
+    run_striped(nthr, work);
 }
 
 // ---- span basis (opt-in, SUM_ALL_MASKS search only) ---------------------------------------------------------

@@ -138,12 +138,20 @@ def test_block_graph_follows_changes_of_shifts_filters_and_tuning():
     conf = cfg.bench_config('bench_GMSK', blockSize=bs, doppCarrierSteps=32)
     one, stages = _pair(conf, 'bench_GMSK')
     sig = sg.s1_stream(12, N, ov, 'GMSK', snr_db=10.0, seed=21)
+    from oracle import mfbank_oracle as orc
+    _, masks0 = loadProtocol('bench_GMSK')(conf=conf).get_filter(N, 16, 3)
+    cur = {'masks': masks0}
 
     def both(b):
         x = sig[b * (N - ov): b * (N - ov) + N]
         raw = one.get_signalBufferHostPointer()
         raw[:] = x
         ra, rb = one.uploadAndFindCarrier(raw), stages.uploadAndFindCarrier(x.copy())
+        # both calls run the same search kernel on the same per-bin spectra: a table left over from the old shifts or filters would
+        # pass the comparison below, so the scores are also held against the oracle's identity for the table and the bank in force
+        want = orc.doppler_scores_parseval(np.fft.fft(x.astype(np.complex128)), cur['masks'], np.asarray(one.doppCyperSymNorm))
+        got = one.bank.get_scores().astype(np.float64)[:, 0]
+        assert np.max(np.abs(got - want)) <= 1e-5 * np.max(want), (b, np.max(np.abs(got - want)) / np.max(want))
         da, db = one.demodulate(), stages.demodulate()
         assert _same([ra[0], ra[1], ra[3]], [rb[0], rb[1], rb[3]]) and int(one.dopplerIdxlast) == int(stages.dopplerIdxlast), b
         assert all(_same(u, v) for u, v in zip(da, db)), b
@@ -163,6 +171,7 @@ def test_block_graph_follows_changes_of_shifts_filters_and_tuning():
         _, masks = p2.get_filter(N, 16, 3)
         for d in (one, stages):
             d.bank.set_filters(masks)
+        cur['masks'] = masks
         [both(b) for b in range(10, 12)]
     finally:
         one.close()
