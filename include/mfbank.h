@@ -131,7 +131,10 @@ int mfb_set_search_mode(mfb_ctx *ctx, int mode);
 int mfb_get_search_mode(mfb_ctx *ctx, int *mode);
 /* Fault injection for tests: the nth device allocation made on behalf of a handle by the calling thread
  * from now on fails as if the device were out of memory (0 disarms).  Lets a test walk the free-on-error
- * path of mfb_create allocation by allocation.  No reference counterpart (teardown on error: __del__ DB:517-530). */
+ * path of mfb_create allocation by allocation.  nth < 0: the |nth|-th one raises std::bad_alloc inside the library instead -- what a
+ * failed HOST allocation in the filter analysis or the table builders looks like; no C++ exception leaves the library: mfb_create,
+ * mfb_set_filters, mfb_set_shifts, mfb_set_search_* and the mfb_analyze_* helpers return MFB_ERR_ALLOC for it, the handle (if any)
+ * stays destroyable and takes a new mfb_set_filters.  No reference counterpart (teardown on error: __del__ DB:517-530). */
 int mfb_debug_fail_alloc(int nth);
 /* Host-only helper (no device work): common circular support window [start, start+len) of the impulse
  * responses ifft(H_m) of a filter bank complex64 [M][N]; len == N when some filter has no short support.
@@ -157,8 +160,9 @@ int mfb_set_shifts(mfb_ctx *ctx, const int32_t *shifts, int count);
  * (overlap carry included).  Replaces pagelocked_empty(...DEVICEMAP) DB:456-457 /
  * get_signalBufferHostPointer DB:1055-1060. */
 int mfb_input_buffer(mfb_ctx *ctx, float **host_c64);
-/* Copy the pinned buffer to the device and run the forward FFT (unnormalised, sign -1).
- * Replaces uploadToGPU DB:548-558 (cufftExecC2C FORWARD). */
+/* Copy the pinned buffer to the device and run the forward FFT (unnormalised, sign -1).  MFB_ERR_STATE on a handle without the
+ * transforms' intermediate (an mfb_set_filters that failed while re-sizing it: set the filters again).  Replaces uploadToGPU
+ * DB:548-558 (cufftExecC2C FORWARD). */
 int mfb_upload(mfb_ctx *ctx);
 /* Same, from an arbitrary host array of N complex64 (pageable is fine; staged through the pinned
  * buffer): the copy into the page-locked buffer that the reference's caller does itself (DB:555-556 in comments,

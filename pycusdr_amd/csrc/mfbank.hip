@@ -220,15 +220,33 @@ static hipError_t sync_streams(mfb_ctx *c) {
 // (mfb_debug_fail_alloc): the only way to exercise the free-on-error path of mfb_create without driving
 // a 288 GB device out of memory.
 static thread_local int g_fail_alloc_countdown = 0;
+static thread_local int g_throw_alloc_countdown = 0;      // nth < 0: the |nth|-th allocation throws std::bad_alloc instead (see guarded)
 static hipError_t dev_alloc(void **p, size_t bytes) {
     if (g_fail_alloc_countdown > 0 && --g_fail_alloc_countdown == 0) {
         *p = nullptr;
         return hipErrorOutOfMemory;
     }
+    if (g_throw_alloc_countdown > 0 && --g_throw_alloc_countdown == 0) {
+        *p = nullptr;
+        throw std::bad_alloc();
+    }
     return hipMalloc(p, bytes);
+}
+// No C++ exception leaves the library: the entry points that do host-side preparation (filter analysis, segment spectra, tables:
+// std::vector, std::thread) run inside this; a failed host allocation is MFB_ERR_ALLOC like a failed device allocation.
+template <class F>
+static int guarded(F &&f) noexcept {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return MFB_ERR_ALLOC;
+    } catch (...) {
+        return MFB_ERR_STATE;
+    }
 }
 extern "C" int mfb_debug_fail_alloc(int nth) {
     g_fail_alloc_countdown = nth > 0 ? nth : 0;
+    g_throw_alloc_countdown = nth < 0 ? -nth : 0;
     return MFB_OK;
 }
 
@@ -507,8 +525,8 @@ static int create_impl(mfb_ctx *c) {
     return MFB_OK;
 }
 
-extern "C" int mfb_create(mfb_ctx **out, int device, int log2N, int num_dopplers, int doppler_offset, int M,
-                          int window_width, int sum_all_masks, int code_search_mask_offset) {
+static int create_body(mfb_ctx **out, int device, int log2N, int num_dopplers, int doppler_offset, int M,
+                       int window_width, int sum_all_masks, int code_search_mask_offset) {
     if (!out) return MFB_ERR_ARG;
     *out = nullptr;
     if (num_dopplers < 1 || doppler_offset < 0 || M < 1 || M > 64 || window_width < 1 || (window_width & 1) == 0 ||
@@ -560,13 +578,23 @@ extern "C" int mfb_create(mfb_ctx **out, int device, int log2N, int num_dopplers
 
     // any failure below frees what was allocated so far (mfb_destroy tolerates partial handles):
     // the counterpart of the reference's context teardown, demodulator_base.py:517-530
-    const int rc = create_impl(c);
+    int rc;
+    try {
+        rc = create_impl(c);
+    } catch (...) {
+        (void)mfb_destroy(c);
+        throw;
+    }
     if (rc) {
         (void)mfb_destroy(c);
         return rc;
     }
     *out = c;
     return MFB_OK;
+}
+extern "C" int mfb_create(mfb_ctx **out, int device, int log2N, int num_dopplers, int doppler_offset, int M,
+                          int window_width, int sum_all_masks, int code_search_mask_offset) {
+    return guarded([&] { return create_body(out, device, log2N, num_dopplers, doppler_offset, M, window_width, sum_all_masks, code_search_mask_offset); });
 }
 
 static void graph_drop(BlockGraph &g);
@@ -851,7 +879,7 @@ static int resolve_path(mfb_ctx *c) {
     return fsm_prepare_eager(c);
 }
 
-extern "C" int mfb_set_search_path(mfb_ctx *c, int path, int log2L, int wg_per_cu, int filters_per_pass) {
+static int set_search_path_body(mfb_ctx *c, int path, int log2L, int wg_per_cu, int filters_per_pass) {
     if (!c || path < 0 || path > MFB_PATH_SEGMENT || log2L < 0 || wg_per_cu < 0 || wg_per_cu > 64 || filters_per_pass < 0 ||
         filters_per_pass > SEG_MPB_MAX)
         return MFB_ERR_ARG;
@@ -872,19 +900,28 @@ extern "C" int mfb_set_search_path(mfb_ctx *c, int path, int log2L, int wg_per_c
     }
     return rc;
 }
+extern "C" int mfb_set_search_path(mfb_ctx *c, int path, int log2L, int wg_per_cu, int filters_per_pass) {
+    return guarded([&] { return set_search_path_body(c, path, log2L, wg_per_cu, filters_per_pass); });
+}
 
-extern "C" int mfb_set_search_basis(mfb_ctx *c, int basis) {
+static int set_search_basis_body(mfb_ctx *c, int basis) {
     if (!c || (basis != MFB_BASIS_FILTERS && basis != MFB_BASIS_SPAN)) return MFB_ERR_ARG;
     if (basis == MFB_BASIS_SPAN && !c->sum_all) return MFB_ERR_STATE;   // per-filter sums need every filter
     HIPCHK(hipSetDevice(c->device));
     c->basis_req = basis;
     return resolve_path(c);
 }
-extern "C" int mfb_set_search_mode(mfb_ctx *c, int mode) {
+extern "C" int mfb_set_search_basis(mfb_ctx *c, int basis) {
+    return guarded([&] { return set_search_basis_body(c, basis); });
+}
+static int set_search_mode_body(mfb_ctx *c, int mode) {
     if (!c || (mode != MFB_SEARCH_TRANSFORMS && mode != MFB_SEARCH_ENERGY)) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     c->search_mode = mode;
     return resolve_path(c);      // the two-pass intermediate is sized for what the search needs
+}
+extern "C" int mfb_set_search_mode(mfb_ctx *c, int mode) {
+    return guarded([&] { return set_search_mode_body(c, mode); });
 }
 extern "C" int mfb_get_search_mode(mfb_ctx *c, int *mode) {
     if (!c || !mode) return MFB_ERR_ARG;
@@ -897,7 +934,7 @@ extern "C" int mfb_get_search_basis(mfb_ctx *c, int *basis, int *transformed_fil
     if (transformed_filters) *transformed_filters = (c->path == MFB_PATH_SEGMENT && c->basis == MFB_BASIS_SPAN) ? c->MB : c->MU;
     return MFB_OK;
 }
-extern "C" int mfb_analyze_rank(const float *masks, int M, int N, int *rank) {
+static int analyze_rank_body(const float *masks, int M, int N, int *rank) {
     if (!masks || !rank || M < 1 || N < 2 || (N & (N - 1))) return MFB_ERR_ARG;
     taps::Bank b, sb;
     taps::analyse(masks, M, N, &b);
@@ -907,6 +944,9 @@ extern "C" int mfb_analyze_rank(const float *masks, int M, int N, int *rank) {
     }
     *rank = taps::span_basis(b, &sb);
     return MFB_OK;
+}
+extern "C" int mfb_analyze_rank(const float *masks, int M, int N, int *rank) {
+    return guarded([&] { return analyze_rank_body(masks, M, N, rank); });
 }
 
 extern "C" int mfb_get_search_path(mfb_ctx *c, int *path, int *log2L, int *taps_out, int *valid_per_segment, int *segments) {
@@ -919,7 +959,7 @@ extern "C" int mfb_get_search_path(mfb_ctx *c, int *path, int *log2L, int *taps_
     return MFB_OK;
 }
 
-extern "C" int mfb_analyze_filters(const float *masks, int M, int N, int *support_start, int *support_len) {
+static int analyze_filters_body(const float *masks, int M, int N, int *support_start, int *support_len) {
     if (!masks || M < 1 || N < 2 || (N & (N - 1))) return MFB_ERR_ARG;
     taps::Bank b;
     taps::analyse(masks, M, N, &b);
@@ -927,8 +967,11 @@ extern "C" int mfb_analyze_filters(const float *masks, int M, int N, int *suppor
     if (support_len) *support_len = b.T;
     return MFB_OK;
 }
+extern "C" int mfb_analyze_filters(const float *masks, int M, int N, int *support_start, int *support_len) {
+    return guarded([&] { return analyze_filters_body(masks, M, N, support_start, support_len); });
+}
 
-extern "C" int mfb_set_filters(mfb_ctx *c, const float *masks, int M, int N) {
+static int set_filters_body(mfb_ctx *c, const float *masks, int M, int N) {
     if (!c || !masks) return MFB_ERR_ARG;
     if (M != c->M || N != c->N) return MFB_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
@@ -977,8 +1020,18 @@ extern "C" int mfb_set_filters(mfb_ctx *c, const float *masks, int M, int N) {
     if (rc) c->have_filters = false;
     return rc;
 }
+extern "C" int mfb_set_filters(mfb_ctx *c, const float *masks, int M, int N) {
+    bool thrown = true;
+    const int rc = guarded([&] {
+        const int r = set_filters_body(c, masks, M, N);
+        thrown = false;
+        return r;
+    });
+    if (thrown && c) c->have_filters = false;      // half a bank: the next mfb_set_filters starts over
+    return rc;
+}
 
-extern "C" int mfb_set_shifts(mfb_ctx *c, const int32_t *shifts, int count) {
+static int set_shifts_body(mfb_ctx *c, const int32_t *shifts, int count) {
     if (!c || !shifts || count != c->Dtot) return MFB_ERR_ARG;
     for (int i = 0; i < count; ++i)
         if (shifts[i] < 0 || shifts[i] >= c->N) return MFB_ERR_ARG;
@@ -992,6 +1045,9 @@ extern "C" int mfb_set_shifts(mfb_ctx *c, const int32_t *shifts, int count) {
     c->have_shifts = true;
     ++c->epoch;
     return fsm_prepare_eager(c);
+}
+extern "C" int mfb_set_shifts(mfb_ctx *c, const int32_t *shifts, int count) {
+    return guarded([&] { return set_shifts_body(c, shifts, count); });
 }
 
 extern "C" int mfb_input_buffer(mfb_ctx *c, float **p) {
@@ -1125,6 +1181,7 @@ static int launch_transpose(mfb_ctx *c, cf *dst, int rows, int conj) {
 // dst + r * N): complex (src_c) or real (src_r) input -> dst natural order.  d_Z must hold `rows` rows.
 static int forward_fft(mfb_ctx *c, const cf *src_c, const float *src_r, cf *dst, int conj_out = 1, int rows = 1, size_t in_stride = 0);
 static int forward_fft(mfb_ctx *c, const cf *src_c, const float *src_r, cf *dst, int conj_out, int rows, size_t in_stride) {
+    if (!(c->use_z2 ? c->z2_rows : c->z_rows)) return MFB_ERR_STATE;       // the transforms' intermediate arrives with the filters
     if (rows < 1 || (size_t)rows > (c->use_z2 ? c->z2_rows : c->z_rows) || in_stride > 0x7fffffffu) return MFB_ERR_ARG;
     P1Args a = p1_base(c);
     a.X = src_c;

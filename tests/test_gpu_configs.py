@@ -273,7 +273,44 @@ def test_failed_create_frees_everything():
     bank.set_shifts([1, 2, 3, 4])
     bank.upload(masks[0])
     bank.find_carrier()
+    want = bank.get_scores().copy()
+    # ... and the same with a C++ exception where the allocation was (nth < 0: std::bad_alloc, what a failed HOST allocation in the
+    # filter analysis looks like): a status code, not a terminated process; nothing left behind by a failed create; the handle takes
+    # the filters again and gives the same table
     bank.close()
+    bank = MFBank(14, 4, 2)                  # (a fresh handle: the first mfb_set_filters is the one that allocates)
+    lib.mfb_debug_fail_alloc(-1)
+    try:
+        with pytest.raises(MemoryError):
+            bank.set_filters(masks)
+    finally:
+        lib.mfb_debug_fail_alloc(0)
+    bank.set_shifts([1, 2, 3, 4])
+    with pytest.raises(RuntimeError):
+        bank.upload(masks[0])                # no filters in force after half a bank: a state error, not a crash
+    with pytest.raises(RuntimeError):
+        bank.find_carrier()
+    bank.set_filters(masks)
+    bank.upload(masks[0])
+    bank.find_carrier()
+    assert np.array_equal(bank.get_scores(), want)
+    bank.close()
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info()
+    thrown = 0
+    for nth in range(1, 40):
+        lib.mfb_debug_fail_alloc(-nth)
+        try:
+            MFBank(18, 64, 8).close()
+            break
+        except MemoryError:
+            thrown += 1
+        finally:
+            lib.mfb_debug_fail_alloc(0)
+    assert thrown == failed
+    torch.cuda.synchronize()
+    free3, _ = torch.cuda.mem_get_info()
+    assert abs(free2 - free3) < (32 << 20), (free2, free3)
 
 
 def test_two_handles_and_concurrent_sync_calls():
