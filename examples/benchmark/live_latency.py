@@ -1,7 +1,8 @@
 """What a live source pays for batches: a producer thread hands the receive loop 4096-sample chunks at a set pace through a queue
 (the reference's ZeroMQ subscriber in miniature, sigFIFO.py:156-163), the loop runs ``run_stream(drain_marked(poll, wait))`` --
 up to 32 blocks (2^20 samples) per device call while there is a backlog, every complete block at once while there is none.  Printed per pace: the
-mean number of blocks per device call and the latency from a block's last sample to its result dict.
+mean number of blocks per device call and the latency from a block's last sample to its result dict.  Then the same paces with a PLAIN
+iterator over the queue (no markers, nothing configured): the loop decides from the time each chunk took to come (round 6).
 usage: python examples/benchmark/live_latency.py [log2N] [blocks per pace]"""
 import os
 import queue
@@ -20,7 +21,7 @@ from pycusdr_amd.protocol import loadProtocol                         # noqa: E4
 CHUNK = 4096
 
 
-def one_pace(run, stream, msamples_per_s):
+def one_pace(run, stream, msamples_per_s, marked=True):
     """Feed ``stream`` at ``msamples_per_s`` (None: as fast as the queue takes it); returns (blocks, mean batch, latencies ms)."""
     q = queue.Queue(maxsize=4096)
     period = CHUNK / (msamples_per_s * 1e6) if msamples_per_s else 0.0
@@ -56,7 +57,13 @@ def one_pace(run, stream, msamples_per_s):
     lat = []
     th.start()
     try:
-        run.run_stream(DemodulatorRunner.drain_marked(poll, wait), sink=lambda d: lat.append(d['latency_ms']))
+        def plain():                 # a source that simply blocks until its next chunk exists
+            while True:
+                c = q.get()
+                if c is None:
+                    return
+                yield c
+        run.run_stream(DemodulatorRunner.drain_marked(poll, wait) if marked else plain(), sink=lambda d: lat.append(d['latency_ms']))
     finally:
         run.demod.beginBlocks = inner
         th.join()
@@ -77,11 +84,13 @@ def main():
         one_pace(run, stream[:20 * (N - ov)], None)          # warm-up: library, graphs of several batch sizes
         print(f'N = 2^{log2N}, 64 bins, {nblocks} blocks per pace; block = {(N - ov) / 1e3:.1f} ksamples')
         print('pace (Msamples/s) | blocks per device call | latency ms: median / 90 % / max | block period ms')
-        for pace in (2, 20, 100, 300, 600, None):
-            n, mean_b, lat = one_pace(run, stream, pace)
-            period = (N - ov) / (pace * 1e6) * 1e3 if pace else 0.0
-            print(f'{pace if pace else "unpaced":>8} | {mean_b:5.2f} | {np.median(lat):7.3f} / {np.percentile(lat, 90):7.3f} / {lat.max():7.3f} | '
-                  f'{period:6.3f}   ({n} blocks)', flush=True)
+        for marked in (True, False):
+            print('-- the source marks where it would block (drain_marked)' if marked else '-- a plain iterator, nothing configured (adaptive)')
+            for pace in (2, 20, 100, 300, 600, None):
+                n, mean_b, lat = one_pace(run, stream, pace, marked=marked)
+                period = (N - ov) / (pace * 1e6) * 1e3 if pace else 0.0
+                print(f'{pace if pace else "unpaced":>8} | {mean_b:5.2f} | {np.median(lat):7.3f} / {np.percentile(lat, 90):7.3f} / {lat.max():7.3f} | '
+                      f'{period:6.3f}   ({n} blocks)', flush=True)
     finally:
         run.close()
 

@@ -275,8 +275,9 @@ class DemodulatorRunner:
         # how many blocks per device call: the caller's word, else the configuration's, else ("auto") whatever the source has ready.
         # A source that marks where it would block (MarkedSource) says so itself; a plain iterator cannot be asked, so the loop
         # watches how long each chunk takes to come (``_run_stream_batched``, adaptive): chunks that are there at once (a
-        # recording, a backlog, a chunk of several blocks) fill windows of auto_blocks_per_call() blocks, and a block whose last
-        # chunk had to be waited for goes out alone, at once -- the one-block loop's latency.
+        # recording, a backlog, a chunk of several blocks) fill windows of auto_blocks_per_call() blocks, and a block that
+        # completes while the source is live (it made the loop wait less than a block of samples ago) goes out at once -- the
+        # one-block loop's latency.
         B = max(1, int(blocks_per_call)) if blocks_per_call not in (None, 'auto') else self.blocks_per_call()
         adaptive = B is None and not isinstance(chunk_source, MarkedSource)
         if B is None:
@@ -427,8 +428,9 @@ class DemodulatorRunner:
         ("nothing more right now"): a live source that puts a ``None`` where it would block gets B blocks per call while it has
         a backlog and every block out as soon as it is complete while it has not (``drain_marked`` builds such a source from
         a poll function).  ``adaptive`` (a plain iterator, nothing configured): the loop decides the same thing from the time
-        each ``next()`` took -- a block whose last chunk had to be waited for (> PULL_SLOW_S) goes out at once with whatever
-        else is complete; chunks that were simply there keep filling the window."""
+        each ``next()`` took -- a block that completes while the source is live (a chunk had to be waited for, > PULL_SLOW_S, less
+        than one block of samples ago) goes out at once with whatever else is complete; chunks that were simply there keep
+        filling the window."""
         from .sigFIFO import WindowAssembler
         wins = self.demod.blockWindows(B)
         # "HIP": {"batch_overlap": true}: the next batch's search beside this batch's small kernels (mfb_set_batch_overlap).  Off
@@ -539,27 +541,34 @@ class DemodulatorRunner:
         rest = [None]                    # what is left of a chunk that straddles two windows
         fill_s = [0.0]                   # how long the last fill() took: a source that is slower than the device is not kept waiting
 
+        since_wait = [1 << 30]           # chunks pulled since one had to be waited for (adaptive)
+
         def fill():
             """Chunks from the source into the window (copies queued, not waited for) until it is complete ('full'), the source
             says it has nothing more right now ('dry') or ends ('end')."""
             t0 = time.time()
-            waited = False
+            live = False
             try:
                 while True:
                     if rest[0] is None:
                         tp = time.perf_counter()
                         chunk = next(it, END)
-                        waited = adaptive and time.perf_counter() - tp > self.PULL_SLOW_S
+                        if adaptive:
+                            # live = the source made the loop wait while THIS block was coming in (sources hand over bursts: a
+                            # producer's wake-up, a transport's message of several chunks -- the chunk that completes a block is
+                            # often not the one that was waited for)
+                            since_wait[0] = 0 if time.perf_counter() - tp > self.PULL_SLOW_S else since_wait[0] + 1
                         if chunk is END:
                             return 'end'
                         if chunk is None:
                             return 'dry'
                         rest[0] = chunk if isinstance(chunk, np.ndarray) else np.asarray(chunk)
+                        live = adaptive and since_wait[0] * len(rest[0]) < self.samplesPerSlice
                     n = asm.take(rest[0])
                     rest[0] = rest[0][n:] if n < len(rest[0]) else None
                     if asm.full():
                         return 'full'
-                    if waited and asm.complete_blocks():
+                    if live and asm.complete_blocks():
                         return 'dry'     # the source had nothing ready: what is complete goes out now
             finally:
                 fill_s[0] = time.time() - t0

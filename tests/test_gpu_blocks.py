@@ -430,8 +430,8 @@ def test_a_batch_on_two_streams_changes_no_number(pname, mod, bs, D, B):
 def test_a_plain_iterator_gets_batches_while_it_has_a_backlog_and_single_blocks_while_it_is_live():
     """Nothing configured, no markers: ``run_stream`` decides from how long each chunk took to come.  A source that hands over a
     backlog (chunks that are there at once, one of them several blocks long) gets them in batches; the same source turned live
-    (every chunk has to be waited for) gets every block out as soon as its last chunk is in -- delivered before the next chunk is
-    asked for -- and everything equals the one-block loop."""
+    (its chunks come in bursts of two that have to be waited for) gets every block out as soon as its last chunk is in -- delivered
+    before the next burst is asked for -- and everything equals the one-block loop."""
     import time
     bs, ov = 13, 1 << 10
     N = 1 << bs
@@ -452,9 +452,12 @@ def test_a_plain_iterator_gets_batches_while_it_has_a_backlog_and_single_blocks_
             yield sig[:5 * step]                      # one chunk of five blocks
             for i in range(5 * step, backlog, 3000):
                 yield sig[i:min(i + 3000, backlog)]
-            for i in range(backlog, len(sig), 2048):  # live: every chunk takes a while to exist
-                time.sleep(2e-3)
-                asked.append((i, len(out)))           # what had been delivered when the loop came back for this chunk
+            for k, i in enumerate(range(backlog, len(sig), 2048)):
+                # live, in bursts of two chunks (a producer's wake-up, a transport's message): the burst takes a while to exist,
+                # its second chunk is there at once -- a block that the SECOND chunk completes still goes out at once
+                if k % 2 == 0:
+                    time.sleep(2e-3)
+                    asked.append((i, len(out)))       # what had been delivered when the loop came back for this burst
                 yield sig[i:i + 2048]
         rb, _ = b.run_stream(source(), sink=out.append)
         assert len(out) == nblocks == len(ra)
