@@ -413,7 +413,9 @@ class DemodulatorRunner:
         return max(1, min(32, (1 << 20) // self.blockSize))
 
     # a chunk that took longer than this to come had to be WAITED for: the source is live and has no backlog (a generator over a
-    # recording answers in ~1 us, a queue with a backlog in a few; 4096 samples at 100 Msamples/s take 41 us to exist)
+    # recording answers in ~1 us, a queue with a backlog in a few; 4096 samples at 100 Msamples/s take 41 us to exist).  A replay
+    # that spends longer than this on every chunk itself (reading, converting) looks live too and gets its blocks one by one --
+    # correct, but slower than it could be: such a source says "blocks_per_call": B.
     PULL_SLOW_S = 25e-6
 
     def _run_stream_batched(self, chunk_source, sink, decoder, B, adaptive=False):
