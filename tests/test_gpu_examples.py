@@ -15,8 +15,10 @@ def test_live_latency_example_runs_and_a_slow_source_is_not_kept_waiting():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     rows = [ln for ln in r.stdout.splitlines() if '|' in ln and '(48 blocks)' in ln]
-    assert len(rows) == 6, r.stdout
-    pace, per_call, lat, period = [c.strip() for c in rows[0].split('|')]
-    assert pace == '2' and float(per_call) <= 2.0
-    median = float(lat.split('/')[0])
-    assert median < 0.5 * float(period.split()[0]), rows[0]          # out well before the next block is complete (15.9 ms apart)
+    assert len(rows) == 12, r.stdout               # six paces with a source that marks where it would block, six with a plain iterator
+    for first in (0, 6):
+        for row, want_pace in ((rows[first], '2'), (rows[first + 1], '20')):
+            pace, per_call, lat, period = [c.strip() for c in row.split('|')]
+            assert pace == want_pace and float(per_call) <= 2.0, row
+            median = float(lat.split('/')[0])
+            assert median < 0.5 * float(period.split()[0]), row         # out well before the next block is complete (15.9 / 1.6 ms apart)
