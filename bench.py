@@ -1185,7 +1185,8 @@ def main():
                 'frac_note': 'frac counts the transforms THIS kernel runs at the nominal 5 L log2 L each (the forward transform of a segment is '
                              'shared by bins_per_forward bins and there is no mixing multiply when the shift sits on the filters; what a transform '
                              'prunes -- dead output slots since round 2, all but the invalid outputs of the second pass in round 6, whose valid '
-                             'energy is the total by Parseval minus the invalid part -- does not change the count); frac_r05_formula is the count '
+                             'energy is the total by Parseval minus the invalid part, the total once per bin from a table of sum_f |G_f|^2 in SUM_ALL '
+                             'searches -- does not change the count); frac_r05_formula is the count '
                              'of rounds 1-5 (a forward transform and a mixing multiply per (bin, segment)) over the same time, for comparison',
                 'hbm_note': 'no length-N intermediate exists on this path: HBM traffic per launch is the 8 MiB block plus partial sums '
                             '(see traffic); the two-pass algorithmic bytes below are context, not bytes moved',

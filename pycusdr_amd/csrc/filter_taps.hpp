@@ -228,10 +228,14 @@ static inline void segment_spectra(const Bank &b, int L, int Te, std::vector<flo
 // so the segment of x can be transformed ONCE for all bins and each bin brings its own spectra of h_s[k] = h[k] e^{+2 pi i s k / N}
 // (k counted from the window start: a constant phase drops out of |y|^2).  Storage: [shift][row][ii][g][e], `rows` = the bank
 // rows wanted (nullptr: all of them), the slot-pair order of segment_spectra.
+// `qout` (optional, with `weights` per row): Q[shift][jj][g][4] = sum over the rows of weights[row] * |spectrum as stored|^2 -- register
+// slots 4 jj ... 4 jj + 3 of lane g side by side (segf_body, SUMQ).
 static inline void segment_spectra_shifted(const Bank &b, const int *rows, int nrows, const int *shifts, int nshifts, int L, int Te,
-                                           std::vector<float> *out, int ppl = 16) {
+                                           std::vector<float> *out, int ppl = 16, std::vector<float> *qout = nullptr,
+                                           const double *weights = nullptr) {
     const Fft plan(L);
     out->assign((size_t)nshifts * nrows * 2 * L, 0.f);
+    if (qout) qout->assign((size_t)nshifts * L, 0.f);
     const double scale = (double)b.N / (double)L;
     const int NT = L / ppl;
     // one host thread per stripe of bins (as analyse does per filter row): D * MU transforms of L points -- 2048 of 256 points at C2,
@@ -243,8 +247,10 @@ static inline void segment_spectra_shifted(const Bank &b, const int *rows, int n
     if (nthr < 1) nthr = 1;
     auto work = [&](int t) {
         std::vector<cd> buf(L);
+        std::vector<double> qacc(qout ? (size_t)L : 0);
         for (int j = t; j < nshifts; j += nthr) {
             const long long s = shifts[j];
+            std::fill(qacc.begin(), qacc.end(), 0.0);
             for (int u = 0; u < nrows; ++u) {
                 const int m = rows ? rows[u] : u;
                 std::fill(buf.begin(), buf.end(), cd(0.0, 0.0));
@@ -261,7 +267,16 @@ static inline void segment_spectra_shifted(const Bank &b, const int *rows, int n
                             const size_t pos = ((size_t)(ii * NT + g) * 2 + e) * 2;
                             o[pos] = (float)v.real();
                             o[pos + 1] = (float)v.imag();
+                            if (qout)          // of the values the kernel multiplies with, i.e. after the rounding to float
+                                qacc[(size_t)g + (size_t)NT * (2 * ii + e)] +=
+                                    (weights ? weights[u] : 1.0) * ((double)o[pos] * (double)o[pos] + (double)o[pos + 1] * (double)o[pos + 1]);
                         }
+            }
+            if (qout) {
+                float *q = qout->data() + (size_t)j * L;
+                for (int jj = 0; jj < ppl / 4; ++jj)
+                    for (int g = 0; g < NT; ++g)
+                        for (int e = 0; e < 4; ++e) q[((size_t)jj * NT + g) * 4 + e] = (float)qacc[(size_t)g + (size_t)NT * (4 * jj + e)];
             }
         }
     };

@@ -189,6 +189,8 @@ struct mfb_ctx {
     std::vector<hipEvent_t> ev_pool;
     // the search with the Doppler shift on the filter side (seg_kernels.hpp, segf_body; 256-point segments): per-bin spectra
     std::vector<int> h_shifts, h_uniq;   // host copies of the shift table and of the unique-filter map
+    std::vector<int> h_mult;             // how many of the M filters each unique one stands for (k_finalize counts its row that often)
+    float *d_Qs = nullptr;               // [Dtot][L]: per-bin sum over the rows of |d_Gs|^2 (SUM_ALL searches; segf_body SUMQ), built with d_Gs
     cf *d_Gs = nullptr;                  // [Dtot][rows][L]: rows = the unique filters, or the span basis
     int gs_rows = 0;                     // rows per bin d_Gs was built for (0: not built)
     int gs_span = -1;                    // ... and for which basis
@@ -454,11 +456,18 @@ static int set_kernel_attributes(const mfb_ctx *c) {
 #define MFB_ATTR_F(PV_) HIPCHK(hipFuncSetAttribute((const void *)k_segf<256, PV_>, hipFuncAttributeMaxDynamicSharedMemorySize, b))
         MFB_ATTR_F(8); MFB_ATTR_F(9); MFB_ATTR_F(10); MFB_ATTR_F(11); MFB_ATTR_F(12); MFB_ATTR_F(13); MFB_ATTR_F(14); MFB_ATTR_F(15); MFB_ATTR_F(16);
 #undef MFB_ATTR_F
+#define MFB_ATTR_Q(L_, PV_, B_)                                                                                                       \
+    if constexpr (segf_has_sumq<L_, PV_>())                                                                                           \
+        HIPCHK(hipFuncSetAttribute((const void *)k_segf<L_, PV_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B_))
+        MFB_ATTR_Q(256, 11, b); MFB_ATTR_Q(256, 12, b); MFB_ATTR_Q(256, 13, b); MFB_ATTR_Q(256, 14, b); MFB_ATTR_Q(256, 15, b);
         const int b2 = (int)(SegCfg<2048>::LDS_ELEMS * sizeof(cf) + (size_t)(SegCfg<2048>::BLOCK / 64) * 8 * SEG_ACC_STRIDE * sizeof(float));
 #define MFB_ATTR_F(PV_) HIPCHK(hipFuncSetAttribute((const void *)k_segf<2048, PV_>, hipFuncAttributeMaxDynamicSharedMemorySize, b2))
         MFB_ATTR_F(16); MFB_ATTR_F(17); MFB_ATTR_F(18); MFB_ATTR_F(19); MFB_ATTR_F(20); MFB_ATTR_F(21); MFB_ATTR_F(22); MFB_ATTR_F(23); MFB_ATTR_F(24);
         MFB_ATTR_F(25); MFB_ATTR_F(26); MFB_ATTR_F(27); MFB_ATTR_F(28); MFB_ATTR_F(29); MFB_ATTR_F(30); MFB_ATTR_F(31); MFB_ATTR_F(32);
 #undef MFB_ATTR_F
+        MFB_ATTR_Q(2048, 22, b2); MFB_ATTR_Q(2048, 23, b2); MFB_ATTR_Q(2048, 24, b2); MFB_ATTR_Q(2048, 25, b2); MFB_ATTR_Q(2048, 26, b2);
+        MFB_ATTR_Q(2048, 27, b2); MFB_ATTR_Q(2048, 28, b2); MFB_ATTR_Q(2048, 29, b2); MFB_ATTR_Q(2048, 30, b2); MFB_ATTR_Q(2048, 31, b2);
+#undef MFB_ATTR_Q
     }
     if ((rc = attr_seg<512>())) return rc;
     if ((rc = attr_seg<1024>())) return rc;
@@ -657,6 +666,7 @@ extern "C" int mfb_destroy(mfb_ctx *c) {
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->d_Gs) (void)hipFree(c->d_Gs);
+    if (c->d_Qs) (void)hipFree(c->d_Qs);
     delete c->bank;
     delete c;
     return MFB_OK;
@@ -999,6 +1009,8 @@ static int set_filters_body(mfb_ctx *c, const float *masks, int M, int N) {
     }
     c->MU = (int)uniq.size();
     c->h_uniq = uniq;
+    c->h_mult.assign(uniq.size(), 0);
+    for (int m = 0; m < M; ++m) ++c->h_mult[(size_t)rep[m]];
     c->gs_rows = 0;
     HIPCHK(hipMemcpyAsync(c->d_uniq, uniq.data(), uniq.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_rep, rep.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -1430,22 +1442,33 @@ static bool fsm_enabled() {
 static int fsm_prepare(mfb_ctx *c, bool span, int rows) {
     if (c->d_Gs && c->gs_rows == rows && c->gs_span == (span ? 1 : 0) && c->gs_l == c->segl) return MFB_OK;
     if ((int)c->h_shifts.size() != c->Dtot || !c->bank) return MFB_ERR_STATE;
-    std::vector<float> G;
+    std::vector<float> G, Q;
+    // SUM_ALL searches: the per-bin table of sum_rows w |G|^2 (segf_body, SUMQ); w = how often k_finalize counts the row, relative to
+    // row 0, whose partial sums carry the bin's total
+    std::vector<float> *q = (c->sum_all && MFB_SEG_SUMQ) ? &Q : nullptr;
     const int L = 1 << c->segl, Te = L - seg_valid(c->segl, c->bank->T) + 1;
     if (span) {
         taps::Bank sb;
         if (taps::span_basis(*c->bank, &sb) != rows) return MFB_ERR_STATE;
-        taps::segment_spectra_shifted(sb, nullptr, rows, c->h_shifts.data(), c->Dtot, L, Te, &G, seg_ppl(L));
+        taps::segment_spectra_shifted(sb, nullptr, rows, c->h_shifts.data(), c->Dtot, L, Te, &G, seg_ppl(L), q, nullptr);
     } else {
-        if ((int)c->h_uniq.size() != rows) return MFB_ERR_STATE;
-        taps::segment_spectra_shifted(*c->bank, c->h_uniq.data(), rows, c->h_shifts.data(), c->Dtot, L, Te, &G, seg_ppl(L));
+        if ((int)c->h_uniq.size() != rows || (int)c->h_mult.size() != rows || c->h_mult[0] < 1) return MFB_ERR_STATE;
+        std::vector<double> wts((size_t)rows);
+        for (int u = 0; u < rows; ++u) wts[(size_t)u] = (double)c->h_mult[(size_t)u] / (double)c->h_mult[0];
+        taps::segment_spectra_shifted(*c->bank, c->h_uniq.data(), rows, c->h_shifts.data(), c->Dtot, L, Te, &G, seg_ppl(L), q, wts.data());
     }
     HIPCHK(sync_streams(c));
     if (c->d_Gs) HIPCHK(hipFree(c->d_Gs));
     c->d_Gs = nullptr;
     c->gs_rows = 0;
+    if (c->d_Qs) HIPCHK(hipFree(c->d_Qs));
+    c->d_Qs = nullptr;
     HIPCHK(dev_alloc((void **)&c->d_Gs, G.size() * sizeof(float)));
     HIPCHK(hipMemcpy(c->d_Gs, G.data(), G.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (q) {
+        HIPCHK(dev_alloc((void **)&c->d_Qs, Q.size() * sizeof(float)));
+        HIPCHK(hipMemcpy(c->d_Qs, Q.data(), Q.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     c->gs_rows = rows;
     c->gs_span = span ? 1 : 0;
     c->gs_l = c->segl;
@@ -1512,7 +1535,14 @@ static int launch_segf_pv(mfb_ctx *c, const SegFArgs &a, int grid, size_t lds, i
         return MFB_ERR_UNSUPPORTED;
     } else {
         if (pv == PV0) {
-            hipLaunchKernelGGL((k_segf<L, PV0>), dim3(grid), dim3(SegCfg<L>::BLOCK), lds, c->stream, a);
+            bool done = false;
+            if constexpr (segf_has_sumq<L, PV0>()) {
+                if (a.Qs) {         // SUM_ALL: the Parseval half of the complement form once per bin
+                    hipLaunchKernelGGL((k_segf<L, PV0, true>), dim3(grid), dim3(SegCfg<L>::BLOCK), lds, c->stream, a);
+                    done = true;
+                }
+            }
+            if (!done) hipLaunchKernelGGL((k_segf<L, PV0, false>), dim3(grid), dim3(SegCfg<L>::BLOCK), lds, c->stream, a);
             HIPCHK(hipGetLastError());
             return MFB_OK;
         }
@@ -1525,6 +1555,7 @@ static int launch_fsm(mfb_ctx *c, int nb, const cf *x, int xstride, int MU, int 
     memset(&a, 0, sizeof(a));
     a.x = x;
     a.Gs = c->d_Gs;
+    a.Qs = c->sum_all ? c->d_Qs : nullptr;
     a.twL = c->d_twL;
     a.partials = c->d_part;
     a.N = c->N;

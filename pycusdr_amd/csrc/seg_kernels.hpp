@@ -97,6 +97,10 @@ constexpr int seg_block_threads(int NT) { return NT <= 64 ? MFB_SEG_BLOCK : (NT 
 #ifndef MFB_SEG_FSM_PROBE_ONE_ROW
 #define MFB_SEG_FSM_PROBE_ONE_ROW 0
 #endif
+// SUM_ALL searches: the Parseval half of the complement form once per bin from a table of sum_f |G_f|^2 instead of once per (bin, filter)
+#ifndef MFB_SEG_SUMQ
+#define MFB_SEG_SUMQ 1
+#endif
 // valid energy = total energy (Parseval on the product) - energy of the invalid outputs (segf_body): 1 on, 0 = every valid output
 #ifndef MFB_SEG_COMPLEMENT
 #define MFB_SEG_COMPLEMENT 1
@@ -554,6 +558,8 @@ DEVI void seg_body(const SegArgs &a, const int blk) {
 struct SegFArgs {
     const cf *x;         // block (or window of a batch)
     const cf *Gs;        // [Dtot][MU][PPL / 2][NT][2]: spectra of filter slot u at bin j, slot-pair layout
+    const float *Qs;     // [Dtot][PPL / 4][NT][4]: sum over the filter slots of |Gs|^2 at bin j, weighted by how often k_finalize counts
+                         // each slot relative to slot 0 (SUM_ALL searches, SUMQ instantiations; else unused)
     const cf *twL;       // W_L table with the fused (cos, tan) pairs behind it
     float *partials;
     int N, V;
@@ -569,7 +575,7 @@ struct SegFArgs {
     int part_row0, parts;
     float scale;
 };
-template <int L, int PV>
+template <int L, int PV, bool SUMQ>
 DEVI void segf_body(const SegFArgs &a, const int blk) {
     static_assert(MFB_FFT_FUSED && (L == 256 || (L == 2048 && MFB_SEG_W32)), "the fused 256- and 2048-point transforms");
     using Cfg = SegCfg<L>;
@@ -599,6 +605,11 @@ DEVI void segf_body(const SegFArgs &a, const int blk) {
     // instead of 106 per filter; 210 instead of 260 in the 2048-point form at 26 of 32).  Worth it from 11 (22) valid slots up.
     // Same number to fp32 rounding: the difference is 4/5 of the minuend, nothing cancels (profiles/r06_fft_ops.md section 4).
     constexpr bool COMPL = MFB_SEG_COMPLEMENT && PV < PPL && (W32 ? PV >= 22 : PV >= 11);
+    // SUM_ALL searches need the sum over the filters only, and the Parseval half of it factors: sum_f L sum_k |A[k] G_f[k]|^2 =
+    // L sum_k |A[k]|^2 Q[k] with Q = sum_f |G_f|^2, a table per bin (host, filter_taps.hpp): PPL / 2 packed FMAs per BIN instead of
+    // PPL per (bin, filter).  The bin's total goes into filter slot 0's partial sum, the other slots carry minus their invalid
+    // outputs' energy; k_finalize adds the slots as it always did (Q carries the weights with which it counts them).
+    constexpr bool QSUM = SUMQ && COMPL;
 
     // ---- this wave's rectangle ----
     const int grp = blk % a.nsg;
@@ -620,6 +631,12 @@ DEVI void segf_body(const SegFArgs &a, const int blk) {
     const unsigned nmask = (unsigned)a.N - 1u;
     const auto xr = mk_rsrc(a.x + (size_t)bk * (size_t)a.xstride, (unsigned)a.N * sizeof(cf));
     const auto gr = mk_rsrc(a.Gs, (unsigned)a.dper * (unsigned)a.MU * (unsigned)(L * sizeof(cf)));
+    [[maybe_unused]] const auto qr = mk_rsrc(QSUM ? (const void *)a.Qs : (const void *)a.Gs, (unsigned)a.dper * (unsigned)(L * sizeof(float)));
+    [[maybe_unused]] auto load_q = [&](cf (&dst)[PPL / 2], int bin) {
+#pragma unroll
+        for (int jj = 0; jj < PPL / 4; ++jj)
+            buf_load_cf2(qr, g * 4 * (int)sizeof(float), bin * (L * (int)sizeof(float)) + jj * NT * 4 * (int)sizeof(float), dst[2 * jj], dst[2 * jj + 1]);
+    };
     constexpr int so_x = NT * (int)sizeof(cf);
     const int vo_g2 = g * 2 * (int)sizeof(cf);
     constexpr int so_g2 = NT * 2 * (int)sizeof(cf);
@@ -665,7 +682,34 @@ DEVI void segf_body(const SegFArgs &a, const int blk) {
             auto keep = [&](int, cf val, auto, auto nu) { A[decltype(nu)::value / NT] = val; };
             transform(v, keep, std::integral_constant<int, 0>{}, all_live);
         }
+        // (|A[2j]|^2, |A[2j + 1]|^2): kept per slot by the 256-point form; the 2048-point form has no 32 registers for them and squares
+        // again for every bin (80 instead of 16 operations per bin, against the 32 per (bin, filter) they replace)
+        constexpr bool PP_REGS = QSUM && !W32;
+        [[maybe_unused]] cf pp[PP_REGS ? PPL / 2 : 1];
+        [[maybe_unused]] cf qq[QSUM ? PPL / 2 : 1];
+        auto power_pair = [&](int j) {
+            const cf s0 = A[2 * j] * A[2 * j], s1 = A[2 * j + 1] * A[2 * j + 1];
+            return mkc(s0.x + s0.y, s1.x + s1.y);
+        };
+        if constexpr (QSUM) {
+            if constexpr (PP_REGS) {
+#pragma unroll
+                for (int j = 0; j < PPL / 2; ++j) pp[j] = power_pair(j);
+            }
+            if constexpr (PP_REGS) load_q(qq, jb0);
+        }
         for (int jb = jb0; jb < jb1; ++jb) {
+            [[maybe_unused]] float tot = 0.f;
+            if constexpr (QSUM) {
+                if constexpr (!PP_REGS) load_q(qq, jb);            // (no registers to hold the next bin's table across the reduce)
+                cf t2[2] = {mkc(0.f, 0.f), mkc(0.f, 0.f)};
+#pragma unroll
+                for (int j = 0; j < PPL / 2; ++j) {
+                    if constexpr (PP_REGS) t2[j & 1] = __builtin_elementwise_fma(pp[j], qq[j], t2[j & 1]);
+                    else t2[j & 1] = __builtin_elementwise_fma(power_pair(j), qq[j], t2[j & 1]);
+                }
+                tot = (t2[0].x + t2[0].y) + (t2[1].x + t2[1].y);
+            }
             for (int mi = 0; mi < MU; ++mi) {
                 cf w[PPL];
                 if constexpr (PREFETCH) {
@@ -685,7 +729,15 @@ DEVI void segf_body(const SegFArgs &a, const int blk) {
                     }
                 }
                 cf racc[4] = {mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f)};
-                if constexpr (COMPL) {
+                if constexpr (QSUM) {
+                    auto acc = [&](int, cf val, auto, auto nu) {
+                        constexpr int k = decltype(nu)::value / NT;
+                        if constexpr (k >= PV) racc[k & 3] = __builtin_elementwise_fma(val, val, racc[k & 3]);
+                    };
+                    transform(w, acc, sum_live, all_live);                 // slots [PV, PPL): the invalid outputs
+                    const cf inv = (racc[0] + racc[1]) + (racc[2] + racc[3]);
+                    lacc[mi * SEG_ACC_STRIDE + lane] = __builtin_fmaf((float)L, mi == 0 ? tot : 0.f, -(inv.x + inv.y));
+                } else if constexpr (COMPL) {
                     cf pacc[4] = {mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f)};
 #pragma unroll
                     for (int i = 0; i < PPL; ++i) pacc[i & 3] = __builtin_elementwise_fma(w[i], w[i], pacc[i & 3]);
@@ -707,6 +759,9 @@ DEVI void segf_body(const SegFArgs &a, const int blk) {
                     lacc[mi * SEG_ACC_STRIDE + lane] = rsum.x + rsum.y;
                 }
             }
+            if constexpr (PP_REGS) {
+                if (jb + 1 < jb1) load_q(qq, jb + 1);              // lands during the reduce below
+            }
             // the wave's lanes in seg_body's fixed order: lane (f, j) adds elements j, j + 4, ... of filter f's row, two quad steps
             xsync<1>();
             const int f = lane >> 2, j = lane & 3;
@@ -724,10 +779,15 @@ DEVI void segf_body(const SegFArgs &a, const int blk) {
         }
     }
 }
-template <int L, int PV>
+template <int L, int PV, bool SUMQ = false>
 __global__ void __launch_bounds__(SegCfg<L>::BLOCK) __attribute__((amdgpu_waves_per_eu(SegCfg<L>::WAVES, SegCfg<L>::WAVES)))
 k_segf(SegFArgs a) {
-    segf_body<L, PV>(a, (int)blockIdx.x);
+    segf_body<L, PV, SUMQ>(a, (int)blockIdx.x);
+}
+// which (L, PV) have a SUMQ form worth instantiating: those that take the complement branch
+template <int L, int PV>
+constexpr bool segf_has_sumq() {
+    return MFB_SEG_SUMQ && MFB_SEG_COMPLEMENT && PV < SegCfg<L>::PPL && (SegCfg<L>::W32 ? PV >= 22 : PV >= 11);
 }
 
 // amdgpu_waves_per_eu pins the register budget: without the upper bound the scheduler chases a fourth
