@@ -307,3 +307,38 @@ def test_the_shift_on_the_filters_side_equals_the_shift_on_the_samples(tmp_path,
     assert np.abs(sa - sb).max() / sa.max() < 2e-6            # two device formulations: fp32 rounding apart (the oracle gate is 1e-5)
     assert not np.array_equal(sa, sb)                          # ... and really two formulations
     assert abs(float(a['pick'][0]) - float(b['pick'][0])) < 1e-3 and np.all(sb[:, 1:] == 0)
+
+
+@pytest.mark.parametrize('log2L,T', [(8, 40), (8, 80), (11, 300)])
+def test_sum_all_total_once_per_bin_with_filters_that_count_differently(log2L, T):
+    """SUM_ALL searches take the Parseval half of a segment's energy once per bin from a host table of sum_f w_f |G_f|^2 (segf_body,
+    SUMQ), w_f = how often k_finalize counts row f relative to row 0.  A bank whose rows count 3, 1, 2 and 1 times (exact copies and an
+    exact negative are transformed once): the SUM_ALL column against the oracle's sum over all seven filters, and against the sum of
+    the per-filter columns of a handle without SUM_ALL (which keeps the per-filter form), both shifts-on-the-filters searches."""
+    log2N, D = 15, 37
+    N = 1 << log2N
+    rs = np.random.RandomState(100 + T)
+    base = _short_masks(rs, 4, N, T, 777)
+    masks = np.stack([base[0], base[1], -base[0], base[2], base[2], base[0], base[3]]).astype(np.complex64)      # rows count 3, 1, 2, 1
+    x = _rc(rs, N)
+    shifts = rs.randint(0, N, D).astype(np.int32)
+    tables = {}
+    for sum_all in (True, False):
+        bank = MFBank(log2N, D, 7, sum_all_masks=sum_all)
+        try:
+            bank.set_filters(masks)
+            bank.set_shifts(shifts)
+            bank.set_search_path('segment', log2L)
+            assert bank.get_info()[2] == 4                                   # four rows transformed
+            info = bank.get_search_info()
+            assert info['filter_side'] and info['bins_per_forward'] >= 1
+            bank.upload(x)
+            bank.find_carrier()
+            tables[sum_all] = bank.get_scores().astype(np.float64)
+            X = bank.get_spectrum()
+        finally:
+            bank.close()
+    ref = orc.doppler_scores(X, masks, shifts, True)[:, 0]
+    assert np.abs(tables[True][:, 0] - ref).max() <= 1e-5 * ref.max()
+    assert np.abs(tables[True][:, 0] - tables[False].sum(axis=1)).max() <= 2e-6 * ref.max()
+    assert np.all(tables[True][:, 1:] == 0)
