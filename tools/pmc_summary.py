@@ -90,8 +90,8 @@ with open(f'profiles/{rnd}_pmc_summary.md', 'w') as f:
             f"operation counts, power experiment and the filter-side shift in `r06_fft_ops.md`.\n")
 p = 'profiles/pmc_traffic.json'
 d = json.load(open(p))
-keys = {'': ('segment_D256_M8_N20_L8', 'k_segf<256,13> + masked tail k_seg<256,REDUCE,-1>'), '_cc': ('segment_D256_M8_N20_L11', 'bench.py --protocol CC11xx: k_segf<2048,26> (wave-local) + masked tail'),
-        '_bpsk': ('segment_D256_M32_N20_L8', 'bench.py --protocol bench_BPSK: k_segf<256,11> + masked tail; 16 unique filter rows')}
+keys = {'': ('segment_D256_M8_N20_L8', 'k_segf<256,13,SUMQ> + masked tail k_seg<256,REDUCE,-1>'), '_cc': ('segment_D256_M8_N20_L11', 'bench.py --protocol CC11xx: k_segf<2048,26,SUMQ> (wave-local) + masked tail'),
+        '_bpsk': ('segment_D256_M32_N20_L8', 'bench.py --protocol bench_BPSK: k_segf<256,11,SUMQ> + masked tail; 16 unique filter rows')}
 for sfx, (key, what) in keys.items():
     tot, bm, bt = traffic[sfx]
     d[key] = {'bytes': tot, 'main_kernel': bm, 'tail_kernel': bt,

@@ -8,7 +8,7 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r06_s1s2'
 out = open(sys.argv[2], 'w') if len(sys.argv) > 2 else sys.stdout
 root = f'gpurun_out/{tag}'
-KERNELS = ('k_segf<256, 13>', 'k_seg<256, 0, 13>')       # the search kernel of C2: round 6's form, or (MFB_SEG_FSM=0) the time-side one
+KERNELS = ('k_segf<256, 13', 'k_seg<256, 0, 13>')       # the search kernel of C2: round 6's form, or (MFB_SEG_FSM=0) the time-side one
 
 
 def p(*a):
