@@ -458,7 +458,9 @@ static int set_kernel_attributes(const mfb_ctx *c) {
 #undef MFB_ATTR_F
 #define MFB_ATTR_Q(L_, PV_, B_)                                                                                                       \
     if constexpr (segf_has_sumq<L_, PV_>())                                                                                           \
-        HIPCHK(hipFuncSetAttribute((const void *)k_segf<L_, PV_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B_))
+        HIPCHK(hipFuncSetAttribute((const void *)k_segf<L_, PV_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, B_));                    \
+    if constexpr (segf_has_presum<L_, PV_>())                                                                                         \
+        HIPCHK(hipFuncSetAttribute((const void *)k_segf<L_, PV_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, B_))
         MFB_ATTR_Q(256, 11, b); MFB_ATTR_Q(256, 12, b); MFB_ATTR_Q(256, 13, b); MFB_ATTR_Q(256, 14, b); MFB_ATTR_Q(256, 15, b);
         const int b2 = (int)(SegCfg<2048>::LDS_ELEMS * sizeof(cf) + (size_t)(SegCfg<2048>::BLOCK / 64) * 8 * SEG_ACC_STRIDE * sizeof(float));
 #define MFB_ATTR_F(PV_) HIPCHK(hipFuncSetAttribute((const void *)k_segf<2048, PV_>, hipFuncAttributeMaxDynamicSharedMemorySize, b2))
@@ -1536,13 +1538,19 @@ static int launch_segf_pv(mfb_ctx *c, const SegFArgs &a, int grid, size_t lds, i
     } else {
         if (pv == PV0) {
             bool done = false;
-            if constexpr (segf_has_sumq<L, PV0>()) {
-                if (a.Qs) {         // SUM_ALL: the Parseval half of the complement form once per bin
-                    hipLaunchKernelGGL((k_segf<L, PV0, true>), dim3(grid), dim3(SegCfg<L>::BLOCK), lds, c->stream, a);
+            if constexpr (segf_has_presum<L, PV0>()) {
+                if (a.Qs && a.presum) {      // ... and the filter rows summed in registers
+                    hipLaunchKernelGGL((k_segf<L, PV0, 2>), dim3(grid), dim3(SegCfg<L>::BLOCK), lds, c->stream, a);
                     done = true;
                 }
             }
-            if (!done) hipLaunchKernelGGL((k_segf<L, PV0, false>), dim3(grid), dim3(SegCfg<L>::BLOCK), lds, c->stream, a);
+            if constexpr (segf_has_sumq<L, PV0>()) {
+                if (a.Qs && !done) {         // SUM_ALL: the Parseval half of the complement form once per bin
+                    hipLaunchKernelGGL((k_segf<L, PV0, 1>), dim3(grid), dim3(SegCfg<L>::BLOCK), lds, c->stream, a);
+                    done = true;
+                }
+            }
+            if (!done) hipLaunchKernelGGL((k_segf<L, PV0, 0>), dim3(grid), dim3(SegCfg<L>::BLOCK), lds, c->stream, a);
             HIPCHK(hipGetLastError());
             return MFB_OK;
         }
@@ -1556,6 +1564,7 @@ static int launch_fsm(mfb_ctx *c, int nb, const cf *x, int xstride, int MU, int 
     a.x = x;
     a.Gs = c->d_Gs;
     a.Qs = c->sum_all ? c->d_Qs : nullptr;
+    a.presum = c->gs_span == 1 || std::all_of(c->h_mult.begin(), c->h_mult.end(), [&](int m) { return m == c->h_mult[0]; }) ? 1 : 0;
     a.twL = c->d_twL;
     a.partials = c->d_part;
     a.N = c->N;

@@ -97,6 +97,11 @@ constexpr int seg_block_threads(int NT) { return NT <= 64 ? MFB_SEG_BLOCK : (NT 
 #ifndef MFB_SEG_FSM_PROBE_ONE_ROW
 #define MFB_SEG_FSM_PROBE_ONE_ROW 0
 #endif
+// ... and the filters of a bin summed in registers, one partial sum per (bin, slot), reduced over the wave by DPP (no LDS round trip):
+// for banks whose rows k_finalize counts equally often (every shipped one)
+#ifndef MFB_SEG_PRESUM
+#define MFB_SEG_PRESUM 1
+#endif
 // SUM_ALL searches: the Parseval half of the complement form once per bin from a table of sum_f |G_f|^2 instead of once per (bin, filter)
 #ifndef MFB_SEG_SUMQ
 #define MFB_SEG_SUMQ 1
@@ -573,9 +578,12 @@ struct SegFArgs {
     int fb, fs;          // bins / slots per rectangle
     int nbc, nsc;        // bin chunks per block (gbins: per group), slot chunks per group (gbins: per block)
     int part_row0, parts;
+    int presum;          // SUMQ searches: the filter rows count equally, one partial sum per (bin, slot) in row 0 (SUMQ = 2)
     float scale;
 };
-template <int L, int PV, bool SUMQ>
+// SUMQ: 0 = the Parseval total per (bin, filter); 1 = once per bin, one partial sum per filter row; 2 = once per bin and the rows summed in
+// registers (256-point form, rows that count equally)
+template <int L, int PV, int SUMQ>
 DEVI void segf_body(const SegFArgs &a, const int blk) {
     static_assert(MFB_FFT_FUSED && (L == 256 || (L == 2048 && MFB_SEG_W32)), "the fused 256- and 2048-point transforms");
     using Cfg = SegCfg<L>;
@@ -609,7 +617,8 @@ DEVI void segf_body(const SegFArgs &a, const int blk) {
     // L sum_k |A[k]|^2 Q[k] with Q = sum_f |G_f|^2, a table per bin (host, filter_taps.hpp): PPL / 2 packed FMAs per BIN instead of
     // PPL per (bin, filter).  The bin's total goes into filter slot 0's partial sum, the other slots carry minus their invalid
     // outputs' energy; k_finalize adds the slots as it always did (Q carries the weights with which it counts them).
-    constexpr bool QSUM = SUMQ && COMPL;
+    constexpr bool QSUM = SUMQ != 0 && COMPL;
+    constexpr bool PRESUM = QSUM && SUMQ == 2;
 
     // ---- this wave's rectangle ----
     const int grp = blk % a.nsg;
@@ -710,6 +719,7 @@ DEVI void segf_body(const SegFArgs &a, const int blk) {
                 }
                 tot = (t2[0].x + t2[0].y) + (t2[1].x + t2[1].y);
             }
+            [[maybe_unused]] float binacc = 0.f;        // minus the invalid outputs' energy, summed over the bin's filters (PRESUM)
             for (int mi = 0; mi < MU; ++mi) {
                 cf w[PPL];
                 if constexpr (PREFETCH) {
@@ -736,7 +746,8 @@ DEVI void segf_body(const SegFArgs &a, const int blk) {
                     };
                     transform(w, acc, sum_live, all_live);                 // slots [PV, PPL): the invalid outputs
                     const cf inv = (racc[0] + racc[1]) + (racc[2] + racc[3]);
-                    lacc[mi * SEG_ACC_STRIDE + lane] = __builtin_fmaf((float)L, mi == 0 ? tot : 0.f, -(inv.x + inv.y));
+                    if constexpr (PRESUM) binacc -= inv.x + inv.y;
+                    else lacc[mi * SEG_ACC_STRIDE + lane] = __builtin_fmaf((float)L, mi == 0 ? tot : 0.f, -(inv.x + inv.y));
                 } else if constexpr (COMPL) {
                     cf pacc[4] = {mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f), mkc(0.f, 0.f)};
 #pragma unroll
@@ -762,6 +773,23 @@ DEVI void segf_body(const SegFArgs &a, const int blk) {
             if constexpr (PP_REGS) {
                 if (jb + 1 < jb1) load_q(qq, jb + 1);              // lands during the reduce below
             }
+            if constexpr (PRESUM) {
+                // the wave's 64 values in a fixed order: quads, the four quads of a row, the four rows
+                float sv = __builtin_fmaf((float)L, tot, binacc);
+                sv += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sv), 0xB1, 0xF, 0xF, true));       // quad_perm [1,0,3,2]
+                sv += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sv), 0x4E, 0xF, 0xF, true));       // quad_perm [2,3,0,1]
+                sv += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sv), 0x124, 0xF, 0xF, true));      // row_ror:4
+                sv += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sv), 0x128, 0xF, 0xF, true));      // row_ror:8
+                const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), 0));
+                const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), 16));
+                const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), 32));
+                const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), 48));
+                const float total = (r0 + r1) + (r2 + r3);
+                // row 0 carries the bin's sum, the other rows zero: k_finalize adds the rows as it always did
+                if (lane < MU)
+                    a.partials[((size_t)(a.part_row0 + bk * a.dper + jb) * MU + lane) * a.parts + slot] = lane == 0 ? total * a.scale : 0.f;
+                continue;
+            }
             // the wave's lanes in seg_body's fixed order: lane (f, j) adds elements j, j + 4, ... of filter f's row, two quad steps
             xsync<1>();
             const int f = lane >> 2, j = lane & 3;
@@ -779,7 +807,7 @@ DEVI void segf_body(const SegFArgs &a, const int blk) {
         }
     }
 }
-template <int L, int PV, bool SUMQ = false>
+template <int L, int PV, int SUMQ = 0>
 __global__ void __launch_bounds__(SegCfg<L>::BLOCK) __attribute__((amdgpu_waves_per_eu(SegCfg<L>::WAVES, SegCfg<L>::WAVES)))
 k_segf(SegFArgs a) {
     segf_body<L, PV, SUMQ>(a, (int)blockIdx.x);
@@ -788,6 +816,11 @@ k_segf(SegFArgs a) {
 template <int L, int PV>
 constexpr bool segf_has_sumq() {
     return MFB_SEG_SUMQ && MFB_SEG_COMPLEMENT && PV < SegCfg<L>::PPL && (SegCfg<L>::W32 ? PV >= 22 : PV >= 11);
+}
+// ... and the rows summed in registers: the 256-point form (the 2048-point one has no registers left for it: spills, measured 0.3 % slower)
+template <int L, int PV>
+constexpr bool segf_has_presum() {
+    return MFB_SEG_PRESUM && segf_has_sumq<L, PV>() && !SegCfg<L>::W32;
 }
 
 // amdgpu_waves_per_eu pins the register budget: without the upper bound the scheduler chases a fourth
